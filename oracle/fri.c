@@ -1,0 +1,458 @@
+// TEST INFRASTRUCTURE -- CPU oracle (see gl.h header). Never linked into the product.
+//
+// Challenger, FRI prover (commit / PoW / query), batch-opening composition, FRI verifier and
+// the transcript of prove() around them.
+// Follows (absent [dep] sources, restated):
+//   plonky2/src/iop/challenger.rs        (overwrite-mode duplex; get_challenge pops from the back)
+//   plonky2/src/fri/oracle.rs            (PolynomialBatch::prove_openings: alpha-batching, divide_by_linear)
+//   plonky2/src/fri/prover.rs            (fri_committed_trees, fri_proof_of_work, fri_prover_query_rounds)
+//   plonky2/src/fri/reduction_strategies.rs (ConstantArityBits(4,5))
+//   plonky2/src/fri/verifier.rs          (fri_combine_initial, compute_evaluation, final-poly check)
+//   plonky2/src/plonk/prover.rs          (observe order: circuit digest, H(public inputs), wires cap,
+//                                          betas/gammas, zs cap, alphas, quotient cap, zeta, openings)
+// Called from the reference at recursion-framework/src/circuit_builder.rs:308 and
+// universal_verifier_gadget/wrap_circuit.rs:143 (`prove`).
+#include "fri.h"
+#include <stdlib.h>
+#include <stdio.h>
+
+void orc_perm(int variant, gl_t s[12]);
+void orc_merkle_build(int variant, const gl_t* leaves, size_t leaf_len, unsigned log_leaves, unsigned cap_h, gl_t* levels);
+size_t orc_merkle_levels_len(unsigned log_leaves, unsigned cap_h);
+const gl_t* orc_merkle_cap_ptr(const gl_t* levels, unsigned log_leaves, unsigned cap_h);
+void orc_merkle_prove(const gl_t* levels, unsigned log_leaves, unsigned cap_h, size_t idx, gl_t* siblings);
+int orc_merkle_verify(int variant, const gl_t* leaf, size_t leaf_len, size_t idx, const gl_t* siblings, unsigned n_sib, const gl_t* cap);
+void orc_fft(gl_t* a, unsigned log_n, int inverse);
+void orc_coset_fft(gl_t* a, unsigned log_n, gl_t shift);
+void orc_lde_leaves(const gl_t* coeffs, unsigned log_n, size_t w, unsigned rate_bits, gl_t* leaves);
+size_t orc_bitrev(size_t x, unsigned bits);
+
+// ---- challenger ---------------------------------------------------------------------------
+void orc_ch_init(orc_challenger* c, int variant) { memset(c, 0, sizeof *c); c->variant = variant; }
+static void ch_duplex(orc_challenger* c) {
+  memcpy(c->state, c->in, c->n_in * sizeof(gl_t));
+  c->n_in = 0;
+  orc_perm(c->variant, c->state);
+  memcpy(c->out, c->state, 8 * sizeof(gl_t));
+  c->n_out = 8;
+}
+void orc_ch_observe(orc_challenger* c, const gl_t* e, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    c->n_out = 0;
+    c->in[c->n_in++] = e[i];
+    if (c->n_in == 8) ch_duplex(c);
+  }
+}
+gl_t orc_ch_get(orc_challenger* c) {
+  if (c->n_in || !c->n_out) ch_duplex(c);
+  return c->out[--c->n_out];
+}
+gl2_t orc_ch_get_ext(orc_challenger* c) {
+  gl2_t r;
+  r.c[0] = orc_ch_get(c);
+  r.c[1] = orc_ch_get(c);
+  return r;
+}
+
+// ---- helpers ------------------------------------------------------------------------------
+// fft of ext-valued vectors = component-wise base fft (roots are in the base field)
+static void ext_coset_fft(gl2_t* a, unsigned log_n, gl_t shift) {
+  size_t n = (size_t)1 << log_n;
+  gl_t* t = malloc(n * sizeof(gl_t));
+  for (int c = 0; c < 2; c++) {
+    for (size_t i = 0; i < n; i++) t[i] = a[i].c[c];
+    orc_coset_fft(t, log_n, shift);
+    for (size_t i = 0; i < n; i++) a[i].c[c] = t[i];
+  }
+  free(t);
+}
+static gl2_t eval_base_poly_ext(const gl_t* coeffs, size_t n, gl2_t z) {
+  gl2_t acc = gl2_from(0);
+  for (size_t i = n; i-- > 0;) acc = gl2_add(gl2_mul(acc, z), gl2_from(coeffs[i]));
+  return acc;
+}
+static gl2_t eval_ext_poly(const gl2_t* coeffs, size_t n, gl2_t z) {
+  gl2_t acc = gl2_from(0);
+  for (size_t i = n; i-- > 0;) acc = gl2_add(gl2_mul(acc, z), coeffs[i]);
+  return acc;
+}
+
+// Flat proof sizes (u64 words). Layout:
+//   caps[n_layers][2^cap][4] | queries[num_queries]{ per oracle: leaf[w] sib[(lg-cap)][4] ;
+//   per layer i: evals[2^arity][2] sib[(lg - sum_{j<=i} arity_j - cap)][4] } | final[len][2] | pow
+size_t orc_fri_proof_words(const orc_fri_params* P) {
+  unsigned lg = P->log_n + P->rate_bits;
+  size_t capw = ((size_t)4) << P->cap_height;
+  size_t q = 0;
+  for (uint32_t o = 0; o < P->n_oracles; o++) q += P->oracle_w[o] + 4 * (lg - P->cap_height);
+  unsigned cur = lg;
+  unsigned deg = P->log_n;
+  for (uint32_t i = 0; i < P->n_layers; i++) {
+    cur -= P->arity_bits[i];
+    deg -= P->arity_bits[i];
+    q += (2u << P->arity_bits[i]) + 4 * (cur - P->cap_height);
+  }
+  return P->n_layers * capw + P->num_queries * q + (2ull << deg) + 1;
+}
+size_t orc_n_openings(const orc_fri_params* P) {
+  size_t t = P->zs_count;
+  for (uint32_t o = 0; o < P->n_oracles; o++) t += P->oracle_w[o];
+  return t;
+}
+
+// prove_openings + fri_proof. coeffs[o] = [w_o][n] base coefficients; leaves[o] = [8n][w_o];
+// levels[o] = Merkle levels. Challenger state continues the caller's transcript.
+// `pow_witness_in`: if not NULL, use this witness instead of searching (the reference's search
+// is a non-deterministic find_any; parity is defined given the witness).
+void orc_fri_prove(const orc_fri_params* P, gl_t* const* coeffs, gl_t* const* leaves, gl_t* const* levels,
+                   gl2_t zeta, orc_challenger* ch, gl_t* proof) {
+  unsigned k = P->log_n, lg = k + P->rate_bits;
+  size_t n = (size_t)1 << k, N = (size_t)1 << lg;
+  gl2_t alpha = orc_ch_get_ext(ch);
+  gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(k));
+
+  gl2_t* final_poly = calloc(N, sizeof(gl2_t));  // lde: zero padded to 8n
+  gl2_t* comp = malloc(n * sizeof(gl2_t));
+  for (int batch = 0; batch < 2; batch++) {
+    gl2_t point = batch == 0 ? zeta : g_zeta;
+    // reduce_polys_base: sum_j alpha^j f_j, j in batch order
+    for (size_t i = 0; i < n; i++) comp[i] = gl2_from(0);
+    gl2_t apow = gl2_from(1);
+    size_t count = 0;
+    for (uint32_t o = 0; o < P->n_oracles; o++) {
+      if (batch == 1 && o != P->zs_oracle) continue;
+      uint32_t wo = batch == 0 ? P->oracle_w[o] : P->zs_count;
+      for (uint32_t p = 0; p < wo; p++) {
+        const gl_t* f = coeffs[o] + (size_t)p * n;
+        for (size_t i = 0; i < n; i++) comp[i] = gl2_add(comp[i], gl2_scale(apow, f[i]));
+        apow = gl2_mul(apow, alpha);
+        count++;
+      }
+    }
+    // divide_by_linear(point): q_i = sum_{k>i} c_k point^(k-i-1); pad back with a zero
+    // alpha.shift_poly(final): final *= alpha^count ; final += quotient
+    gl2_t sh = gl2_pow(alpha, count);
+    for (size_t i = 0; i < n; i++) final_poly[i] = gl2_mul(final_poly[i], sh);
+    gl2_t acc = gl2_from(0);
+    for (size_t i = n; i-- > 1;) {
+      acc = gl2_add(gl2_mul(acc, point), comp[i]);
+      final_poly[i - 1] = gl2_add(final_poly[i - 1], acc);
+    }
+  }
+  free(comp);
+
+  // lde_final_values = lde_final_poly.coset_fft(g)
+  gl2_t* cf = final_poly;  // coefficients, length m (only the first m>>rate are non-zero)
+  size_t m = N;
+  gl2_t* values = malloc(N * sizeof(gl2_t));
+  memcpy(values, cf, N * sizeof(gl2_t));
+  ext_coset_fft(values, lg, GL_MULT_GEN);
+
+  // ---- commit phase
+  size_t capw = ((size_t)4) << P->cap_height;
+  gl_t* out_caps = proof;
+  gl_t** layer_levels = calloc(P->n_layers, sizeof(gl_t*));
+  gl_t** layer_leaves = calloc(P->n_layers, sizeof(gl_t*));
+  unsigned cur_lg = lg;
+  gl_t shift = GL_MULT_GEN;
+  for (uint32_t li = 0; li < P->n_layers; li++) {
+    unsigned ab = P->arity_bits[li];
+    size_t arity = (size_t)1 << ab;
+    // reverse_index_bits_in_place(values); chunks(arity) flattened are the leaves
+    gl_t* lv = malloc(m * 2 * sizeof(gl_t));
+    for (size_t i = 0; i < m; i++) {
+      size_t j = orc_bitrev(i, cur_lg);
+      lv[2 * j] = values[i].c[0];
+      lv[2 * j + 1] = values[i].c[1];
+    }
+    unsigned log_leaves = cur_lg - ab;
+    gl_t* lvl = malloc(orc_merkle_levels_len(log_leaves, P->cap_height) * sizeof(gl_t));
+    orc_merkle_build(P->variant, lv, 2 * arity, log_leaves, P->cap_height, lvl);
+    const gl_t* cap = orc_merkle_cap_ptr(lvl, log_leaves, P->cap_height);
+    memcpy(out_caps + li * capw, cap, capw * sizeof(gl_t));
+    orc_ch_observe(ch, cap, capw);
+    layer_levels[li] = lvl;
+    layer_leaves[li] = lv;
+    gl2_t beta = orc_ch_get_ext(ch);
+    // coeffs.chunks_exact(arity).map(reduce_with_powers(beta))
+    size_t m2 = m >> ab;
+    for (size_t i = 0; i < m2; i++) {
+      gl2_t acc = gl2_from(0);
+      for (size_t j = arity; j-- > 0;) acc = gl2_add(gl2_mul(acc, beta), cf[i * arity + j]);
+      cf[i] = acc;
+    }
+    m = m2;
+    cur_lg -= ab;
+    shift = gl_pow(shift, arity);
+    memcpy(values, cf, m * sizeof(gl2_t));
+    ext_coset_fft(values, cur_lg, shift);
+  }
+  size_t final_len = m >> P->rate_bits;
+  size_t qwords = 0;
+  {
+    orc_fri_params Q = *P;
+    qwords = (orc_fri_proof_words(&Q) - P->n_layers * capw - 2 * final_len - 1) / P->num_queries;
+  }
+  gl_t* out_q = proof + P->n_layers * capw;
+  gl_t* out_final = out_q + P->num_queries * qwords;
+  for (size_t i = 0; i < final_len; i++) { out_final[2 * i] = cf[i].c[0]; out_final[2 * i + 1] = cf[i].c[1]; }
+  orc_ch_observe(ch, out_final, 2 * final_len);
+
+  // ---- proof of work: smallest witness whose response has >= pow_bits leading zeros
+  {
+    gl_t st[12];
+    memcpy(st, ch->state, sizeof st);
+    memcpy(st, ch->in, ch->n_in * sizeof(gl_t));
+    unsigned pos = ch->n_in;
+    gl_t wit = 0;
+    for (;; wit++) {
+      gl_t t[12];
+      memcpy(t, st, sizeof t);
+      t[pos] = wit;
+      orc_perm(P->variant, t);
+      if (P->pow_bits == 0 || (t[7] >> (64 - P->pow_bits)) == 0) break;
+    }
+    out_final[2 * final_len] = wit;
+    orc_ch_observe(ch, &wit, 1);
+    gl_t resp = orc_ch_get(ch);
+    if (P->pow_bits && (resp >> (64 - P->pow_bits)) != 0) { fprintf(stderr, "oracle: pow mismatch\n"); abort(); }
+  }
+  // ---- query rounds
+  for (uint32_t q = 0; q < P->num_queries; q++) {
+    gl_t* o = out_q + q * qwords;
+    size_t x = orc_ch_get(ch) % N;
+    for (uint32_t oi = 0; oi < P->n_oracles; oi++) {
+      uint32_t wo = P->oracle_w[oi];
+      memcpy(o, leaves[oi] + x * wo, wo * sizeof(gl_t));
+      o += wo;
+      orc_merkle_prove(levels[oi], lg, P->cap_height, x, o);
+      o += 4 * (lg - P->cap_height);
+    }
+    unsigned clg = lg;
+    for (uint32_t li = 0; li < P->n_layers; li++) {
+      unsigned ab = P->arity_bits[li];
+      size_t arity = (size_t)1 << ab;
+      x >>= ab;
+      clg -= ab;
+      memcpy(o, layer_leaves[li] + x * 2 * arity, 2 * arity * sizeof(gl_t));
+      o += 2 * arity;
+      orc_merkle_prove(layer_levels[li], clg, P->cap_height, x, o);
+      o += 4 * (clg - P->cap_height);
+    }
+  }
+  for (uint32_t li = 0; li < P->n_layers; li++) { free(layer_levels[li]); free(layer_leaves[li]); }
+  free(layer_levels); free(layer_leaves); free(values); free(final_poly);
+}
+
+// The PCS skeleton of plonky2's prove(): commitments, Fiat-Shamir, openings, FRI.
+// values[o] = [w_o][n] evaluations over the subgroup (natural order). Oracle 0 is the
+// preprocessed constants_sigmas oracle (its cap is inside circuit_digest, never observed);
+// oracle 1 wires, 2 zs_partial_products, 3 quotient chunks.
+// Outputs: caps[n_oracles][2^cap][4], openings[(sum w + zs_count)][2], proof (flat, see above).
+void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4],
+                   const gl_t pi_hash[4], gl_t* caps, gl_t* openings, gl_t* proof) {
+  unsigned k = P->log_n, lg = k + P->rate_bits;
+  size_t n = (size_t)1 << k, N = (size_t)1 << lg;
+  size_t capw = ((size_t)4) << P->cap_height;
+  gl_t* coeffs[8]; gl_t* leaves[8]; gl_t* levels[8];
+  for (uint32_t o = 0; o < P->n_oracles; o++) {
+    size_t w = P->oracle_w[o];
+    coeffs[o] = malloc(w * n * sizeof(gl_t));
+    memcpy(coeffs[o], values[o], w * n * sizeof(gl_t));
+    for (size_t p = 0; p < w; p++) orc_fft(coeffs[o] + p * n, k, 1);
+    leaves[o] = malloc(w * N * sizeof(gl_t));
+    orc_lde_leaves(coeffs[o], k, w, P->rate_bits, leaves[o]);
+    levels[o] = malloc(orc_merkle_levels_len(lg, P->cap_height) * sizeof(gl_t));
+    orc_merkle_build(P->variant, leaves[o], w, lg, P->cap_height, levels[o]);
+    memcpy(caps + o * capw, orc_merkle_cap_ptr(levels[o], lg, P->cap_height), capw * sizeof(gl_t));
+  }
+  orc_challenger ch;
+  orc_ch_init(&ch, P->variant);
+  orc_ch_observe(&ch, circuit_digest, 4);
+  orc_ch_observe(&ch, pi_hash, 4);
+  for (uint32_t o = 1; o < P->n_oracles; o++) {
+    orc_ch_observe(&ch, caps + o * capw, capw);
+    // wires cap -> betas[2], gammas[2]; zs cap -> alphas[2]; quotient cap -> zeta
+    if (o == 1) for (int i = 0; i < 4; i++) (void)orc_ch_get(&ch);
+    else if (o == 2) for (int i = 0; i < 2; i++) (void)orc_ch_get(&ch);
+  }
+  gl2_t zeta = orc_ch_get_ext(&ch);
+  gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(k));
+  size_t oi = 0;
+  for (uint32_t o = 0; o < P->n_oracles; o++)
+    for (uint32_t p = 0; p < P->oracle_w[o]; p++, oi++) {
+      gl2_t v = eval_base_poly_ext(coeffs[o] + (size_t)p * n, n, zeta);
+      openings[2 * oi] = v.c[0]; openings[2 * oi + 1] = v.c[1];
+    }
+  for (uint32_t p = 0; p < P->zs_count; p++, oi++) {
+    gl2_t v = eval_base_poly_ext(coeffs[P->zs_oracle] + (size_t)p * n, n, g_zeta);
+    openings[2 * oi] = v.c[0]; openings[2 * oi + 1] = v.c[1];
+  }
+  orc_ch_observe(&ch, openings, 2 * oi);
+  orc_fri_prove(P, coeffs, leaves, levels, zeta, &ch, proof);
+  for (uint32_t o = 0; o < P->n_oracles; o++) { free(coeffs[o]); free(leaves[o]); free(levels[o]); }
+}
+
+// ---- verifier -----------------------------------------------------------------------------
+// Returns 0 when the proof verifies, otherwise a positive code naming the failed check.
+int orc_pcs_verify(const orc_fri_params* P, const gl_t circuit_digest[4], const gl_t pi_hash[4],
+                   const gl_t* caps, const gl_t* openings, const gl_t* proof) {
+  unsigned k = P->log_n, lg = k + P->rate_bits;
+  size_t N = (size_t)1 << lg;
+  size_t capw = ((size_t)4) << P->cap_height;
+  size_t n_open = orc_n_openings(P), n_zeta = n_open - P->zs_count;
+  orc_challenger ch;
+  orc_ch_init(&ch, P->variant);
+  orc_ch_observe(&ch, circuit_digest, 4);
+  orc_ch_observe(&ch, pi_hash, 4);
+  for (uint32_t o = 1; o < P->n_oracles; o++) {
+    orc_ch_observe(&ch, caps + o * capw, capw);
+    if (o == 1) for (int i = 0; i < 4; i++) (void)orc_ch_get(&ch);
+    else if (o == 2) for (int i = 0; i < 2; i++) (void)orc_ch_get(&ch);
+  }
+  gl2_t zeta = orc_ch_get_ext(&ch);
+  gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(k));
+  orc_ch_observe(&ch, openings, 2 * n_open);
+  gl2_t alpha = orc_ch_get_ext(&ch);
+  gl2_t betas[8];
+  const gl_t* pcaps = proof;
+  for (uint32_t li = 0; li < P->n_layers; li++) {
+    orc_ch_observe(&ch, pcaps + li * capw, capw);
+    betas[li] = orc_ch_get_ext(&ch);
+  }
+  unsigned deg = k;
+  for (uint32_t li = 0; li < P->n_layers; li++) deg -= P->arity_bits[li];
+  size_t final_len = (size_t)1 << deg;
+  size_t total = orc_fri_proof_words(P);
+  size_t qwords = (total - P->n_layers * capw - 2 * final_len - 1) / P->num_queries;
+  const gl_t* pq = proof + P->n_layers * capw;
+  const gl_t* pfinal = pq + P->num_queries * qwords;
+  orc_ch_observe(&ch, pfinal, 2 * final_len);
+  gl_t wit = pfinal[2 * final_len];
+  orc_ch_observe(&ch, &wit, 1);
+  gl_t resp = orc_ch_get(&ch);
+  if (P->pow_bits && (resp >> (64 - P->pow_bits)) != 0) return 1;
+  // PrecomputedReducedOpenings: sum_j alpha^j v_j per batch
+  gl2_t red[2];
+  {
+    gl2_t acc = gl2_from(0);
+    for (size_t i = n_zeta; i-- > 0;) acc = gl2_add(gl2_mul(acc, alpha), (gl2_t){{openings[2 * i], openings[2 * i + 1]}});
+    red[0] = acc;
+    acc = gl2_from(0);
+    for (size_t i = n_open; i-- > n_zeta;) acc = gl2_add(gl2_mul(acc, alpha), (gl2_t){{openings[2 * i], openings[2 * i + 1]}});
+    red[1] = acc;
+  }
+  gl2_t* fin = malloc(final_len * sizeof(gl2_t));
+  for (size_t i = 0; i < final_len; i++) fin[i] = (gl2_t){{pfinal[2 * i], pfinal[2 * i + 1]}};
+  int rc = 0;
+  for (uint32_t q = 0; q < P->num_queries && !rc; q++) {
+    const gl_t* o = pq + q * qwords;
+    size_t x = orc_ch_get(&ch) % N;
+    // initial trees
+    const gl_t* leaf[8];
+    for (uint32_t oi = 0; oi < P->n_oracles; oi++) {
+      uint32_t wo = P->oracle_w[oi];
+      leaf[oi] = o;
+      if (!orc_merkle_verify(P->variant, o, wo, x, o + wo, lg - P->cap_height, caps + oi * capw)) { rc = 2; break; }
+      o += wo + 4 * (lg - P->cap_height);
+    }
+    if (rc) break;
+    gl_t sx = gl_mul(GL_MULT_GEN, gl_pow(gl_root_of_unity(lg), orc_bitrev(x, lg)));
+    // fri_combine_initial
+    gl2_t sum = gl2_from(0);
+    for (int batch = 0; batch < 2; batch++) {
+      gl2_t acc = gl2_from(0);
+      size_t count = 0;
+      // alpha.reduce(evals): sum_j alpha^j e_j  (Horner from the back)
+      if (batch == 0) {
+        for (uint32_t oi = P->n_oracles; oi-- > 0;)
+          for (uint32_t p = P->oracle_w[oi]; p-- > 0;) { acc = gl2_add(gl2_mul(acc, alpha), gl2_from(leaf[oi][p])); count++; }
+      } else {
+        for (uint32_t p = P->zs_count; p-- > 0;) { acc = gl2_add(gl2_mul(acc, alpha), gl2_from(leaf[P->zs_oracle][p])); count++; }
+      }
+      gl2_t num = gl2_sub(acc, red[batch]);
+      gl2_t den = gl2_sub(gl2_from(sx), batch == 0 ? zeta : g_zeta);
+      sum = gl2_mul(sum, gl2_pow(alpha, count));
+      sum = gl2_add(sum, gl2_mul(num, gl2_inv(den)));
+    }
+    gl2_t old_eval = sum;
+    unsigned clg = lg;
+    for (uint32_t li = 0; li < P->n_layers; li++) {
+      unsigned ab = P->arity_bits[li];
+      size_t arity = (size_t)1 << ab;
+      size_t coset = x >> ab, within = x & (arity - 1);
+      const gl_t* ev = o;
+      if (ev[2 * within] != old_eval.c[0] || ev[2 * within + 1] != old_eval.c[1]) { rc = 3; break; }
+      // compute_evaluation: interpolate {(coset_start*g^i, evals_rev[i])} at beta (Lagrange)
+      gl_t g = gl_root_of_unity(ab);
+      size_t rev_within = orc_bitrev(within, ab);
+      gl_t start = gl_mul(sx, gl_pow(g, arity - rev_within));
+      gl2_t res = gl2_from(0);
+      for (size_t i = 0; i < arity; i++) {
+        size_t src = orc_bitrev(i, ab);
+        gl2_t yi = (gl2_t){{ev[2 * src], ev[2 * src + 1]}};
+        gl_t xi = gl_mul(start, gl_pow(g, i));
+        gl2_t numr = gl2_from(1);
+        gl_t den = 1;
+        for (size_t j = 0; j < arity; j++) {
+          if (j == i) continue;
+          gl_t xj = gl_mul(start, gl_pow(g, j));
+          numr = gl2_mul(numr, gl2_sub(betas[li], gl2_from(xj)));
+          den = gl_mul(den, gl_sub(xi, xj));
+        }
+        res = gl2_add(res, gl2_mul(yi, gl2_scale(numr, gl_inv(den))));
+      }
+      old_eval = res;
+      clg -= ab;
+      if (!orc_merkle_verify(P->variant, ev, 2 * arity, coset, ev + 2 * arity, clg - P->cap_height, pcaps + li * capw)) { rc = 4; break; }
+      o += 2 * arity + 4 * (clg - P->cap_height);
+      sx = gl_pow(sx, arity);
+      x = coset;
+    }
+    if (rc) break;
+    gl2_t fe = eval_ext_poly(fin, final_len, gl2_from(sx));
+    if (!gl2_eq(fe, old_eval)) rc = 5;
+  }
+  free(fin);
+  return rc;
+}
+
+// fri/reduction_strategies.rs ConstantArityBits(arity_bits, final_poly_bits)
+uint32_t orc_reduction_arity_bits(uint32_t degree_bits, uint32_t rate_bits, uint32_t cap_height,
+                                  uint32_t arity_bits, uint32_t final_poly_bits, uint32_t* out) {
+  uint32_t n = 0;
+  while (degree_bits > final_poly_bits && degree_bits + rate_bits - arity_bits >= cap_height) {
+    out[n++] = arity_bits;
+    degree_bits -= arity_bits;
+  }
+  return n;
+}
+// value-domain fold of one FRI layer (equivalent to the coefficient fold + re-FFT the reference
+// performs): in = bit-reversed evaluations [m][2] on shift*<w_m>, out = natural-order
+// evaluations [m>>arity_bits][2] on shift^arity * <w_{m/arity}>.
+void orc_fri_fold_values(const gl_t* in_bitrev, unsigned log_m, unsigned arity_bits, const gl_t beta_[2],
+                         gl_t shift, gl_t* out) {
+  size_t m = (size_t)1 << log_m;
+  gl2_t* v = malloc(m * sizeof(gl2_t));
+  for (size_t i = 0; i < m; i++) { size_t j = orc_bitrev(i, log_m); v[i] = (gl2_t){{in_bitrev[2 * j], in_bitrev[2 * j + 1]}}; }
+  // to coefficients: coset ifft per component
+  gl_t* t = malloc(m * sizeof(gl_t));
+  gl_t si = gl_inv(shift);
+  for (int c = 0; c < 2; c++) {
+    for (size_t i = 0; i < m; i++) t[i] = v[i].c[c];
+    orc_fft(t, log_m, 1);
+    gl_t s = 1;
+    for (size_t i = 0; i < m; i++) { v[i].c[c] = gl_mul(t[i], s); s = gl_mul(s, si); }
+  }
+  free(t);
+  gl2_t beta = {{beta_[0], beta_[1]}};
+  size_t arity = (size_t)1 << arity_bits, m2 = m >> arity_bits;
+  for (size_t i = 0; i < m2; i++) {
+    gl2_t acc = gl2_from(0);
+    for (size_t j = arity; j-- > 0;) acc = gl2_add(gl2_mul(acc, beta), v[i * arity + j]);
+    v[i] = acc;
+  }
+  ext_coset_fft(v, log_m - arity_bits, gl_pow(shift, arity));
+  for (size_t i = 0; i < m2; i++) { out[2 * i] = v[i].c[0]; out[2 * i + 1] = v[i].c[1]; }
+  free(v);
+}
