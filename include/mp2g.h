@@ -1,0 +1,108 @@
+/* libmp2gpu -- C ABI of the MI355X (gfx950) back end for the Plonky2 prover path of
+ * Lagrange-Labs/mapreduce-plonky2 (mp2-v1 / recursion-framework).
+ *
+ * The reference has no FFI for this path: every proof is produced by plonky2's
+ * `CircuitData::prove(pw)` called at recursion-framework/src/circuit_builder.rs:308,
+ * recursion-framework/src/universal_verifier_gadget/wrap_circuit.rs:143 and
+ * verifiable-db/src/api.rs:207, with the hasher chosen by `type C = Poseidon2GoldilocksConfig`
+ * (mp2-common/src/lib.rs:37-42). A Rust host keeps those signatures and replaces the bodies of
+ * plonky2's PolynomialBatch::{from_values,from_coeffs}, MerkleTree::new, fri_proof and the
+ * Hasher impl with the calls below (binding sketch: INTEGRATION.md).
+ *
+ * Conventions follow the only in-tree C ABI, gnark-utils (gnark-utils/src/lib.rs:13-52,
+ * lib/lib.go:40-47,142-161,213-216): plain pointers and sizes, an int status (0 = ok), the
+ * message of the last failure via mp2g_last_error(), callee-owned handles freed by the matching
+ * *_free. Field elements are canonical u64 (< 2^64 - 2^32 + 1), little-endian in memory.
+ * `variant` selects the permutation: 0 = Poseidon2 (default C), 1 = Poseidon (WrapC,
+ * verifiable-db/src/api.rs:148). A context is bound to one GPU and one HIP stream; it is
+ * thread-compatible, not thread-safe. Pointers named d_* are device pointers on the context's
+ * GPU, all others are host pointers. No entry point falls back to the CPU.
+ */
+#ifndef MP2G_H
+#define MP2G_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mp2g_ctx mp2g_ctx;
+typedef struct mp2g_tree mp2g_tree;   /* plonky2 MerkleTree   (hash/merkle_tree.rs)  */
+typedef struct mp2g_batch mp2g_batch; /* plonky2 PolynomialBatch (fri/oracle.rs)     */
+
+#define MP2G_POSEIDON2 0
+#define MP2G_POSEIDON 1
+
+/* ---- library / context ------------------------------------------------------------------ */
+const char* mp2g_last_error(void);
+int mp2g_device_count(void);
+int mp2g_ctx_create(int device, mp2g_ctx** out);
+void mp2g_ctx_destroy(mp2g_ctx* ctx);
+int mp2g_ctx_sync(mp2g_ctx* ctx);
+void* mp2g_ctx_stream(mp2g_ctx* ctx);                 /* hipStream_t the context launches on */
+int mp2g_ctx_set_stream(mp2g_ctx* ctx, void* stream); /* adopt a caller-owned hipStream_t     */
+int mp2g_dev_alloc(mp2g_ctx* ctx, size_t bytes, void** d_ptr);
+int mp2g_dev_free(mp2g_ctx* ctx, void* d_ptr);
+int mp2g_h2d(mp2g_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int mp2g_d2h(mp2g_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+/* HIP-event stopwatch on the context's stream (used by bench.py) */
+int mp2g_timer_start(mp2g_ctx* ctx);
+int mp2g_timer_stop(mp2g_ctx* ctx, float* ms);
+
+/* ---- NTT / LDE: replaces plonky2_field fft.rs fft/ifft/coset_fft and the LDE loop of
+ *      PolynomialBatch::from_coeffs ------------------------------------------------------ */
+/* `batch` transforms of 2^log_n points, in place. inverse=0: coefficients -> values
+ * v[i] = P(shift * w^i) (coset_shift 0 = no shift); inverse=1: values -> coefficients.
+ * bitrev_out!=0 leaves the output in bit-reversed index order. */
+int mp2g_ntt(mp2g_ctx* ctx, uint64_t* data, uint32_t log_n, uint32_t batch, int inverse,
+             uint64_t coset_shift, int bitrev_out);
+int mp2g_ntt_dev(mp2g_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, uint32_t log_n, uint32_t batch,
+                 int inverse, uint64_t coset_shift, int bitrev_out);
+/* coeffs [w][n] -> leaves [n << rate_bits][w]: row i = evaluations at g * w_N^bitrev(i)
+ * (transpose + reverse_index_bits of from_coeffs). Host layout of plonky2. */
+int mp2g_lde_leaves(mp2g_ctx* ctx, const uint64_t* coeffs, uint32_t log_n, uint32_t w, uint32_t rate_bits,
+                    uint64_t* leaves);
+/* same values, kept polynomial-major on the device: d_values [w][n << rate_bits], index
+ * bit-reversed (column i of that matrix is leaf i). */
+int mp2g_lde_dev(mp2g_ctx* ctx, const uint64_t* d_coeffs, uint32_t log_n, uint32_t w, uint32_t rate_bits,
+                 uint64_t* d_values);
+
+/* ---- hashing / Merkle: replaces Hasher::{hash_no_pad,hash_or_noop,two_to_one} and
+ *      MerkleTree::{new,prove} ------------------------------------------------------------- */
+/* out[i][0..out_len) = hash_n_to_m_no_pad(in[i][0..in_len)), out_len = 4 (HashOut) or 5
+ * (map-to-curve, mp2-common/src/group_hashing/field_to_curve.rs:41-47) */
+int mp2g_hash_no_pad_batch(mp2g_ctx* ctx, int variant, const uint64_t* in, uint32_t in_len, uint32_t count,
+                           uint32_t out_len, uint64_t* out);
+int mp2g_hash_no_pad_batch_dev(mp2g_ctx* ctx, int variant, const uint64_t* d_in, uint32_t in_len,
+                               uint32_t count, uint32_t out_len, uint64_t* d_out);
+/* MerkleTree::new(leaves, cap_height); leaves [2^log_leaves][leaf_len] */
+int mp2g_merkle_build(mp2g_ctx* ctx, int variant, const uint64_t* leaves, uint32_t leaf_len,
+                      uint32_t log_leaves, uint32_t cap_height, mp2g_tree** out);
+int mp2g_merkle_cap(const mp2g_tree* tree, uint64_t* cap /* [1<<cap_height][4] */);
+/* leaves_out [n_idx][leaf_len] (may be NULL), siblings_out [n_idx][log_leaves-cap_height][4] bottom-up */
+int mp2g_merkle_open(const mp2g_tree* tree, const uint32_t* idx, uint32_t n_idx, uint64_t* leaves_out,
+                     uint64_t* siblings_out);
+void mp2g_merkle_free(mp2g_tree* tree);
+
+/* ---- polynomial commitment: replaces PolynomialBatch::{from_values,from_coeffs} ----------- */
+/* values [w][n] over the subgroup (natural order): per-poly iFFT, LDE x 2^rate_bits on the
+ * coset g<w_N>, Merkle tree with cap. */
+int mp2g_commit_from_values(mp2g_ctx* ctx, int variant, const uint64_t* values, uint32_t log_n, uint32_t w,
+                            uint32_t rate_bits, uint32_t cap_height, mp2g_batch** out);
+int mp2g_commit_from_values_dev(mp2g_ctx* ctx, int variant, const uint64_t* d_values, uint32_t log_n,
+                                uint32_t w, uint32_t rate_bits, uint32_t cap_height, mp2g_batch** out);
+int mp2g_commit_from_coeffs_dev(mp2g_ctx* ctx, int variant, const uint64_t* d_coeffs, uint32_t log_n,
+                                uint32_t w, uint32_t rate_bits, uint32_t cap_height, mp2g_batch** out);
+/* re-run the commitment into an existing batch of the same shape (no allocation: the form the
+ * batched prover and bench.py use) */
+int mp2g_recommit_from_values_dev(mp2g_ctx* ctx, mp2g_batch* batch, const uint64_t* d_values);
+int mp2g_batch_cap(const mp2g_batch* batch, uint64_t* cap);
+int mp2g_batch_coeffs(const mp2g_batch* batch, uint64_t* coeffs /* [w][n] */);
+int mp2g_batch_open(const mp2g_batch* batch, const uint32_t* idx, uint32_t n_idx,
+                    uint64_t* leaves_out /* [n_idx][w] */, uint64_t* siblings_out);
+void mp2g_batch_free(mp2g_batch* batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

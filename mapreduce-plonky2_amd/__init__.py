@@ -1,0 +1,256 @@
+"""Host-side (Python) mirror of the prover interface of Lagrange-Labs/mapreduce-plonky2's hot
+path, over the C ABI of libmp2gpu (include/mp2g.h).
+
+The reference is Rust: the Python layer here is only the test / bench harness. The names follow
+plonky2's as used behind `prove()` (recursion-framework/src/circuit_builder.rs:308):
+PolynomialBatch.from_values / from_coeffs, MerkleTree.new / prove, Hasher.hash_no_pad.
+There is no CPU fallback: loading fails loudly when the HIP library is missing, and
+Context() fails when no GPU is visible.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmp2gpu.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mp2g.h")
+
+P = 0xFFFFFFFF00000001
+MULT_GEN = 14293326489335486720
+POSEIDON2, POSEIDON = 0, 1
+
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_lib = None
+
+
+class Mp2gError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libmp2gpu.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Mp2gError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                            "there is no CPU fallback for the product path")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.mp2g_last_error.restype = ctypes.c_char_p
+        _lib.mp2g_ctx_stream.restype = ctypes.c_void_p
+        _lib.mp2g_ctx_stream.argtypes = [ctypes.c_void_p]
+    return _lib
+
+
+def _ck(rc):
+    if rc != 0:
+        raise Mp2gError(load().mp2g_last_error().decode())
+
+
+def _arr(a, dtype=np.uint64):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class DeviceBuffer:
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        ptr = ctypes.c_void_p()
+        _ck(load().mp2g_dev_alloc(ctx.h, ctypes.c_size_t(nbytes), ctypes.byref(ptr)))
+        self.ptr = ptr
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        _ck(load().mp2g_h2d(self.ctx.h, self.ptr, _p(a), ctypes.c_size_t(a.nbytes)))
+        return self
+
+    def download(self, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _ck(load().mp2g_d2h(self.ctx.h, _p(out), self.ptr, ctypes.c_size_t(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            load().mp2g_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per GPU (mp2g_ctx)."""
+
+    def __init__(self, device=0):
+        self.h = ctypes.c_void_p()
+        _ck(load().mp2g_ctx_create(int(device), ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            load().mp2g_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        _ck(load().mp2g_ctx_sync(self.h))
+
+    def stream(self):
+        return load().mp2g_ctx_stream(self.h)
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, a):
+        a = np.ascontiguousarray(a)
+        return DeviceBuffer(self, a.nbytes).upload(a)
+
+    def timer_start(self):
+        _ck(load().mp2g_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        _ck(load().mp2g_timer_stop(self.h, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- plonky2_field fft.rs ---------------------------------------------------------------
+    def ntt(self, data, inverse=False, coset_shift=0, bitrev_out=False):
+        a = _arr(data).copy()
+        batch, n = (1, a.shape[0]) if a.ndim == 1 else a.shape
+        log_n = int(n).bit_length() - 1
+        assert 1 << log_n == n
+        _ck(load().mp2g_ntt(self.h, _p(a), log_n, batch, int(inverse), ctypes.c_uint64(coset_shift), int(bitrev_out)))
+        return a
+
+    def ntt_dev(self, d_in, d_out, log_n, batch, inverse=False, coset_shift=0, bitrev_out=False):
+        _ck(load().mp2g_ntt_dev(self.h, d_in.ptr, d_out.ptr, log_n, batch, int(inverse), ctypes.c_uint64(coset_shift), int(bitrev_out)))
+
+    def lde_leaves(self, coeffs, rate_bits):
+        c = _arr(coeffs)
+        w, n = c.shape
+        log_n = int(n).bit_length() - 1
+        out = np.empty((n << rate_bits, w), dtype=np.uint64)
+        _ck(load().mp2g_lde_leaves(self.h, _p(c), log_n, w, rate_bits, _p(out)))
+        return out
+
+    def lde_dev(self, d_coeffs, log_n, w, rate_bits, d_values):
+        _ck(load().mp2g_lde_dev(self.h, d_coeffs.ptr, log_n, w, rate_bits, d_values.ptr))
+
+    # ---- Hasher -------------------------------------------------------------------------------
+    def hash_no_pad_batch(self, inputs, out_len=4, variant=POSEIDON2):
+        a = _arr(inputs)
+        count, in_len = a.shape
+        out = np.empty((count, out_len), dtype=np.uint64)
+        _ck(load().mp2g_hash_no_pad_batch(self.h, variant, _p(a), in_len, count, out_len, _p(out)))
+        return out
+
+    def hash_no_pad(self, values, variant=POSEIDON2):
+        return self.hash_no_pad_batch(_arr(values).reshape(1, -1), 4, variant)[0]
+
+
+class MerkleTree:
+    """plonky2 hash/merkle_tree.rs MerkleTree."""
+
+    def __init__(self, ctx, leaves, cap_height, variant=POSEIDON2):
+        a = _arr(leaves)
+        L, leaf_len = a.shape
+        self.log_leaves = int(L).bit_length() - 1
+        assert 1 << self.log_leaves == L
+        self.ctx, self.cap_height, self.leaf_len = ctx, cap_height, leaf_len
+        self.h = ctypes.c_void_p()
+        _ck(load().mp2g_merkle_build(ctx.h, variant, _p(a), leaf_len, self.log_leaves, cap_height, ctypes.byref(self.h)))
+
+    @property
+    def cap(self):
+        out = np.empty((1 << self.cap_height, 4), dtype=np.uint64)
+        _ck(load().mp2g_merkle_cap(self.h, _p(out)))
+        return out
+
+    def prove(self, indices):
+        idx = _arr(indices, np.uint32)
+        depth = self.log_leaves - self.cap_height
+        leaves = np.empty((len(idx), self.leaf_len), dtype=np.uint64)
+        sib = np.empty((len(idx), depth, 4), dtype=np.uint64)
+        _ck(load().mp2g_merkle_open(self.h, _p(idx), len(idx), _p(leaves), _p(sib)))
+        return leaves, sib
+
+    def free(self):
+        if self.h:
+            load().mp2g_merkle_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PolynomialBatch:
+    """plonky2 fri/oracle.rs PolynomialBatch: coefficients + LDE Merkle tree."""
+
+    def __init__(self, ctx, handle, log_n, w, rate_bits, cap_height):
+        self.ctx, self.h = ctx, handle
+        self.log_n, self.w, self.rate_bits, self.cap_height = log_n, w, rate_bits, cap_height
+
+    @classmethod
+    def from_values(cls, ctx, values, rate_bits=3, cap_height=4, variant=POSEIDON2):
+        v = _arr(values)
+        w, n = v.shape
+        log_n = int(n).bit_length() - 1
+        h = ctypes.c_void_p()
+        _ck(load().mp2g_commit_from_values(ctx.h, variant, _p(v), log_n, w, rate_bits, cap_height, ctypes.byref(h)))
+        return cls(ctx, h, log_n, w, rate_bits, cap_height)
+
+    @classmethod
+    def from_values_dev(cls, ctx, d_values, log_n, w, rate_bits=3, cap_height=4, variant=POSEIDON2):
+        h = ctypes.c_void_p()
+        _ck(load().mp2g_commit_from_values_dev(ctx.h, variant, d_values.ptr, log_n, w, rate_bits, cap_height, ctypes.byref(h)))
+        return cls(ctx, h, log_n, w, rate_bits, cap_height)
+
+    @classmethod
+    def from_coeffs_dev(cls, ctx, d_coeffs, log_n, w, rate_bits=3, cap_height=4, variant=POSEIDON2):
+        h = ctypes.c_void_p()
+        _ck(load().mp2g_commit_from_coeffs_dev(ctx.h, variant, d_coeffs.ptr, log_n, w, rate_bits, cap_height, ctypes.byref(h)))
+        return cls(ctx, h, log_n, w, rate_bits, cap_height)
+
+    def recommit_from_values_dev(self, d_values):
+        _ck(load().mp2g_recommit_from_values_dev(self.ctx.h, self.h, d_values.ptr))
+
+    @property
+    def cap(self):
+        out = np.empty((1 << self.cap_height, 4), dtype=np.uint64)
+        _ck(load().mp2g_batch_cap(self.h, _p(out)))
+        return out
+
+    @property
+    def coeffs(self):
+        out = np.empty((self.w, 1 << self.log_n), dtype=np.uint64)
+        _ck(load().mp2g_batch_coeffs(self.h, _p(out)))
+        return out
+
+    def open(self, indices):
+        idx = _arr(indices, np.uint32)
+        depth = self.log_n + self.rate_bits - self.cap_height
+        leaves = np.empty((len(idx), self.w), dtype=np.uint64)
+        sib = np.empty((len(idx), depth, 4), dtype=np.uint64)
+        _ck(load().mp2g_batch_open(self.h, _p(idx), len(idx), _p(leaves), _p(sib)))
+        return leaves, sib
+
+    def free(self):
+        if self.h:
+            load().mp2g_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,47 @@
+// Internal definitions behind the opaque handles of include/mp2g.h.
+#pragma once
+#include "../../include/mp2g.h"
+#include "merkle.h"
+#include "ntt.h"
+
+namespace mp2g {
+int fail(const char* fmt, ...);  // records mp2g_last_error(), returns 1
+
+// owning device buffer of u64 words
+struct DevBuf {
+  u64* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t b) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = b;
+    return hipMalloc((void**)&p, b ? b : 8);
+  }
+};
+}  // namespace mp2g
+
+struct mp2g_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  mp2g::NttEngine ntt;
+};
+struct mp2g_tree {
+  mp2g_ctx* ctx = nullptr;
+  int variant = 0;
+  uint32_t leaf_len = 0, log_leaves = 0, cap_h = 0;
+  mp2g::DevBuf leaves;  // [L][leaf_len]
+  mp2g::DevBuf levels;  // level 0 .. cap level, concatenated
+};
+// PolynomialBatch: coefficients [w][n], LDE values [w][n<<rate] (polynomial-major, index
+// bit-reversed = leaf order), Merkle levels
+struct mp2g_batch {
+  mp2g_ctx* ctx = nullptr;
+  int variant = 0;
+  uint32_t log_n = 0, w = 0, rate_bits = 0, cap_h = 0;
+  mp2g::DevBuf coeffs, values, levels;
+};

@@ -1,0 +1,222 @@
+// Poseidon2 / Poseidon sponge hashing of Merkle leaves, tree reduction to the cap, batched
+// hash_no_pad and opening gathers for gfx950.
+//
+// Replaces [dep] plonky2 hash/merkle_tree.rs MerkleTree::new (leaf hash_or_noop + two_to_one
+// levels + cap), hash/hashing.rs hash_n_to_m_no_pad, and the off-circuit H::hash_no_pad call
+// sites listed in SURVEY 8(a5) (mp2-common/src/poseidon.rs:49-51, mp2-v1/src/values_extraction/
+// mod.rs:58,159,197,295,362,431,509,519, mp2-v1/src/indexing/cell.rs:145, row.rs:316).
+//
+// This is the integer-ALU-bound part of a commitment (about 0.74 k modular multiplies per
+// permutation, 17 permutations per 135-limb leaf). One lane owns one leaf; the LDE values stay
+// polynomial-major in HBM so that lane i reading limb p of leaf i is a perfectly coalesced
+// 8 B/lane stream (no transposed copy of the 8n x w matrix is ever materialised).
+#include "merkle.h"
+#include "poseidon.cuh"
+
+namespace mp2g {
+
+template <int V>
+__global__ void __launch_bounds__(256) leaf_hash_poly_major_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ digests) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = 0;
+  if (w <= 4) {
+    for (u32 p = 0; p < w; p++) s[p] = values[p * stride + i];
+  } else {
+    const u64* v = values + i;
+    u32 p = 0;
+    for (; p + 8 <= w; p += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = v[(u64)(p + k) * stride];
+      perm<V>(s);
+    }
+    if (p < w) {
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (p + k < w) s[k] = v[(u64)(p + k) * stride];
+      perm<V>(s);
+    }
+  }
+  ulonglong2* d = reinterpret_cast<ulonglong2*>(digests + 4 * i);
+  d[0] = make_ulonglong2(s[0], s[1]);
+  d[1] = make_ulonglong2(s[2], s[3]);
+}
+template <int V>
+__global__ void __launch_bounds__(256) leaf_hash_row_major_kernel(const u64* __restrict__ leaves, u32 len, u64 n, u64* __restrict__ digests) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64* v = leaves + i * len;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = 0;
+  if (len <= 4) {
+    for (u32 p = 0; p < len; p++) s[p] = v[p];
+  } else {
+    u32 p = 0;
+    for (; p + 8 <= len; p += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = v[p + k];
+      perm<V>(s);
+    }
+    if (p < len) {
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (p + k < len) s[k] = v[p + k];
+      perm<V>(s);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) digests[4 * i + k] = s[k];
+}
+template <int V>
+__global__ void __launch_bounds__(256) leaf_hash_ext_soa_kernel(const u64* __restrict__ c0, const u64* __restrict__ c1, u32 arity_bits, u64 n, u64* __restrict__ digests) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  u32 arity = 1u << arity_bits;
+  const u64* a = c0 + (i << arity_bits);
+  const u64* b = c1 + (i << arity_bits);
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = 0;
+  if (arity == 1) {  // 2 limbs: noop
+    s[0] = a[0]; s[1] = b[0];
+  } else if (arity == 2) {
+    s[0] = a[0]; s[1] = b[0]; s[2] = a[1]; s[3] = b[1];
+  } else {
+    for (u32 p = 0; p < arity; p += 4) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) { s[2 * k] = a[p + k]; s[2 * k + 1] = b[p + k]; }
+      perm<V>(s);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) digests[4 * i + k] = s[k];
+}
+template <int V>
+__global__ void __launch_bounds__(256) merkle_level_kernel(const u64* __restrict__ in, u64* __restrict__ out, u64 n_out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const ulonglong2* src = reinterpret_cast<const ulonglong2*>(in + 8 * i);
+  ulonglong2 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+  u64 s[12] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y, 0, 0, 0, 0};
+  perm<V>(s);
+  ulonglong2* d = reinterpret_cast<ulonglong2*>(out + 4 * i);
+  d[0] = make_ulonglong2(s[0], s[1]);
+  d[1] = make_ulonglong2(s[2], s[3]);
+}
+template <int V>
+__global__ void __launch_bounds__(256) hash_no_pad_batch_kernel(const u64* __restrict__ in, u32 in_len, u64 count, u32 out_len, u64* __restrict__ out) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const u64* v = in + i * in_len;
+  u64 s[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) s[k] = 0;
+  for (u32 p = 0; p < in_len; p += 8) {
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (p + k < in_len) s[k] = v[p + k];
+    perm<V>(s);
+  }
+  u64* o = out + i * out_len;
+  u32 done = 0;
+  for (;;) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (done < out_len) o[done] = s[k];
+      done++;
+    }
+    if (done >= out_len) break;
+    perm<V>(s);
+  }
+}
+__global__ void merkle_open_kernel(const u64* __restrict__ levels, u32 log_leaves, u32 cap_h, const u32* __restrict__ idx, u32 n_idx, u64* __restrict__ sib) {
+  u32 depth = log_leaves - cap_h;
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_idx * depth * 4) return;
+  u32 k = t & 3, l = (t >> 2) % depth, q = (t >> 2) / depth;
+  u64 off = 0;
+  for (u32 j = 0; j < l; j++) off += (u64)4 << (log_leaves - j);
+  u32 node = (idx[q] >> l) ^ 1;
+  sib[t] = levels[off + 4 * (u64)node + k];
+}
+__global__ void gather_rows_kernel(const u64* __restrict__ values, u32 w, u64 stride, const u32* __restrict__ idx, u32 n_idx, u64* __restrict__ out) {
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_idx * w) return;
+  u32 p = t % w, q = t / w;
+  out[t] = values[(u64)p * stride + idx[q]];
+}
+// 64x64 LDS tile transpose: in[p][i] -> out[i][p]
+__global__ void __launch_bounds__(256) transpose_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ out) {
+  __shared__ u64 tile[64][65];
+  u64 i0 = (u64)blockIdx.x * 64;
+  u32 p0 = blockIdx.y * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    int pi = e >> 6, ii = e & 63;
+    if (p0 + pi < w && i0 + ii < n) tile[pi][ii] = values[(u64)(p0 + pi) * stride + i0 + ii];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    int ii = e >> 6, pi = e & 63;
+    if (p0 + pi < w && i0 + ii < n) out[(i0 + ii) * w + p0 + pi] = tile[pi][ii];
+  }
+}
+
+#define LAUNCH_V(kernel, grid, block, st, ...)                                              \
+  do {                                                                                      \
+    if (variant == MP2G_POSEIDON2) hipLaunchKernelGGL((kernel<MP2G_POSEIDON2>), grid, block, 0, st, __VA_ARGS__); \
+    else if (variant == MP2G_POSEIDON) hipLaunchKernelGGL((kernel<MP2G_POSEIDON>), grid, block, 0, st, __VA_ARGS__); \
+    else return hipErrorInvalidValue;                                                       \
+  } while (0)
+static inline dim3 grid1(u64 n, u32 block) { return dim3((u32)((n + block - 1) / block)); }
+
+hipError_t leaf_hash_poly_major(hipStream_t st, int variant, const u64* values, u32 w, u64 stride, u64 n, u64* digests) {
+  if (!n) return hipSuccess;
+  LAUNCH_V(leaf_hash_poly_major_kernel, grid1(n, 256), dim3(256), st, values, w, stride, n, digests);
+  return hipGetLastError();
+}
+hipError_t leaf_hash_row_major(hipStream_t st, int variant, const u64* leaves, u32 len, u64 n, u64* digests) {
+  if (!n) return hipSuccess;
+  LAUNCH_V(leaf_hash_row_major_kernel, grid1(n, 256), dim3(256), st, leaves, len, n, digests);
+  return hipGetLastError();
+}
+hipError_t leaf_hash_ext_soa(hipStream_t st, int variant, const u64* c0, const u64* c1, u32 arity_bits, u64 n, u64* digests) {
+  if (!n) return hipSuccess;
+  LAUNCH_V(leaf_hash_ext_soa_kernel, grid1(n, 256), dim3(256), st, c0, c1, arity_bits, n, digests);
+  return hipGetLastError();
+}
+hipError_t merkle_reduce(hipStream_t st, int variant, u64* levels, u32 log_leaves, u32 cap_h) {
+  u64* cur = levels;
+  for (u32 lv = log_leaves; lv > cap_h; lv--) {
+    u64 n_in = (u64)1 << lv;
+    u64* nxt = cur + 4 * n_in;
+    LAUNCH_V(merkle_level_kernel, grid1(n_in / 2, 256), dim3(256), st, cur, nxt, n_in / 2);
+    cur = nxt;
+  }
+  return hipGetLastError();
+}
+hipError_t hash_no_pad_batch(hipStream_t st, int variant, const u64* in, u32 in_len, u64 count, u32 out_len, u64* out) {
+  if (!count) return hipSuccess;
+  LAUNCH_V(hash_no_pad_batch_kernel, grid1(count, 256), dim3(256), st, in, in_len, count, out_len, out);
+  return hipGetLastError();
+}
+hipError_t merkle_open(hipStream_t st, const u64* levels, u32 log_leaves, u32 cap_h, const u32* idx, u32 n_idx, u64* siblings) {
+  u32 total = n_idx * (log_leaves - cap_h) * 4;
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(merkle_open_kernel, grid1(total, 256), dim3(256), 0, st, levels, log_leaves, cap_h, idx, n_idx, siblings);
+  return hipGetLastError();
+}
+hipError_t gather_rows(hipStream_t st, const u64* values, u32 w, u64 stride, const u32* idx, u32 n_idx, u64* out) {
+  u32 total = n_idx * w;
+  if (!total) return hipSuccess;
+  hipLaunchKernelGGL(gather_rows_kernel, grid1(total, 256), dim3(256), 0, st, values, w, stride, idx, n_idx, out);
+  return hipGetLastError();
+}
+hipError_t transpose_to_leaves(hipStream_t st, const u64* values, u32 w, u64 stride, u64 n, u64* out) {
+  if (!n || !w) return hipSuccess;
+  hipLaunchKernelGGL(transpose_kernel, dim3((u32)((n + 63) / 64), (w + 63) / 64), dim3(256), 0, st, values, w, stride, n, out);
+  return hipGetLastError();
+}
+}  // namespace mp2g

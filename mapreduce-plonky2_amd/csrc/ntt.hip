@@ -1,0 +1,410 @@
+// Batched radix-2 NTT / LDE over Goldilocks for gfx950.
+//
+// Replaces [dep] plonky2_field fft.rs (fft / ifft / coset_fft) and the per-polynomial
+// `lde(rate_bits).coset_fft(g)` loop of plonky2 fri/oracle.rs PolynomialBatch::from_coeffs, as
+// reached from recursion-framework/src/circuit_builder.rs:308 and wrap_circuit.rs:143.
+//
+// Structure (HBM-bound op: 16 B of algorithmic traffic per point):
+//   * n <= 2^12 : one launch; a 256-thread block owns 4096 points in LDS (several small
+//     transforms per block), every global access is a contiguous 8 B/lane stream.
+//   * n  > 2^12 : Cooley-Tukey n = n1*n2 in two launches. Pass A transforms the strided
+//     dimension for a tile of 2^LC adjacent columns (>= 32..128 B contiguous per row), multiplies
+//     by w_n^(i2*k1) and leaves row j in DIF order; pass B transforms contiguous rows in place.
+//   * inside a block every lane keeps 16 points in registers (radix-16 = four DIF stages)
+//     between LDS exchanges; LDS indices are padded by 1/16 so the stride-16 round is
+//     bank-conflict free; twiddles for the inner DFT are staged in LDS once per block.
+//   * LDE: the 2^r cosets of the blown-up domain are 2^r independent size-n transforms of the
+//     same coefficients scaled by (g w_{N}^j)^i; outputs land bit-reversed, i.e. already in
+//     Merkle-leaf order, so there is no separate transpose / bit-reverse pass.
+#include "ntt.h"
+
+namespace mp2g {
+
+#define NTT_THREADS 256
+__device__ __forceinline__ int lds_pad(int a) { return a + (a >> 4); }
+
+struct NttArgs {
+  const u64* in;
+  u64* out;
+  u64 in_poly_stride, out_poly_stride;
+  u32 logK;              // cosets per polynomial (batch index b -> poly b>>logK, coset b&(K-1))
+  u32 log_n, log_n1, log_n2;
+  u32 batch;             // polys << logK
+  const u64* tw;         // inner-DFT twiddles w_T^k, k < T/2 (this pass)
+  const u64* tw4_lo;     // w_n^e, e < 4096
+  const u64* tw4_hi;     // w_n^(e << 12)
+  const u64* pre_lo;     // [K][n2] (or [K][n] when single pass)
+  const u64* pre_hi;     // [K][n1]
+  u64 post;              // scalar multiplied on the final store (n^-1 for inverse), 0 = none
+  u32 bitrev_out;
+  u32 src_is_out;        // pass B of a two-pass bit-reversed transform reads `out`
+};
+
+template <int LT, int HI, int R, bool COLS, int LW>
+__device__ __forceinline__ void dif_round(u64* s, const u64* tw, int tid) {
+  constexpr int T = 1 << LT, LO = HI - R + 1, W = 1 << LW;
+  constexpr int ITEMS = W << (LT - R);
+  for (int item = tid; item < ITEMS; item += NTT_THREADS) {
+    int c, rest;
+    if (COLS) { c = item & (W - 1); rest = item >> LW; }
+    else { rest = item & ((T >> R) - 1); c = item >> (LT - R); }
+    int below = rest & ((1 << LO) - 1), above = rest >> LO;
+    int j0 = (above << (HI + 1)) | below;
+    u64 x[1 << R];
+#pragma unroll
+    for (int m = 0; m < (1 << R); m++) {
+      int j = j0 + (m << LO);
+      x[m] = s[lds_pad(COLS ? (j << LW) + c : (c << LT) + j)];
+    }
+#pragma unroll
+    for (int t = 0; t < R; t++) {
+      constexpr int dummy = 0; (void)dummy;
+      const int half = 1 << (R - 1 - t);
+      const int b = HI - t;  // bit of j handled by this stage
+#pragma unroll
+      for (int m = 0; m < (1 << R); m++) {
+        if (m & half) continue;
+        int m_low = m & (half - 1);
+        u64 u = x[m], v = x[m + half];
+        x[m] = gl_add(u, v);
+        u64 d = gl_sub(u, v);
+        if (b > 0) {
+          int idx = ((m_low << LO) + below) << (LT - 1 - b);
+          d = gl_mul(d, tw[idx]);
+        }
+        x[m + half] = d;
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < (1 << R); m++) {
+      int j = j0 + (m << LO);
+      s[lds_pad(COLS ? (j << LW) + c : (c << LT) + j)] = x[m];
+    }
+  }
+}
+template <int LT, int HI, bool COLS, int LW>
+__device__ __forceinline__ void dif_all(u64* s, const u64* tw, int tid) {
+  if constexpr (HI >= 0) {
+    constexpr int R = (HI + 1 >= 4) ? 4 : HI + 1;
+    dif_round<LT, HI, R, COLS, LW>(s, tw, tid);
+    __syncthreads();
+    dif_all<LT, HI - R, COLS, LW>(s, tw, tid);
+  }
+}
+
+__device__ __forceinline__ const u64* in_base(const NttArgs& a, u32 b) {
+  return a.in + (u64)(b >> a.logK) * a.in_poly_stride;
+}
+__device__ __forceinline__ u64* out_base(const NttArgs& a, u32 b) {
+  u32 coset = b & ((1u << a.logK) - 1);
+  return a.out + (u64)(b >> a.logK) * a.out_poly_stride + ((u64)bitrev32(coset, a.logK) << a.log_n);
+}
+
+// ---- pass B / single pass: contiguous rows of length T = 2^LT, 2^LW rows per block ----------
+template <int LT, int LW>
+__global__ void __launch_bounds__(NTT_THREADS) ntt_rows_kernel(NttArgs a) {
+  constexpr int T = 1 << LT, W = 1 << LW, E = T << LW;
+  extern __shared__ __align__(16) u64 smem[];
+  u64* s = smem;
+  u64* tw = smem + lds_pad(E) + 1;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < T / 2; i += NTT_THREADS) tw[i] = a.tw[i];
+  const u32 n1 = 1u << a.log_n1;
+  const u64 total_rows = (u64)a.batch << a.log_n1;
+  const u64 row0 = (u64)blockIdx.x << LW;
+  const bool two_pass = a.log_n1 != 0;
+  // load
+  for (int e = tid; e < E; e += NTT_THREADS) {
+    int r = e >> LT, j = e & (T - 1);
+    u64 g = row0 + r;
+    u64 v = 0;
+    if (g < total_rows) {
+      u32 b = (u32)(g >> a.log_n1), jr = (u32)(g & (n1 - 1));
+      if (two_pass) {
+        v = out_base(a, b)[((u64)jr << LT) + j];  // pass A left row jr in place
+      } else {
+        v = in_base(a, b)[j];
+        if (a.pre_lo) v = gl_mul(v, a.pre_lo[((u64)(b & ((1u << a.logK) - 1)) << LT) + j]);
+      }
+    }
+    s[lds_pad(e)] = v;
+  }
+  __syncthreads();
+  dif_all<LT, LT - 1, false, LW>(s, tw, tid);
+  // store
+  if (a.bitrev_out) {
+    for (int e = tid; e < E; e += NTT_THREADS) {
+      int r = e >> LT, p = e & (T - 1);
+      u64 g = row0 + r;
+      if (g >= total_rows) continue;
+      u32 b = (u32)(g >> a.log_n1), jr = (u32)(g & (n1 - 1));
+      u64 v = s[lds_pad(e)];
+      if (a.post) v = gl_mul(v, a.post);
+      out_base(a, b)[((u64)jr << LT) + p] = v;
+    }
+  } else if (!two_pass) {
+    for (int e = tid; e < E; e += NTT_THREADS) {
+      int r = e >> LT, k = e & (T - 1);
+      u64 g = row0 + r;
+      if (g >= total_rows) continue;
+      u64 v = s[lds_pad((r << LT) + (int)bitrev32(k, LT))];
+      if (a.post) v = gl_mul(v, a.post);
+      out_base(a, (u32)g)[k] = v;
+    }
+  }
+}
+// Natural-order pass B of a two-pass transform: X[k1 + n1*k2]. A tile takes the rows
+// jr = (r << lo_bits) | jr_lo, r = 0..W-1 of the dense scratch buffer, whose k1 = bitrev(jr) share
+// their high bits, so each k2 yields W*8 B of contiguous output.
+template <int LT, int LW>
+__global__ void __launch_bounds__(NTT_THREADS) ntt_rows_nat_kernel(NttArgs a) {
+  constexpr int T = 1 << LT, W = 1 << LW, E = T << LW;
+  extern __shared__ __align__(16) u64 smem[];
+  u64* s = smem;
+  u64* tw = smem + lds_pad(E) + 1;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < T / 2; i += NTT_THREADS) tw[i] = a.tw[i];
+  const u32 lo_bits = a.log_n1 - LW;
+  const u64 tile = blockIdx.x;
+  const u32 b = (u32)(tile >> lo_bits), jr_lo = (u32)(tile & ((1u << lo_bits) - 1));
+  const u64* src = a.in + (u64)b * ((u64)1 << a.log_n);  // scratch is dense [batch][n]
+  for (int e = tid; e < E; e += NTT_THREADS) {
+    int r = e >> LT, j = e & (T - 1);
+    u32 jr = ((u32)r << lo_bits) | jr_lo;
+    s[lds_pad(e)] = src[((u64)jr << LT) + j];
+  }
+  __syncthreads();
+  dif_all<LT, LT - 1, false, LW>(s, tw, tid);
+  u64* dst = out_base(a, b);
+  const u32 k1_hi = bitrev32(jr_lo, lo_bits) << LW;
+  for (int e = tid; e < E; e += NTT_THREADS) {
+    int q = e & (W - 1), k2 = e >> LW;
+    int r = (int)bitrev32((u32)q, LW);
+    u64 v = s[lds_pad((r << LT) + (int)bitrev32((u32)k2, LT))];
+    if (a.post) v = gl_mul(v, a.post);
+    dst[(u64)(k1_hi | (u32)q) + ((u64)k2 << a.log_n1)] = v;
+  }
+}
+
+// ---- pass A: strided dimension, T = n1 rows x 2^LW adjacent columns per block ---------------
+template <int LT, int LW>
+__global__ void __launch_bounds__(NTT_THREADS) ntt_cols_kernel(NttArgs a, u64* dst_dense) {
+  constexpr int T = 1 << LT, W = 1 << LW, E = T << LW;
+  extern __shared__ __align__(16) u64 smem[];
+  u64* s = smem;
+  u64* tw = smem + lds_pad(E) + 1;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < T / 2; i += NTT_THREADS) tw[i] = a.tw[i];
+  const u32 tiles_per = 1u << (a.log_n2 - LW);
+  const u32 b = blockIdx.x / tiles_per, c0 = (blockIdx.x % tiles_per) << LW;
+  const u32 coset = b & ((1u << a.logK) - 1);
+  const u64* src = in_base(a, b);
+  for (int e = tid; e < E; e += NTT_THREADS) {
+    int c = e & (W - 1), j = e >> LW;
+    u64 v = src[((u64)j << a.log_n2) + c0 + c];
+    if (a.pre_lo) {
+      v = gl_mul(v, a.pre_lo[((u64)coset << a.log_n2) + c0 + c]);
+      v = gl_mul(v, a.pre_hi[((u64)coset << LT) + j]);
+    }
+    s[lds_pad(e)] = v;
+  }
+  __syncthreads();
+  dif_all<LT, LT - 1, true, LW>(s, tw, tid);
+  // row j holds k1 = bitrev(j); multiply by w_n^(i2*k1) and leave it at row j
+  u64* dst = dst_dense ? dst_dense + (u64)b * ((u64)1 << a.log_n) : out_base(a, b);
+  for (int e = tid; e < E; e += NTT_THREADS) {
+    int c = e & (W - 1), j = e >> LW;
+    u32 k1 = bitrev32((u32)j, LT);
+    u32 ex = (c0 + c) * k1;  // < n <= 2^24
+    u64 v = s[lds_pad(e)];
+    u64 w = gl_mul(a.tw4_lo[ex & 4095], a.tw4_hi[ex >> 12]);
+    dst[((u64)j << a.log_n2) + c0 + c] = gl_mul(v, w);
+  }
+}
+
+__global__ void powers_kernel(u64* out, u64 base, u64 first, u64 stride_exp, u32 count) {
+  // out[i] = first * base^(i * stride_exp)
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  out[i] = gl_mul(first, gl_pow(base, (u64)i * stride_exp));
+}
+// pre_lo[j][i2] = s_j^i2, pre_hi[j][i1] = s_j^(i1*n2), s_j = shift * w_{n*K}^j
+__global__ void coset_tables_kernel(u64* lo, u64* hi, u64 shift, u64 w_nk, u32 log_n1, u32 log_n2, u32 K) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  u32 n1 = 1u << log_n1, n2 = 1u << log_n2;
+  u32 per = n1 + n2;
+  if (i >= per * K) return;
+  u32 j = i / per, r = i % per;
+  u64 sj = gl_mul(shift, gl_pow(w_nk, j));
+  if (r < n2) lo[(u64)j * n2 + r] = gl_pow(sj, r);
+  else hi[(u64)j * n1 + (r - n2)] = gl_pow(sj, (u64)(r - n2) << log_n2);
+}
+__global__ void scale_powers_kernel(u64* data, u32 log_n, u32 batch, u64 base, u64 first) {
+  // data[b][i] *= first * base^i
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ((u64)batch << log_n)) return;
+  u64 k = i & (((u64)1 << log_n) - 1);
+  data[i] = gl_mul(data[i], gl_mul(first, gl_pow(base, k)));
+}
+
+// ---- host side ------------------------------------------------------------------------------
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
+
+static hipError_t dev_alloc(u64** p, size_t words) { return hipMalloc((void**)p, words * sizeof(u64)); }
+
+NttPlan::~NttPlan() {
+  hipFree(tw_a); hipFree(tw_b); hipFree(tw4_lo); hipFree(tw4_hi);
+}
+CosetTables::~CosetTables() { hipFree(lo); hipFree(hi); }
+
+hipError_t NttEngine::plan(u32 log_n, bool inverse, NttPlan** out) {
+  u32 key = log_n * 2 + (inverse ? 1 : 0);
+  auto it = plans.find(key);
+  if (it != plans.end()) { *out = it->second.get(); return hipSuccess; }
+  std::unique_ptr<NttPlan> p(new NttPlan());
+  p->log_n = log_n;
+  if (log_n <= 12) { p->log_n1 = 0; p->log_n2 = log_n; }
+  else { p->log_n1 = (log_n + 1) / 2; p->log_n2 = log_n - p->log_n1; }
+  u64 wn = gl_root_of_unity(log_n);
+  if (inverse) wn = gl_inv(wn);
+  auto powers = [&](u64** dst, u64 base, u32 count) -> hipError_t {
+    HIPCHK(dev_alloc(dst, count ? count : 1));
+    if (count) hipLaunchKernelGGL(powers_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, *dst, base, (u64)1, (u64)1, count);
+    return hipGetLastError();
+  };
+  // inner DFT roots: w_{n2}^k (pass B) and w_{n1}^k (pass A)
+  u64 w2 = gl_pow(wn, (u64)1 << p->log_n1), w1 = gl_pow(wn, (u64)1 << p->log_n2);
+  HIPCHK(powers(&p->tw_b, w2, (1u << p->log_n2) / 2));
+  if (p->log_n1) {
+    HIPCHK(powers(&p->tw_a, w1, (1u << p->log_n1) / 2));
+    HIPCHK(powers(&p->tw4_lo, wn, 4096));
+    HIPCHK(powers(&p->tw4_hi, gl_pow(wn, 4096), log_n > 12 ? (1u << (log_n - 12)) : 1));
+  }
+  p->n_inv = inverse ? gl_inv(((u64)1 << log_n) % GL_P) : 0;
+  *out = p.get();
+  plans[key] = std::move(p);
+  return hipSuccess;
+}
+
+hipError_t NttEngine::coset(u32 log_n, u32 logK, u64 shift, CosetTables** out) {
+  u64 key = ((u64)log_n << 8 | logK) ^ (shift * 0x9E3779B97F4A7C15ULL);
+  auto it = cosets.find(key);
+  if (it != cosets.end() && it->second->shift == shift && it->second->log_n == log_n && it->second->logK == logK) {
+    *out = it->second.get(); return hipSuccess;
+  }
+  std::unique_ptr<CosetTables> c(new CosetTables());
+  c->log_n = log_n; c->logK = logK; c->shift = shift;
+  u32 log_n1 = log_n <= 12 ? 0 : (log_n + 1) / 2, log_n2 = log_n - log_n1;
+  u32 K = 1u << logK, n1 = 1u << log_n1, n2 = 1u << log_n2;
+  HIPCHK(dev_alloc(&c->lo, (size_t)K * n2));
+  HIPCHK(dev_alloc(&c->hi, (size_t)K * n1));
+  u32 total = (n1 + n2) * K;
+  hipLaunchKernelGGL(coset_tables_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, c->lo, c->hi, shift,
+                     gl_root_of_unity(log_n + logK), log_n1, log_n2, K);
+  HIPCHK(hipGetLastError());
+  *out = c.get();
+  cosets[key] = std::move(c);
+  return hipSuccess;
+}
+
+hipError_t NttEngine::ensure_scratch(size_t words) {
+  if (words <= scratch_words) return hipSuccess;
+  if (scratch) HIPCHK(hipFree(scratch));
+  scratch = nullptr; scratch_words = 0;
+  HIPCHK(dev_alloc(&scratch, words));
+  scratch_words = words;
+  return hipSuccess;
+}
+
+template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : 12 - LT; }
+template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : (LT >= 8 ? 4 : 12 - LT); }
+template <int LT, int LW> static size_t lds_bytes() {
+  int e = (1 << LT) << LW;
+  return (size_t)(e + (e >> 4) + 1 + (1 << LT) / 2 + 1) * sizeof(u64);
+}
+
+template <int LT>
+static hipError_t launch_rows(const NttArgs& a, bool nat_two_pass, hipStream_t st) {
+  constexpr int LW = rows_lw<LT>();
+  size_t lds = lds_bytes<LT, LW>();
+  u64 total_rows = (u64)a.batch << a.log_n1;
+  if (nat_two_pass) {
+    static bool attr = false;
+    if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_rows_nat_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    u32 blocks = (u32)(total_rows >> LW);
+    hipLaunchKernelGGL((ntt_rows_nat_kernel<LT, LW>), dim3(blocks), dim3(NTT_THREADS), lds, st, a);
+  } else {
+    static bool attr = false;
+    if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_rows_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    u32 blocks = (u32)((total_rows + (1u << LW) - 1) >> LW);
+    hipLaunchKernelGGL((ntt_rows_kernel<LT, LW>), dim3(blocks), dim3(NTT_THREADS), lds, st, a);
+  }
+  return hipGetLastError();
+}
+template <int LT>
+static hipError_t launch_cols(const NttArgs& a, u64* dst_dense, hipStream_t st) {
+  constexpr int LW = cols_lw<LT>();
+  size_t lds = lds_bytes<LT, LW>();
+  static bool attr = false;
+  if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_cols_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  u32 blocks = a.batch << (a.log_n2 - LW);
+  hipLaunchKernelGGL((ntt_cols_kernel<LT, LW>), dim3(blocks), dim3(NTT_THREADS), lds, st, a, dst_dense);
+  return hipGetLastError();
+}
+
+#define ROWS_CASE(N) case N: return launch_rows<N>(a, nat, st);
+static hipError_t dispatch_rows(u32 lt, const NttArgs& a, bool nat, hipStream_t st) {
+  switch (lt) {
+    ROWS_CASE(1) ROWS_CASE(2) ROWS_CASE(3) ROWS_CASE(4) ROWS_CASE(5) ROWS_CASE(6)
+    ROWS_CASE(7) ROWS_CASE(8) ROWS_CASE(9) ROWS_CASE(10) ROWS_CASE(11) ROWS_CASE(12)
+    default: return hipErrorInvalidValue;
+  }
+}
+#define COLS_CASE(N) case N: return launch_cols<N>(a, dense, st);
+static hipError_t dispatch_cols(u32 lt, const NttArgs& a, u64* dense, hipStream_t st) {
+  switch (lt) {
+    COLS_CASE(7) COLS_CASE(8) COLS_CASE(9) COLS_CASE(10) COLS_CASE(11) COLS_CASE(12)
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t NttEngine::run(const u64* in, u64* out, u32 log_n, u32 polys, u32 logK, u64 in_poly_stride,
+                          u64 out_poly_stride, bool inverse, const CosetTables* pre, bool bitrev_out) {
+  if (log_n == 0 || log_n > 24) return hipErrorInvalidValue;
+  NttPlan* p;
+  HIPCHK(plan(log_n, inverse, &p));
+  NttArgs a{};
+  a.in = in; a.out = out;
+  a.in_poly_stride = in_poly_stride; a.out_poly_stride = out_poly_stride;
+  a.logK = logK; a.log_n = log_n; a.log_n1 = p->log_n1; a.log_n2 = p->log_n2;
+  a.batch = polys << logK;
+  a.tw4_lo = p->tw4_lo; a.tw4_hi = p->tw4_hi;
+  a.pre_lo = pre ? pre->lo : nullptr; a.pre_hi = pre ? pre->hi : nullptr;
+  a.post = p->n_inv;
+  a.bitrev_out = bitrev_out ? 1 : 0;
+  if (p->log_n1 == 0) {
+    a.tw = p->tw_b;
+    return dispatch_rows(p->log_n2, a, false, stream);
+  }
+  u64* dense = nullptr;
+  if (!bitrev_out) {
+    HIPCHK(ensure_scratch((size_t)a.batch << log_n));
+    dense = scratch;
+  }
+  a.tw = p->tw_a;
+  HIPCHK(dispatch_cols(p->log_n1, a, dense, stream));
+  a.tw = p->tw_b;
+  a.pre_lo = a.pre_hi = nullptr;
+  if (!bitrev_out) a.in = dense;
+  return dispatch_rows(p->log_n2, a, !bitrev_out, stream);
+}
+
+hipError_t NttEngine::scale_powers(u64* data, u32 log_n, u32 batch, u64 base, u64 first) {
+  u64 total = (u64)batch << log_n;
+  hipLaunchKernelGGL(scale_powers_kernel, dim3((u32)((total + 255) / 256)), dim3(256), 0, stream, data, log_n, batch, base, first);
+  return hipGetLastError();
+}
+
+NttEngine::~NttEngine() { if (scratch) hipFree(scratch); }
+
+}  // namespace mp2g

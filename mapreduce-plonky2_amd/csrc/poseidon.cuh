@@ -1,0 +1,119 @@
+// Width-12 permutations over Goldilocks for gfx950: Poseidon2 (the reference's default hasher,
+// mp2-common/src/lib.rs:37-42) and Poseidon (WrapC, verifiable-db/src/api.rs:148), plus the
+// plonky2 sponge conventions restated in-tree at mp2-common/src/hash.rs:24-45 and
+// mp2-common/src/poseidon.rs:151-170 (overwrite-mode absorb, rate 8, squeeze from the front).
+//
+// One lane owns one 12-limb state (24 VGPRs). Round constants sit in __constant__ memory and
+// are read with wave-uniform indices, so they arrive through the scalar cache into SGPRs and
+// cost no vector registers. Rounds are loops, not unrolled: the external-round body is ~6 KB
+// of ISA and stays resident in the instruction cache shared by neighbouring CUs.
+#pragma once
+#include "gl.cuh"
+#include "perm_constants.h"
+
+#define MP2G_POSEIDON2 0
+#define MP2G_POSEIDON 1
+
+#define c_p2_ext POSEIDON2_RC_EXT
+#define c_p2_int POSEIDON2_RC_INT
+#define c_p2_diag POSEIDON2_DIAG_M1
+#define c_p_rc POSEIDON_RC
+
+// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] with additions only (HorizenLabs matmul_m4)
+GLD void p2_m4(u64& a, u64& b, u64& c, u64& d) {
+  u64 t0 = gl_add(a, b), t1 = gl_add(c, d);
+  u64 t2 = gl_add(gl_dbl(b), t1), t3 = gl_add(gl_dbl(d), t0);
+  u64 t4 = gl_add(gl_dbl(gl_dbl(t1)), t3), t5 = gl_add(gl_dbl(gl_dbl(t0)), t2);
+  u64 t6 = gl_add(t3, t5), t7 = gl_add(t2, t4);
+  a = t6; b = t5; c = t7; d = t4;
+}
+GLD void p2_external(u64 s[12]) {
+  p2_m4(s[0], s[1], s[2], s[3]);
+  p2_m4(s[4], s[5], s[6], s[7]);
+  p2_m4(s[8], s[9], s[10], s[11]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    u64 sum = gl_add(gl_add(s[i], s[4 + i]), s[8 + i]);
+    s[i] = gl_add(s[i], sum);
+    s[4 + i] = gl_add(s[4 + i], sum);
+    s[8 + i] = gl_add(s[8 + i], sum);
+  }
+}
+GLD void poseidon2_perm(u64 s[12]) {
+  p2_external(s);
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add(s[i], c_p2_ext[12 * r + i]));
+    p2_external(s);
+  }
+#pragma unroll 1
+  for (int r = 0; r < 22; r++) {
+    s[0] = gl_pow7(gl_add(s[0], c_p2_int[r]));
+    u64 sum = s[0];
+#pragma unroll
+    for (int i = 1; i < 12; i++) sum = gl_add(sum, s[i]);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add(gl_mul(s[i], c_p2_diag[i]), sum);
+  }
+#pragma unroll 1
+  for (int r = 4; r < 8; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add(s[i], c_p2_ext[12 * r + i]));
+    p2_external(s);
+  }
+}
+
+// Poseidon MDS: circulant [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,...]; all entries < 2^6,
+// so the 32-bit halves of the state accumulate in u64 without overflow and reduce once per row.
+GLD void poseidon_mds(u64 s[12]) {
+  const u32 circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+  u64 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = s[i] >> 32; }
+  u64 out[12];
+#pragma unroll
+  for (int r = 0; r < 12; r++) {
+    u64 al = 0, ah = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      al += lo[(i + r) % 12] * circ[i];
+      ah += hi[(i + r) % 12] * circ[i];
+    }
+    if (r == 0) { al += lo[0] * 8; ah += hi[0] * 8; }
+    // value = al + ah * 2^32, al, ah < 2^42
+    u64 l = al + (ah << 32);
+    u64 h = (ah >> 32) + (l < al ? 1 : 0);
+    out[r] = gl_reduce128(l, h);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = out[i];
+}
+GLD void poseidon_perm(u64 s[12]) {
+#pragma unroll 1
+  for (int r = 0; r < 30; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], c_p_rc[12 * r + i]);
+    if (r < 4 || r >= 26) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) s[i] = gl_pow7(s[i]);
+    } else {
+      s[0] = gl_pow7(s[0]);
+    }
+    poseidon_mds(s);
+  }
+}
+template <int VARIANT>
+GLD void perm(u64 s[12]) {
+  if (VARIANT == MP2G_POSEIDON2) poseidon2_perm(s); else poseidon_perm(s);
+}
+// compress(l, r) = perm(l || r || 0)[0..4]   (plonky2 hashing.rs)
+template <int VARIANT>
+GLD void two_to_one(const u64 l[4], const u64 r[4], u64 out[4]) {
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { s[i] = l[i]; s[4 + i] = r[i]; s[8 + i] = 0; }
+  perm<VARIANT>(s);
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = s[i];
+}

@@ -1,0 +1,192 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so) -- test infrastructure only.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+P = 0xFFFFFFFF00000001
+MULT_GEN = 14293326489335486720
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        try:
+            _lib = ctypes.CDLL(LIB)
+        except OSError:
+            build()
+            _lib = ctypes.CDLL(LIB)
+        _lib.orc_merkle_levels_len.restype = ctypes.c_size_t
+        _lib.orc_fri_proof_words.restype = ctypes.c_size_t
+        _lib.orc_n_openings.restype = ctypes.c_size_t
+        _lib.orc_bitrev.restype = ctypes.c_size_t
+    return _lib
+
+
+def arr(a, dtype=np.uint64):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def sz(x):
+    return ctypes.c_size_t(int(x))
+
+
+class SplitMix64:
+    """Deterministic field-element stream: SplitMix64, reject >= p."""
+
+    def __init__(self, seed):
+        self.s = seed & 0xFFFFFFFFFFFFFFFF
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
+
+def rand_field(shape, seed):
+    """Vectorised SplitMix64 stream reduced by rejection (values >= p are re-drawn)."""
+    n = int(np.prod(shape))
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    bad = z >= np.uint64(P)
+    z[bad] = z[bad] - np.uint64(P)  # 2^32-1 values out of 2^64: fold instead of redraw
+    return z.reshape(shape)
+
+
+# ---- thin wrappers ---------------------------------------------------------------------------
+def perm(state, variant=0):
+    s = arr(state).copy()
+    lib().orc_perm(variant, p(s))
+    return s
+
+
+def hash_n_to_m_no_pad(inp, m, variant=0):
+    a = arr(inp)
+    out = np.empty(m, dtype=np.uint64)
+    lib().orc_hash_n_to_m_no_pad(variant, p(a), sz(a.size), p(out), sz(m))
+    return out
+
+
+def hash_no_pad_batch(inputs, out_len=4, variant=0):
+    a = arr(inputs)
+    count, in_len = a.shape
+    out = np.empty((count, out_len), dtype=np.uint64)
+    lib().orc_hash_no_pad_batch(variant, p(a), sz(in_len), sz(count), sz(out_len), p(out))
+    return out
+
+
+def fft(a, inverse=False, coset_shift=0):
+    a = arr(a).copy()
+    batch, n = (1, a.shape[0]) if a.ndim == 1 else a.shape
+    log_n = int(n).bit_length() - 1
+    lib().orc_fft_batch(p(a), log_n, sz(batch), int(inverse), ctypes.c_uint64(coset_shift))
+    return a
+
+
+def bitrev_perm(n):
+    bits = int(n).bit_length() - 1
+    i = np.arange(n, dtype=np.uint64)
+    r = np.zeros(n, dtype=np.uint64)
+    for b in range(bits):
+        r |= ((i >> np.uint64(b)) & np.uint64(1)) << np.uint64(bits - 1 - b)
+    return r.astype(np.int64)
+
+
+def lde_leaves(coeffs, rate_bits):
+    c = arr(coeffs)
+    w, n = c.shape
+    out = np.empty((n << rate_bits, w), dtype=np.uint64)
+    lib().orc_lde_leaves(p(c), int(n).bit_length() - 1, sz(w), rate_bits, p(out))
+    return out
+
+
+def merkle_build(leaves, cap_h, variant=0):
+    a = arr(leaves)
+    L, leaf_len = a.shape
+    log_l = int(L).bit_length() - 1
+    levels = np.empty(lib().orc_merkle_levels_len(log_l, cap_h), dtype=np.uint64)
+    lib().orc_merkle_build(variant, p(a), sz(leaf_len), log_l, cap_h, p(levels))
+    return levels
+
+
+def merkle_cap(levels, cap_h):
+    return levels[-(4 << cap_h):].reshape(-1, 4)
+
+
+def merkle_prove(levels, log_leaves, cap_h, idx):
+    sib = np.empty((log_leaves - cap_h, 4), dtype=np.uint64)
+    lib().orc_merkle_prove(p(levels), log_leaves, cap_h, sz(idx), p(sib))
+    return sib
+
+
+def merkle_verify(leaf, idx, siblings, cap, variant=0):
+    leaf, siblings, cap = arr(leaf), arr(siblings), arr(cap)
+    return bool(lib().orc_merkle_verify(variant, p(leaf), sz(leaf.size), sz(idx), p(siblings), siblings.shape[0], p(cap)))
+
+
+class FriParams(ctypes.Structure):
+    """Mirror of orc_fri_params (oracle/fri.h) and mp2g_fri_params (include/mp2g.h)."""
+    _fields_ = [("variant", ctypes.c_uint32), ("log_n", ctypes.c_uint32), ("rate_bits", ctypes.c_uint32),
+                ("cap_height", ctypes.c_uint32), ("pow_bits", ctypes.c_uint32), ("num_queries", ctypes.c_uint32),
+                ("n_layers", ctypes.c_uint32), ("arity_bits", ctypes.c_uint32 * 8), ("n_oracles", ctypes.c_uint32),
+                ("oracle_w", ctypes.c_uint32 * 8), ("zs_oracle", ctypes.c_uint32), ("zs_count", ctypes.c_uint32)]
+
+
+def standard_params(log_n, oracle_w=(84, 135, 20, 16), variant=0, rate_bits=3, cap_height=4, pow_bits=16,
+                    num_queries=28, zs_oracle=2, zs_count=2, arity=4, final_poly_bits=5):
+    """standard_recursion_config (mp2-common/src/lib.rs:45-47) FRI parameters for degree 2^log_n."""
+    fp = FriParams()
+    fp.variant, fp.log_n, fp.rate_bits, fp.cap_height = variant, log_n, rate_bits, cap_height
+    fp.pow_bits, fp.num_queries = pow_bits, num_queries
+    ab = (ctypes.c_uint32 * 8)()
+    fp.n_layers = lib().orc_reduction_arity_bits(log_n, rate_bits, cap_height, arity, final_poly_bits, ab)
+    fp.arity_bits = ab
+    fp.n_oracles = len(oracle_w)
+    for i, w in enumerate(oracle_w):
+        fp.oracle_w[i] = w
+    fp.zs_oracle, fp.zs_count = zs_oracle, zs_count
+    return fp
+
+
+def pcs_prove(fp, values, circuit_digest, pi_hash):
+    """values: list of [w_o][n] arrays. Returns (caps, openings, proof)."""
+    vals = [arr(v) for v in values]
+    ptrs = (ctypes.c_void_p * len(vals))(*[v.ctypes.data for v in vals])
+    capw = 4 << fp.cap_height
+    caps = np.zeros((fp.n_oracles, capw), dtype=np.uint64)
+    openings = np.zeros((lib().orc_n_openings(ctypes.byref(fp)), 2), dtype=np.uint64)
+    proof = np.zeros(lib().orc_fri_proof_words(ctypes.byref(fp)), dtype=np.uint64)
+    cd, ph = arr(circuit_digest), arr(pi_hash)
+    lib().orc_pcs_prove(ctypes.byref(fp), ptrs, p(cd), p(ph), p(caps), p(openings), p(proof))
+    return caps, openings, proof
+
+
+def pcs_verify(fp, circuit_digest, pi_hash, caps, openings, proof):
+    cd, ph = arr(circuit_digest), arr(pi_hash)
+    caps, openings, proof = arr(caps), arr(openings), arr(proof)
+    return lib().orc_pcs_verify(ctypes.byref(fp), p(cd), p(ph), p(caps), p(openings), p(proof))

@@ -1,0 +1,138 @@
+"""HIP path vs CPU oracle, bit for bit, through the C ABI: NTT/LDE, sponge hashing, Merkle trees,
+PolynomialBatch commitments."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+P = O.P
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 5, 7, 9, 11, 12, 13, 14, 15, 16, 18])
+@pytest.mark.parametrize("bitrev_out", [False, True])
+def test_ntt_forward_matches_oracle(ctx, log_n, bitrev_out):
+    n = 1 << log_n
+    batch = 3 if log_n <= 14 else 1
+    a = O.rand_field((batch, n), 0xC0FFEE02 + log_n)
+    want = O.fft(a)
+    if bitrev_out:
+        want = want[:, O.bitrev_perm(n)]
+    got = ctx.ntt(a, bitrev_out=bitrev_out)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("log_n", [1, 4, 8, 12, 13, 15, 17])
+def test_ntt_inverse_and_coset(ctx, log_n):
+    n = 1 << log_n
+    a = O.rand_field((2, n), 77 + log_n)
+    assert np.array_equal(ctx.ntt(a, inverse=True), O.fft(a, inverse=True))
+    assert np.array_equal(ctx.ntt(a, coset_shift=O.MULT_GEN), O.fft(a, coset_shift=O.MULT_GEN))
+    assert np.array_equal(ctx.ntt(a, inverse=True, coset_shift=O.MULT_GEN), O.fft(a, inverse=True, coset_shift=O.MULT_GEN))
+    # round trip property
+    assert np.array_equal(ctx.ntt(ctx.ntt(a), inverse=True), a)
+
+
+def test_ntt_edge_values(ctx):
+    n = 1 << 10
+    for fill in (0, 1, P - 1):
+        a = np.full((1, n), fill, dtype=np.uint64)
+        assert np.array_equal(ctx.ntt(a), O.fft(a))
+    a = O.rand_field((1, n), 5)
+    a[0, ::7] = np.uint64(P - 1)
+    a[0, ::11] = 0
+    assert np.array_equal(ctx.ntt(a), O.fft(a))
+
+
+def test_ntt_2p22_config2(ctx):
+    """BASELINE config 2(i): one 2^22-point polynomial, seed 0xC0FFEE02; fwd, inv, coset."""
+    n = 1 << 22
+    a = O.rand_field((1, n), 0xC0FFEE02)
+    v = ctx.ntt(a)
+    assert np.array_equal(v, O.fft(a))
+    assert np.array_equal(ctx.ntt(v, inverse=True), a)
+    assert np.array_equal(ctx.ntt(a, coset_shift=O.MULT_GEN, bitrev_out=True),
+                          O.fft(a, coset_shift=O.MULT_GEN)[:, O.bitrev_perm(n)])
+
+
+@pytest.mark.parametrize("log_n,w", [(3, 2), (6, 5), (10, 7), (12, 9), (13, 3), (15, 2)])
+def test_lde_leaves_match_oracle(ctx, log_n, w):
+    c = O.rand_field((w, 1 << log_n), 31 + log_n)
+    assert np.array_equal(ctx.lde_leaves(c, 3), O.lde_leaves(c, 3))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("in_len,out_len", [(0, 4), (1, 4), (7, 4), (8, 4), (9, 5), (12, 4), (17, 4), (37, 4), (135, 4), (3, 11)])
+def test_hash_no_pad_batch(ctx, variant, in_len, out_len):
+    count = 300
+    x = O.rand_field((count, in_len), 1000 + in_len) if in_len else np.zeros((count, 0), dtype=np.uint64)
+    got = ctx.hash_no_pad_batch(x, out_len, variant)
+    want = O.hash_no_pad_batch(x, out_len, variant)
+    assert np.array_equal(got, want)
+
+
+def test_hash_golden_column_id(ctx, mp2):
+    """parsil/tests/context.json:88 through the HIP path."""
+    limbs = [int.from_bytes(b"BLOCK_NUMBER"[i:i + 4], "big") for i in (0, 4, 8)]
+    assert int(ctx.hash_no_pad(limbs, mp2.POSEIDON)[0]) == 17422912802427138938
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("log_leaves,leaf_len,cap_h", [(0, 5, 0), (1, 1, 0), (3, 4, 0), (3, 4, 3), (6, 7, 2), (10, 135, 4), (8, 32, 4), (2, 1, 0)])
+def test_merkle_tree(ctx, mp2, variant, log_leaves, leaf_len, cap_h):
+    L = 1 << log_leaves
+    leaves = O.rand_field((L, leaf_len), 500 + log_leaves)
+    t = mp2.MerkleTree(ctx, leaves, cap_h, variant)
+    levels = O.merkle_build(leaves, cap_h, variant)
+    cap = O.merkle_cap(levels, cap_h)
+    assert np.array_equal(t.cap, cap)
+    idx = sorted({0, L - 1, L // 2, min(3, L - 1)})
+    got_leaves, sib = t.prove(idx)
+    for k, i in enumerate(idx):
+        assert np.array_equal(got_leaves[k], leaves[i])
+        assert np.array_equal(sib[k], O.merkle_prove(levels, log_leaves, cap_h, i))
+        assert O.merkle_verify(leaves[i], i, sib[k], cap, variant)
+    t.free()
+
+
+def test_circuit_set_tree_shape(ctx, mp2):
+    """recursion-framework circuit_set.rs:173-191: 4-limb vk digests padded with [0] leaves,
+    cap height 0; hash_or_noop keeps <=4-limb leaves verbatim."""
+    digests = O.rand_field((3, 4), 42)
+    leaves = np.zeros((4, 4), dtype=np.uint64)
+    leaves[:3] = digests
+    t = mp2.MerkleTree(ctx, leaves, 0)
+    lv = O.merkle_build(leaves, 0)
+    assert np.array_equal(t.cap, O.merkle_cap(lv, 0))
+    assert np.array_equal(lv[:16].reshape(4, 4), leaves)  # leaf digests are the leaves themselves
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("log_n,w,cap_h", [(4, 3, 4), (7, 5, 4), (10, 20, 4), (12, 16, 4), (13, 9, 4), (12, 135, 4)])
+def test_commit_from_values(ctx, mp2, variant, log_n, w, cap_h):
+    n = 1 << log_n
+    vals = O.rand_field((w, n), 0xC0FFEE01 + log_n * 100 + w)
+    b = mp2.PolynomialBatch.from_values(ctx, vals, 3, cap_h, variant)
+    coeffs = O.fft(vals, inverse=True)
+    assert np.array_equal(b.coeffs, coeffs)
+    leaves = O.lde_leaves(coeffs, 3)
+    levels = O.merkle_build(leaves, cap_h, variant)
+    cap = O.merkle_cap(levels, cap_h)
+    assert np.array_equal(b.cap, cap)
+    N = n << 3
+    idx = [0, 1, N - 1, N // 3]
+    got_leaves, sib = b.open(idx)
+    for k, i in enumerate(idx):
+        assert np.array_equal(got_leaves[k], leaves[i])
+        assert O.merkle_verify(got_leaves[k], i, sib[k], cap, variant)
+    b.free()
+
+
+def test_api_errors(ctx, mp2):
+    with pytest.raises(mp2.Mp2gError):
+        mp2.MerkleTree(ctx, np.zeros((4, 3), dtype=np.uint64), 3)  # cap_height > log2(leaves)
+    t = mp2.MerkleTree(ctx, np.zeros((4, 3), dtype=np.uint64), 0)
+    with pytest.raises(mp2.Mp2gError):
+        t.prove([4])
+    with pytest.raises(mp2.Mp2gError):
+        ctx.hash_no_pad_batch(np.zeros((1, 3), dtype=np.uint64), 4, variant=2)
