@@ -9,6 +9,7 @@ Context() fails when no GPU is visible.
 """
 import ctypes
 import os
+import weakref
 
 import numpy as np
 
@@ -62,6 +63,7 @@ class DeviceBuffer:
         ptr = ctypes.c_void_p()
         _ck(load().mp2g_dev_alloc(ctx.h, ctypes.c_size_t(nbytes), ctypes.byref(ptr)))
         self.ptr = ptr
+        ctx._adopt(self)
 
     def upload(self, a):
         a = np.ascontiguousarray(a)
@@ -76,9 +78,9 @@ class DeviceBuffer:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.ctx.h:
             load().mp2g_dev_free(self.ctx.h, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -92,12 +94,27 @@ class Context:
 
     def __init__(self, device=0):
         self.h = ctypes.c_void_p()
+        self._children = weakref.WeakSet()
         _ck(load().mp2g_ctx_create(int(device), ctypes.byref(self.h)))
 
+    def _adopt(self, obj):
+        self._children.add(obj)
+        return obj
+
     def close(self):
+        """Free every handle that lives on this context, then the context itself (handles keep
+        a raw pointer to their context, so they must never outlive it)."""
         if self.h:
+            for obj in list(self._children):
+                obj.free()
             load().mp2g_ctx_destroy(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def sync(self):
         _ck(load().mp2g_ctx_sync(self.h))
@@ -166,6 +183,7 @@ class MerkleTree:
         self.ctx, self.cap_height, self.leaf_len = ctx, cap_height, leaf_len
         self.h = ctypes.c_void_p()
         _ck(load().mp2g_merkle_build(ctx.h, variant, _p(a), leaf_len, self.log_leaves, cap_height, ctypes.byref(self.h)))
+        ctx._adopt(self)
 
     @property
     def cap(self):
@@ -182,9 +200,9 @@ class MerkleTree:
         return leaves, sib
 
     def free(self):
-        if self.h:
+        if self.h and self.ctx.h:
             load().mp2g_merkle_free(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -199,6 +217,7 @@ class PolynomialBatch:
     def __init__(self, ctx, handle, log_n, w, rate_bits, cap_height):
         self.ctx, self.h = ctx, handle
         self.log_n, self.w, self.rate_bits, self.cap_height = log_n, w, rate_bits, cap_height
+        ctx._adopt(self)
 
     @classmethod
     def from_values(cls, ctx, values, rate_bits=3, cap_height=4, variant=POSEIDON2):
@@ -245,9 +264,9 @@ class PolynomialBatch:
         return leaves, sib
 
     def free(self):
-        if self.h:
+        if self.h and self.ctx.h:
             load().mp2g_batch_free(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
