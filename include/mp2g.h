@@ -102,6 +102,74 @@ int mp2g_batch_open(const mp2g_batch* batch, const uint32_t* idx, uint32_t n_idx
                     uint64_t* leaves_out /* [n_idx][w] */, uint64_t* siblings_out);
 void mp2g_batch_free(mp2g_batch* batch);
 
+/* ---- Fiat-Shamir + FRI: replaces iop/challenger.rs, fri/prover.rs fri_proof and
+ *      PolynomialBatch::prove_openings ---------------------------------------------------- */
+/* FRI / PCS parameters of one circuit shape. standard_recursion_config
+ * (mp2-common/src/lib.rs:45-47): rate_bits 3, cap_height 4, pow_bits 16, num_queries 28,
+ * reduction ConstantArityBits(4,5); oracles = constants_sigmas, wires, zs_partial_products,
+ * quotient; the first zs_count polynomials of oracle zs_oracle are also opened at g*zeta. */
+typedef struct mp2g_fri_params {
+  uint32_t variant;
+  uint32_t log_n;       /* degree_bits */
+  uint32_t rate_bits;
+  uint32_t cap_height;
+  uint32_t pow_bits;
+  uint32_t num_queries;
+  uint32_t n_layers;    /* len(reduction_arity_bits) */
+  uint32_t arity_bits[8];
+  uint32_t n_oracles;
+  uint32_t oracle_w[8];
+  uint32_t zs_oracle;
+  uint32_t zs_count;
+} mp2g_fri_params;
+/* fri/reduction_strategies.rs ConstantArityBits(arity_bits, final_poly_bits); returns the count */
+uint32_t mp2g_reduction_arity_bits(uint32_t degree_bits, uint32_t rate_bits, uint32_t cap_height,
+                                   uint32_t arity_bits, uint32_t final_poly_bits, uint32_t* out);
+/* Flat FriProof layout in u64 words (the fields of plonky2's FriProof in serde order, without
+ * bincode length prefixes):
+ *   commit_phase_merkle_caps [n_layers][1<<cap][4]
+ *   query_round_proofs [num_queries] { initial_trees_proof: per oracle { leaf[w], siblings[lg-cap][4] };
+ *                                      steps: per layer { evals[1<<arity][2], siblings[..][4] } }
+ *   final_poly [final_len][2]
+ *   pow_witness */
+size_t mp2g_fri_proof_words(const mp2g_fri_params* p);
+size_t mp2g_fri_n_openings(const mp2g_fri_params* p); /* sum(oracle_w) + zs_count extension values */
+
+/* Device-resident challengers: `count` independent transcripts stepped in lockstep. */
+typedef struct mp2g_challenger mp2g_challenger;
+int mp2g_challenger_create(mp2g_ctx* ctx, int variant, uint32_t count, mp2g_challenger** out);
+/* transcript t observes elems[t*n .. t*n+n) */
+int mp2g_challenger_observe(mp2g_challenger* ch, const uint64_t* elems, uint32_t n);
+int mp2g_challenger_get(mp2g_challenger* ch, uint32_t n, uint64_t* out /* [count][n] */);
+void mp2g_challenger_free(mp2g_challenger* ch);
+
+/* One FRI layer fold in the value domain. evals [1<<log_m][2]: bit-reversed evaluations on
+ * shift*<w_m>; out [(1<<log_m)>>arity_bits][2]: bit-reversed evaluations of the folded polynomial
+ * on shift^(2^arity_bits). Equals coeffs.chunks(arity).map(reduce_with_powers(beta)) + coset_fft. */
+int mp2g_fri_fold(mp2g_ctx* ctx, const uint64_t* evals, uint32_t log_m, uint32_t arity_bits,
+                  const uint64_t beta[2], uint64_t shift, uint64_t* out);
+/* fri_proof_of_work: smallest witness w such that permute(state with state[pos] = w)[7] has
+ * >= bits leading zeros; `state` = sponge state already overwritten with the pending inputs. */
+int mp2g_fri_pow(mp2g_ctx* ctx, int variant, const uint64_t state[12], uint32_t pos, uint32_t bits,
+                 uint64_t* witness);
+
+/* Batched PCS prover: the commitment / Fiat-Shamir / opening / FRI skeleton of plonky2's prove()
+ * for `batch` same-shape proofs at once, everything resident on the device. */
+typedef struct mp2g_prover mp2g_prover;
+int mp2g_prover_create(mp2g_ctx* ctx, const mp2g_fri_params* params, uint32_t batch, mp2g_prover** out);
+/* commit oracle 0 (constants_sigmas, [w0][n] subgroup values), shared by every proof */
+int mp2g_prover_set_preprocessed_dev(mp2g_prover* pr, const uint64_t* d_values);
+/* d_values[o-1] = [batch][w_o][n] subgroup values of oracle o = 1..n_oracles-1;
+ * d_circuit_digest [4]; d_pi_hash [batch][4]. Outputs (device): d_caps [batch][n_oracles][1<<cap][4],
+ * d_openings [batch][n_openings][2], d_proof [batch][proof_words]. Asynchronous on the stream. */
+int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, const uint64_t* d_circuit_digest,
+                          const uint64_t* d_pi_hash, uint64_t* d_caps, uint64_t* d_openings, uint64_t* d_proof);
+void mp2g_prover_free(mp2g_prover* pr);
+/* single proof, host pointers: values[o] = [w_o][n] for o = 0..n_oracles-1 */
+int mp2g_pcs_prove(mp2g_ctx* ctx, const mp2g_fri_params* params, const uint64_t* const* values,
+                   const uint64_t circuit_digest[4], const uint64_t pi_hash[4], uint64_t* caps,
+                   uint64_t* openings, uint64_t* proof);
+
 #ifdef __cplusplus
 }
 #endif

@@ -273,3 +273,130 @@ class PolynomialBatch:
             self.free()
         except Exception:
             pass
+
+
+class FriParams(ctypes.Structure):
+    """mp2g_fri_params (include/mp2g.h)."""
+    _fields_ = [("variant", ctypes.c_uint32), ("log_n", ctypes.c_uint32), ("rate_bits", ctypes.c_uint32),
+                ("cap_height", ctypes.c_uint32), ("pow_bits", ctypes.c_uint32), ("num_queries", ctypes.c_uint32),
+                ("n_layers", ctypes.c_uint32), ("arity_bits", ctypes.c_uint32 * 8), ("n_oracles", ctypes.c_uint32),
+                ("oracle_w", ctypes.c_uint32 * 8), ("zs_oracle", ctypes.c_uint32), ("zs_count", ctypes.c_uint32)]
+
+    @property
+    def proof_words(self):
+        f = load().mp2g_fri_proof_words
+        f.restype = ctypes.c_size_t
+        return f(ctypes.byref(self))
+
+    @property
+    def n_openings(self):
+        f = load().mp2g_fri_n_openings
+        f.restype = ctypes.c_size_t
+        return f(ctypes.byref(self))
+
+    @property
+    def cap_words(self):
+        return 4 << self.cap_height
+
+
+def standard_recursion_params(log_n, oracle_w=(84, 135, 20, 16), variant=POSEIDON2, rate_bits=3, cap_height=4,
+                              pow_bits=16, num_queries=28, zs_oracle=2, zs_count=2, arity_bits=4, final_poly_bits=5):
+    """FRI parameters of standard_recursion_config (mp2-common/src/lib.rs:45-47) for 2^log_n rows:
+    135 wires, 2 challenges (=> 20 Z/partial-product and 16 quotient-chunk polynomials),
+    ConstantArityBits(4, 5). 84 = constants + 80 sigma polynomials of a typical circuit."""
+    fp = FriParams()
+    fp.variant, fp.log_n, fp.rate_bits, fp.cap_height = variant, log_n, rate_bits, cap_height
+    fp.pow_bits, fp.num_queries = pow_bits, num_queries
+    ab = (ctypes.c_uint32 * 8)()
+    fp.n_layers = load().mp2g_reduction_arity_bits(log_n, rate_bits, cap_height, arity_bits, final_poly_bits, ab)
+    fp.arity_bits = ab
+    fp.n_oracles = len(oracle_w)
+    for i, w in enumerate(oracle_w):
+        fp.oracle_w[i] = w
+    fp.zs_oracle, fp.zs_count = zs_oracle, zs_count
+    return fp
+
+
+class Challenger:
+    """plonky2 iop/challenger.rs Challenger; `count` transcripts in lockstep on the device."""
+
+    def __init__(self, ctx, variant=POSEIDON2, count=1):
+        self.ctx, self.count = ctx, count
+        self.h = ctypes.c_void_p()
+        _ck(load().mp2g_challenger_create(ctx.h, variant, count, ctypes.byref(self.h)))
+        ctx._adopt(self)
+
+    def observe_elements(self, elems):
+        a = _arr(elems).reshape(self.count, -1)
+        _ck(load().mp2g_challenger_observe(self.h, _p(a), a.shape[1]))
+
+    def get_n_challenges(self, n):
+        out = np.empty((self.count, n), dtype=np.uint64)
+        _ck(load().mp2g_challenger_get(self.h, n, _p(out)))
+        return out
+
+    def free(self):
+        if self.h and self.ctx.h:
+            load().mp2g_challenger_free(self.h)
+        self.h = None
+
+
+def fri_fold(ctx, evals, arity_bits, beta, shift):
+    a = _arr(evals)
+    m = a.shape[0]
+    log_m = int(m).bit_length() - 1
+    out = np.empty((m >> arity_bits, 2), dtype=np.uint64)
+    b = _arr(beta)
+    _ck(load().mp2g_fri_fold(ctx.h, _p(a), log_m, arity_bits, _p(b), ctypes.c_uint64(shift), _p(out)))
+    return out
+
+
+def fri_pow(ctx, state, pos, bits, variant=POSEIDON2):
+    s = _arr(state)
+    w = ctypes.c_uint64()
+    _ck(load().mp2g_fri_pow(ctx.h, variant, _p(s), pos, bits, ctypes.byref(w)))
+    return w.value
+
+
+def pcs_prove(ctx, fp, values, circuit_digest, pi_hash):
+    """Single proof, host arrays: the PCS skeleton of prove(). Returns (caps, openings, proof)."""
+    vals = [_arr(v) for v in values]
+    ptrs = (ctypes.c_void_p * len(vals))(*[v.ctypes.data for v in vals])
+    caps = np.empty((fp.n_oracles, fp.cap_words), dtype=np.uint64)
+    openings = np.empty((fp.n_openings, 2), dtype=np.uint64)
+    proof = np.empty(fp.proof_words, dtype=np.uint64)
+    cd, ph = _arr(circuit_digest), _arr(pi_hash)
+    _ck(load().mp2g_pcs_prove(ctx.h, ctypes.byref(fp), ptrs, _p(cd), _p(ph), _p(caps), _p(openings), _p(proof)))
+    return caps, openings, proof
+
+
+class BatchedProver:
+    """mp2g_prover: `batch` same-shape proofs per call, device resident."""
+
+    def __init__(self, ctx, fp, batch):
+        self.ctx, self.fp, self.batch = ctx, fp, batch
+        self.h = ctypes.c_void_p()
+        _ck(load().mp2g_prover_create(ctx.h, ctypes.byref(fp), batch, ctypes.byref(self.h)))
+        ctx._adopt(self)
+        self.d_caps = ctx.alloc(batch * fp.n_oracles * fp.cap_words * 8)
+        self.d_openings = ctx.alloc(batch * fp.n_openings * 2 * 8)
+        self.d_proof = ctx.alloc(batch * fp.proof_words * 8)
+
+    def set_preprocessed(self, d_values):
+        _ck(load().mp2g_prover_set_preprocessed_dev(self.h, d_values.ptr))
+
+    def prove(self, d_values, d_circuit_digest, d_pi_hash):
+        """d_values: device buffers [batch][w_o][n] for oracles 1..; asynchronous."""
+        ptrs = (ctypes.c_void_p * len(d_values))(*[d.ptr.value for d in d_values])
+        _ck(load().mp2g_prover_prove_dev(self.h, ptrs, d_circuit_digest.ptr, d_pi_hash.ptr, self.d_caps.ptr,
+                                         self.d_openings.ptr, self.d_proof.ptr))
+
+    def results(self):
+        fp, B = self.fp, self.batch
+        return (self.d_caps.download((B, fp.n_oracles, fp.cap_words)), self.d_openings.download((B, fp.n_openings, 2)),
+                self.d_proof.download((B, fp.proof_words)))
+
+    def free(self):
+        if self.h and self.ctx.h:
+            load().mp2g_prover_free(self.h)
+        self.h = None

@@ -8,13 +8,16 @@ inline size_t merkle_levels_words(u32 log_leaves, u32 cap_h) {
   return 4 * ((((size_t)1 << log_leaves) << 1) - ((size_t)1 << cap_h));
 }
 // digests[i] = hash_or_noop(values[0..w)[i]); values poly-major with `stride` words between polys
-hipError_t leaf_hash_poly_major(hipStream_t st, int variant, const u64* values, u32 w, u64 stride, u64 n_leaves, u64* digests);
+// `batch` independent trees: tree b reads values + b*in_bstride and writes digests + b*out_bstride
+hipError_t leaf_hash_poly_major(hipStream_t st, int variant, const u64* values, u32 w, u64 stride, u64 n_leaves, u64* digests,
+                                u32 batch = 1, u64 in_bstride = 0, u64 out_bstride = 0);
 // digests[i] = hash_or_noop(leaves[i][0..len))
 hipError_t leaf_hash_row_major(hipStream_t st, int variant, const u64* leaves, u32 len, u64 n_leaves, u64* digests);
 // FRI layer leaves: leaf i = 2^arity_bits extension values [c0,c1] interleaved, read from SoA
-hipError_t leaf_hash_ext_soa(hipStream_t st, int variant, const u64* c0, const u64* c1, u32 arity_bits, u64 n_leaves, u64* digests);
+hipError_t leaf_hash_ext_soa(hipStream_t st, int variant, const u64* c0, const u64* c1, u32 arity_bits, u64 n_leaves, u64* digests,
+                             u32 batch = 1, u64 in_bstride = 0, u64 out_bstride = 0);
 // levels[0] already holds the leaf digests; fills levels 1..(log_leaves-cap_h)
-hipError_t merkle_reduce(hipStream_t st, int variant, u64* levels, u32 log_leaves, u32 cap_h);
+hipError_t merkle_reduce(hipStream_t st, int variant, u64* levels, u32 log_leaves, u32 cap_h, u32 batch = 1, u64 bstride = 0);
 // out[i][0..out_len) = hash_n_to_m_no_pad(in[i][0..in_len))
 hipError_t hash_no_pad_batch(hipStream_t st, int variant, const u64* in, u32 in_len, u64 count, u32 out_len, u64* out);
 // siblings[q][l][4] bottom-up for idx[q]

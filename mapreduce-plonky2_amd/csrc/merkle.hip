@@ -16,9 +16,12 @@
 namespace mp2g {
 
 template <int V>
-__global__ void __launch_bounds__(256) leaf_hash_poly_major_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ digests) {
+__global__ void __launch_bounds__(256) leaf_hash_poly_major_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ digests,
+                                                                   u64 in_bstride, u64 out_bstride) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  values += blockIdx.y * in_bstride;
+  digests += blockIdx.y * out_bstride;
   u64 s[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) s[k] = 0;
@@ -71,9 +74,13 @@ __global__ void __launch_bounds__(256) leaf_hash_row_major_kernel(const u64* __r
   for (int k = 0; k < 4; k++) digests[4 * i + k] = s[k];
 }
 template <int V>
-__global__ void __launch_bounds__(256) leaf_hash_ext_soa_kernel(const u64* __restrict__ c0, const u64* __restrict__ c1, u32 arity_bits, u64 n, u64* __restrict__ digests) {
+__global__ void __launch_bounds__(256) leaf_hash_ext_soa_kernel(const u64* __restrict__ c0, const u64* __restrict__ c1, u32 arity_bits, u64 n, u64* __restrict__ digests,
+                                                                u64 in_bstride, u64 out_bstride) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  c0 += blockIdx.y * in_bstride;
+  c1 += blockIdx.y * in_bstride;
+  digests += blockIdx.y * out_bstride;
   u32 arity = 1u << arity_bits;
   const u64* a = c0 + (i << arity_bits);
   const u64* b = c1 + (i << arity_bits);
@@ -95,9 +102,11 @@ __global__ void __launch_bounds__(256) leaf_hash_ext_soa_kernel(const u64* __res
   for (int k = 0; k < 4; k++) digests[4 * i + k] = s[k];
 }
 template <int V>
-__global__ void __launch_bounds__(256) merkle_level_kernel(const u64* __restrict__ in, u64* __restrict__ out, u64 n_out) {
+__global__ void __launch_bounds__(256) merkle_level_kernel(const u64* __restrict__ in, u64* __restrict__ out, u64 n_out, u64 bstride) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_out) return;
+  in += blockIdx.y * bstride;
+  out += blockIdx.y * bstride;
   const ulonglong2* src = reinterpret_cast<const ulonglong2*>(in + 8 * i);
   ulonglong2 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
   u64 s[12] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y, 0, 0, 0, 0};
@@ -170,11 +179,12 @@ __global__ void __launch_bounds__(256) transpose_kernel(const u64* __restrict__ 
     else if (variant == MP2G_POSEIDON) hipLaunchKernelGGL((kernel<MP2G_POSEIDON>), grid, block, 0, st, __VA_ARGS__); \
     else return hipErrorInvalidValue;                                                       \
   } while (0)
-static inline dim3 grid1(u64 n, u32 block) { return dim3((u32)((n + block - 1) / block)); }
+static inline dim3 grid1(u64 n, u32 block, u32 batch = 1) { return dim3((u32)((n + block - 1) / block), batch); }
 
-hipError_t leaf_hash_poly_major(hipStream_t st, int variant, const u64* values, u32 w, u64 stride, u64 n, u64* digests) {
-  if (!n) return hipSuccess;
-  LAUNCH_V(leaf_hash_poly_major_kernel, grid1(n, 256), dim3(256), st, values, w, stride, n, digests);
+hipError_t leaf_hash_poly_major(hipStream_t st, int variant, const u64* values, u32 w, u64 stride, u64 n, u64* digests,
+                                u32 batch, u64 in_bstride, u64 out_bstride) {
+  if (!n || !batch) return hipSuccess;
+  LAUNCH_V(leaf_hash_poly_major_kernel, grid1(n, 256, batch), dim3(256), st, values, w, stride, n, digests, in_bstride, out_bstride);
   return hipGetLastError();
 }
 hipError_t leaf_hash_row_major(hipStream_t st, int variant, const u64* leaves, u32 len, u64 n, u64* digests) {
@@ -182,17 +192,19 @@ hipError_t leaf_hash_row_major(hipStream_t st, int variant, const u64* leaves, u
   LAUNCH_V(leaf_hash_row_major_kernel, grid1(n, 256), dim3(256), st, leaves, len, n, digests);
   return hipGetLastError();
 }
-hipError_t leaf_hash_ext_soa(hipStream_t st, int variant, const u64* c0, const u64* c1, u32 arity_bits, u64 n, u64* digests) {
-  if (!n) return hipSuccess;
-  LAUNCH_V(leaf_hash_ext_soa_kernel, grid1(n, 256), dim3(256), st, c0, c1, arity_bits, n, digests);
+hipError_t leaf_hash_ext_soa(hipStream_t st, int variant, const u64* c0, const u64* c1, u32 arity_bits, u64 n, u64* digests,
+                             u32 batch, u64 in_bstride, u64 out_bstride) {
+  if (!n || !batch) return hipSuccess;
+  LAUNCH_V(leaf_hash_ext_soa_kernel, grid1(n, 256, batch), dim3(256), st, c0, c1, arity_bits, n, digests, in_bstride, out_bstride);
   return hipGetLastError();
 }
-hipError_t merkle_reduce(hipStream_t st, int variant, u64* levels, u32 log_leaves, u32 cap_h) {
+hipError_t merkle_reduce(hipStream_t st, int variant, u64* levels, u32 log_leaves, u32 cap_h, u32 batch, u64 bstride) {
   u64* cur = levels;
+  if (!batch) return hipSuccess;
   for (u32 lv = log_leaves; lv > cap_h; lv--) {
     u64 n_in = (u64)1 << lv;
     u64* nxt = cur + 4 * n_in;
-    LAUNCH_V(merkle_level_kernel, grid1(n_in / 2, 256), dim3(256), st, cur, nxt, n_in / 2);
+    LAUNCH_V(merkle_level_kernel, grid1(n_in / 2, 256, batch), dim3(256), st, cur, nxt, n_in / 2, bstride);
     cur = nxt;
   }
   return hipGetLastError();

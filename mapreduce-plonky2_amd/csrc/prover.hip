@@ -1,0 +1,373 @@
+// Batched PCS prover: host-side orchestration of the commitment / Fiat-Shamir / opening / FRI
+// skeleton of plonky2's prove() (plonk/prover.rs) for B same-shape proofs, plus the granular
+// challenger / fold / proof-of-work entry points of include/mp2g.h. Everything between the
+// input matrices and the finished proofs stays in HBM on one stream: no host synchronisation.
+// Reference call sites: recursion-framework/src/circuit_builder.rs:308 (base proof),
+// universal_verifier_gadget/wrap_circuit.rs:143 (wrap proofs), verifiable-db/src/api.rs:207.
+#include "ctx.h"
+#include "fri.h"
+#include <new>
+#include <vector>
+
+using namespace mp2g;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define NEED(c, msg) do { if (!(c)) return fail("invalid argument: %s", msg); } while (0)
+
+struct mp2g_challenger {
+  mp2g_ctx* ctx = nullptr;
+  int variant = 0;
+  uint32_t count = 0;
+  DevBuf st;
+};
+
+struct mp2g_prover {
+  mp2g_ctx* ctx = nullptr;
+  mp2g_fri_params P{};
+  uint32_t B = 0;
+  bool have_pre = false;
+  size_t capw = 0, levels_words = 0, proof_words = 0, q_words = 0, q_off = 0, final_off = 0, final_len = 0, n_open = 0;
+  DevBuf coeffs[8], values[8], levels[8];
+  DevBuf ch, chal, zeta, alpha, betas, comp, quot, final_poly, witness, qchal;
+  DevBuf fvals[9], flevels[8], fcoeffs[9];
+};
+
+static int params_check(const mp2g_fri_params* p) {
+  NEED(p, "params");
+  NEED(p->variant <= 1, "variant");
+  NEED(p->log_n >= 1 && p->log_n <= 20, "1 <= log_n <= 20");
+  NEED(p->rate_bits >= 1 && p->rate_bits <= 6, "rate_bits");
+  NEED(p->n_oracles >= 1 && p->n_oracles <= 8, "n_oracles");
+  NEED(p->n_layers <= 8, "n_layers");
+  NEED(p->pow_bits <= 32, "pow_bits <= 32");
+  NEED(p->num_queries <= 64, "num_queries <= 64");
+  NEED(p->zs_oracle < p->n_oracles && p->zs_count <= p->oracle_w[p->zs_oracle], "zs_oracle/zs_count");
+  uint32_t deg = p->log_n, lg = p->log_n + p->rate_bits;
+  NEED(p->cap_height <= lg, "cap_height");
+  for (uint32_t i = 0; i < p->n_layers; i++) {
+    NEED(p->arity_bits[i] >= 1 && p->arity_bits[i] <= 4, "arity_bits in 1..4");
+    NEED(deg >= p->arity_bits[i], "arity exceeds degree");
+    deg -= p->arity_bits[i];
+    lg -= p->arity_bits[i];
+    NEED(lg >= p->cap_height, "layer smaller than cap");
+  }
+  for (uint32_t o = 0; o < p->n_oracles; o++) NEED(p->oracle_w[o] >= 1, "oracle_w >= 1");
+  return 0;
+}
+
+extern "C" {
+
+uint32_t mp2g_reduction_arity_bits(uint32_t degree_bits, uint32_t rate_bits, uint32_t cap_height, uint32_t arity_bits,
+                                   uint32_t final_poly_bits, uint32_t* out) {
+  uint32_t n = 0;
+  if (arity_bits == 0) return 0;
+  while (degree_bits > final_poly_bits && degree_bits + rate_bits >= cap_height + arity_bits && n < 8) {
+    out[n++] = arity_bits;
+    degree_bits -= arity_bits;
+  }
+  return n;
+}
+size_t mp2g_fri_n_openings(const mp2g_fri_params* p) {
+  size_t t = p->zs_count;
+  for (uint32_t o = 0; o < p->n_oracles; o++) t += p->oracle_w[o];
+  return t;
+}
+static size_t query_words(const mp2g_fri_params* p) {
+  uint32_t lg = p->log_n + p->rate_bits;
+  size_t q = 0;
+  for (uint32_t o = 0; o < p->n_oracles; o++) q += p->oracle_w[o] + 4 * (lg - p->cap_height);
+  uint32_t cur = lg;
+  for (uint32_t i = 0; i < p->n_layers; i++) {
+    cur -= p->arity_bits[i];
+    q += ((size_t)2 << p->arity_bits[i]) + 4 * (cur - p->cap_height);
+  }
+  return q;
+}
+static size_t final_poly_len(const mp2g_fri_params* p) {
+  uint32_t deg = p->log_n;
+  for (uint32_t i = 0; i < p->n_layers; i++) deg -= p->arity_bits[i];
+  return (size_t)1 << deg;
+}
+size_t mp2g_fri_proof_words(const mp2g_fri_params* p) {
+  return p->n_layers * ((size_t)4 << p->cap_height) + p->num_queries * query_words(p) + 2 * final_poly_len(p) + 1;
+}
+
+// ---- challenger ------------------------------------------------------------------------------
+int mp2g_challenger_create(mp2g_ctx* c, int variant, uint32_t count, mp2g_challenger** out) {
+  NEED(c && out && count >= 1, "ctx/out/count");
+  NEED(variant == 0 || variant == 1, "variant");
+  mp2g_challenger* ch = new (std::nothrow) mp2g_challenger();
+  if (!ch) return fail("out of memory");
+  ch->ctx = c; ch->variant = variant; ch->count = count;
+  hipError_t e = ch->st.alloc(sizeof(ChState) * count);
+  if (e == hipSuccess) e = challenger_init(c->stream, (ChState*)ch->st.p, count);
+  if (e != hipSuccess) { delete ch; return fail("challenger_create: %s", hipGetErrorString(e)); }
+  *out = ch;
+  return 0;
+}
+int mp2g_challenger_observe(mp2g_challenger* ch, const uint64_t* elems, uint32_t n) {
+  NEED(ch && (elems || !n), "challenger/elems");
+  if (!n) return 0;
+  mp2g_ctx* c = ch->ctx;
+  DevBuf d;
+  CK(d.alloc((size_t)ch->count * n * sizeof(u64)));
+  CK(hipMemcpyAsync(d.p, elems, (size_t)ch->count * n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(challenger_step(c->stream, ch->variant, (ChState*)ch->st.p, ch->count, d.p, n, n, d.p, 0, 0));
+  CK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int mp2g_challenger_get(mp2g_challenger* ch, uint32_t n, uint64_t* out) {
+  NEED(ch && (out || !n), "challenger/out");
+  if (!n) return 0;
+  mp2g_ctx* c = ch->ctx;
+  DevBuf d;
+  CK(d.alloc((size_t)ch->count * n * sizeof(u64)));
+  CK(challenger_step(c->stream, ch->variant, (ChState*)ch->st.p, ch->count, d.p, 0, 0, d.p, n, n));
+  CK(hipMemcpyAsync(out, d.p, (size_t)ch->count * n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+void mp2g_challenger_free(mp2g_challenger* ch) {
+  if (!ch) return;
+  (void)hipStreamSynchronize(ch->ctx->stream);
+  delete ch;
+}
+
+// ---- stand-alone fold / proof of work --------------------------------------------------------
+int mp2g_fri_fold(mp2g_ctx* c, const uint64_t* evals, uint32_t log_m, uint32_t arity_bits, const uint64_t beta[2],
+                  uint64_t shift, uint64_t* out) {
+  NEED(c && evals && beta && out, "ctx/pointers");
+  NEED(arity_bits >= 1 && arity_bits <= 4 && log_m >= arity_bits && log_m <= 28, "arity_bits in 1..4, log_m >= arity_bits");
+  NEED(shift != 0 && shift < GL_P, "shift");
+  const size_t m = (size_t)1 << log_m, m2 = m >> arity_bits;
+  // AoS host layout -> SoA device layout
+  std::vector<u64> soa(2 * m);
+  for (size_t i = 0; i < m; i++) { soa[i] = evals[2 * i]; soa[m + i] = evals[2 * i + 1]; }
+  DevBuf din, dout, db;
+  CK(din.alloc(2 * m * sizeof(u64)));
+  CK(dout.alloc(2 * m2 * sizeof(u64)));
+  CK(db.alloc(2 * sizeof(u64)));
+  CK(hipMemcpyAsync(din.p, soa.data(), 2 * m * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(hipMemcpyAsync(db.p, beta, 2 * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(fri_fold_values(c->stream, 1, log_m, arity_bits, din.p, 0, dout.p, 0, db.p, 0, shift));
+  std::vector<u64> res(2 * m2);
+  CK(hipMemcpyAsync(res.data(), dout.p, 2 * m2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < m2; i++) { out[2 * i] = res[i]; out[2 * i + 1] = res[m2 + i]; }
+  return 0;
+}
+int mp2g_fri_pow(mp2g_ctx* c, int variant, const uint64_t state[12], uint32_t pos, uint32_t bits, uint64_t* witness) {
+  NEED(c && state && witness, "ctx/pointers");
+  NEED(variant == 0 || variant == 1, "variant");
+  NEED(pos < 8 && bits <= 32, "pos < 8, bits <= 32");
+  ChState h{};
+  for (int i = 0; i < 12; i++) h.state[i] = state[i];
+  for (uint32_t i = 0; i < pos; i++) h.in[i] = state[i];
+  h.n_in = pos;
+  DevBuf ds, dw;
+  CK(ds.alloc(sizeof(ChState)));
+  CK(dw.alloc(sizeof(u64)));
+  CK(hipMemcpyAsync(ds.p, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+  CK(fri_pow(c->stream, variant, (const ChState*)ds.p, 1, bits, dw.p));
+  CK(hipMemcpyAsync(witness, dw.p, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---- batched prover --------------------------------------------------------------------------
+int mp2g_prover_create(mp2g_ctx* c, const mp2g_fri_params* params, uint32_t batch, mp2g_prover** out) {
+  NEED(c && out, "ctx/out");
+  NEED(batch >= 1 && batch <= 4096, "1 <= batch <= 4096");
+  int rc = params_check(params);
+  if (rc) return rc;
+  mp2g_prover* pr = new (std::nothrow) mp2g_prover();
+  if (!pr) return fail("out of memory");
+  pr->ctx = c; pr->P = *params; pr->B = batch;
+  const mp2g_fri_params& P = pr->P;
+  const size_t n = (size_t)1 << P.log_n, N = n << P.rate_bits, B = batch;
+  const uint32_t lg = P.log_n + P.rate_bits;
+  pr->capw = (size_t)4 << P.cap_height;
+  pr->levels_words = merkle_levels_words(lg, P.cap_height);
+  pr->proof_words = mp2g_fri_proof_words(&P);
+  pr->q_words = query_words(&P);
+  pr->q_off = P.n_layers * pr->capw;
+  pr->final_len = final_poly_len(&P);
+  pr->final_off = pr->q_off + P.num_queries * pr->q_words;
+  pr->n_open = mp2g_fri_n_openings(&P);
+  hipError_t e = hipSuccess;
+  auto A = [&](DevBuf& d, size_t words) { if (e == hipSuccess) e = d.alloc(words * sizeof(u64)); };
+  for (uint32_t o = 0; o < P.n_oracles; o++) {
+    size_t nb = o == 0 ? 1 : B;
+    A(pr->coeffs[o], nb * P.oracle_w[o] * n);
+    A(pr->values[o], nb * P.oracle_w[o] * N);
+    A(pr->levels[o], nb * pr->levels_words);
+  }
+  if (e == hipSuccess) e = pr->ch.alloc(B * sizeof(ChState));
+  A(pr->chal, B * 8); A(pr->zeta, B * 2); A(pr->alpha, B * 2); A(pr->betas, B * 16);
+  A(pr->comp, B * 4 * n); A(pr->quot, B * 4 * n); A(pr->final_poly, B * 2 * n);
+  A(pr->witness, B); A(pr->qchal, B * (P.num_queries ? P.num_queries : 1));
+  size_t m = N, nc = n;
+  uint32_t clg = lg;
+  A(pr->fvals[0], B * 2 * m);
+  for (uint32_t li = 0; li < P.n_layers; li++) {
+    clg -= P.arity_bits[li];
+    A(pr->flevels[li], B * merkle_levels_words(clg, P.cap_height));
+    m >>= P.arity_bits[li]; nc >>= P.arity_bits[li];
+    A(pr->fvals[li + 1], B * 2 * m);
+    A(pr->fcoeffs[li + 1], B * 2 * nc);
+  }
+  if (e != hipSuccess) { delete pr; return fail("prover_create: %s", hipGetErrorString(e)); }
+  *out = pr;
+  return 0;
+}
+void mp2g_prover_free(mp2g_prover* pr) {
+  if (!pr) return;
+  (void)hipStreamSynchronize(pr->ctx->stream);
+  delete pr;
+}
+// values [nb][w][n] -> coeffs, LDE values, Merkle levels of oracle o
+static hipError_t commit_oracle(mp2g_prover* pr, uint32_t o, const u64* d_values, uint32_t nb) {
+  mp2g_ctx* c = pr->ctx;
+  const mp2g_fri_params& P = pr->P;
+  const u64 n = (u64)1 << P.log_n, N = n << P.rate_bits;
+  const uint32_t w = P.oracle_w[o], lg = P.log_n + P.rate_bits;
+  hipError_t e = c->ntt.run(d_values, pr->coeffs[o].p, P.log_n, nb * w, 0, n, n, true, nullptr, false);
+  if (e != hipSuccess) return e;
+  CosetTables* pre;
+  e = c->ntt.coset(P.log_n, P.rate_bits, GL_MULT_GEN, &pre);
+  if (e != hipSuccess) return e;
+  e = c->ntt.run(pr->coeffs[o].p, pr->values[o].p, P.log_n, nb * w, P.rate_bits, n, N, false, pre, true);
+  if (e != hipSuccess) return e;
+  e = leaf_hash_poly_major(c->stream, P.variant, pr->values[o].p, w, N, N, pr->levels[o].p, nb, (u64)w * N, pr->levels_words);
+  if (e != hipSuccess) return e;
+  return merkle_reduce(c->stream, P.variant, pr->levels[o].p, lg, P.cap_height, nb, pr->levels_words);
+}
+int mp2g_prover_set_preprocessed_dev(mp2g_prover* pr, const uint64_t* d_values) {
+  NEED(pr && d_values, "prover/values");
+  CK(commit_oracle(pr, 0, (const u64*)d_values, 1));
+  pr->have_pre = true;
+  return 0;
+}
+int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, const uint64_t* d_circuit_digest,
+                          const uint64_t* d_pi_hash, uint64_t* d_caps, uint64_t* d_openings, uint64_t* d_proof) {
+  NEED(pr && d_values && d_circuit_digest && d_pi_hash && d_caps && d_openings && d_proof, "prover/pointers");
+  NEED(pr->have_pre, "call mp2g_prover_set_preprocessed_dev first");
+  mp2g_ctx* c = pr->ctx;
+  hipStream_t s = c->stream;
+  const mp2g_fri_params& P = pr->P;
+  const uint32_t B = pr->B, lg = P.log_n + P.rate_bits, V = P.variant;
+  const u64 n = (u64)1 << P.log_n, N = n << P.rate_bits;
+  const size_t capw = pr->capw, LW = pr->levels_words;
+  ChState* st = (ChState*)pr->ch.p;
+  u64* chal = pr->chal.p;
+  const u64 caps_b = P.n_oracles * capw;
+
+  CK(challenger_init(s, st, B));
+  CK(challenger_step(s, V, st, B, (const u64*)d_circuit_digest, 0, 4, chal, 8, 0));
+  CK(challenger_step(s, V, st, B, (const u64*)d_pi_hash, 4, 4, chal, 8, 0));
+  CK(copy_rows(s, B, pr->levels[0].p + LW - capw, 0, (u64*)d_caps, caps_b, (u32)capw));
+  for (uint32_t o = 1; o < P.n_oracles; o++) {
+    NEED(d_values[o - 1], "d_values[o]");
+    CK(commit_oracle(pr, o, (const u64*)d_values[o - 1], B));
+    u64* cap_dst = (u64*)d_caps + o * capw;
+    CK(copy_rows(s, B, pr->levels[o].p + LW - capw, LW, cap_dst, caps_b, (u32)capw));
+    // plonk/prover.rs: wires cap -> betas, gammas (2+2); zs cap -> alphas (2); all other caps -> 0
+    uint32_t n_get = o == 1 ? 4 : (o == 2 ? 2 : 0);
+    CK(challenger_step(s, V, st, B, cap_dst, caps_b, (u32)capw, chal, 8, n_get));
+  }
+  CK(challenger_step(s, V, st, B, chal, 0, 0, pr->zeta.p, 2, 2));  // zeta
+
+  FriShape sh{};
+  sh.log_n = P.log_n; sh.rate_bits = P.rate_bits; sh.cap_h = P.cap_height; sh.n_oracles = P.n_oracles;
+  sh.zs_oracle = P.zs_oracle; sh.zs_count = P.zs_count;
+  for (uint32_t o = 0; o < P.n_oracles; o++) {
+    OracleRef& r = sh.o[o];
+    r.coeffs = pr->coeffs[o].p; r.values = pr->values[o].p; r.levels = pr->levels[o].p; r.w = P.oracle_w[o];
+    r.coeff_bstride = o ? (u64)r.w * n : 0;
+    r.value_bstride = o ? (u64)r.w * N : 0;
+    r.level_bstride = o ? LW : 0;
+    sh.n_polys += r.w;
+  }
+  CK(fri_openings(s, sh, B, pr->zeta.p, 2, (u64*)d_openings));
+  CK(challenger_step(s, V, st, B, (const u64*)d_openings, 2 * pr->n_open, (u32)(2 * pr->n_open), pr->alpha.p, 2, 2));
+  CK(fri_final_poly(s, sh, B, pr->alpha.p, 2, pr->zeta.p, 2, pr->comp.p, pr->quot.p, pr->final_poly.p));
+  CosetTables* pre;
+  CK(c->ntt.coset(P.log_n, P.rate_bits, GL_MULT_GEN, &pre));
+  CK(c->ntt.run(pr->final_poly.p, pr->fvals[0].p, P.log_n, 2 * B, P.rate_bits, n, N, false, pre, true));
+
+  FriLayers ly{};
+  ly.n_layers = P.n_layers;
+  u64 m = N, nc = n, shift = GL_MULT_GEN;
+  uint32_t clg = lg;
+  u64* proof = (u64*)d_proof;
+  const u64* cur_coeffs = pr->final_poly.p;
+  for (uint32_t li = 0; li < P.n_layers; li++) {
+    const uint32_t ab = P.arity_bits[li];
+    const uint32_t log_leaves = clg - ab;
+    const size_t lw = merkle_levels_words(log_leaves, P.cap_height);
+    CK(leaf_hash_ext_soa(s, V, pr->fvals[li].p, pr->fvals[li].p + m, ab, (u64)1 << log_leaves, pr->flevels[li].p, B, 2 * m, lw));
+    CK(merkle_reduce(s, V, pr->flevels[li].p, log_leaves, P.cap_height, B, lw));
+    CK(copy_rows(s, B, pr->flevels[li].p + lw - capw, lw, proof + li * capw, pr->proof_words, (u32)capw));
+    u64* beta = pr->betas.p + 2 * li;
+    CK(challenger_step(s, V, st, B, proof + li * capw, pr->proof_words, (u32)capw, beta, 16, 2));
+    ly.arity_bits[li] = ab;
+    ly.values[li] = pr->fvals[li].p; ly.value_bstride[li] = 2 * m;
+    ly.levels[li] = pr->flevels[li].p; ly.level_bstride[li] = lw;
+    CK(fri_fold_values(s, B, clg, ab, pr->fvals[li].p, 2 * m, pr->fvals[li + 1].p, 2 * (m >> ab), beta, 16, shift));
+    const bool last = li + 1 == P.n_layers;
+    if (last) CK(fri_fold_coeffs(s, B, (u32)nc, ab, cur_coeffs, 2 * nc, proof + pr->final_off, pr->proof_words, beta, 16, true));
+    else CK(fri_fold_coeffs(s, B, (u32)nc, ab, cur_coeffs, 2 * nc, pr->fcoeffs[li + 1].p, 2 * (nc >> ab), beta, 16, false));
+    cur_coeffs = pr->fcoeffs[li + 1].p;
+    shift = gl_pow(shift, (u64)1 << ab);
+    m >>= ab; nc >>= ab; clg -= ab;
+  }
+  if (P.n_layers == 0) CK(fri_soa_to_aos(s, B, (u32)n, pr->final_poly.p, 2 * n, (u32)n, proof + pr->final_off, pr->proof_words));
+  CK(challenger_step(s, V, st, B, proof + pr->final_off, pr->proof_words, (u32)(2 * pr->final_len), chal, 8, 0));
+  CK(fri_pow(s, V, st, B, P.pow_bits, pr->witness.p));
+  CK(copy_rows(s, B, pr->witness.p, 1, proof + pr->final_off + 2 * pr->final_len, pr->proof_words, 1));
+  CK(challenger_step(s, V, st, B, pr->witness.p, 1, 1, chal, 8, 1));  // observe witness, draw pow response
+  if (P.num_queries) {
+    CK(challenger_step(s, V, st, B, chal, 0, 0, pr->qchal.p, P.num_queries, P.num_queries));
+    CK(fri_queries(s, sh, ly, B, P.num_queries, pr->qchal.p, P.num_queries, proof, pr->proof_words, pr->q_off, pr->q_words));
+  }
+  return 0;
+}
+
+int mp2g_pcs_prove(mp2g_ctx* c, const mp2g_fri_params* params, const uint64_t* const* values, const uint64_t circuit_digest[4],
+                   const uint64_t pi_hash[4], uint64_t* caps, uint64_t* openings, uint64_t* proof) {
+  NEED(c && values && circuit_digest && pi_hash && caps && openings && proof, "ctx/pointers");
+  mp2g_prover* pr;
+  int rc = mp2g_prover_create(c, params, 1, &pr);
+  if (rc) return rc;
+  const mp2g_fri_params& P = pr->P;
+  const size_t n = (size_t)1 << P.log_n;
+  DevBuf dv[8], dd, dp, dcaps, dopen, dproof;
+  const uint64_t* dptr[8] = {};
+  hipError_t e = hipSuccess;
+  for (uint32_t o = 0; o < P.n_oracles && e == hipSuccess; o++) {
+    e = dv[o].alloc(P.oracle_w[o] * n * sizeof(u64));
+    if (e == hipSuccess) e = hipMemcpyAsync(dv[o].p, values[o], P.oracle_w[o] * n * sizeof(u64), hipMemcpyHostToDevice, c->stream);
+    if (o) dptr[o - 1] = dv[o].p;
+  }
+  if (e == hipSuccess) e = dd.alloc(32);
+  if (e == hipSuccess) e = dp.alloc(32);
+  if (e == hipSuccess) e = dcaps.alloc(P.n_oracles * pr->capw * sizeof(u64));
+  if (e == hipSuccess) e = dopen.alloc(pr->n_open * 2 * sizeof(u64));
+  if (e == hipSuccess) e = dproof.alloc(pr->proof_words * sizeof(u64));
+  if (e == hipSuccess) e = hipMemcpyAsync(dd.p, circuit_digest, 32, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dp.p, pi_hash, 32, hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) { mp2g_prover_free(pr); return fail("pcs_prove setup: %s", hipGetErrorString(e)); }
+  rc = mp2g_prover_set_preprocessed_dev(pr, dv[0].p);
+  if (!rc) rc = mp2g_prover_prove_dev(pr, dptr, dd.p, dp.p, dcaps.p, dopen.p, dproof.p);
+  if (!rc) {
+    e = hipMemcpyAsync(caps, dcaps.p, P.n_oracles * pr->capw * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(openings, dopen.p, pr->n_open * 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(proof, dproof.p, pr->proof_words * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail("pcs_prove copy-out: %s", hipGetErrorString(e));
+  }
+  mp2g_prover_free(pr);
+  return rc;
+}
+
+}  // extern "C"
