@@ -170,6 +170,38 @@ int mp2g_pcs_prove(mp2g_ctx* ctx, const mp2g_fri_params* params, const uint64_t*
                    const uint64_t circuit_digest[4], const uint64_t pi_hash[4], uint64_t* caps,
                    uint64_t* openings, uint64_t* proof);
 
+/* ---- Ecgfp5 multiset digest (off-circuit value side) -------------------------------------- */
+/* A point is returned as its canonical 5-limb encoding w = y/x (plonky2_ecgfp5 Point::encode;
+ * the form the reference's known-answer test holds, sswu_value.rs:88-118) and/or as the 11-limb
+ * short-Weierstrass form [x0..x4, y0..y4, is_inf] of mp2-common/src/group_hashing/mod.rs:163-174.
+ * Either output pointer may be NULL. */
+/* map_to_curve_point (field_to_curve.rs:36-48) of `count` inputs of in_len limbs each */
+int mp2g_map_to_curve_batch(mp2g_ctx* ctx, int variant, const uint64_t* in, uint32_t in_len, uint32_t count,
+                            uint64_t* out_w /* [count][5] */, uint64_t* out_weierstrass /* [count][11] */);
+/* add_curve_point (curve_add.rs:17-22) over `count` encoded points; fails on an invalid encoding */
+int mp2g_curve_sum(mp2g_ctx* ctx, const uint64_t* pts_w /* [count][5] */, uint32_t count, uint64_t out_w[5],
+                   uint64_t out_weierstrass[11]);
+/* scalar * point for 128-bit scalars given as 4 little-endian u32 limbs (hash_to_int_value,
+ * mp2-common/src/poseidon.rs:120-133) */
+int mp2g_scalar_mul_batch(mp2g_ctx* ctx, const uint64_t* pts_w /* [count][5] */, const uint32_t* scalars /* [count][4] */,
+                          uint32_t count, uint64_t* out_w /* [count][5] */, uint64_t* out_weierstrass);
+/* field_hashed_scalar_mul (group_hashing/mod.rs:220-225): HashToInt(H(inputs)) * base */
+int mp2g_field_hashed_scalar_mul(mp2g_ctx* ctx, int variant, const uint64_t* inputs, uint32_t n_inputs,
+                                 const uint64_t base_w[5], uint64_t out_w[5], uint64_t out_weierstrass[11]);
+/* compute_table_row_digest (mp2-v1/src/values_extraction/mod.rs:527-571):
+ *   sum over rows of row_id * sum over columns of D(id_c || value_c), row_id =
+ *   HashToInt(H(H(unique column values) || n_cols)).
+ * col_ids [n_cols]; values [rows][n_cols][8] and unique [rows][n_unique][8]: each U256 as 8
+ * big-endian u32 words, most significant first (mp2-common/src/u256.rs:870-877). */
+int mp2g_row_digest_batch(mp2g_ctx* ctx, int variant, const uint64_t* col_ids, uint32_t n_cols,
+                          const uint32_t* values, const uint32_t* unique, uint32_t n_unique, uint32_t rows,
+                          uint64_t out_w[5], uint64_t out_weierstrass[11]);
+/* same with device-resident inputs; d_frac_out [20] receives the sum in fractional coordinates
+ * (X:Z:U:T) for further accumulation, out_w / out_weierstrass are host pointers (may be NULL) */
+int mp2g_row_digest_batch_dev(mp2g_ctx* ctx, int variant, const uint64_t* d_col_ids, uint32_t n_cols,
+                              const uint32_t* d_values, const uint32_t* d_unique, uint32_t n_unique, uint32_t rows,
+                              uint64_t* d_frac_out, uint64_t out_w[5], uint64_t out_weierstrass[11]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -400,3 +400,64 @@ class BatchedProver:
         if self.h and self.ctx.h:
             load().mp2g_prover_free(self.h)
         self.h = None
+
+
+# ---- Ecgfp5 multiset digest (mp2-common/src/group_hashing) ---------------------------------
+def map_to_curve_batch(ctx, inputs, variant=POSEIDON2, weierstrass=False):
+    """map_to_curve_point for each row of `inputs`; returns encodings [count][5] (and the 11-limb
+    Weierstrass form when asked)."""
+    a = _arr(inputs)
+    count, in_len = a.shape
+    w = np.empty((count, 5), dtype=np.uint64)
+    wei = np.empty((count, 11), dtype=np.uint64) if weierstrass else None
+    _ck(load().mp2g_map_to_curve_batch(ctx.h, variant, _p(a), in_len, count, _p(w), _p(wei) if weierstrass else None))
+    return (w, wei) if weierstrass else w
+
+
+def curve_sum(ctx, pts_w, weierstrass=False):
+    a = _arr(pts_w).reshape(-1, 5)
+    w = np.empty(5, dtype=np.uint64)
+    wei = np.empty(11, dtype=np.uint64)
+    _ck(load().mp2g_curve_sum(ctx.h, _p(a), a.shape[0], _p(w), _p(wei)))
+    return (w, wei) if weierstrass else w
+
+
+def scalar_mul_batch(ctx, pts_w, scalars):
+    """scalars: python ints < 2^128 (hash_to_int_value range)."""
+    a = _arr(pts_w).reshape(-1, 5)
+    k = _arr([[(int(s) >> (32 * i)) & 0xFFFFFFFF for i in range(4)] for s in scalars], np.uint32)
+    out = np.empty((a.shape[0], 5), dtype=np.uint64)
+    _ck(load().mp2g_scalar_mul_batch(ctx.h, _p(a), _p(k), a.shape[0], _p(out), None))
+    return out
+
+
+def field_hashed_scalar_mul(ctx, inputs, base_w, variant=POSEIDON2):
+    a, b = _arr(inputs), _arr(base_w)
+    w = np.empty(5, dtype=np.uint64)
+    wei = np.empty(11, dtype=np.uint64)
+    _ck(load().mp2g_field_hashed_scalar_mul(ctx.h, variant, _p(a), a.size, _p(b), _p(w), _p(wei)))
+    return w, wei
+
+
+def u256_to_limbs(values):
+    """U256 -> 8 big-endian u32 words, most significant first (mp2-common/src/u256.rs:870-877)."""
+    out = np.empty((len(values), 8), dtype=np.uint32)
+    for i, v in enumerate(values):
+        v = int(v)
+        for j in range(8):
+            out[i, j] = (v >> (32 * (7 - j))) & 0xFFFFFFFF
+    return out
+
+
+def compute_table_row_digest(ctx, col_ids, values, unique, variant=POSEIDON2):
+    """compute_table_row_digest (mp2-v1/src/values_extraction/mod.rs:527-571).
+    values: uint32 [rows][n_cols][8]; unique: uint32 [rows][n_unique][8]."""
+    ids = _arr(col_ids)
+    v = _arr(values, np.uint32)
+    u = _arr(unique, np.uint32)
+    rows, n_cols = v.shape[0], ids.size
+    n_unique = u.shape[1] if u.ndim == 3 else 0
+    w = np.empty(5, dtype=np.uint64)
+    wei = np.empty(11, dtype=np.uint64)
+    _ck(load().mp2g_row_digest_batch(ctx.h, variant, _p(ids), n_cols, _p(v), _p(u), n_unique, rows, _p(w), _p(wei)))
+    return w, wei
