@@ -202,6 +202,28 @@ int mp2g_row_digest_batch_dev(mp2g_ctx* ctx, int variant, const uint64_t* d_col_
                               const uint32_t* d_values, const uint32_t* d_unique, uint32_t n_unique, uint32_t rows,
                               uint64_t* d_frac_out, uint64_t out_w[5], uint64_t out_weierstrass[11]);
 
+/* ---- proof wire format between tree levels / GPUs ------------------------------------------ */
+/* bincode 1.3 (little-endian fixed-width ints, u64 length prefixes) serialization of plonky2's
+ * ProofWithPublicInputs<F, C, 2> exactly as mp2-common/src/proof.rs:84-98 `serialize_proof`
+ * produces it, from the prover's flat outputs. `caps` = [n_oracles][1<<cap][4] (oracle 0, the
+ * preprocessed one, is not part of a proof and is skipped); `openings` as produced by the prover
+ * ([sum w][2] at zeta in oracle order, then [zs_count][2] at g*zeta); the first num_constants
+ * polynomials of oracle 0 are `constants`, the rest `plonk_sigmas`; the first zs_count of oracle
+ * zs_oracle are `plonk_zs`, the rest `partial_products`; lookup vectors are empty.
+ * Call with out = NULL to get the size in *out_len. */
+int mp2g_proof_serialize(const mp2g_fri_params* params, uint32_t num_constants, const uint64_t* caps,
+                         const uint64_t* openings, const uint64_t* fri_proof, const uint64_t* public_inputs,
+                         uint32_t n_public_inputs, uint8_t* out, size_t* out_len);
+/* inverse of the above; all output arrays sized as the prover's; fails on malformed input */
+int mp2g_proof_deserialize(const mp2g_fri_params* params, uint32_t num_constants, const uint8_t* bytes, size_t len,
+                           uint64_t* caps, uint64_t* openings, uint64_t* fri_proof, uint64_t* public_inputs,
+                           uint32_t n_public_inputs);
+/* ProofWithVK::serialize (mp2-common/src/proof.rs:42-52): bincode(proof) followed by the verifier
+ * key as a length-prefixed byte blob (plonky2 VerifierOnlyCircuitData::to_bytes: cap length as
+ * u64, the cap hashes, the circuit digest). */
+int mp2g_proof_with_vk_serialize(const uint8_t* proof_bytes, size_t proof_len, const uint64_t* vk_cap,
+                                 uint32_t vk_cap_len, const uint64_t vk_circuit_digest[4], uint8_t* out, size_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

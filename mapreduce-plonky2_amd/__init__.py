@@ -461,3 +461,92 @@ def compute_table_row_digest(ctx, col_ids, values, unique, variant=POSEIDON2):
     wei = np.empty(11, dtype=np.uint64)
     _ck(load().mp2g_row_digest_batch(ctx.h, variant, _p(ids), n_cols, _p(v), _p(u), n_unique, rows, _p(w), _p(wei)))
     return w, wei
+
+
+# ---- proof wire format (mp2-common/src/proof.rs) ---------------------------------------------
+def serialize_proof(fp, num_constants, caps, openings, fri_proof, public_inputs):
+    """bincode bytes of ProofWithPublicInputs (mp2-common/src/proof.rs:84-98 serialize_proof)."""
+    caps, openings, fri_proof = _arr(caps), _arr(openings), _arr(fri_proof)
+    pis = _arr(public_inputs)
+    n = ctypes.c_size_t()
+    _ck(load().mp2g_proof_serialize(ctypes.byref(fp), num_constants, _p(caps), _p(openings), _p(fri_proof), _p(pis), pis.size, None, ctypes.byref(n)))
+    out = np.empty(n.value, dtype=np.uint8)
+    _ck(load().mp2g_proof_serialize(ctypes.byref(fp), num_constants, _p(caps), _p(openings), _p(fri_proof), _p(pis), pis.size, _p(out), ctypes.byref(n)))
+    return out.tobytes()
+
+
+def deserialize_proof(fp, num_constants, data, n_public_inputs):
+    buf = np.frombuffer(data, dtype=np.uint8).copy()
+    caps = np.zeros((fp.n_oracles, fp.cap_words), dtype=np.uint64)
+    openings = np.zeros((fp.n_openings, 2), dtype=np.uint64)
+    fri = np.zeros(fp.proof_words, dtype=np.uint64)
+    pis = np.zeros(n_public_inputs, dtype=np.uint64)
+    _ck(load().mp2g_proof_deserialize(ctypes.byref(fp), num_constants, _p(buf), ctypes.c_size_t(buf.size), _p(caps), _p(openings),
+                                      _p(fri), _p(pis), n_public_inputs))
+    return caps, openings, fri, pis
+
+
+def serialize_proof_with_vk(proof_bytes, vk_cap, vk_circuit_digest):
+    """ProofWithVK::serialize (mp2-common/src/proof.rs:42-52)."""
+    pb = np.frombuffer(proof_bytes, dtype=np.uint8).copy()
+    cap, dig = _arr(vk_cap).reshape(-1, 4), _arr(vk_circuit_digest)
+    n = ctypes.c_size_t()
+    _ck(load().mp2g_proof_with_vk_serialize(_p(pb), ctypes.c_size_t(pb.size), _p(cap), cap.shape[0], _p(dig), None, ctypes.byref(n)))
+    out = np.empty(n.value, dtype=np.uint8)
+    _ck(load().mp2g_proof_with_vk_serialize(_p(pb), ctypes.c_size_t(pb.size), _p(cap), cap.shape[0], _p(dig), _p(out), ctypes.byref(n)))
+    return out.tobytes()
+
+
+# ---- recursion-framework pieces that sit on the path ------------------------------------------
+# recursion-framework/src/universal_verifier_gadget/mod.rs:27-40, circuit_builder.rs:26
+CIRCUIT_SET_CAP_HEIGHT = 0
+RECURSION_THRESHOLD = 12
+SHRINK_LIMIT = 15
+MIN_CIRCUIT_SIZE = 64
+NUM_HASH_OUT_ELTS = 4
+
+
+def hash_pad_input(values):
+    """plonky2 Hasher::hash_pad padding: append 1, zeros to rate-1 (mod 8), append 1."""
+    v = [int(x) for x in values] + [1]
+    while (len(v) + 1) % 8:
+        v.append(0)
+    return v + [1]
+
+
+def circuit_digest(ctx, constants_sigmas_cap, degree_bits, variant=POSEIDON2):
+    """recursion-framework/src/universal_verifier_gadget/circuit_set.rs:136-158:
+    H(flatten(constants_sigmas_cap) || H_pad([]) || degree_bits) (no domain separator)."""
+    cap = [int(x) for x in _arr(constants_sigmas_cap).reshape(-1)]
+    domain_sep = [int(x) for x in ctx.hash_no_pad(hash_pad_input([]), variant)]
+    return ctx.hash_no_pad(cap + domain_sep + [degree_bits], variant)
+
+
+class CircuitSet:
+    """Merkle set of circuit digests (circuit_set.rs:173-237): leaves in insertion order, padded
+    to a power of two with [0] leaves, cap height 0; the root is the 4 extra public inputs of
+    every framework proof (circuit_builder.rs:169-171)."""
+
+    def __init__(self, ctx, digests, variant=POSEIDON2):
+        d = _arr(digests).reshape(-1, 4)
+        self.digests = d
+        n = max(1, d.shape[0])
+        size = 1 << (n - 1).bit_length()
+        leaves = np.zeros((size, 4), dtype=np.uint64)
+        leaves[:d.shape[0]] = d
+        self.tree = MerkleTree(ctx, leaves, CIRCUIT_SET_CAP_HEIGHT, variant)
+
+    def circuit_set_digest(self):
+        return self.tree.cap[0]
+
+    def membership_proof(self, digest):
+        """(leaf index little-endian bits, siblings) as set_circuit_membership_target assigns them
+        (circuit_set.rs:205-237)."""
+        digest = _arr(digest)
+        hits = [i for i in range(self.digests.shape[0]) if np.array_equal(self.digests[i], digest)]
+        if not hits:
+            raise KeyError("circuit digest not found")  # circuit_set.rs:212 "circuit digest not found"
+        idx = hits[0]
+        _, sib = self.tree.prove([idx])
+        bits = [(idx >> i) & 1 for i in range(self.tree.log_leaves)]
+        return bits, sib[0]

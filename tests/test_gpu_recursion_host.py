@@ -1,0 +1,77 @@
+"""Recursion-framework pieces on the path and the off-circuit tree hashes
+(a13) through the HIP hashing kernels, against the oracle."""
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def o_hash(v, variant=0):
+    return O.hash_n_to_m_no_pad(O.arr(v), 4, variant)
+
+
+def test_circuit_digest_formula(ctx, mp2):
+    """circuit_set.rs:136-158: 64 cap limbs + 4 (H_pad([])) + 1 = 69 limbs."""
+    cap = O.rand_field((16, 4), 9)
+    got = mp2.circuit_digest(ctx, cap, 12)
+    pad = np.zeros(4, dtype=np.uint64)
+    empty = O.arr([])
+    O.lib().orc_hash_pad(0, O.p(np.zeros(1, dtype=np.uint64)), O.sz(0), O.p(pad))
+    inp = list(cap.reshape(-1)) + list(pad) + [12]
+    assert len(inp) == 69
+    assert np.array_equal(got, o_hash(inp))
+
+
+@pytest.mark.parametrize("n_digests", [1, 3, 4, 7])
+def test_circuit_set(ctx, mp2, n_digests):
+    """Set sizes 3/4/7 occur in-tree (row_tree/api.rs:47, cells_tree/api.rs:143, values_extraction/api.rs:377)."""
+    digests = O.rand_field((n_digests, 4), 21 + n_digests)
+    cs = mp2.CircuitSet(ctx, digests)
+    size = 1 << (n_digests - 1).bit_length()
+    leaves = np.zeros((size, 4), dtype=np.uint64)
+    leaves[:n_digests] = digests
+    lv = O.merkle_build(leaves, 0)
+    root = O.merkle_cap(lv, 0)[0]
+    assert np.array_equal(cs.circuit_set_digest(), root)
+    for i in range(n_digests):
+        bits, sib = cs.membership_proof(digests[i])
+        assert sum(b << k for k, b in enumerate(bits)) == i
+        assert O.merkle_verify(digests[i], i, sib, root.reshape(1, 4))
+    with pytest.raises(KeyError):
+        cs.membership_proof(O.rand_field(4, 999))
+
+
+def test_cell_and_row_tree_hash_shapes(ctx, mp2):
+    """mp2-v1/src/indexing/cell.rs:120-157: H(hL || hR || id || value) = 17 limbs;
+    row.rs:257-317: H(hL || hR || min || max || id || value || cells_root) = 37 limbs."""
+    for width in (17, 37):
+        x = O.rand_field((1000, width), width)
+        assert np.array_equal(ctx.hash_no_pad_batch(x), O.hash_no_pad_batch(x))
+
+
+def test_full_scale_properties(ctx, mp2):
+    """BASELINE config 2(ii) at full size through size-independent properties: every opened leaf
+    of the 135 x 2^15 commitment verifies against the cap, and the LDE restricted to the first
+    coset agrees with a direct coset evaluation of the coefficients."""
+    log_n, w = 15, 135
+    vals = O.rand_field((w, 1 << log_n), 0xC0FFEE02 + 1000)
+    b = mp2.PolynomialBatch.from_values(ctx, vals, 3, 4)
+    cap = b.cap
+    N = 1 << (log_n + 3)
+    rng = np.random.default_rng(1)
+    idx = [0, N - 1] + [int(x) for x in rng.integers(0, N, size=26)]
+    leaves, sib = b.open(idx)
+    for k, i in enumerate(idx):
+        assert O.merkle_verify(leaves[k], i, sib[k], cap)
+    # leaf 0 = evaluations at g * w^bitrev(0) = g
+    coeffs = b.coeffs
+    assert np.array_equal(ctx.ntt(coeffs[:4], inverse=False), vals[:4])  # round trip of the iNTT
+    g = O.MULT_GEN
+    for p in range(0, w, 45):
+        acc = 0
+        for c in reversed([int(t) for t in coeffs[p]]):
+            acc = (acc * g + c) % O.P
+        assert acc == int(leaves[0][p])
+    b.free()

@@ -1,0 +1,90 @@
+"""Host logic that needs no GPU: bincode proof wire format (round trip, layout), sharding plans,
+FRI parameter derivation."""
+import ctypes
+import struct
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+
+def make_fp(mp2, log_n=6, ws=(5, 9, 4, 3)):
+    ofp = O.standard_params(log_n, ws, pow_bits=4, num_queries=3)
+    fp = mp2.FriParams()
+    ctypes.memmove(ctypes.byref(fp), ctypes.byref(ofp), ctypes.sizeof(fp))
+    return ofp, fp
+
+
+def test_params_match_oracle(mp2):
+    for k in (5, 6, 12, 13, 14, 15):
+        ofp = O.standard_params(k)
+        fp = mp2.standard_recursion_params(k)
+        assert bytes(fp) == bytes(ofp)
+        assert fp.proof_words == O.lib().orc_fri_proof_words(ctypes.byref(ofp))
+        assert fp.n_openings == O.lib().orc_n_openings(ctypes.byref(ofp))
+
+
+def test_proof_wire_round_trip_and_layout(mp2):
+    ofp, fp = make_fp(mp2)
+    n = 1 << fp.log_n
+    vals = [O.rand_field((w, n), 40 + i) for i, w in enumerate((5, 9, 4, 3))]
+    cd, ph = O.rand_field(4, 1), O.rand_field(4, 2)
+    caps, openings, proof = O.pcs_prove(ofp, vals, cd, ph)  # the oracle as the producer of a valid proof
+    pis = O.rand_field(7, 3)
+    data = mp2.serialize_proof(fp, 2, caps, openings, proof, pis)
+    # bincode: first field is wires_cap = Vec<HashOut>: u64 length 16 then 64 limbs
+    assert struct.unpack_from("<Q", data, 0)[0] == 16
+    assert np.array_equal(np.frombuffer(data, dtype="<u8", count=64, offset=8), caps[1])
+    # trailing: public_inputs Vec<F>
+    assert np.array_equal(np.frombuffer(data[-56:], dtype="<u8"), pis)
+    assert struct.unpack_from("<Q", data, len(data) - 64)[0] == 7
+    c2, o2, p2, pi2 = mp2.deserialize_proof(fp, 2, data, 7)
+    assert np.array_equal(c2[1:], caps[1:]) and np.array_equal(o2, openings) and np.array_equal(p2, proof)
+    assert np.array_equal(pi2, pis)
+    # a deserialized proof still verifies
+    c2[0] = caps[0]
+    assert O.pcs_verify(ofp, cd, ph, c2, o2, p2) == 0
+    # malformed inputs are rejected
+    with pytest.raises(mp2.Mp2gError):
+        mp2.deserialize_proof(fp, 2, data[:-8], 7)
+    bad = bytearray(data)
+    bad[8:16] = struct.pack("<Q", 0xFFFFFFFFFFFFFFFF)  # non-canonical field element
+    with pytest.raises(mp2.Mp2gError):
+        mp2.deserialize_proof(fp, 2, bytes(bad), 7)
+
+
+def test_proof_with_vk_blob(mp2):
+    proof = bytes(range(40))
+    cap = O.rand_field((16, 4), 1)
+    dig = O.rand_field(4, 2)
+    out = mp2.serialize_proof_with_vk(proof, cap, dig)
+    assert out[:40] == proof
+    blob_len = struct.unpack_from("<Q", out, 40)[0]
+    assert blob_len == len(out) - 48 == 8 + 16 * 32 + 32
+    assert struct.unpack_from("<Q", out, 48)[0] == 16
+
+
+def test_shard_ranges_cover(mp2):
+    sh = __import__("importlib").import_module("mapreduce-plonky2_amd.sharding")
+    for n, world in ((1 << 20, 8), (1024, 3), (5, 8), (0, 4)):
+        got = [sh.shard_range(n, r, world) for r in range(world)]
+        assert got[0][0] == 0 and got[-1][1] == n
+        assert all(got[i][1] == got[i + 1][0] for i in range(world - 1))
+        for i in range(0, n, max(1, n // 97)):
+            r = sh.owner_of(i, n, world)
+            assert got[r][0] <= i < got[r][1]
+
+
+def test_tree_handoff_plan(mp2):
+    sh = __import__("importlib").import_module("mapreduce-plonky2_amd.sharding")
+    # 1024 leaves, binary tree, 8 ranks: 1023 parents; only the top log2(8)=3 levels move proofs
+    plan = sh.subtree_plan(1024, 2, 8)
+    assert sum(len(l) for l in plan) == 1023
+    moves = sh.tree_handoff_plan(1024, 2, 8)
+    assert len(moves) == 4 + 2 + 1 and {m[0] for m in moves} == {7, 8, 9}
+    # children before parents: every child index at level l was produced at level l-1
+    for l, lvl in enumerate(plan[1:], 1):
+        produced = {node for node, _, _ in plan[l - 1]}
+        assert all(c in produced for _, _, ch in lvl for c in ch)
+    assert sh.tree_handoff_plan(64, 2, 1) == []
