@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric on the MI355X hot path.
+"""bench.py -- BASELINE.json metric ("leaf proofs/sec (whole node) + NTT GB/s vs HBM peak") on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): BASELINE.json configs[1], "2^22-point Goldilocks NTT + Poseidon
-Merkle-cap on 1 MI355X" with the concrete shapes of SURVEY 8(d) config 2, seed 0xC0FFEE02:
-  (i)  one 2^22-point forward NTT (coefficients -> evaluations),
-  (ii) PolynomialBatch::from_values of a 135 x 2^15 wire matrix: 135 iNTTs, LDE x8 on the coset
-       g<w>, Poseidon2 leaf sponge over 2^18 leaves of 135 limbs, Merkle tree to a 16-hash cap.
-(ii) is exactly the wires commitment of one 2^15-row leaf proof at standard_recursion_config.
-One step = (i) + (ii), inputs resident in HBM. `value` = commitment-equivalent leaf proofs per
-second over all ranks (each rank runs its own independent steps: the map-reduce leaf proofs shard
-with no data-path collective, "scaling": "weak").  The NTT GB/s-vs-HBM-peak half of the metric is
-the `roofline` object (algorithmic 16 B/point over the measured duration of the NTT launches).
+Workload. The metric is quoted on the 2^20-row table build (configs[3]); its unit of work is the
+framework leaf proof, which the recursion framework always produces as one base `prove()` plus
+one wrap `prove()` down to 2^12 rows (recursion-framework/src/circuit_builder.rs:286-311,
+wrap_circuit.rs:122-148). One step = one batch of `--batch` such leaf proofs, shaped as SURVEY
+8(d) config 3 says (base 2^13 + wrap 2^12, standard_recursion_config: 84 constants/sigmas + 135
+wires + 20 Z/partial products + 16 quotient chunks, rate 1/8, cap 16, FRI [4,4], 16-bit PoW, 28
+queries), on synthetic witness matrices that are resident in HBM before the timed region. What
+runs per proof is the whole commitment / Fiat-Shamir / opening / FRI pipeline of `prove()`
+(HOT LOOPS 1 and 3 of SURVEY 3.1); witness generation and gate-constraint evaluation (HOT LOOP 2,
+SURVEY 8(f)-1 "next") are not part of this round and the polynomials are random -- see DESIGN.md.
+Leaf proofs shard across ranks with no data-path collective ("scaling": "weak"); the per-rank
+multiset digests meet in one 160-byte all_gather outside the per-proof path.
+
+The NTT half of the metric is the `roofline` object: BASELINE configs[1]'s 2^22-point forward NTT,
+timed with HIP events on the context's stream in this same run, algorithmic 16 B/point.
 """
 import argparse
+import ctypes
 import importlib
 import json
 import os
@@ -30,29 +36,36 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 LOG_NTT = 22
-LOG_N, W, RATE, CAP = 15, 135, 3, 4
-SEED = 0xC0FFEE02
+ORACLE_W = (84, 135, 20, 16)
+SEED = 0xC0FFEE03
 
 
-def cpu_baseline(log_ntt, reps=3):
-    """CPU oracle (our restatement of the plonky2 FFT; 'port'), one thread, bounded sample."""
+def cpu_baseline(base_bits, n_proofs=1):
+    """The CPU oracle (our restatement of the same pipeline; kind 'port'), OpenMP over
+    polynomials / leaves on all host cores, on a bounded sample of the same workload."""
     import oracle as O
-    a = O.rand_field((1, 1 << log_ntt), SEED)
-    os.environ.setdefault("OMP_NUM_THREADS", "1")
-    O.fft(a[:, :1024])
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        O.fft(a)
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": 16.0 * (1 << log_ntt) / dt / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} x 2^{log_ntt}-point forward NTT by oracle/ntt.c (radix-2, single thread)"}
+    cores = os.cpu_count() or 1
+    t_total = 0.0
+    for k in (base_bits, 12):
+        ofp = O.standard_params(k, ORACLE_W)
+        vals = [O.rand_field((w, 1 << k), SEED + i) for i, w in enumerate(ORACLE_W)]
+        cd, ph = O.rand_field(4, 1), O.rand_field(4, 2)
+        t0 = time.perf_counter()
+        for _ in range(n_proofs):
+            O.pcs_prove(ofp, vals, cd, ph)
+        t_total += time.perf_counter() - t0
+    return {"value": n_proofs / t_total, "unit": "leaf proofs/s", "cores": cores, "kind": "port",
+            "sample": f"{n_proofs} leaf proof(s) = base 2^{base_bits} + wrap 2^12 PCS pipelines by oracle/ (OpenMP, {cores} threads; "
+                      "FRI composition and transcript are single-threaded)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="leaf proofs per step and rank")
+    ap.add_argument("--base-bits", type=int, default=13)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -67,34 +80,49 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
-    import oracle as O  # only for the synthetic input stream and the cpu_baseline leg
+    sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
+    import oracle as O  # synthetic input stream + cpu_baseline leg only
     ctx = mp2.Context(local_rank)
+    B = args.batch
 
-    # ---- synthetic inputs, resident in HBM before the timed region
+    # ---- synthetic inputs, resident in HBM before the timed region -----------------------------
+    provers = []
+    for k in (args.base_bits, 12):
+        fp = mp2.standard_recursion_params(k, ORACLE_W)
+        n = 1 << k
+        pr = mp2.BatchedProver(ctx, fp, B)
+        pr.set_preprocessed(ctx.to_device(O.rand_field((ORACLE_W[0], n), SEED + k)))
+        # one random matrix per oracle, tiled over the batch (distinct public-input hashes keep
+        # the B transcripts, challenges and proofs distinct)
+        d_vals = []
+        for i, w in enumerate(ORACLE_W[1:]):
+            one = O.rand_field((w, n), SEED + 100 * k + i + 1000 * rank)
+            buf = ctx.alloc(B * w * n * 8)
+            for b in range(B):
+                mp2._ck(mp2.load().mp2g_h2d(ctx.h, ctypes.c_void_p(buf.ptr.value + b * w * n * 8), mp2._p(one), ctypes.c_size_t(one.nbytes)))
+            d_vals.append(buf)
+        d_cd = ctx.to_device(O.rand_field(4, SEED + 7))
+        d_ph = ctx.to_device(O.rand_field((B, 4), SEED + 8 + rank))
+        provers.append((pr, d_vals, d_cd, d_ph))
     n_ntt = 1 << LOG_NTT
-    d_poly = ctx.to_device(O.rand_field((1, n_ntt), SEED + rank))
+    d_poly = ctx.to_device(O.rand_field((1, n_ntt), 0xC0FFEE02 + rank))
     d_out = ctx.alloc(n_ntt * 8)
-    d_wires = ctx.to_device(O.rand_field((W, 1 << LOG_N), SEED + 1000 + rank))
-    batch = mp2.PolynomialBatch.from_values_dev(ctx, d_wires, LOG_N, W, RATE, CAP)
 
     def step():
-        ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
-        batch.recommit_from_values_dev(d_wires)
+        for pr, d_vals, d_cd, d_ph in provers:
+            pr.prove(d_vals, d_cd, d_ph)
 
     for _ in range(args.warmup):
         step()
     ctx.sync()
-    # dominant-kernel timing for the roofline line: HIP events on the context's stream
+
+    # roofline leg: the 2^22 NTT, HIP events on the stream the kernels are launched on
+    ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
     ntt_ms = []
-    for _ in range(5):
+    for _ in range(10):
         ctx.timer_start()
         ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
         ntt_ms.append(ctx.timer_stop())
-    commit_ms = []
-    for _ in range(3):
-        ctx.timer_start()
-        batch.recommit_from_values_dev(d_wires)
-        commit_ms.append(ctx.timer_stop())
 
     def barrier():
         if dist is not None:
@@ -114,29 +142,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the per-rank multiset digest meets in one all_gather (outside the per-proof path)
+    rows = 1 << 12
+    rng = np.random.default_rng(0xC0FFEE04 + rank)
+    col_ids = O.rand_field(4, 0xC0FFEE04)
+    values = rng.integers(0, 1 << 32, size=(rows, 4, 8), dtype=np.uint32)
+    unique = values[:, :1, :].copy()
+    t1 = time.perf_counter()
+    w, _ = mp2.compute_table_row_digest(ctx, col_ids, values, unique)
+    digest_s = time.perf_counter() - t1
+    if dist is not None:
+        allw = sharding.all_gather_words(dist, w, device=torch.device("cuda", local_rank))
+        w = mp2.curve_sum(ctx, allw)
+
     if rank == 0:
         ntt_s = float(np.median(ntt_ms)) / 1e3
         achieved = 16.0 * n_ntt / ntt_s / 1e9
         out = {
             "metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak",
-            "value": world * args.steps / dt,
-            "unit": "commitment-equivalent leaf proofs/s (one 2^22 NTT + one 135x2^15 wires commitment each)",
+            "value": world * args.steps * B / dt,
+            "unit": "leaf proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 (Goldilocks)", "data": "synthetic",
-            "config": {"workload": "configs[1]: 2^22-point Goldilocks NTT + 135x2^15 -> 2^18-leaf Poseidon2 Merkle cap(4)",
-                       "log_ntt": LOG_NTT, "commit": f"{W}x2^{LOG_N}, rate_bits {RATE}, cap_height {CAP}",
-                       "hasher": "Poseidon2", "sharding": f"{world} independent ranks"},
-            "roofline": {"bound": "hbm", "kernel": "ntt_cols_kernel<11>+ntt_rows_kernel<11> (2^22 forward)",
+            "dtype": "u64 (Goldilocks field)", "data": "synthetic",
+            "config": {"workload": f"configs[3]-shaped leaf proofs: base 2^{args.base_bits} + wrap 2^12 prove() PCS pipeline "
+                                   "(commitments, Fiat-Shamir, openings, FRI) at standard_recursion_config; "
+                                   "roofline leg = configs[1] 2^22-point NTT",
+                       "batch_per_rank": B, "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
+                       "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B"},
+            "roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, both launches)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "launch_ms": ntt_s * 1e3, "algorithmic_bytes": 16 * n_ntt},
-            "commit_ms": float(np.median(commit_ms)),
-            "merkle_perms_per_s": ((1 << (LOG_N + RATE)) * 17 + (2 << (LOG_N + RATE)) - 16) / (float(np.median(commit_ms)) / 1e3),
+            "digest_rows_per_s": rows / digest_s,
+            "digest_check": [int(x) for x in w],
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(LOG_NTT)
+            out["cpu_baseline"] = cpu_baseline(args.base_bits)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

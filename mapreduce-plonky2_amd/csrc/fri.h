@@ -45,6 +45,8 @@ hipError_t fri_fold_values(hipStream_t s, u32 B, u32 log_m, u32 ab, const u64* i
 hipError_t fri_fold_coeffs(hipStream_t s, u32 B, u32 n_in, u32 ab, const u64* in, u64 in_bstride, u64* out, u64 out_bstride,
                            const u64* beta, u64 beta_bstride, bool aos_out);
 hipError_t fri_soa_to_aos(hipStream_t s, u32 B, u32 n, const u64* in, u64 in_bstride, u32 n_in, u64* out, u64 out_bstride);
+// witness: B * FRI_POW_STRIDE words, proof b's result at witness[b * FRI_POW_STRIDE]
+#define FRI_POW_STRIDE 16
 hipError_t fri_pow(hipStream_t s, int variant, const ChState* st, u32 B, u32 bits, u64* witness);
 hipError_t fri_queries(hipStream_t s, const FriShape& sh, const FriLayers& ly, u32 B, u32 num_queries, const u64* chal,
                        u64 chal_bstride, u64* proof, u64 proof_bstride, u64 q_off, u64 q_words);

@@ -268,11 +268,20 @@ __global__ void soa_to_aos_kernel(u32 n, const u64* in, u64 in_bstride, u32 n_in
 }
 
 // ---- proof of work ----------------------------------------------------------------------------
-// witness[b] = min { w : perm(state with w at position n_in)[7] has >= bits leading zeros }
+// witness[b * POW_STRIDE] = min { w : perm(state with w at position n_in)[7] has >= bits leading zeros }.
+// POW_BLOCKS blocks of 1024 lanes per proof sweep the candidates in order. Blocks of one proof
+// talk through one word: a finder publishes with atomicMin, and once per sweep lane 0 of every
+// block reads it back with a returning (no-op) atomicMin -- the per-XCD L2s are not coherent, a
+// plain or sc1 load of a word that another XCD updates atomically can stay stale for seconds,
+// while an atomic executes at the coherence point. Each proof's word sits in its own 128-B line.
+#define POW_BLOCKS 16
+#define POW_STRIDE 16
 template <int V>
-__global__ void __launch_bounds__(256) pow_kernel(const ChState* st, u32 bits, unsigned long long* witness) {
+__global__ void __launch_bounds__(1024) pow_kernel(const ChState* st, u32 bits, unsigned long long* witness) {
   const u32 b = blockIdx.y;
   const ChState& c = st[b];
+  unsigned long long* wit = witness + (u64)b * POW_STRIDE;
+  __shared__ unsigned long long s_best;
   u64 base[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) base[i] = c.state[i];
@@ -282,8 +291,12 @@ __global__ void __launch_bounds__(256) pow_kernel(const ChState* st, u32 bits, u
     if ((u32)i < pos) base[i] = c.in[i];
   const u64 stride = (u64)gridDim.x * blockDim.x;
   for (u64 cand = (u64)blockIdx.x * blockDim.x + threadIdx.x;; cand += stride) {
-    unsigned long long best = __hip_atomic_load(&witness[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cand > best || cand >= GL_P) break;
+    if (threadIdx.x == 0) s_best = atomicMin(wit, ~0ull);
+    __syncthreads();
+    const unsigned long long best = s_best;
+    __syncthreads();
+    // block-uniform exit: the block's smallest candidate of this sweep is already beaten
+    if (cand - threadIdx.x > best) break;
     u64 s[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = base[i];
@@ -291,7 +304,7 @@ __global__ void __launch_bounds__(256) pow_kernel(const ChState* st, u32 bits, u
     for (int i = 0; i < 8; i++)
       if ((u32)i == pos) s[i] = cand;
     perm<V>(s);
-    if (bits == 0 || (s[7] >> (64 - bits)) == 0) { atomicMin(&witness[b], (unsigned long long)cand); break; }
+    if (cand < GL_P && (bits == 0 || (s[7] >> (64 - bits)) == 0)) atomicMin(wit, (unsigned long long)cand);
   }
 }
 __global__ void fill_u64_kernel(u64* p, u64 v, u32 n) {
@@ -385,8 +398,8 @@ hipError_t fri_soa_to_aos(hipStream_t s, u32 B, u32 n, const u64* in, u64 in_bst
   return hipGetLastError();
 }
 hipError_t fri_pow(hipStream_t s, int variant, const ChState* st, u32 B, u32 bits, u64* witness) {
-  hipLaunchKernelGGL(fill_u64_kernel, dim3((B + 63) / 64), dim3(64), 0, s, witness, ~(u64)0, B);
-  dim3 g(256, B), bl(256);  // 2^16 candidates per sweep
+  hipLaunchKernelGGL(fill_u64_kernel, dim3((B * POW_STRIDE + 63) / 64), dim3(64), 0, s, witness, ~(u64)0, B * POW_STRIDE);
+  dim3 g(POW_BLOCKS, B), bl(1024);  // 2^14 candidates per sweep and proof
   if (variant == MP2G_POSEIDON2) hipLaunchKernelGGL((pow_kernel<MP2G_POSEIDON2>), g, bl, 0, s, st, bits, (unsigned long long*)witness);
   else hipLaunchKernelGGL((pow_kernel<MP2G_POSEIDON>), g, bl, 0, s, st, bits, (unsigned long long*)witness);
   return hipGetLastError();

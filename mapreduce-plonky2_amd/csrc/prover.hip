@@ -166,7 +166,7 @@ int mp2g_fri_pow(mp2g_ctx* c, int variant, const uint64_t state[12], uint32_t po
   h.n_in = pos;
   DevBuf ds, dw;
   CK(ds.alloc(sizeof(ChState)));
-  CK(dw.alloc(sizeof(u64)));
+  CK(dw.alloc(FRI_POW_STRIDE * sizeof(u64)));
   CK(hipMemcpyAsync(ds.p, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
   CK(fri_pow(c->stream, variant, (const ChState*)ds.p, 1, bits, dw.p));
   CK(hipMemcpyAsync(witness, dw.p, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -205,7 +205,7 @@ int mp2g_prover_create(mp2g_ctx* c, const mp2g_fri_params* params, uint32_t batc
   if (e == hipSuccess) e = pr->ch.alloc(B * sizeof(ChState));
   A(pr->chal, B * 8); A(pr->zeta, B * 2); A(pr->alpha, B * 2); A(pr->betas, B * 16);
   A(pr->comp, B * 4 * n); A(pr->quot, B * 4 * n); A(pr->final_poly, B * 2 * n);
-  A(pr->witness, B); A(pr->qchal, B * (P.num_queries ? P.num_queries : 1));
+  A(pr->witness, B * FRI_POW_STRIDE); A(pr->qchal, B * (P.num_queries ? P.num_queries : 1));
   size_t m = N, nc = n;
   uint32_t clg = lg;
   A(pr->fvals[0], B * 2 * m);
@@ -324,8 +324,8 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
   if (P.n_layers == 0) CK(fri_soa_to_aos(s, B, (u32)n, pr->final_poly.p, 2 * n, (u32)n, proof + pr->final_off, pr->proof_words));
   CK(challenger_step(s, V, st, B, proof + pr->final_off, pr->proof_words, (u32)(2 * pr->final_len), chal, 8, 0));
   CK(fri_pow(s, V, st, B, P.pow_bits, pr->witness.p));
-  CK(copy_rows(s, B, pr->witness.p, 1, proof + pr->final_off + 2 * pr->final_len, pr->proof_words, 1));
-  CK(challenger_step(s, V, st, B, pr->witness.p, 1, 1, chal, 8, 1));  // observe witness, draw pow response
+  CK(copy_rows(s, B, pr->witness.p, FRI_POW_STRIDE, proof + pr->final_off + 2 * pr->final_len, pr->proof_words, 1));
+  CK(challenger_step(s, V, st, B, pr->witness.p, FRI_POW_STRIDE, 1, chal, 8, 1));  // observe witness, draw pow response
   if (P.num_queries) {
     CK(challenger_step(s, V, st, B, chal, 0, 0, pr->qchal.p, P.num_queries, P.num_queries));
     CK(fri_queries(s, sh, ly, B, P.num_queries, pr->qchal.p, P.num_queries, proof, pr->proof_words, pr->q_off, pr->q_words));
