@@ -19,54 +19,92 @@
 #define c_p2_diag POSEIDON2_DIAG_M1
 #define c_p_rc POSEIDON_RC
 
-// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] with additions only (HorizenLabs matmul_m4)
-GLD void p2_m4(u64& a, u64& b, u64& c, u64& d) {
-  u64 t0 = gl_add(a, b), t1 = gl_add(c, d);
-  u64 t2 = gl_add(gl_dbl(b), t1), t3 = gl_add(gl_dbl(d), t0);
-  u64 t4 = gl_add(gl_dbl(gl_dbl(t1)), t3), t5 = gl_add(gl_dbl(gl_dbl(t0)), t2);
-  u64 t6 = gl_add(t3, t5), t7 = gl_add(t2, t4);
-  a = t6; b = t5; c = t7; d = t4;
+// ---- Poseidon2, weak-representative form ------------------------------------------------------
+// State limbs are arbitrary u64 representatives between rounds (gl.cuh "weak"); outputs are
+// canonicalised once at the end. Linear layers run on the 32-bit halves of the limbs in plain
+// 64-bit arithmetic (all weights are small) and reduce once per output limb.
+// x <- (x + rc)^7 ; x any u64, rc canonical
+GLHD u64 p2_sbox(u64 x, u64 rc) {
+  u64 t = gl_addw(x, rc);
+  u64 t2 = gl_mulw(t, t), t4 = gl_mulw(t2, t2), t3 = gl_mulw(t, t2);
+  return gl_mulw(t3, t4);
 }
-GLD void p2_external(u64 s[12]) {
-  p2_m4(s[0], s[1], s[2], s[3]);
-  p2_m4(s[4], s[5], s[6], s[7]);
-  p2_m4(s[8], s[9], s[10], s[11]);
+// M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] with additions only (HorizenLabs matmul_m4), on
+// un-reduced integers: inputs < 2^32 give outputs < 2^37.
+GLHD void p2_m4_plain(u64& a, u64& b, u64& c, u64& d) {
+  u64 t0 = a + b, t1 = c + d;
+  u64 t2 = (b << 1) + t1, t3 = (d << 1) + t0;
+  u64 t4 = (t1 << 2) + t3, t5 = (t0 << 2) + t2;
+  a = t3 + t5; b = t5; c = t2 + t4; d = t4;
+}
+GLHD void p2_external_half(u64 v[12]) {
+  p2_m4_plain(v[0], v[1], v[2], v[3]);
+  p2_m4_plain(v[4], v[5], v[6], v[7]);
+  p2_m4_plain(v[8], v[9], v[10], v[11]);
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    u64 sum = gl_add(gl_add(s[i], s[4 + i]), s[8 + i]);
-    s[i] = gl_add(s[i], sum);
-    s[4 + i] = gl_add(s[4 + i], sum);
-    s[8 + i] = gl_add(s[8 + i], sum);
+    u64 sum = v[i] + v[4 + i] + v[8 + i];
+    v[i] += sum; v[4 + i] += sum; v[8 + i] += sum;  // < 2^39
   }
 }
-GLD void poseidon2_perm(u64 s[12]) {
+// circ(2 M4, M4, M4) on weak limbs
+GLHD void p2_external(u64 s[12]) {
+  u64 lo[12], hi[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = s[i] >> 32; }
+  p2_external_half(lo);
+  p2_external_half(hi);
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    // value = lo + hi * 2^32, lo, hi < 2^39
+    u64 l;
+    bool c = __builtin_add_overflow(lo[i], hi[i] << 32, &l);
+    s[i] = gl_reduce96w(l, (hi[i] >> 32) + (c ? 1 : 0));
+  }
+}
+// s_i <- d_i s_i + sum_j s_j, exactly: 128-bit product plus the 68-bit sum, one reduction
+GLHD void p2_internal(u64 s[12]) {
+  u64 acc = s[0];
+  u64 top = 0;
+#pragma unroll
+  for (int i = 1; i < 12; i++) {
+    bool c = __builtin_add_overflow(acc, s[i], &acc);
+    top += c ? 1 : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    u64 lo, hi;
+    gl_mul_wide(s[i], c_p2_diag[i], lo, hi);  // hi <= 2^64 - 2^32 - 1: adding top + carry cannot wrap
+    bool c = __builtin_add_overflow(lo, acc, &lo);
+    s[i] = gl_reduce128w(lo, hi + top + (c ? 1 : 0));
+  }
+}
+GLHD void poseidon2_perm(u64 s[12]) {
   p2_external(s);
 #pragma unroll 1
   for (int r = 0; r < 4; r++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add(s[i], c_p2_ext[12 * r + i]));
+    for (int i = 0; i < 12; i++) s[i] = p2_sbox(s[i], c_p2_ext[12 * r + i]);
     p2_external(s);
   }
 #pragma unroll 1
   for (int r = 0; r < 22; r++) {
-    s[0] = gl_pow7(gl_add(s[0], c_p2_int[r]));
-    u64 sum = s[0];
-#pragma unroll
-    for (int i = 1; i < 12; i++) sum = gl_add(sum, s[i]);
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add(gl_mul(s[i], c_p2_diag[i]), sum);
+    s[0] = p2_sbox(s[0], c_p2_int[r]);
+    p2_internal(s);
   }
 #pragma unroll 1
   for (int r = 4; r < 8; r++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_pow7(gl_add(s[i], c_p2_ext[12 * r + i]));
+    for (int i = 0; i < 12; i++) s[i] = p2_sbox(s[i], c_p2_ext[12 * r + i]);
     p2_external(s);
   }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
 
 // Poseidon MDS: circulant [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,...]; all entries < 2^6,
 // so the 32-bit halves of the state accumulate in u64 without overflow and reduce once per row.
-GLD void poseidon_mds(u64 s[12]) {
+GLHD void poseidon_mds(u64 s[12]) {
   const u32 circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   u64 lo[12], hi[12];
 #pragma unroll
@@ -89,7 +127,7 @@ GLD void poseidon_mds(u64 s[12]) {
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = out[i];
 }
-GLD void poseidon_perm(u64 s[12]) {
+GLHD void poseidon_perm(u64 s[12]) {
 #pragma unroll 1
   for (int r = 0; r < 30; r++) {
 #pragma unroll
@@ -104,7 +142,7 @@ GLD void poseidon_perm(u64 s[12]) {
   }
 }
 template <int VARIANT>
-GLD void perm(u64 s[12]) {
+GLHD void perm(u64 s[12]) {
   if (VARIANT == MP2G_POSEIDON2) poseidon2_perm(s); else poseidon_perm(s);
 }
 // compress(l, r) = perm(l || r || 0)[0..4]   (plonky2 hashing.rs)
