@@ -14,7 +14,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmp2gpu.so")
+LIB_PATH = os.environ.get("MP2G_LIB", os.path.join(_HERE, "libmp2gpu.so"))
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mp2g.h")
 
 P = 0xFFFFFFFF00000001

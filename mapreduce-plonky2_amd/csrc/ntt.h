@@ -9,14 +9,14 @@ namespace mp2g {
 
 struct NttPlan {
   u32 log_n = 0, log_n1 = 0, log_n2 = 0;
-  u64 *tw_a = nullptr, *tw_b = nullptr, *tw4_lo = nullptr, *tw4_hi = nullptr;
+  u64 *tw_a = nullptr, *tw_b = nullptr, *tw4_lo = nullptr, *tw4_hi = nullptr, *tw4_full = nullptr;
   u64 n_inv = 0;
   ~NttPlan();
 };
 struct CosetTables {
   u32 log_n = 0, logK = 0;
   u64 shift = 0;
-  u64 *lo = nullptr, *hi = nullptr;
+  u64 *lo = nullptr, *hi = nullptr, *full = nullptr;
   ~CosetTables();
 };
 

@@ -20,7 +20,6 @@
 
 namespace mp2g {
 
-#define NTT_THREADS 256
 __device__ __forceinline__ int lds_pad(int a) { return a + (a >> 4); }
 
 struct NttArgs {
@@ -35,12 +34,19 @@ struct NttArgs {
   const u64* tw4_hi;     // w_n^(e << 12)
   const u64* pre_lo;     // [K][n2] (or [K][n] when single pass)
   const u64* pre_hi;     // [K][n1]
+  const u64* tw4_full;   // [n1][n2] in DIF row order: row j holds w_n^(i2 * bitrev(j)); null -> two-level tables
+  const u64* pre_full;   // [K][n]: s_j^i; null -> pre_lo * pre_hi
   u64 post;              // scalar multiplied on the final store (n^-1 for inverse), 0 = none
   u32 bitrev_out;
   u32 src_is_out;        // pass B of a two-pass bit-reversed transform reads `out`
 };
 
-template <int LT, int HI, int R, bool COLS, int LW>
+// lanes per block: one radix-16 item per lane and round
+template <int LT, int LW> struct NttGeom {
+  static constexpr int E = (1 << LT) << LW;
+  static constexpr int NT = E / 16 < 64 ? 64 : (E / 16 > 1024 ? 1024 : E / 16);
+};
+template <int LT, int HI, int R, bool COLS, int LW, int NTT_THREADS>
 __device__ __forceinline__ void dif_round(u64* s, const u64* tw, int tid) {
   constexpr int T = 1 << LT, LO = HI - R + 1, W = 1 << LW;
   constexpr int ITEMS = W << (LT - R);
@@ -82,13 +88,13 @@ __device__ __forceinline__ void dif_round(u64* s, const u64* tw, int tid) {
     }
   }
 }
-template <int LT, int HI, bool COLS, int LW>
+template <int LT, int HI, bool COLS, int LW, int NTT_THREADS>
 __device__ __forceinline__ void dif_all(u64* s, const u64* tw, int tid) {
   if constexpr (HI >= 0) {
     constexpr int R = (HI + 1 >= 4) ? 4 : HI + 1;
-    dif_round<LT, HI, R, COLS, LW>(s, tw, tid);
+    dif_round<LT, HI, R, COLS, LW, NTT_THREADS>(s, tw, tid);
     __syncthreads();
-    dif_all<LT, HI - R, COLS, LW>(s, tw, tid);
+    dif_all<LT, HI - R, COLS, LW, NTT_THREADS>(s, tw, tid);
   }
 }
 
@@ -100,21 +106,24 @@ __device__ __forceinline__ u64* out_base(const NttArgs& a, u32 b) {
   return a.out + (u64)(b >> a.logK) * a.out_poly_stride + ((u64)bitrev32(coset, a.logK) << a.log_n);
 }
 
+// (A persistent, register-prefetching variant of these kernels was measured and dropped: the 16
+// staged points per lane cost 32 VGPRs, pushed the kernels into spills at 4 waves/SIMD and ran
+// 15-35 % slower; the limiter is VALU issue, not HBM latency -- see DESIGN.md "NTT".)
+
 // ---- pass B / single pass: contiguous rows of length T = 2^LT, 2^LW rows per block ----------
 template <int LT, int LW>
-__global__ void __launch_bounds__(NTT_THREADS) ntt_rows_kernel(NttArgs a) {
-  constexpr int T = 1 << LT, W = 1 << LW, E = T << LW;
+__global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_kernel(NttArgs a) {
+  constexpr int T = 1 << LT, E = T << LW, NT = NttGeom<LT, LW>::NT;
   extern __shared__ __align__(16) u64 smem[];
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < T / 2; i += NTT_THREADS) tw[i] = a.tw[i];
+  for (int i = tid; i < T / 2; i += NT) tw[i] = a.tw[i];
   const u32 n1 = 1u << a.log_n1;
   const u64 total_rows = (u64)a.batch << a.log_n1;
   const u64 row0 = (u64)blockIdx.x << LW;
   const bool two_pass = a.log_n1 != 0;
-  // load
-  for (int e = tid; e < E; e += NTT_THREADS) {
+  for (int e = tid; e < E; e += NT) {
     int r = e >> LT, j = e & (T - 1);
     u64 g = row0 + r;
     u64 v = 0;
@@ -130,57 +139,44 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_rows_kernel(NttArgs a) {
     s[lds_pad(e)] = v;
   }
   __syncthreads();
-  dif_all<LT, LT - 1, false, LW>(s, tw, tid);
-  // store
-  if (a.bitrev_out) {
-    for (int e = tid; e < E; e += NTT_THREADS) {
-      int r = e >> LT, p = e & (T - 1);
-      u64 g = row0 + r;
-      if (g >= total_rows) continue;
-      u32 b = (u32)(g >> a.log_n1), jr = (u32)(g & (n1 - 1));
-      u64 v = s[lds_pad(e)];
-      if (a.post) v = gl_mul(v, a.post);
-      out_base(a, b)[((u64)jr << LT) + p] = v;
-    }
-  } else if (!two_pass) {
-    for (int e = tid; e < E; e += NTT_THREADS) {
-      int r = e >> LT, k = e & (T - 1);
-      u64 g = row0 + r;
-      if (g >= total_rows) continue;
-      u64 v = s[lds_pad((r << LT) + (int)bitrev32(k, LT))];
-      if (a.post) v = gl_mul(v, a.post);
-      out_base(a, (u32)g)[k] = v;
-    }
+  dif_all<LT, LT - 1, false, LW, NT>(s, tw, tid);
+  for (int e = tid; e < E; e += NT) {
+    int r = e >> LT, p = e & (T - 1);
+    u64 g = row0 + r;
+    if (g >= total_rows) continue;
+    u32 b = (u32)(g >> a.log_n1), jr = (u32)(g & (n1 - 1));
+    u64 v = a.bitrev_out ? s[lds_pad(e)] : s[lds_pad((r << LT) + (int)bitrev32((u32)p, LT))];
+    if (a.post) v = gl_mul(v, a.post);
+    out_base(a, b)[((u64)jr << LT) + p] = v;
   }
 }
 // Natural-order pass B of a two-pass transform: X[k1 + n1*k2]. A tile takes the rows
 // jr = (r << lo_bits) | jr_lo, r = 0..W-1 of the dense scratch buffer, whose k1 = bitrev(jr) share
 // their high bits, so each k2 yields W*8 B of contiguous output.
 template <int LT, int LW>
-__global__ void __launch_bounds__(NTT_THREADS) ntt_rows_nat_kernel(NttArgs a) {
-  constexpr int T = 1 << LT, W = 1 << LW, E = T << LW;
+__global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_nat_kernel(NttArgs a) {
+  constexpr int T = 1 << LT, W = 1 << LW, E = T << LW, NT = NttGeom<LT, LW>::NT;
   extern __shared__ __align__(16) u64 smem[];
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < T / 2; i += NTT_THREADS) tw[i] = a.tw[i];
+  for (int i = tid; i < T / 2; i += NT) tw[i] = a.tw[i];
   const u32 lo_bits = a.log_n1 - LW;
-  const u64 tile = blockIdx.x;
-  const u32 b = (u32)(tile >> lo_bits), jr_lo = (u32)(tile & ((1u << lo_bits) - 1));
+  const u32 tile = blockIdx.x;
+  const u32 b = tile >> lo_bits, jr_lo = tile & ((1u << lo_bits) - 1);
   const u64* src = a.in + (u64)b * ((u64)1 << a.log_n);  // scratch is dense [batch][n]
-  for (int e = tid; e < E; e += NTT_THREADS) {
-    int r = e >> LT, j = e & (T - 1);
-    u32 jr = ((u32)r << lo_bits) | jr_lo;
-    s[lds_pad(e)] = src[((u64)jr << LT) + j];
+  for (int e = tid; e < E; e += NT) {
+    u32 jr = ((u32)(e >> LT) << lo_bits) | jr_lo;
+    s[lds_pad(e)] = src[((u64)jr << LT) + (e & (T - 1))];
   }
   __syncthreads();
-  dif_all<LT, LT - 1, false, LW>(s, tw, tid);
+  dif_all<LT, LT - 1, false, LW, NT>(s, tw, tid);
   u64* dst = out_base(a, b);
   const u32 k1_hi = bitrev32(jr_lo, lo_bits) << LW;
-  for (int e = tid; e < E; e += NTT_THREADS) {
+  for (int e = tid; e < E; e += NT) {
     int q = e & (W - 1), k2 = e >> LW;
-    int r = (int)bitrev32((u32)q, LW);
-    u64 v = s[lds_pad((r << LT) + (int)bitrev32((u32)k2, LT))];
+    int row = (int)bitrev32((u32)q, LW);
+    u64 v = s[lds_pad((row << LT) + (int)bitrev32((u32)k2, LT))];
     if (a.post) v = gl_mul(v, a.post);
     dst[(u64)(k1_hi | (u32)q) + ((u64)k2 << a.log_n1)] = v;
   }
@@ -188,36 +184,47 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_rows_nat_kernel(NttArgs a) {
 
 // ---- pass A: strided dimension, T = n1 rows x 2^LW adjacent columns per block ---------------
 template <int LT, int LW>
-__global__ void __launch_bounds__(NTT_THREADS) ntt_cols_kernel(NttArgs a, u64* dst_dense) {
-  constexpr int T = 1 << LT, W = 1 << LW, E = T << LW;
+__global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs a, u64* dst_dense) {
+  constexpr int T = 1 << LT, W = 1 << LW, E = T << LW, NT = NttGeom<LT, LW>::NT;
   extern __shared__ __align__(16) u64 smem[];
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < T / 2; i += NTT_THREADS) tw[i] = a.tw[i];
+  for (int i = tid; i < T / 2; i += NT) tw[i] = a.tw[i];
   const u32 tiles_per = 1u << (a.log_n2 - LW);
-  const u32 b = blockIdx.x / tiles_per, c0 = (blockIdx.x % tiles_per) << LW;
+  // XCD-aware order: blocks i and i+8 land on one XCD (round-robin dispatch, speed only), so give
+  // each XCD a contiguous run of column tiles -- neighbouring tiles share 128-B lines and L2 sets
+  u32 bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const u32 b = bid / tiles_per, c0 = (bid % tiles_per) << LW;
   const u32 coset = b & ((1u << a.logK) - 1);
   const u64* src = in_base(a, b);
-  for (int e = tid; e < E; e += NTT_THREADS) {
+  for (int e = tid; e < E; e += NT) {
     int c = e & (W - 1), j = e >> LW;
     u64 v = src[((u64)j << a.log_n2) + c0 + c];
-    if (a.pre_lo) {
+    if (a.pre_full) {
+      v = gl_mul(v, a.pre_full[((u64)coset << a.log_n) + ((u64)j << a.log_n2) + c0 + c]);
+    } else if (a.pre_lo) {
       v = gl_mul(v, a.pre_lo[((u64)coset << a.log_n2) + c0 + c]);
       v = gl_mul(v, a.pre_hi[((u64)coset << LT) + j]);
     }
     s[lds_pad(e)] = v;
   }
   __syncthreads();
-  dif_all<LT, LT - 1, true, LW>(s, tw, tid);
+  dif_all<LT, LT - 1, true, LW, NT>(s, tw, tid);
   // row j holds k1 = bitrev(j); multiply by w_n^(i2*k1) and leave it at row j
   u64* dst = dst_dense ? dst_dense + (u64)b * ((u64)1 << a.log_n) : out_base(a, b);
-  for (int e = tid; e < E; e += NTT_THREADS) {
+  for (int e = tid; e < E; e += NT) {
     int c = e & (W - 1), j = e >> LW;
-    u32 k1 = bitrev32((u32)j, LT);
-    u32 ex = (c0 + c) * k1;  // < n <= 2^24
     u64 v = s[lds_pad(e)];
-    u64 w = gl_mul(a.tw4_lo[ex & 4095], a.tw4_hi[ex >> 12]);
+    u64 w;
+    if (a.tw4_full) {
+      w = a.tw4_full[((u64)j << a.log_n2) + c0 + c];
+    } else {
+      u32 k1 = bitrev32((u32)j, LT);
+      u32 ex = (c0 + c) * k1;  // < n <= 2^24
+      w = gl_mul(a.tw4_lo[ex & 4095], a.tw4_hi[ex >> 12]);
+    }
     dst[((u64)j << a.log_n2) + c0 + c] = gl_mul(v, w);
   }
 }
@@ -239,6 +246,20 @@ __global__ void coset_tables_kernel(u64* lo, u64* hi, u64 shift, u64 w_nk, u32 l
   if (r < n2) lo[(u64)j * n2 + r] = gl_pow(sj, r);
   else hi[(u64)j * n1 + (r - n2)] = gl_pow(sj, (u64)(r - n2) << log_n2);
 }
+// tw4_full[j][i2] = w_n^(i2 * bitrev(j))
+__global__ void tw4_full_kernel(u64* out, u64 wn, u32 log_n1, u32 log_n2) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ((u64)1 << (log_n1 + log_n2))) return;
+  u32 j = (u32)(i >> log_n2), i2 = (u32)(i & ((1u << log_n2) - 1));
+  out[i] = gl_pow(wn, (u64)i2 * bitrev32(j, log_n1));
+}
+// pre_full[c][i] = (shift * w_nk^c)^i
+__global__ void pre_full_kernel(u64* out, u64 shift, u64 w_nk, u32 log_n, u32 K) {
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ((u64)K << log_n)) return;
+  u32 c = (u32)(i >> log_n);
+  out[i] = gl_pow(gl_mul(shift, gl_pow(w_nk, c)), i & (((u64)1 << log_n) - 1));
+}
 __global__ void scale_powers_kernel(u64* data, u32 log_n, u32 batch, u64 base, u64 first) {
   // data[b][i] *= first * base^i
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -253,9 +274,9 @@ __global__ void scale_powers_kernel(u64* data, u32 log_n, u32 batch, u64 base, u
 static hipError_t dev_alloc(u64** p, size_t words) { return hipMalloc((void**)p, words * sizeof(u64)); }
 
 NttPlan::~NttPlan() {
-  hipFree(tw_a); hipFree(tw_b); hipFree(tw4_lo); hipFree(tw4_hi);
+  (void)hipFree(tw_a); (void)hipFree(tw_b); (void)hipFree(tw4_lo); (void)hipFree(tw4_hi); (void)hipFree(tw4_full);
 }
-CosetTables::~CosetTables() { hipFree(lo); hipFree(hi); }
+CosetTables::~CosetTables() { (void)hipFree(lo); (void)hipFree(hi); (void)hipFree(full); }
 
 hipError_t NttEngine::plan(u32 log_n, bool inverse, NttPlan** out) {
   u32 key = log_n * 2 + (inverse ? 1 : 0);
@@ -279,6 +300,11 @@ hipError_t NttEngine::plan(u32 log_n, bool inverse, NttPlan** out) {
     HIPCHK(powers(&p->tw_a, w1, (1u << p->log_n1) / 2));
     HIPCHK(powers(&p->tw4_lo, wn, 4096));
     HIPCHK(powers(&p->tw4_hi, gl_pow(wn, 4096), log_n > 12 ? (1u << (log_n - 12)) : 1));
+    if (log_n <= 22) {  // full 4-step table (<= 32 MB): one multiply per point instead of two
+      HIPCHK(dev_alloc(&p->tw4_full, (size_t)1 << log_n));
+      hipLaunchKernelGGL(tw4_full_kernel, dim3((u32)((((u64)1 << log_n) + 255) / 256)), dim3(256), 0, stream, p->tw4_full, wn, p->log_n1, p->log_n2);
+      HIPCHK(hipGetLastError());
+    }
   }
   p->n_inv = inverse ? gl_inv(((u64)1 << log_n) % GL_P) : 0;
   *out = p.get();
@@ -302,6 +328,13 @@ hipError_t NttEngine::coset(u32 log_n, u32 logK, u64 shift, CosetTables** out) {
   hipLaunchKernelGGL(coset_tables_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, c->lo, c->hi, shift,
                      gl_root_of_unity(log_n + logK), log_n1, log_n2, K);
   HIPCHK(hipGetLastError());
+  if (log_n1 && ((u64)K << log_n) <= ((u64)1 << 23)) {  // <= 64 MB: single-table pre-scale for two-pass sizes
+    HIPCHK(dev_alloc(&c->full, (size_t)K << log_n));
+    u64 tot = (u64)K << log_n;
+    hipLaunchKernelGGL(pre_full_kernel, dim3((u32)((tot + 255) / 256)), dim3(256), 0, stream, c->full, shift,
+                       gl_root_of_unity(log_n + logK), log_n, K);
+    HIPCHK(hipGetLastError());
+  }
   *out = c.get();
   cosets[key] = std::move(c);
   return hipSuccess;
@@ -316,39 +349,40 @@ hipError_t NttEngine::ensure_scratch(size_t words) {
   return hipSuccess;
 }
 
-template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : 12 - LT; }
-template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : (LT >= 8 ? 4 : 12 - LT); }
+// points per block (measured on MI355X, tools/dbg/ntt_only.py): 4096 (256 lanes) for T <= 2^10 and
+// T = 2^12, 8192 (512 lanes, two blocks per CU) for T = 2^11 where the twiddle table is amortised
+template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : (LT == 11 ? 2 : 12 - LT); }
+template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : 12 - LT; }
 template <int LT, int LW> static size_t lds_bytes() {
   int e = (1 << LT) << LW;
-  return (size_t)(e + (e >> 4) + 1 + (1 << LT) / 2 + 1) * sizeof(u64);
+  return (size_t)(e + (e >> 4) + 1 + ((1 << LT) / 2 + 1)) * sizeof(u64);
 }
 
 template <int LT>
 static hipError_t launch_rows(const NttArgs& a, bool nat_two_pass, hipStream_t st) {
   constexpr int LW = rows_lw<LT>();
+  constexpr int NT = NttGeom<LT, LW>::NT;
   size_t lds = lds_bytes<LT, LW>();
   u64 total_rows = (u64)a.batch << a.log_n1;
   if (nat_two_pass) {
     static bool attr = false;
     if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_rows_nat_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    u32 blocks = (u32)(total_rows >> LW);
-    hipLaunchKernelGGL((ntt_rows_nat_kernel<LT, LW>), dim3(blocks), dim3(NTT_THREADS), lds, st, a);
+    hipLaunchKernelGGL((ntt_rows_nat_kernel<LT, LW>), dim3((u32)(total_rows >> LW)), dim3(NT), lds, st, a);
   } else {
     static bool attr = false;
     if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_rows_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-    u32 blocks = (u32)((total_rows + (1u << LW) - 1) >> LW);
-    hipLaunchKernelGGL((ntt_rows_kernel<LT, LW>), dim3(blocks), dim3(NTT_THREADS), lds, st, a);
+    hipLaunchKernelGGL((ntt_rows_kernel<LT, LW>), dim3((u32)((total_rows + (1u << LW) - 1) >> LW)), dim3(NT), lds, st, a);
   }
   return hipGetLastError();
 }
 template <int LT>
 static hipError_t launch_cols(const NttArgs& a, u64* dst_dense, hipStream_t st) {
   constexpr int LW = cols_lw<LT>();
+  constexpr int NT = NttGeom<LT, LW>::NT;
   size_t lds = lds_bytes<LT, LW>();
   static bool attr = false;
   if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_cols_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
-  u32 blocks = a.batch << (a.log_n2 - LW);
-  hipLaunchKernelGGL((ntt_cols_kernel<LT, LW>), dim3(blocks), dim3(NTT_THREADS), lds, st, a, dst_dense);
+  hipLaunchKernelGGL((ntt_cols_kernel<LT, LW>), dim3(a.batch << (a.log_n2 - LW)), dim3(NT), lds, st, a, dst_dense);
   return hipGetLastError();
 }
 
@@ -378,8 +412,8 @@ hipError_t NttEngine::run(const u64* in, u64* out, u32 log_n, u32 polys, u32 log
   a.in_poly_stride = in_poly_stride; a.out_poly_stride = out_poly_stride;
   a.logK = logK; a.log_n = log_n; a.log_n1 = p->log_n1; a.log_n2 = p->log_n2;
   a.batch = polys << logK;
-  a.tw4_lo = p->tw4_lo; a.tw4_hi = p->tw4_hi;
-  a.pre_lo = pre ? pre->lo : nullptr; a.pre_hi = pre ? pre->hi : nullptr;
+  a.tw4_lo = p->tw4_lo; a.tw4_hi = p->tw4_hi; a.tw4_full = p->tw4_full;
+  a.pre_lo = pre ? pre->lo : nullptr; a.pre_hi = pre ? pre->hi : nullptr; a.pre_full = pre ? pre->full : nullptr;
   a.post = p->n_inv;
   a.bitrev_out = bitrev_out ? 1 : 0;
   if (p->log_n1 == 0) {
@@ -394,7 +428,7 @@ hipError_t NttEngine::run(const u64* in, u64* out, u32 log_n, u32 polys, u32 log
   a.tw = p->tw_a;
   HIPCHK(dispatch_cols(p->log_n1, a, dense, stream));
   a.tw = p->tw_b;
-  a.pre_lo = a.pre_hi = nullptr;
+  a.pre_lo = a.pre_hi = a.pre_full = nullptr;
   if (!bitrev_out) a.in = dense;
   return dispatch_rows(p->log_n2, a, !bitrev_out, stream);
 }
@@ -405,6 +439,6 @@ hipError_t NttEngine::scale_powers(u64* data, u32 log_n, u32 batch, u64 base, u6
   return hipGetLastError();
 }
 
-NttEngine::~NttEngine() { if (scratch) hipFree(scratch); }
+NttEngine::~NttEngine() { if (scratch) (void)hipFree(scratch); }
 
 }  // namespace mp2g
