@@ -64,8 +64,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="leaf proofs per step and rank")
+    ap.add_argument("--batch", type=int, default=128, help="leaf proofs per step and rank")
     ap.add_argument("--base-bits", type=int, default=13)
+    ap.add_argument("--streams", type=int, default=2, help="1: base and wrap provers share one stream; 2: one stream each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -82,27 +83,30 @@ def main():
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
     import oracle as O  # synthetic input stream + cpu_baseline leg only
+    # two contexts = two HIP streams on the same GPU: the base and the wrap prover run concurrently, so
+    # the latency-bound stretches of one (transcript, top Merkle levels) hide under the other's sponges
     ctx = mp2.Context(local_rank)
+    ctx2 = mp2.Context(local_rank) if args.streams > 1 else ctx
     B = args.batch
 
     # ---- synthetic inputs, resident in HBM before the timed region -----------------------------
     provers = []
-    for k in (args.base_bits, 12):
+    for k, cx in ((args.base_bits, ctx), (12, ctx2)):
         fp = mp2.standard_recursion_params(k, ORACLE_W)
         n = 1 << k
-        pr = mp2.BatchedProver(ctx, fp, B)
-        pr.set_preprocessed(ctx.to_device(O.rand_field((ORACLE_W[0], n), SEED + k)))
+        pr = mp2.BatchedProver(cx, fp, B)
+        pr.set_preprocessed(cx.to_device(O.rand_field((ORACLE_W[0], n), SEED + k)))
         # one random matrix per oracle, tiled over the batch (distinct public-input hashes keep
         # the B transcripts, challenges and proofs distinct)
         d_vals = []
         for i, w in enumerate(ORACLE_W[1:]):
             one = O.rand_field((w, n), SEED + 100 * k + i + 1000 * rank)
-            buf = ctx.alloc(B * w * n * 8)
+            buf = cx.alloc(B * w * n * 8)
             for b in range(B):
-                mp2._ck(mp2.load().mp2g_h2d(ctx.h, ctypes.c_void_p(buf.ptr.value + b * w * n * 8), mp2._p(one), ctypes.c_size_t(one.nbytes)))
+                mp2._ck(mp2.load().mp2g_h2d(cx.h, ctypes.c_void_p(buf.ptr.value + b * w * n * 8), mp2._p(one), ctypes.c_size_t(one.nbytes)))
             d_vals.append(buf)
-        d_cd = ctx.to_device(O.rand_field(4, SEED + 7))
-        d_ph = ctx.to_device(O.rand_field((B, 4), SEED + 8 + rank))
+        d_cd = cx.to_device(O.rand_field(4, SEED + 7))
+        d_ph = cx.to_device(O.rand_field((B, 4), SEED + 8 + rank))
         provers.append((pr, d_vals, d_cd, d_ph))
     n_ntt = 1 << LOG_NTT
     d_poly = ctx.to_device(O.rand_field((1, n_ntt), 0xC0FFEE02 + rank))
@@ -112,9 +116,14 @@ def main():
         for pr, d_vals, d_cd, d_ph in provers:
             pr.prove(d_vals, d_cd, d_ph)
 
+    def sync_all():
+        ctx.sync()
+        if ctx2 is not ctx:
+            ctx2.sync()
+
     for _ in range(args.warmup):
         step()
-    ctx.sync()
+    sync_all()
 
     # roofline leg: the 2^22 NTT, HIP events on the stream the kernels are launched on
     ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
@@ -128,13 +137,13 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.sync()
+        sync_all()
 
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ctx.sync()
+    sync_all()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -156,6 +165,14 @@ def main():
         w = mp2.curve_sum(ctx, allw)
 
     if rank == 0:
+        # HBM-side bytes of the same two launches from the TCC counters (collected in separate
+        # --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/r01/ntt_traffic.json)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "ntt_traffic.json")) as f:
+                traffic = json.load(f)["ntt_2p22_forward_bitrev"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         ntt_s = float(np.median(ntt_ms)) / 1e3
         achieved = 16.0 * n_ntt / ntt_s / 1e9
         out = {
@@ -169,11 +186,11 @@ def main():
             "config": {"workload": f"configs[3]-shaped leaf proofs: base 2^{args.base_bits} + wrap 2^12 prove() PCS pipeline "
                                    "(commitments, Fiat-Shamir, openings, FRI) at standard_recursion_config; "
                                    "roofline leg = configs[1] 2^22-point NTT",
-                       "batch_per_rank": B, "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
+                       "batch_per_rank": B, "streams": args.streams, "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
                        "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B"},
             "roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, both launches)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "launch_ms": ntt_s * 1e3, "algorithmic_bytes": 16 * n_ntt},
             "digest_rows_per_s": rows / digest_s,
             "digest_check": [int(x) for x in w],
@@ -183,6 +200,8 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if ctx2 is not ctx:
+        ctx2.close()
     ctx.close()
 
 
