@@ -151,14 +151,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # the per-rank multiset digest meets in one all_gather (outside the per-proof path)
-    rows = 1 << 12
+    # the per-rank multiset digest (2^16 rows x 4 value columns, device resident) meets in one
+    # all_gather of one encoded point per rank, outside the per-proof path
+    rows, n_cols = 1 << 16, 4
     rng = np.random.default_rng(0xC0FFEE04 + rank)
-    col_ids = O.rand_field(4, 0xC0FFEE04)
-    values = rng.integers(0, 1 << 32, size=(rows, 4, 8), dtype=np.uint32)
-    unique = values[:, :1, :].copy()
+    d_ids = ctx.to_device(O.rand_field(n_cols, 0xC0FFEE04))
+    d_values = ctx.to_device(rng.integers(0, 1 << 32, size=(rows, n_cols, 8), dtype=np.uint32))
+    d_unique = ctx.to_device(rng.integers(0, 1 << 32, size=(rows, 1, 8), dtype=np.uint32))
+    mp2.compute_table_row_digest_dev(ctx, d_ids, n_cols, d_values, d_unique, 1, rows)
     t1 = time.perf_counter()
-    w, _ = mp2.compute_table_row_digest(ctx, col_ids, values, unique)
+    w = mp2.compute_table_row_digest_dev(ctx, d_ids, n_cols, d_values, d_unique, 1, rows)
     digest_s = time.perf_counter() - t1
     if dist is not None:
         allw = sharding.all_gather_words(dist, w, device=torch.device("cuda", local_rank))

@@ -550,3 +550,43 @@ class CircuitSet:
         _, sib = self.tree.prove([idx])
         bits = [(idx >> i) & 1 for i in range(self.tree.log_leaves)]
         return bits, sib[0]
+
+
+def compute_table_row_digest_dev(ctx, d_col_ids, n_cols, d_values, d_unique, n_unique, rows, variant=POSEIDON2):
+    """Device-resident form of compute_table_row_digest; returns the encoded digest."""
+    w = np.empty(5, dtype=np.uint64)
+    _ck(load().mp2g_row_digest_batch_dev(ctx.h, variant, d_col_ids.ptr, n_cols, d_values.ptr, d_unique.ptr, n_unique, rows,
+                                         None, _p(w), None))
+    return w
+
+
+# ---- map-reduce over an aggregation tree (recursion-framework/tests/integration.rs:138-261) -------
+def prove_aggregation_tree(ctx, fp, preprocessed, leaf_values, circuit_digest, arity=2, variant=POSEIDON2):
+    """Bottom-up batched proving of a complete `arity`-ary tree, one batched launch per level
+    (children before parents, as ryhope's work plan orders them). Level 0 proves the leaves from
+    `leaf_values` (list over oracles 1.. of arrays [n_leaves][w][n]); a parent's witness is modelled by
+    re-using its first child's matrices, and its public-input hash is
+    H(wires cap of child 0 || ... || wires cap of child arity-1) -- the data dependency that forces
+    the level order. Returns a list of levels, each (pi_hash [nodes][4], caps, openings, proofs).
+    The circuit logic itself (universal verifier gadget) is out of scope: DESIGN.md section 6."""
+    n_nodes = leaf_values[0].shape[0]
+    pi = np.zeros((n_nodes, 4), dtype=np.uint64)
+    pi[:, 0] = np.arange(n_nodes, dtype=np.uint64)  # leaf index as the leaf's public input hash stand-in
+    vals = [np.ascontiguousarray(v, dtype=np.uint64) for v in leaf_values]
+    d_pre = ctx.to_device(preprocessed)
+    d_cd = ctx.to_device(circuit_digest)
+    levels = []
+    while True:
+        pr = BatchedProver(ctx, fp, n_nodes)
+        pr.set_preprocessed(d_pre)
+        pr.prove([ctx.to_device(v) for v in vals], d_cd, ctx.to_device(pi))
+        caps, openings, proofs = pr.results()
+        pr.free()
+        levels.append((pi, caps, openings, proofs))
+        if n_nodes == 1:
+            return levels
+        assert n_nodes % arity == 0
+        n_nodes //= arity
+        child_caps = caps[:, 1, :].reshape(n_nodes, arity * fp.cap_words)
+        pi = ctx.hash_no_pad_batch(child_caps, 4, variant)
+        vals = [np.ascontiguousarray(v[::arity]) for v in vals]
