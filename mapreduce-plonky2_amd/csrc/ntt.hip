@@ -41,13 +41,20 @@ struct NttArgs {
   u32 src_is_out;        // pass B of a two-pass bit-reversed transform reads `out`
 };
 
-// lanes per block: one radix-16 item per lane and round
+// lanes per block: one radix-2^NTT_RMAX item per lane and round
+#ifndef NTT_RMAX
+#define NTT_RMAX 3
+#endif
 template <int LT, int LW> struct NttGeom {
   static constexpr int E = (1 << LT) << LW;
-  static constexpr int NT = E / 16 < 64 ? 64 : (E / 16 > 1024 ? 1024 : E / 16);
+  static constexpr int NT = (E >> NTT_RMAX) < 64 ? 64 : ((E >> NTT_RMAX) > 1024 ? 1024 : (E >> NTT_RMAX));
 };
+// Twiddles w_T^k: stages whose indices are multiples of 2^TWS read the sub-sampled LDS copy, the
+// first TWS stages (full-resolution, lane-contiguous indices) read the global table through L1.
+// TWS = 2 for T = 4096 keeps a 4096-point tile at 38.9 KB of LDS: four blocks = 32 waves per CU.
+template <int LT> struct NttTw { static constexpr int TWS = LT >= 12 ? 2 : 0; };
 template <int LT, int HI, int R, bool COLS, int LW, int NTT_THREADS>
-__device__ __forceinline__ void dif_round(u64* s, const u64* tw, int tid) {
+__device__ __forceinline__ void dif_round(u64* s, const u64* tw, const u64* __restrict__ twg, int tid) {
   constexpr int T = 1 << LT, LO = HI - R + 1, W = 1 << LW;
   constexpr int ITEMS = W << (LT - R);
   for (int item = tid; item < ITEMS; item += NTT_THREADS) {
@@ -76,7 +83,8 @@ __device__ __forceinline__ void dif_round(u64* s, const u64* tw, int tid) {
         u64 d = gl_sub(u, v);
         if (b > 0) {
           int idx = ((m_low << LO) + below) << (LT - 1 - b);
-          d = gl_mul(d, tw[idx]);
+          u64 w = (LT - 1 - b) >= NttTw<LT>::TWS ? tw[idx >> NttTw<LT>::TWS] : twg[idx];
+          d = gl_mul(d, w);
         }
         x[m + half] = d;
       }
@@ -89,12 +97,12 @@ __device__ __forceinline__ void dif_round(u64* s, const u64* tw, int tid) {
   }
 }
 template <int LT, int HI, bool COLS, int LW, int NTT_THREADS>
-__device__ __forceinline__ void dif_all(u64* s, const u64* tw, int tid) {
+__device__ __forceinline__ void dif_all(u64* s, const u64* tw, const u64* __restrict__ twg, int tid) {
   if constexpr (HI >= 0) {
-    constexpr int R = (HI + 1 >= 4) ? 4 : HI + 1;
-    dif_round<LT, HI, R, COLS, LW, NTT_THREADS>(s, tw, tid);
+    constexpr int R = (HI + 1 >= NTT_RMAX) ? NTT_RMAX : HI + 1;
+    dif_round<LT, HI, R, COLS, LW, NTT_THREADS>(s, tw, twg, tid);
     __syncthreads();
-    dif_all<LT, HI - R, COLS, LW, NTT_THREADS>(s, tw, tid);
+    dif_all<LT, HI - R, COLS, LW, NTT_THREADS>(s, tw, twg, tid);
   }
 }
 
@@ -118,7 +126,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_kernel(NttArgs
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < T / 2; i += NT) tw[i] = a.tw[i];
+  for (int i = tid; i < ((T / 2) >> NttTw<LT>::TWS); i += NT) tw[i] = a.tw[i << NttTw<LT>::TWS];
   const u32 n1 = 1u << a.log_n1;
   const u64 total_rows = (u64)a.batch << a.log_n1;
   const u64 row0 = (u64)blockIdx.x << LW;
@@ -139,7 +147,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_kernel(NttArgs
     s[lds_pad(e)] = v;
   }
   __syncthreads();
-  dif_all<LT, LT - 1, false, LW, NT>(s, tw, tid);
+  dif_all<LT, LT - 1, false, LW, NT>(s, tw, a.tw, tid);
   for (int e = tid; e < E; e += NT) {
     int r = e >> LT, p = e & (T - 1);
     u64 g = row0 + r;
@@ -160,7 +168,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_nat_kernel(Ntt
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < T / 2; i += NT) tw[i] = a.tw[i];
+  for (int i = tid; i < ((T / 2) >> NttTw<LT>::TWS); i += NT) tw[i] = a.tw[i << NttTw<LT>::TWS];
   const u32 lo_bits = a.log_n1 - LW;
   const u32 tile = blockIdx.x;
   const u32 b = tile >> lo_bits, jr_lo = tile & ((1u << lo_bits) - 1);
@@ -170,7 +178,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_nat_kernel(Ntt
     s[lds_pad(e)] = src[((u64)jr << LT) + (e & (T - 1))];
   }
   __syncthreads();
-  dif_all<LT, LT - 1, false, LW, NT>(s, tw, tid);
+  dif_all<LT, LT - 1, false, LW, NT>(s, tw, a.tw, tid);
   u64* dst = out_base(a, b);
   const u32 k1_hi = bitrev32(jr_lo, lo_bits) << LW;
   for (int e = tid; e < E; e += NT) {
@@ -190,7 +198,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < T / 2; i += NT) tw[i] = a.tw[i];
+  for (int i = tid; i < ((T / 2) >> NttTw<LT>::TWS); i += NT) tw[i] = a.tw[i << NttTw<LT>::TWS];
   const u32 tiles_per = 1u << (a.log_n2 - LW);
   // XCD-aware order: blocks i and i+8 land on one XCD (round-robin dispatch, speed only), so give
   // each XCD a contiguous run of column tiles -- neighbouring tiles share 128-B lines and L2 sets
@@ -211,7 +219,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
     s[lds_pad(e)] = v;
   }
   __syncthreads();
-  dif_all<LT, LT - 1, true, LW, NT>(s, tw, tid);
+  dif_all<LT, LT - 1, true, LW, NT>(s, tw, a.tw, tid);
   // row j holds k1 = bitrev(j); multiply by w_n^(i2*k1) and leave it at row j
   u64* dst = dst_dense ? dst_dense + (u64)b * ((u64)1 << a.log_n) : out_base(a, b);
   for (int e = tid; e < E; e += NT) {
@@ -355,7 +363,7 @@ template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : (LT == 
 template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : 12 - LT; }
 template <int LT, int LW> static size_t lds_bytes() {
   int e = (1 << LT) << LW;
-  return (size_t)(e + (e >> 4) + 1 + ((1 << LT) / 2 + 1)) * sizeof(u64);
+  return (size_t)(e + (e >> 4) + 1 + (((1 << LT) / 2) >> NttTw<LT>::TWS) + 1) * sizeof(u64);
 }
 
 template <int LT>
