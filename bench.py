@@ -11,9 +11,10 @@ wrap_circuit.rs:122-148). One step = one batch of `--batch` such leaf proofs, sh
 8(d) config 3 says (base 2^13 + wrap 2^12, standard_recursion_config: 84 constants/sigmas + 135
 wires + 20 Z/partial products + 16 quotient chunks, rate 1/8, cap 16, FRI [4,4], 16-bit PoW, 28
 queries), on synthetic witness matrices that are resident in HBM before the timed region. What
-runs per proof is the whole commitment / Fiat-Shamir / opening / FRI pipeline of `prove()`
-(HOT LOOPS 1 and 3 of SURVEY 3.1); witness generation and gate-constraint evaluation (HOT LOOP 2,
-SURVEY 8(f)-1 "next") are not part of this round and the polynomials are random -- see DESIGN.md.
+runs per proof is the commitment / permutation-argument / Fiat-Shamir / opening / FRI pipeline of
+`prove()` (HOT LOOPS 1 and 3 of SURVEY 3.1, plus the Z / partial-product polynomials); witness
+generation and gate-constraint evaluation (HOT LOOP 2, SURVEY 8(f)-1 "next") are not part of this
+round, so the wire and quotient matrices are random -- see DESIGN.md.
 Leaf proofs shard across ranks with no data-path collective ("scaling": "weak"); the per-rank
 multiset digests meet in one 160-byte all_gather outside the per-proof path.
 
@@ -37,6 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 LOG_NTT = 22
 ORACLE_W = (84, 135, 20, 16)
+NUM_ROUTED = 80  # standard_recursion_config: 80 routed wires, quotient_degree_factor 8 => 2 x (1 + 9) Z / partial products
 SEED = 0xC0FFEE03
 
 
@@ -52,7 +54,7 @@ def cpu_baseline(base_bits, n_proofs=1):
         cd, ph = O.rand_field(4, 1), O.rand_field(4, 2)
         t0 = time.perf_counter()
         for _ in range(n_proofs):
-            O.pcs_prove(ofp, vals, cd, ph)
+            O.pcs_prove(ofp, vals, cd, ph, num_routed=NUM_ROUTED, degree=8)
         t_total += time.perf_counter() - t0
     return {"value": n_proofs / t_total, "unit": "leaf proofs/s", "cores": cores, "kind": "port",
             "sample": f"{n_proofs} leaf proof(s) = base 2^{base_bits} + wrap 2^12 PCS pipelines by oracle/ (OpenMP, {cores} threads; "
@@ -96,10 +98,14 @@ def main():
         n = 1 << k
         pr = mp2.BatchedProver(cx, fp, B)
         pr.set_preprocessed(cx.to_device(O.rand_field((ORACLE_W[0], n), SEED + k)))
+        pr.enable_permutation(NUM_ROUTED, 8)  # Z / partial products are computed on the device from wires + sigmas
         # one random matrix per oracle, tiled over the batch (distinct public-input hashes keep
         # the B transcripts, challenges and proofs distinct)
         d_vals = []
         for i, w in enumerate(ORACLE_W[1:]):
+            if i == 1:
+                d_vals.append(None)  # oracle 2: permutation argument, produced by the prover itself
+                continue
             one = O.rand_field((w, n), SEED + 100 * k + i + 1000 * rank)
             buf = cx.alloc(B * w * n * 8)
             for b in range(B):

@@ -224,6 +224,19 @@ int mp2g_proof_deserialize(const mp2g_fri_params* params, uint32_t num_constants
 int mp2g_proof_with_vk_serialize(const uint8_t* proof_bytes, size_t proof_len, const uint64_t* vk_cap,
                                  uint32_t vk_cap_len, const uint64_t vk_circuit_digest[4], uint8_t* out, size_t* out_len);
 
+/* ---- permutation argument: replaces plonk/prover.rs all_wires_permutation_partial_products ---- */
+/* wires [wires_w][n] and sigmas [num_routed][n]: subgroup values (natural order); only the first
+ * num_routed wire columns are read. degree = quotient_degree_factor (8 in standard_recursion_config),
+ * num_routed % degree == 0. out [nc * num_routed/degree][n] in the order prove() commits:
+ * Z of every challenge, then each challenge's num_routed/degree - 1 partial products. */
+int mp2g_partial_products_and_zs(mp2g_ctx* ctx, const uint64_t* wires, uint32_t wires_w, const uint64_t* sigmas,
+                                 uint32_t log_n, uint32_t num_routed, uint32_t degree, const uint64_t* betas,
+                                 const uint64_t* gammas, uint32_t nc, uint64_t* out);
+/* Let the batched prover compute oracle 2 itself (d_values[1] of mp2g_prover_prove_dev may then be
+ * NULL): the sigmas are the last num_routed polynomials of the preprocessed oracle, betas/gammas
+ * the challenges drawn after the wires cap. Call after mp2g_prover_set_preprocessed_dev. */
+int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_t degree);
+
 #ifdef __cplusplus
 }
 #endif

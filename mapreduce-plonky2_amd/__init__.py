@@ -385,9 +385,14 @@ class BatchedProver:
     def set_preprocessed(self, d_values):
         _ck(load().mp2g_prover_set_preprocessed_dev(self.h, d_values.ptr))
 
+    def enable_permutation(self, num_routed=80, degree=8):
+        """Compute the Z / partial-product oracle on the device from the wires and the sigma
+        polynomials (prove()'s permutation argument); d_values[1] may then be None."""
+        _ck(load().mp2g_prover_enable_permutation(self.h, num_routed, degree))
+
     def prove(self, d_values, d_circuit_digest, d_pi_hash):
         """d_values: device buffers [batch][w_o][n] for oracles 1..; asynchronous."""
-        ptrs = (ctypes.c_void_p * len(d_values))(*[d.ptr.value for d in d_values])
+        ptrs = (ctypes.c_void_p * len(d_values))(*[(d.ptr.value if d is not None else None) for d in d_values])
         _ck(load().mp2g_prover_prove_dev(self.h, ptrs, d_circuit_digest.ptr, d_pi_hash.ptr, self.d_caps.ptr,
                                          self.d_openings.ptr, self.d_proof.ptr))
 
@@ -590,3 +595,13 @@ def prove_aggregation_tree(ctx, fp, preprocessed, leaf_values, circuit_digest, a
         child_caps = caps[:, 1, :].reshape(n_nodes, arity * fp.cap_words)
         pi = ctx.hash_no_pad_batch(child_caps, 4, variant)
         vals = [np.ascontiguousarray(v[::arity]) for v in vals]
+
+
+def partial_products_and_zs(ctx, wires, sigmas, betas, gammas, degree=8):
+    """plonk/prover.rs all_wires_permutation_partial_products in prove()'s commit order."""
+    wv, sg, b, g = _arr(wires), _arr(sigmas), _arr(betas), _arr(gammas)
+    num_routed, n = sg.shape
+    out = np.empty((b.size * (num_routed // degree), n), dtype=np.uint64)
+    _ck(load().mp2g_partial_products_and_zs(ctx.h, _p(wv), wv.shape[0], _p(sg), int(n).bit_length() - 1, num_routed, degree,
+                                            _p(b), _p(g), b.size, _p(out)))
+    return out

@@ -6,6 +6,7 @@
 // universal_verifier_gadget/wrap_circuit.rs:143 (wrap proofs), verifiable-db/src/api.rs:207.
 #include "ctx.h"
 #include "fri.h"
+#include "zperm.h"
 #include <new>
 #include <vector>
 
@@ -30,6 +31,9 @@ struct mp2g_prover {
   DevBuf coeffs[8], values[8], levels[8];
   DevBuf ch, chal, zeta, alpha, betas, comp, quot, final_poly, witness, qchal;
   DevBuf fvals[9], flevels[8], fcoeffs[9];
+  // permutation argument computed on the device (mp2g_prover_enable_permutation)
+  uint32_t num_routed = 0, degree = 0;
+  DevBuf pre_values, zs_values, chunk_q;
 };
 
 static int params_check(const mp2g_fri_params* p) {
@@ -244,8 +248,25 @@ static hipError_t commit_oracle(mp2g_prover* pr, uint32_t o, const u64* d_values
 }
 int mp2g_prover_set_preprocessed_dev(mp2g_prover* pr, const uint64_t* d_values) {
   NEED(pr && d_values, "prover/values");
+  const size_t words = (size_t)pr->P.oracle_w[0] << pr->P.log_n;
+  CK(pr->pre_values.alloc(words * sizeof(u64)));  // the sigma values are needed again for Z
+  CK(hipMemcpyAsync(pr->pre_values.p, d_values, words * sizeof(u64), hipMemcpyDeviceToDevice, pr->ctx->stream));
   CK(commit_oracle(pr, 0, (const u64*)d_values, 1));
   pr->have_pre = true;
+  return 0;
+}
+int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_t degree) {
+  NEED(pr && pr->have_pre, "call mp2g_prover_set_preprocessed_dev first");
+  const mp2g_fri_params& P = pr->P;
+  NEED(P.n_oracles >= 3 && P.zs_oracle == 2, "needs wires = oracle 1 and Z/partial products = oracle 2");
+  NEED(degree >= 1 && num_routed >= degree && num_routed % degree == 0 && num_routed / degree <= 16, "num_routed/degree");
+  NEED(num_routed <= P.oracle_w[0] && num_routed <= P.oracle_w[1], "num_routed exceeds the sigma / wire counts");
+  NEED(P.zs_count >= 1 && P.zs_count <= 2, "1 or 2 challenges");
+  NEED(P.oracle_w[2] == P.zs_count * (num_routed / degree), "oracle_w[2] must be zs_count * num_routed/degree");
+  const size_t n = (size_t)1 << P.log_n;
+  CK(pr->zs_values.alloc((size_t)pr->B * P.oracle_w[2] * n * sizeof(u64)));
+  CK(pr->chunk_q.alloc((size_t)pr->B * P.zs_count * (num_routed / degree) * n * sizeof(u64)));
+  pr->num_routed = num_routed; pr->degree = degree;
   return 0;
 }
 int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, const uint64_t* d_circuit_digest,
@@ -267,8 +288,16 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
   CK(challenger_step(s, V, st, B, (const u64*)d_pi_hash, 4, 4, chal, 8, 0));
   CK(copy_rows(s, B, pr->levels[0].p + LW - capw, 0, (u64*)d_caps, caps_b, (u32)capw));
   for (uint32_t o = 1; o < P.n_oracles; o++) {
-    NEED(d_values[o - 1], "d_values[o]");
-    CK(commit_oracle(pr, o, (const u64*)d_values[o - 1], B));
+    const u64* vals = (const u64*)d_values[o - 1];
+    if (o == 2 && pr->num_routed) {
+      // betas = chal[0..2), gammas = chal[2..4) of every transcript (drawn after the wires cap)
+      CK(zpp_compute(s, B, (const u64*)d_values[0], (u64)P.oracle_w[1] * n, pr->pre_values.p + (u64)(P.oracle_w[0] - pr->num_routed) * n,
+                     P.log_n, pr->num_routed, pr->degree, chal, chal + 2, 8, P.zs_count, pr->chunk_q.p, pr->zs_values.p,
+                     (u64)P.oracle_w[2] * n));
+      vals = pr->zs_values.p;
+    }
+    NEED(vals, "d_values[o]");
+    CK(commit_oracle(pr, o, vals, B));
     u64* cap_dst = (u64*)d_caps + o * capw;
     CK(copy_rows(s, B, pr->levels[o].p + LW - capw, LW, cap_dst, caps_b, (u32)capw));
     // plonk/prover.rs: wires cap -> betas, gammas (2+2); zs cap -> alphas (2); all other caps -> 0
@@ -330,6 +359,29 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
     CK(challenger_step(s, V, st, B, chal, 0, 0, pr->qchal.p, P.num_queries, P.num_queries));
     CK(fri_queries(s, sh, ly, B, P.num_queries, pr->qchal.p, P.num_queries, proof, pr->proof_words, pr->q_off, pr->q_words));
   }
+  return 0;
+}
+
+int mp2g_partial_products_and_zs(mp2g_ctx* c, const uint64_t* wires, uint32_t wires_w, const uint64_t* sigmas, uint32_t log_n,
+                                 uint32_t num_routed, uint32_t degree, const uint64_t* betas, const uint64_t* gammas, uint32_t nc,
+                                 uint64_t* out) {
+  NEED(c && wires && sigmas && betas && gammas && out, "ctx/pointers");
+  NEED(log_n >= 1 && log_n <= 20 && nc >= 1 && nc <= 4, "log_n/nc");
+  NEED(degree >= 1 && num_routed >= degree && num_routed % degree == 0 && num_routed / degree <= 16 && num_routed <= wires_w, "num_routed/degree");
+  const size_t n = (size_t)1 << log_n, chunks = num_routed / degree;
+  DevBuf dw, ds, dc, dq, dout;
+  CK(dw.alloc(wires_w * n * sizeof(u64)));
+  CK(ds.alloc(num_routed * n * sizeof(u64)));
+  CK(dc.alloc(2 * nc * sizeof(u64)));
+  CK(dq.alloc(nc * chunks * n * sizeof(u64)));
+  CK(dout.alloc(nc * chunks * n * sizeof(u64)));
+  CK(hipMemcpyAsync(dw.p, wires, wires_w * n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(hipMemcpyAsync(ds.p, sigmas, num_routed * n * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(hipMemcpyAsync(dc.p, betas, nc * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(hipMemcpyAsync(dc.p + nc, gammas, nc * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(zpp_compute(c->stream, 1, dw.p, 0, ds.p, log_n, num_routed, degree, dc.p, dc.p + nc, 0, nc, dq.p, dout.p, 0));
+  CK(hipMemcpyAsync(out, dout.p, nc * chunks * n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -26,6 +26,8 @@ void orc_fft(gl_t* a, unsigned log_n, int inverse);
 void orc_coset_fft(gl_t* a, unsigned log_n, gl_t shift);
 void orc_lde_leaves(const gl_t* coeffs, unsigned log_n, size_t w, unsigned rate_bits, gl_t* leaves);
 size_t orc_bitrev(size_t x, unsigned bits);
+void orc_partial_products_and_zs(const gl_t* wires, const gl_t* sigmas, unsigned log_n, unsigned num_routed,
+                                 unsigned degree, const gl_t* betas, const gl_t* gammas, unsigned nc, gl_t* out);
 
 // ---- challenger ---------------------------------------------------------------------------
 void orc_ch_init(orc_challenger* c, int variant) { memset(c, 0, sizeof *c); c->variant = variant; }
@@ -249,33 +251,45 @@ void orc_fri_prove(const orc_fri_params* P, gl_t* const* coeffs, gl_t* const* le
 // preprocessed constants_sigmas oracle (its cap is inside circuit_digest, never observed);
 // oracle 1 wires, 2 zs_partial_products, 3 quotient chunks.
 // Outputs: caps[n_oracles][2^cap][4], openings[(sum w + zs_count)][2], proof (flat, see above).
+// num_routed > 0: oracle 2 (Z / partial products) is not taken from values[2] but computed from the
+// wires (values[1]), the sigma values (last num_routed polynomials of values[0]) and the betas /
+// gammas drawn after the wires cap, as prove() does; needs oracle_w[2] = zs_count * num_routed/degree.
 void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4],
-                   const gl_t pi_hash[4], gl_t* caps, gl_t* openings, gl_t* proof) {
+                   const gl_t pi_hash[4], unsigned num_routed, unsigned degree, gl_t* caps, gl_t* openings, gl_t* proof) {
   unsigned k = P->log_n, lg = k + P->rate_bits;
   size_t n = (size_t)1 << k, N = (size_t)1 << lg;
   size_t capw = ((size_t)4) << P->cap_height;
   gl_t* coeffs[8]; gl_t* leaves[8]; gl_t* levels[8];
+  orc_challenger ch;
+  orc_ch_init(&ch, P->variant);
+  orc_ch_observe(&ch, circuit_digest, 4);
+  orc_ch_observe(&ch, pi_hash, 4);
+  gl_t bg[4] = {0, 0, 0, 0};
+  gl_t* zs_vals = NULL;
   for (uint32_t o = 0; o < P->n_oracles; o++) {
     size_t w = P->oracle_w[o];
+    const gl_t* src = values[o];
+    if (o == 2 && num_routed) {
+      zs_vals = malloc(w * n * sizeof(gl_t));
+      orc_partial_products_and_zs(values[1], values[0] + (size_t)(P->oracle_w[0] - num_routed) * n, k, num_routed, degree,
+                                  bg, bg + 2, P->zs_count, zs_vals);
+      src = zs_vals;
+    }
     coeffs[o] = malloc(w * n * sizeof(gl_t));
-    memcpy(coeffs[o], values[o], w * n * sizeof(gl_t));
+    memcpy(coeffs[o], src, w * n * sizeof(gl_t));
     for (size_t p = 0; p < w; p++) orc_fft(coeffs[o] + p * n, k, 1);
     leaves[o] = malloc(w * N * sizeof(gl_t));
     orc_lde_leaves(coeffs[o], k, w, P->rate_bits, leaves[o]);
     levels[o] = malloc(orc_merkle_levels_len(lg, P->cap_height) * sizeof(gl_t));
     orc_merkle_build(P->variant, leaves[o], w, lg, P->cap_height, levels[o]);
     memcpy(caps + o * capw, orc_merkle_cap_ptr(levels[o], lg, P->cap_height), capw * sizeof(gl_t));
-  }
-  orc_challenger ch;
-  orc_ch_init(&ch, P->variant);
-  orc_ch_observe(&ch, circuit_digest, 4);
-  orc_ch_observe(&ch, pi_hash, 4);
-  for (uint32_t o = 1; o < P->n_oracles; o++) {
+    if (o == 0) continue;
     orc_ch_observe(&ch, caps + o * capw, capw);
     // wires cap -> betas[2], gammas[2]; zs cap -> alphas[2]; quotient cap -> zeta
-    if (o == 1) for (int i = 0; i < 4; i++) (void)orc_ch_get(&ch);
+    if (o == 1) for (int i = 0; i < 4; i++) bg[i] = orc_ch_get(&ch);
     else if (o == 2) for (int i = 0; i < 2; i++) (void)orc_ch_get(&ch);
   }
+  free(zs_vals);
   gl2_t zeta = orc_ch_get_ext(&ch);
   gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(k));
   size_t oi = 0;
@@ -455,4 +469,55 @@ void orc_fri_fold_values(const gl_t* in_bitrev, unsigned log_m, unsigned arity_b
   ext_coset_fft(v, log_m - arity_bits, gl_pow(shift, arity));
   for (size_t i = 0; i < m2; i++) { out[2 * i] = v[i].c[0]; out[2 * i + 1] = v[i].c[1]; }
   free(v);
+}
+
+// ---- permutation argument: Z and partial products ---------------------------------------------
+// [dep] plonky2 plonk/prover.rs all_wires_permutation_partial_products /
+// wires_permutation_partial_products_and_zs, plonk/vanishing_poly / plonk_common.rs
+// quotient_chunk_products + partial_products_and_z_gx, plonk/permutation_argument /
+// field/src/cosets.rs get_unique_coset_shifts (k_i = g^i), and the Z-first ordering of prove():
+//   zs_partial_products = [Z_0 .. Z_{nc-1}, pp(challenge 0)[0..num_prods), pp(challenge 1) ...].
+// wires: [>= num_routed][n] subgroup values (row j = wire column j), sigmas: [num_routed][n] values
+// of the sigma polynomials, degree = quotient_degree_factor (8), num_routed % degree == 0.
+// out: [nc * (1 + num_prods)][n], num_prods = num_routed/degree - 1.
+void orc_partial_products_and_zs(const gl_t* wires, const gl_t* sigmas, unsigned log_n, unsigned num_routed,
+                                 unsigned degree, const gl_t* betas, const gl_t* gammas, unsigned nc, gl_t* out) {
+  size_t n = (size_t)1 << log_n;
+  unsigned chunks = num_routed / degree, num_prods = chunks - 1;
+  gl_t* k_is = malloc(num_routed * sizeof(gl_t));
+  k_is[0] = 1;
+  for (unsigned j = 1; j < num_routed; j++) k_is[j] = gl_mul(k_is[j - 1], GL_MULT_GEN);
+  gl_t w = gl_root_of_unity(log_n);
+  gl_t* chunk_prod = malloc(n * chunks * sizeof(gl_t));
+  for (unsigned c = 0; c < nc; c++) {
+    gl_t beta = betas[c], gamma = gammas[c];
+    gl_t x = 1;
+    for (size_t i = 0; i < n; i++) {
+      for (unsigned k = 0; k < chunks; k++) {
+        gl_t num = 1, den = 1;
+        for (unsigned j = k * degree; j < (k + 1) * degree; j++) {
+          gl_t wv = wires[(size_t)j * n + i];
+          num = gl_mul(num, gl_add(gl_add(wv, gl_mul(beta, gl_mul(k_is[j], x))), gamma));
+          den = gl_mul(den, gl_add(gl_add(wv, gl_mul(beta, sigmas[(size_t)j * n + i])), gamma));
+        }
+        chunk_prod[i * chunks + k] = gl_mul(num, gl_inv(den));
+      }
+      x = gl_mul(x, w);
+    }
+    // running products; Z(x) at the front of the batch, partial products after all Z's
+    gl_t z_x = 1;
+    gl_t* zrow = out + (size_t)c * n;
+    gl_t* pp = out + (size_t)nc * n + (size_t)c * num_prods * n;
+    for (size_t i = 0; i < n; i++) {
+      zrow[i] = z_x;
+      gl_t acc = z_x;
+      for (unsigned k = 0; k < chunks; k++) {
+        acc = gl_mul(acc, chunk_prod[i * chunks + k]);
+        if (k < num_prods) pp[(size_t)k * n + i] = acc;
+      }
+      z_x = acc;  // Z(g x)
+    }
+  }
+  free(chunk_prod);
+  free(k_is);
 }

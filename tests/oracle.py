@@ -173,8 +173,9 @@ def standard_params(log_n, oracle_w=(84, 135, 20, 16), variant=0, rate_bits=3, c
     return fp
 
 
-def pcs_prove(fp, values, circuit_digest, pi_hash):
-    """values: list of [w_o][n] arrays. Returns (caps, openings, proof)."""
+def pcs_prove(fp, values, circuit_digest, pi_hash, num_routed=0, degree=8):
+    """values: list of [w_o][n] arrays. Returns (caps, openings, proof). num_routed > 0: the Z /
+    partial-product oracle is computed from the wires and sigmas (values[2] is ignored)."""
     vals = [arr(v) for v in values]
     ptrs = (ctypes.c_void_p * len(vals))(*[v.ctypes.data for v in vals])
     capw = 4 << fp.cap_height
@@ -182,7 +183,7 @@ def pcs_prove(fp, values, circuit_digest, pi_hash):
     openings = np.zeros((lib().orc_n_openings(ctypes.byref(fp)), 2), dtype=np.uint64)
     proof = np.zeros(lib().orc_fri_proof_words(ctypes.byref(fp)), dtype=np.uint64)
     cd, ph = arr(circuit_digest), arr(pi_hash)
-    lib().orc_pcs_prove(ctypes.byref(fp), ptrs, p(cd), p(ph), p(caps), p(openings), p(proof))
+    lib().orc_pcs_prove(ctypes.byref(fp), ptrs, p(cd), p(ph), num_routed, degree, p(caps), p(openings), p(proof))
     return caps, openings, proof
 
 
@@ -190,3 +191,12 @@ def pcs_verify(fp, circuit_digest, pi_hash, caps, openings, proof):
     cd, ph = arr(circuit_digest), arr(pi_hash)
     caps, openings, proof = arr(caps), arr(openings), arr(proof)
     return lib().orc_pcs_verify(ctypes.byref(fp), p(cd), p(ph), p(caps), p(openings), p(proof))
+
+
+def partial_products_and_zs(wires, sigmas, betas, gammas, degree=8):
+    wires, sigmas, betas, gammas = arr(wires), arr(sigmas), arr(betas), arr(gammas)
+    num_routed, n = sigmas.shape
+    nc = betas.size
+    out = np.zeros((nc * (num_routed // degree), n), dtype=np.uint64)
+    lib().orc_partial_products_and_zs(p(wires), p(sigmas), int(n).bit_length() - 1, num_routed, degree, p(betas), p(gammas), nc, p(out))
+    return out
