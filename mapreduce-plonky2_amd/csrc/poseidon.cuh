@@ -79,20 +79,28 @@ GLHD void p2_internal(u64 s[12]) {
     s[i] = gl_reduce128w(lo, hi + top + (c ? 1 : 0));
   }
 }
+#ifndef P2_UNROLL_EXT
+#define P2_UNROLL_EXT 1
+#endif
+#ifndef P2_UNROLL_INT
+#define P2_UNROLL_INT 1
+#endif
+#define P2_PRAGMA(x) _Pragma(#x)
+#define P2_UNROLL(n) P2_PRAGMA(unroll n)
 GLHD void poseidon2_perm(u64 s[12]) {
   p2_external(s);
-#pragma unroll 1
+P2_UNROLL(P2_UNROLL_EXT)
   for (int r = 0; r < 4; r++) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = p2_sbox(s[i], c_p2_ext[12 * r + i]);
     p2_external(s);
   }
-#pragma unroll 1
+P2_UNROLL(P2_UNROLL_INT)
   for (int r = 0; r < 22; r++) {
     s[0] = p2_sbox(s[0], c_p2_int[r]);
     p2_internal(s);
   }
-#pragma unroll 1
+P2_UNROLL(P2_UNROLL_EXT)
   for (int r = 4; r < 8; r++) {
 #pragma unroll
     for (int i = 0; i < 12; i++) s[i] = p2_sbox(s[i], c_p2_ext[12 * r + i]);
