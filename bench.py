@@ -203,7 +203,7 @@ def main():
             "digest_rows_per_s": rows / digest_s,
             "digest_check": [int(x) for x in w],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.base_bits)
         print(json.dumps(out))
     if dist is not None:
