@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=128, help="leaf proofs per step and rank")
     ap.add_argument("--base-bits", type=int, default=13)
-    ap.add_argument("--streams", type=int, default=2, help="1: base and wrap provers share one stream; 2: one stream each")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams: 1 = both shapes on one; 2 = one per shape; 4 = two half-batches per shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -88,31 +88,40 @@ def main():
     # two contexts = two HIP streams on the same GPU: the base and the wrap prover run concurrently, so
     # the latency-bound stretches of one (transcript, top Merkle levels) hide under the other's sponges
     ctx = mp2.Context(local_rank)
-    ctx2 = mp2.Context(local_rank) if args.streams > 1 else ctx
+    n_ctx = max(1, args.streams)
+    ctxs = [ctx] + [mp2.Context(local_rank) for _ in range(n_ctx - 1)]
     B = args.batch
+    # provers: (shape, context, share of the batch). 1 stream: both shapes on it; 2: one each;
+    # 4: every shape split into two half-batches
+    if n_ctx >= 4:
+        plan = [(args.base_bits, ctxs[0], B // 2), (12, ctxs[1], B // 2), (args.base_bits, ctxs[2], B - B // 2), (12, ctxs[3], B - B // 2)]
+    elif n_ctx >= 2:
+        plan = [(args.base_bits, ctxs[0], B), (12, ctxs[1], B)]
+    else:
+        plan = [(args.base_bits, ctx, B), (12, ctx, B)]
 
     # ---- synthetic inputs, resident in HBM before the timed region -----------------------------
     provers = []
-    for k, cx in ((args.base_bits, ctx), (12, ctx2)):
+    for k, cx, nb in plan:
         fp = mp2.standard_recursion_params(k, ORACLE_W)
         n = 1 << k
-        pr = mp2.BatchedProver(cx, fp, B)
+        pr = mp2.BatchedProver(cx, fp, nb)
         pr.set_preprocessed(cx.to_device(O.rand_field((ORACLE_W[0], n), SEED + k)))
         pr.enable_permutation(NUM_ROUTED, 8)  # Z / partial products are computed on the device from wires + sigmas
         # one random matrix per oracle, tiled over the batch (distinct public-input hashes keep
-        # the B transcripts, challenges and proofs distinct)
+        # the transcripts, challenges and proofs distinct)
         d_vals = []
         for i, w in enumerate(ORACLE_W[1:]):
             if i == 1:
                 d_vals.append(None)  # oracle 2: permutation argument, produced by the prover itself
                 continue
             one = O.rand_field((w, n), SEED + 100 * k + i + 1000 * rank)
-            buf = cx.alloc(B * w * n * 8)
-            for b in range(B):
+            buf = cx.alloc(nb * w * n * 8)
+            for b in range(nb):
                 mp2._ck(mp2.load().mp2g_h2d(cx.h, ctypes.c_void_p(buf.ptr.value + b * w * n * 8), mp2._p(one), ctypes.c_size_t(one.nbytes)))
             d_vals.append(buf)
         d_cd = cx.to_device(O.rand_field(4, SEED + 7))
-        d_ph = cx.to_device(O.rand_field((B, 4), SEED + 8 + rank))
+        d_ph = cx.to_device(O.rand_field((nb, 4), SEED + 8 + rank + 97 * len(provers)))
         provers.append((pr, d_vals, d_cd, d_ph))
     n_ntt = 1 << LOG_NTT
     d_poly = ctx.to_device(O.rand_field((1, n_ntt), 0xC0FFEE02 + rank))
@@ -123,9 +132,8 @@ def main():
             pr.prove(d_vals, d_cd, d_ph)
 
     def sync_all():
-        ctx.sync()
-        if ctx2 is not ctx:
-            ctx2.sync()
+        for c in ctxs:
+            c.sync()
 
     for _ in range(args.warmup):
         step()
@@ -208,9 +216,8 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
-    if ctx2 is not ctx:
-        ctx2.close()
-    ctx.close()
+    for c in reversed(ctxs):
+        c.close()
 
 
 if __name__ == "__main__":

@@ -9,10 +9,12 @@
 //     transforms per block), every global access is a contiguous 8 B/lane stream.
 //   * n  > 2^12 : Cooley-Tukey n = n1*n2 in two launches. Pass A transforms the strided
 //     dimension for a tile of 2^LC adjacent columns (>= 32..128 B contiguous per row), multiplies
-//     by w_n^(i2*k1) and leaves row j in DIF order; pass B transforms contiguous rows in place.
-//   * inside a block every lane keeps 16 points in registers (radix-16 = four DIF stages)
-//     between LDS exchanges; LDS indices are padded by 1/16 so the stride-16 round is
-//     bank-conflict free; twiddles for the inner DFT are staged in LDS once per block.
+//     by w_n^(i2*k1) (streamed from a precomputed table: one multiply per point) and leaves row j
+//     in DIF order; pass B transforms contiguous rows in place.
+//   * inside a block every lane keeps 8 points in registers (radix-8 = three DIF stages) between
+//     LDS exchanges -- radix-16 halves the LDS round trips but also the waves per tile and measured
+//     15 % slower; LDS indices are padded by 1/16 so the strided rounds are bank-conflict free;
+//     twiddles for the inner DFT are staged in LDS once per block.
 //   * LDE: the 2^r cosets of the blown-up domain are 2^r independent size-n transforms of the
 //     same coefficients scaled by (g w_{N}^j)^i; outputs land bit-reversed, i.e. already in
 //     Merkle-leaf order, so there is no separate transpose / bit-reverse pass.
@@ -38,7 +40,6 @@ struct NttArgs {
   const u64* pre_full;   // [K][n]: s_j^i; null -> pre_lo * pre_hi
   u64 post;              // scalar multiplied on the final store (n^-1 for inverse), 0 = none
   u32 bitrev_out;
-  u32 src_is_out;        // pass B of a two-pass bit-reversed transform reads `out`
 };
 
 // lanes per block: one radix-2^NTT_RMAX item per lane and round
