@@ -1,0 +1,47 @@
+"""Cells / rows tree payload hashes through the HIP sponge vs the oracle."""
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def limbs(v):
+    return [(int(v) >> (32 * (7 - j))) & 0xFFFFFFFF for j in range(8)]
+
+
+def test_cell_and_row_node_hashes(ctx, mp2):
+    ix = importlib.import_module("mapreduce-plonky2_amd.indexing")
+    rng = np.random.default_rng(4)
+    cnt = 50
+    left, right, root = O.rand_field((cnt, 4), 1), O.rand_field((cnt, 4), 2), O.rand_field((cnt, 4), 3)
+    ids = O.rand_field(cnt, 4)
+    vals = [int.from_bytes(rng.bytes(32), "big") for _ in range(cnt)]
+    mins = [int.from_bytes(rng.bytes(32), "big") for _ in range(cnt)]
+    maxs = [int.from_bytes(rng.bytes(32), "big") for _ in range(cnt)]
+    got = ix.cell_node_hashes(ctx, left, right, ids, vals)
+    got_row = ix.row_node_hashes(ctx, left, right, mins, maxs, ids, vals, root)
+    for i in range(cnt):
+        inp = list(left[i]) + list(right[i]) + [ids[i]] + limbs(vals[i])
+        assert np.array_equal(got[i], O.hash_n_to_m_no_pad(inp, 4))
+        inp = list(left[i]) + list(right[i]) + limbs(mins[i]) + limbs(maxs[i]) + [ids[i]] + limbs(vals[i]) + list(root[i])
+        assert len(inp) == 37
+        assert np.array_equal(got_row[i], O.hash_n_to_m_no_pad(inp, 4))
+
+
+def test_cells_tree_root_and_empty_hash(ctx, mp2):
+    ix = importlib.import_module("mapreduce-plonky2_amd.indexing")
+    empty = ix.empty_poseidon_hash(ctx)
+    assert not empty.any()  # hash_no_pad(&[]) squeezes the all-zero state
+    ids = [int(x) for x in O.rand_field(5, 9)]
+    vals = [3, 2 ** 200 + 7, 0, 2 ** 256 - 1, 12345]
+    root, hashes = ix.cells_tree_root(ctx, ids, vals)
+
+    def node(i):
+        if i >= 5:
+            return [0, 0, 0, 0]
+        return [int(x) for x in O.hash_n_to_m_no_pad(node(2 * i + 1) + node(2 * i + 2) + [ids[i]] + limbs(vals[i]), 4)]
+    assert [int(x) for x in root] == node(0)
