@@ -399,7 +399,12 @@ hipError_t fri_soa_to_aos(hipStream_t s, u32 B, u32 n, const u64* in, u64 in_bst
 }
 hipError_t fri_pow(hipStream_t s, int variant, const ChState* st, u32 B, u32 bits, u64* witness) {
   hipLaunchKernelGGL(fill_u64_kernel, dim3((B * POW_STRIDE + 63) / 64), dim3(64), 0, s, witness, ~(u64)0, B * POW_STRIDE);
-  dim3 g(POW_BLOCKS, B), bl(1024);  // 2^14 candidates per sweep and proof
+  // blocks per proof: 2^14 candidates per sweep when many proofs share the chip, up to 2^18 for a
+  // lone proof (its search is otherwise confined to 16 CUs and dominates single-proof latency)
+  u32 blocks = 1024 / (B ? B : 1);
+  if (blocks < POW_BLOCKS) blocks = POW_BLOCKS;
+  if (blocks > 256) blocks = 256;
+  dim3 g(blocks, B), bl(1024);
   if (variant == MP2G_POSEIDON2) hipLaunchKernelGGL((pow_kernel<MP2G_POSEIDON2>), g, bl, 0, s, st, bits, (unsigned long long*)witness);
   else hipLaunchKernelGGL((pow_kernel<MP2G_POSEIDON>), g, bl, 0, s, st, bits, (unsigned long long*)witness);
   return hipGetLastError();

@@ -50,10 +50,17 @@ template <int LT, int LW> struct NttGeom {
   static constexpr int E = (1 << LT) << LW;
   static constexpr int NT = (E >> NTT_RMAX) < 64 ? 64 : ((E >> NTT_RMAX) > 1024 ? 1024 : (E >> NTT_RMAX));
 };
-// Twiddles w_T^k: stages whose indices are multiples of 2^TWS read the sub-sampled LDS copy, the
-// first TWS stages (full-resolution, lane-contiguous indices) read the global table through L1.
-// TWS = 2 for T = 4096 keeps a 4096-point tile at 38.9 KB of LDS: four blocks = 32 waves per CU.
-template <int LT> struct NttTw { static constexpr int TWS = LT >= 12 ? 2 : 0; };
+// Twiddles of the inner DFT are stored stage-compact: stage s (butterflies on bit LT-1-s) uses
+// w_T^(v << s), v < 2^(LT-1-s), kept contiguously at offset 2^LT - 2^(LT-s). Lanes of a wave walk
+// consecutive v, so both the LDS copy (stages >= TWS) and the global table (first TWS stages, through
+// L1) are read conflict-free / coalesced; a single strided w_T^k table cost up to 32-way LDS bank
+// conflicts in the later stages (SQ_LDS_BANK_CONFLICT was 0.5-0.67 of SQ_LDS_IDX_ACTIVE).
+// TWS keeps the LDS footprint at 8192 points + 8 KB (T = 2^11) and 4096 points + 4 KB (T = 2^12).
+template <int LT> struct NttTw {
+  static constexpr int TWS = LT >= 12 ? 3 : (LT == 11 ? 1 : 0);
+  static constexpr int off(int s) { return (1 << LT) - (1 << (LT - s)); }
+  static constexpr int LDS_WORDS = (1 << (LT - TWS)) - 1;  // stages TWS .. LT-1
+};
 template <int LT, int HI, int R, bool COLS, int LW, int NTT_THREADS>
 __device__ __forceinline__ void dif_round(u64* s, const u64* tw, const u64* __restrict__ twg, int tid) {
   constexpr int T = 1 << LT, LO = HI - R + 1, W = 1 << LW;
@@ -83,8 +90,10 @@ __device__ __forceinline__ void dif_round(u64* s, const u64* tw, const u64* __re
         x[m] = gl_add(u, v);
         u64 d = gl_sub(u, v);
         if (b > 0) {
-          int idx = ((m_low << LO) + below) << (LT - 1 - b);
-          u64 w = (LT - 1 - b) >= NttTw<LT>::TWS ? tw[idx >> NttTw<LT>::TWS] : twg[idx];
+          constexpr int dummy2 = 0; (void)dummy2;
+          const int st = LT - 1 - b;  // stage index
+          const int v = (m_low << LO) + below;
+          u64 w = st >= NttTw<LT>::TWS ? tw[NttTw<LT>::off(st) - NttTw<LT>::off(NttTw<LT>::TWS) + v] : twg[NttTw<LT>::off(st) + v];
           d = gl_mul(d, w);
         }
         x[m + half] = d;
@@ -127,7 +136,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_kernel(NttArgs
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < ((T / 2) >> NttTw<LT>::TWS); i += NT) tw[i] = a.tw[i << NttTw<LT>::TWS];
+  for (int i = tid; i < NttTw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[NttTw<LT>::off(NttTw<LT>::TWS) + i];
   const u32 n1 = 1u << a.log_n1;
   const u64 total_rows = (u64)a.batch << a.log_n1;
   const u64 row0 = (u64)blockIdx.x << LW;
@@ -169,7 +178,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_nat_kernel(Ntt
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < ((T / 2) >> NttTw<LT>::TWS); i += NT) tw[i] = a.tw[i << NttTw<LT>::TWS];
+  for (int i = tid; i < NttTw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[NttTw<LT>::off(NttTw<LT>::TWS) + i];
   const u32 lo_bits = a.log_n1 - LW;
   const u32 tile = blockIdx.x;
   const u32 b = tile >> lo_bits, jr_lo = tile & ((1u << lo_bits) - 1);
@@ -199,7 +208,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < ((T / 2) >> NttTw<LT>::TWS); i += NT) tw[i] = a.tw[i << NttTw<LT>::TWS];
+  for (int i = tid; i < NttTw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[NttTw<LT>::off(NttTw<LT>::TWS) + i];
   const u32 tiles_per = 1u << (a.log_n2 - LW);
   // XCD-aware order: blocks i and i+8 land on one XCD (round-robin dispatch, speed only), so give
   // each XCD a contiguous run of column tiles -- neighbouring tiles share 128-B lines and L2 sets
@@ -238,6 +247,16 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
   }
 }
 
+// out[2^lt - 2^(lt-s) + v] = w^(v << s) for s < lt, v < 2^(lt-1-s)   (stage-compact twiddles)
+__global__ void stage_twiddles_kernel(u64* out, u64 w, u32 lt) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i + 1 >= (1u << lt)) return;
+  // stage s covers offsets [2^lt - 2^(lt-s), 2^lt - 2^(lt-s-1)): s = number of leading ones of i in lt bits
+  u32 s = 0;
+  while (i >= (1u << lt) - (1u << (lt - s - 1))) s++;
+  u32 v = i - ((1u << lt) - (1u << (lt - s)));
+  out[i] = gl_pow(w, (u64)v << s);
+}
 __global__ void powers_kernel(u64* out, u64 base, u64 first, u64 stride_exp, u32 count) {
   // out[i] = first * base^(i * stride_exp)
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -304,9 +323,15 @@ hipError_t NttEngine::plan(u32 log_n, bool inverse, NttPlan** out) {
   };
   // inner DFT roots: w_{n2}^k (pass B) and w_{n1}^k (pass A)
   u64 w2 = gl_pow(wn, (u64)1 << p->log_n1), w1 = gl_pow(wn, (u64)1 << p->log_n2);
-  HIPCHK(powers(&p->tw_b, w2, (1u << p->log_n2) / 2));
+  auto stage_tw = [&](u64** dst, u64 base, u32 lt) -> hipError_t {
+    u32 count = (1u << lt);
+    HIPCHK(dev_alloc(dst, count));
+    hipLaunchKernelGGL(stage_twiddles_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, *dst, base, lt);
+    return hipGetLastError();
+  };
+  HIPCHK(stage_tw(&p->tw_b, w2, p->log_n2));
   if (p->log_n1) {
-    HIPCHK(powers(&p->tw_a, w1, (1u << p->log_n1) / 2));
+    HIPCHK(stage_tw(&p->tw_a, w1, p->log_n1));
     HIPCHK(powers(&p->tw4_lo, wn, 4096));
     HIPCHK(powers(&p->tw4_hi, gl_pow(wn, 4096), log_n > 12 ? (1u << (log_n - 12)) : 1));
     if (log_n <= 22) {  // full 4-step table (<= 32 MB): one multiply per point instead of two
@@ -364,7 +389,7 @@ template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : (LT == 
 template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : 12 - LT; }
 template <int LT, int LW> static size_t lds_bytes() {
   int e = (1 << LT) << LW;
-  return (size_t)(e + (e >> 4) + 1 + (((1 << LT) / 2) >> NttTw<LT>::TWS) + 1) * sizeof(u64);
+  return (size_t)(e + (e >> 4) + 1 + NttTw<LT>::LDS_WORDS + 1) * sizeof(u64);
 }
 
 template <int LT>

@@ -5,7 +5,7 @@ import numpy as np
 mp2 = importlib.import_module("mapreduce-plonky2_amd")
 import oracle as O
 ctx = mp2.Context(0)
-for log_n, batch in ((22, 1), (15, 135), (12, 135 * 8)):
+for log_n, batch in ((22, 1), (22, 4), (22, 16), (15, 135), (15, 1024), (12, 135 * 8), (12, 16384)):
     n = 1 << log_n
     d_in = ctx.to_device(O.rand_field((batch, n), 1))
     d_out = ctx.alloc(batch * n * 8)
