@@ -153,6 +153,17 @@ int mp2g_fri_fold(mp2g_ctx* ctx, const uint64_t* evals, uint32_t log_m, uint32_t
 int mp2g_fri_pow(mp2g_ctx* ctx, int variant, const uint64_t state[12], uint32_t pos, uint32_t bits,
                  uint64_t* witness);
 
+/* Openings of one committed batch at an extension point (plonk/prover.rs eval_commitment):
+ * out[p] = [c0, c1] of polynomial p evaluated at point. */
+int mp2g_batch_eval_ext(const mp2g_batch* batch, const uint64_t point[2], uint64_t* out /* [w][2] */);
+/* PolynomialBatch::prove_openings / fri_proof over committed batches: `oracles` in FRI order
+ * (constants_sigmas, wires, zs_partial_products, quotient), zeta the opening point, `ch` a count-1
+ * challenger that has already observed the openings; on return it has absorbed the FRI transcript.
+ * proof: mp2g_fri_proof_words(params) words, host. This is the call a host makes after computing the
+ * quotient polynomials itself. */
+int mp2g_fri_prove(mp2g_ctx* ctx, const mp2g_fri_params* params, mp2g_batch* const* oracles, const uint64_t zeta[2],
+                   mp2g_challenger* ch, uint64_t* proof);
+
 /* Batched PCS prover: the commitment / Fiat-Shamir / opening / FRI skeleton of plonky2's prove()
  * for `batch` same-shape proofs at once, everything resident on the device. */
 typedef struct mp2g_prover mp2g_prover;

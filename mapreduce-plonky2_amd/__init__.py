@@ -255,6 +255,13 @@ class PolynomialBatch:
         _ck(load().mp2g_batch_coeffs(self.h, _p(out)))
         return out
 
+    def eval_ext(self, point):
+        """Evaluate every polynomial of the batch at an extension-field point (the openings)."""
+        pt = _arr(point)
+        out = np.empty((self.w, 2), dtype=np.uint64)
+        _ck(load().mp2g_batch_eval_ext(self.h, _p(pt), _p(out)))
+        return out
+
     def open(self, indices):
         idx = _arr(indices, np.uint32)
         depth = self.log_n + self.rate_bits - self.cap_height
@@ -605,3 +612,13 @@ def partial_products_and_zs(ctx, wires, sigmas, betas, gammas, degree=8):
     _ck(load().mp2g_partial_products_and_zs(ctx.h, _p(wv), wv.shape[0], _p(sg), int(n).bit_length() - 1, num_routed, degree,
                                             _p(b), _p(g), b.size, _p(out)))
     return out
+
+
+def fri_prove(ctx, fp, oracles, zeta, challenger):
+    """PolynomialBatch::prove_openings over committed batches (granular path for hosts that compute
+    the quotient polynomials themselves). Returns the flat FriProof."""
+    hs = (ctypes.c_void_p * len(oracles))(*[o.h.value for o in oracles])
+    z = _arr(zeta)
+    proof = np.empty(fp.proof_words, dtype=np.uint64)
+    _ck(load().mp2g_fri_prove(ctx.h, ctypes.byref(fp), hs, _p(z), challenger.h, _p(proof)))
+    return proof

@@ -179,7 +179,7 @@ int mp2g_fri_pow(mp2g_ctx* c, int variant, const uint64_t state[12], uint32_t po
 }
 
 // ---- batched prover --------------------------------------------------------------------------
-int mp2g_prover_create(mp2g_ctx* c, const mp2g_fri_params* params, uint32_t batch, mp2g_prover** out) {
+static int prover_create_impl(mp2g_ctx* c, const mp2g_fri_params* params, uint32_t batch, bool alloc_oracles, mp2g_prover** out) {
   NEED(c && out, "ctx/out");
   NEED(batch >= 1 && batch <= 4096, "1 <= batch <= 4096");
   int rc = params_check(params);
@@ -200,7 +200,7 @@ int mp2g_prover_create(mp2g_ctx* c, const mp2g_fri_params* params, uint32_t batc
   pr->n_open = mp2g_fri_n_openings(&P);
   hipError_t e = hipSuccess;
   auto A = [&](DevBuf& d, size_t words) { if (e == hipSuccess) e = d.alloc(words * sizeof(u64)); };
-  for (uint32_t o = 0; o < P.n_oracles; o++) {
+  for (uint32_t o = 0; o < P.n_oracles && alloc_oracles; o++) {
     size_t nb = o == 0 ? 1 : B;
     A(pr->coeffs[o], nb * P.oracle_w[o] * n);
     A(pr->values[o], nb * P.oracle_w[o] * N);
@@ -223,6 +223,9 @@ int mp2g_prover_create(mp2g_ctx* c, const mp2g_fri_params* params, uint32_t batc
   if (e != hipSuccess) { delete pr; return fail("prover_create: %s", hipGetErrorString(e)); }
   *out = pr;
   return 0;
+}
+int mp2g_prover_create(mp2g_ctx* c, const mp2g_fri_params* params, uint32_t batch, mp2g_prover** out) {
+  return prover_create_impl(c, params, batch, true, out);
 }
 void mp2g_prover_free(mp2g_prover* pr) {
   if (!pr) return;
@@ -269,56 +272,20 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
   pr->num_routed = num_routed; pr->degree = degree;
   return 0;
 }
-int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, const uint64_t* d_circuit_digest,
-                          const uint64_t* d_pi_hash, uint64_t* d_caps, uint64_t* d_openings, uint64_t* d_proof) {
-  NEED(pr && d_values && d_circuit_digest && d_pi_hash && d_caps && d_openings && d_proof, "prover/pointers");
-  NEED(pr->have_pre, "call mp2g_prover_set_preprocessed_dev first");
+}  // extern "C"
+
+// fri/oracle.rs prove_openings + fri/prover.rs fri_proof for B transcripts: alpha, batch composition,
+// LDE, commit phase, final polynomial, proof of work, query rounds. `sh` names the committed
+// oracles, `st` the challengers (openings already observed), pr->zeta the opening points.
+static int fri_tail(mp2g_prover* pr, const FriShape& sh, ChState* st, u64* d_proof) {
   mp2g_ctx* c = pr->ctx;
   hipStream_t s = c->stream;
   const mp2g_fri_params& P = pr->P;
   const uint32_t B = pr->B, lg = P.log_n + P.rate_bits, V = P.variant;
   const u64 n = (u64)1 << P.log_n, N = n << P.rate_bits;
-  const size_t capw = pr->capw, LW = pr->levels_words;
-  ChState* st = (ChState*)pr->ch.p;
+  const size_t capw = pr->capw;
   u64* chal = pr->chal.p;
-  const u64 caps_b = P.n_oracles * capw;
-
-  CK(challenger_init(s, st, B));
-  CK(challenger_step(s, V, st, B, (const u64*)d_circuit_digest, 0, 4, chal, 8, 0));
-  CK(challenger_step(s, V, st, B, (const u64*)d_pi_hash, 4, 4, chal, 8, 0));
-  CK(copy_rows(s, B, pr->levels[0].p + LW - capw, 0, (u64*)d_caps, caps_b, (u32)capw));
-  for (uint32_t o = 1; o < P.n_oracles; o++) {
-    const u64* vals = (const u64*)d_values[o - 1];
-    if (o == 2 && pr->num_routed) {
-      // betas = chal[0..2), gammas = chal[2..4) of every transcript (drawn after the wires cap)
-      CK(zpp_compute(s, B, (const u64*)d_values[0], (u64)P.oracle_w[1] * n, pr->pre_values.p + (u64)(P.oracle_w[0] - pr->num_routed) * n,
-                     P.log_n, pr->num_routed, pr->degree, chal, chal + 2, 8, P.zs_count, pr->chunk_q.p, pr->zs_values.p,
-                     (u64)P.oracle_w[2] * n));
-      vals = pr->zs_values.p;
-    }
-    NEED(vals, "d_values[o]");
-    CK(commit_oracle(pr, o, vals, B));
-    u64* cap_dst = (u64*)d_caps + o * capw;
-    CK(copy_rows(s, B, pr->levels[o].p + LW - capw, LW, cap_dst, caps_b, (u32)capw));
-    // plonk/prover.rs: wires cap -> betas, gammas (2+2); zs cap -> alphas (2); all other caps -> 0
-    uint32_t n_get = o == 1 ? 4 : (o == 2 ? 2 : 0);
-    CK(challenger_step(s, V, st, B, cap_dst, caps_b, (u32)capw, chal, 8, n_get));
-  }
-  CK(challenger_step(s, V, st, B, chal, 0, 0, pr->zeta.p, 2, 2));  // zeta
-
-  FriShape sh{};
-  sh.log_n = P.log_n; sh.rate_bits = P.rate_bits; sh.cap_h = P.cap_height; sh.n_oracles = P.n_oracles;
-  sh.zs_oracle = P.zs_oracle; sh.zs_count = P.zs_count;
-  for (uint32_t o = 0; o < P.n_oracles; o++) {
-    OracleRef& r = sh.o[o];
-    r.coeffs = pr->coeffs[o].p; r.values = pr->values[o].p; r.levels = pr->levels[o].p; r.w = P.oracle_w[o];
-    r.coeff_bstride = o ? (u64)r.w * n : 0;
-    r.value_bstride = o ? (u64)r.w * N : 0;
-    r.level_bstride = o ? LW : 0;
-    sh.n_polys += r.w;
-  }
-  CK(fri_openings(s, sh, B, pr->zeta.p, 2, (u64*)d_openings));
-  CK(challenger_step(s, V, st, B, (const u64*)d_openings, 2 * pr->n_open, (u32)(2 * pr->n_open), pr->alpha.p, 2, 2));
+  CK(challenger_step(s, V, st, B, chal, 0, 0, pr->alpha.p, 2, 2));  // alpha
   CK(fri_final_poly(s, sh, B, pr->alpha.p, 2, pr->zeta.p, 2, pr->comp.p, pr->quot.p, pr->final_poly.p));
   CosetTables* pre;
   CK(c->ntt.coset(P.log_n, P.rate_bits, GL_MULT_GEN, &pre));
@@ -362,6 +329,61 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
   return 0;
 }
 
+extern "C" {
+
+int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, const uint64_t* d_circuit_digest,
+                          const uint64_t* d_pi_hash, uint64_t* d_caps, uint64_t* d_openings, uint64_t* d_proof) {
+  NEED(pr && d_values && d_circuit_digest && d_pi_hash && d_caps && d_openings && d_proof, "prover/pointers");
+  NEED(pr->have_pre, "call mp2g_prover_set_preprocessed_dev first");
+  mp2g_ctx* c = pr->ctx;
+  hipStream_t s = c->stream;
+  const mp2g_fri_params& P = pr->P;
+  const uint32_t B = pr->B, V = P.variant;
+  const u64 n = (u64)1 << P.log_n, N = n << P.rate_bits;
+  const size_t capw = pr->capw, LW = pr->levels_words;
+  ChState* st = (ChState*)pr->ch.p;
+  u64* chal = pr->chal.p;
+  const u64 caps_b = P.n_oracles * capw;
+
+  CK(challenger_init(s, st, B));
+  CK(challenger_step(s, V, st, B, (const u64*)d_circuit_digest, 0, 4, chal, 8, 0));
+  CK(challenger_step(s, V, st, B, (const u64*)d_pi_hash, 4, 4, chal, 8, 0));
+  CK(copy_rows(s, B, pr->levels[0].p + LW - capw, 0, (u64*)d_caps, caps_b, (u32)capw));
+  for (uint32_t o = 1; o < P.n_oracles; o++) {
+    const u64* vals = (const u64*)d_values[o - 1];
+    if (o == 2 && pr->num_routed) {
+      // betas = chal[0..2), gammas = chal[2..4) of every transcript (drawn after the wires cap)
+      CK(zpp_compute(s, B, (const u64*)d_values[0], (u64)P.oracle_w[1] * n, pr->pre_values.p + (u64)(P.oracle_w[0] - pr->num_routed) * n,
+                     P.log_n, pr->num_routed, pr->degree, chal, chal + 2, 8, P.zs_count, pr->chunk_q.p, pr->zs_values.p,
+                     (u64)P.oracle_w[2] * n));
+      vals = pr->zs_values.p;
+    }
+    NEED(vals, "d_values[o]");
+    CK(commit_oracle(pr, o, vals, B));
+    u64* cap_dst = (u64*)d_caps + o * capw;
+    CK(copy_rows(s, B, pr->levels[o].p + LW - capw, LW, cap_dst, caps_b, (u32)capw));
+    // plonk/prover.rs: wires cap -> betas, gammas (2+2); zs cap -> alphas (2); all other caps -> 0
+    uint32_t n_get = o == 1 ? 4 : (o == 2 ? 2 : 0);
+    CK(challenger_step(s, V, st, B, cap_dst, caps_b, (u32)capw, chal, 8, n_get));
+  }
+  CK(challenger_step(s, V, st, B, chal, 0, 0, pr->zeta.p, 2, 2));  // zeta
+
+  FriShape sh{};
+  sh.log_n = P.log_n; sh.rate_bits = P.rate_bits; sh.cap_h = P.cap_height; sh.n_oracles = P.n_oracles;
+  sh.zs_oracle = P.zs_oracle; sh.zs_count = P.zs_count;
+  for (uint32_t o = 0; o < P.n_oracles; o++) {
+    OracleRef& r = sh.o[o];
+    r.coeffs = pr->coeffs[o].p; r.values = pr->values[o].p; r.levels = pr->levels[o].p; r.w = P.oracle_w[o];
+    r.coeff_bstride = o ? (u64)r.w * n : 0;
+    r.value_bstride = o ? (u64)r.w * N : 0;
+    r.level_bstride = o ? LW : 0;
+    sh.n_polys += r.w;
+  }
+  CK(fri_openings(s, sh, B, pr->zeta.p, 2, (u64*)d_openings));
+  CK(challenger_step(s, V, st, B, (const u64*)d_openings, 2 * pr->n_open, (u32)(2 * pr->n_open), chal, 8, 0));
+  return fri_tail(pr, sh, st, (u64*)d_proof);
+}
+
 int mp2g_partial_products_and_zs(mp2g_ctx* c, const uint64_t* wires, uint32_t wires_w, const uint64_t* sigmas, uint32_t log_n,
                                  uint32_t num_routed, uint32_t degree, const uint64_t* betas, const uint64_t* gammas, uint32_t nc,
                                  uint64_t* out) {
@@ -383,6 +405,61 @@ int mp2g_partial_products_and_zs(mp2g_ctx* c, const uint64_t* wires, uint32_t wi
   CK(hipMemcpyAsync(out, dout.p, nc * chunks * n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
   return 0;
+}
+
+// ---- granular entry points over PolynomialBatch handles ----------------------------------------
+int mp2g_batch_eval_ext(const mp2g_batch* b, const uint64_t point[2], uint64_t* out) {
+  NEED(b && point && out, "batch/point/out");
+  NEED(point[0] < GL_P && point[1] < GL_P, "point canonical");
+  mp2g_ctx* c = b->ctx;
+  FriShape sh{};
+  sh.log_n = b->log_n; sh.rate_bits = b->rate_bits; sh.cap_h = b->cap_h; sh.n_oracles = 1; sh.n_polys = b->w;
+  sh.o[0].coeffs = b->coeffs.p; sh.o[0].w = b->w;
+  DevBuf dz, dout;
+  CK(dz.alloc(2 * sizeof(u64)));
+  CK(dout.alloc((size_t)b->w * 2 * sizeof(u64)));
+  CK(hipMemcpyAsync(dz.p, point, 2 * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(fri_openings(c->stream, sh, 1, dz.p, 0, dout.p));
+  CK(hipMemcpyAsync(out, dout.p, (size_t)b->w * 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int mp2g_fri_prove(mp2g_ctx* c, const mp2g_fri_params* params, mp2g_batch* const* oracles, const uint64_t zeta[2],
+                   mp2g_challenger* ch, uint64_t* proof) {
+  NEED(c && params && oracles && zeta && ch && proof, "ctx/pointers");
+  NEED(ch->ctx == c && ch->count == 1, "challenger must live on this context with count 1");
+  NEED(ch->variant == (int)params->variant, "challenger / params hash variant differ");
+  mp2g_prover* pr;
+  int rc = prover_create_impl(c, params, 1, false, &pr);
+  if (rc) return rc;
+  const mp2g_fri_params& P = pr->P;
+  FriShape sh{};
+  sh.log_n = P.log_n; sh.rate_bits = P.rate_bits; sh.cap_h = P.cap_height; sh.n_oracles = P.n_oracles;
+  sh.zs_oracle = P.zs_oracle; sh.zs_count = P.zs_count;
+  for (uint32_t o = 0; o < P.n_oracles; o++) {
+    const mp2g_batch* b = oracles[o];
+    if (!b || b->ctx != c || b->log_n != P.log_n || b->w != P.oracle_w[o] || b->rate_bits != P.rate_bits ||
+        b->cap_h != P.cap_height || b->variant != (int)P.variant) {
+      mp2g_prover_free(pr);
+      return fail("oracle %u does not match the FRI parameters", o);
+    }
+    OracleRef& r = sh.o[o];
+    r.coeffs = b->coeffs.p; r.values = b->values.p; r.levels = b->levels.p; r.w = b->w;
+    sh.n_polys += r.w;
+  }
+  DevBuf dproof;
+  hipError_t e = dproof.alloc(pr->proof_words * sizeof(u64));
+  if (e == hipSuccess) e = hipMemcpyAsync(pr->zeta.p, zeta, 2 * sizeof(u64), hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) { mp2g_prover_free(pr); return fail("fri_prove setup: %s", hipGetErrorString(e)); }
+  rc = fri_tail(pr, sh, (ChState*)ch->st.p, dproof.p);
+  if (!rc) {
+    e = hipMemcpyAsync(proof, dproof.p, pr->proof_words * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail("fri_prove copy-out: %s", hipGetErrorString(e));
+  }
+  mp2g_prover_free(pr);
+  return rc;
 }
 
 int mp2g_pcs_prove(mp2g_ctx* c, const mp2g_fri_params* params, const uint64_t* const* values, const uint64_t circuit_digest[4],

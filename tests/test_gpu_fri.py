@@ -115,3 +115,37 @@ def test_prover_param_errors(ctx, mp2):
     fp.zs_count = 9
     with pytest.raises(mp2.Mp2gError):
         mp2.BatchedProver(ctx, fp, 1)
+
+
+def test_granular_prove_matches_fused(ctx, mp2):
+    """The step-by-step path a Rust host would drive (commit, challenger, Z, commit, ..., openings,
+    fri_prove) produces the same proof as the fused pipeline and the oracle."""
+    log_n, num_routed = 7, 16
+    ws = (2 + num_routed, num_routed + 5, 2 * (num_routed // 8), 4)
+    ofp = O.standard_params(log_n, ws, pow_bits=6, num_queries=4)
+    fp = to_mp2(mp2, ofp)
+    n = 1 << log_n
+    pre, wires, quot = O.rand_field((ws[0], n), 1), O.rand_field((ws[1], n), 2), O.rand_field((ws[3], n), 3)
+    cd, ph = O.rand_field(4, 4), O.rand_field(4, 5)
+    ch = mp2.Challenger(ctx)
+    ch.observe_elements(cd); ch.observe_elements(ph)
+    b0 = mp2.PolynomialBatch.from_values(ctx, pre)
+    b1 = mp2.PolynomialBatch.from_values(ctx, wires)
+    ch.observe_elements(b1.cap.reshape(-1))
+    bg = ch.get_n_challenges(4)[0]
+    zs = mp2.partial_products_and_zs(ctx, wires, pre[ws[0] - num_routed:], bg[:2], bg[2:], 8)
+    b2 = mp2.PolynomialBatch.from_values(ctx, zs)
+    ch.observe_elements(b2.cap.reshape(-1))
+    ch.get_n_challenges(2)  # alphas
+    b3 = mp2.PolynomialBatch.from_values(ctx, quot)  # a host would compute the quotient here
+    ch.observe_elements(b3.cap.reshape(-1))
+    zeta = ch.get_n_challenges(2)[0]
+    g = pow(7277203076849721926, 1 << (32 - log_n), O.P)
+    gz = [int(zeta[0]) * g % O.P, int(zeta[1]) * g % O.P]
+    openings = np.concatenate([b.eval_ext(zeta) for b in (b0, b1, b2, b3)] + [b2.eval_ext(gz)[:2]])
+    ch.observe_elements(openings.reshape(-1))
+    proof = mp2.fri_prove(ctx, fp, [b0, b1, b2, b3], zeta, ch)
+    caps = np.stack([b.cap.reshape(-1) for b in (b0, b1, b2, b3)])
+    oc, oo, op = O.pcs_prove(ofp, [pre, wires, zs, quot], cd, ph, num_routed=num_routed, degree=8)
+    assert np.array_equal(caps, oc) and np.array_equal(openings, oo) and np.array_equal(proof, op)
+    assert O.pcs_verify(ofp, cd, ph, caps, openings, proof) == 0
