@@ -1,0 +1,61 @@
+"""Committed golden vectors (tests/golden/oracle_vectors.json, made by tools/gen_golden.py): the
+oracle reproduces them on CPU, the HIP path reproduces them on the GPU."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+
+
+def fnv(a):
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(a).tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return f"{h:016x}"
+
+
+def digest_inputs():
+    rng = np.random.default_rng(20)
+    col_ids = O.rand_field(4, 0xC0FFEE04)
+    values = rng.integers(0, 1 << 32, size=(10, 4, 8), dtype=np.uint32)
+    return col_ids, values, values[:, :1, :].copy()
+
+
+def test_oracle_reproduces_golden():
+    x = O.rand_field((4, 9), 0xC0FFEE04)
+    assert O.hash_no_pad_batch(x, 4, 0).tolist() == G["hash_no_pad_9_to_4"]["poseidon2"]
+    assert O.hash_no_pad_batch(x, 4, 1).tolist() == G["hash_no_pad_9_to_4"]["poseidon"]
+    a = O.rand_field((1, 16), 0xC0FFEE02)
+    assert O.fft(a)[0].tolist() == G["ntt_16"]["forward"]
+    ws = tuple(G["pcs_prove_2p6"]["oracle_w"])
+    ofp = O.standard_params(6, ws, pow_bits=6, num_queries=4)
+    pv = [O.rand_field((w, 64), 100 + i) for i, w in enumerate(ws)]
+    _, openings, proof = O.pcs_prove(ofp, pv, O.rand_field(4, 1), O.rand_field(4, 2))
+    assert fnv(proof) == G["pcs_prove_2p6"]["proof_fnv1a"] and int(proof[-1]) == G["pcs_prove_2p6"]["pow_witness"]
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden(ctx, mp2):
+    x = O.rand_field((4, 9), 0xC0FFEE04)
+    assert ctx.hash_no_pad_batch(x, 4, 0).tolist() == G["hash_no_pad_9_to_4"]["poseidon2"]
+    assert ctx.hash_no_pad_batch(x, 4, 1).tolist() == G["hash_no_pad_9_to_4"]["poseidon"]
+    a = O.rand_field((1, 16), 0xC0FFEE02)
+    assert ctx.ntt(a)[0].tolist() == G["ntt_16"]["forward"]
+    assert ctx.ntt(a, coset_shift=O.MULT_GEN)[0].tolist() == G["ntt_16"]["coset_g"]
+    b = mp2.PolynomialBatch.from_values(ctx, O.rand_field((5, 64), 0xC0FFEE01))
+    assert fnv(b.cap) == G["commit_5x64"]["cap_fnv1a"] and b.cap[0].tolist() == G["commit_5x64"]["cap0"]
+    ws = tuple(G["pcs_prove_2p6"]["oracle_w"])
+    fp = mp2.standard_recursion_params(6, ws, pow_bits=6, num_queries=4)
+    pv = [O.rand_field((w, 64), 100 + i) for i, w in enumerate(ws)]
+    _, openings, proof = mp2.pcs_prove(ctx, fp, pv, O.rand_field(4, 1), O.rand_field(4, 2))
+    assert fnv(proof) == G["pcs_prove_2p6"]["proof_fnv1a"] and fnv(openings) == G["pcs_prove_2p6"]["openings_fnv1a"]
+    w, wei = mp2.map_to_curve_batch(ctx, O.rand_field((3, 9), 7), weierstrass=True)
+    assert w.tolist() == G["map_to_curve_9"]["encodings"] and wei.tolist() == G["map_to_curve_9"]["weierstrass"]
+    col_ids, values, unique = digest_inputs()
+    dw, _ = mp2.compute_table_row_digest(ctx, col_ids, values, unique)
+    assert dw.tolist() == G["row_digest_10x4"]["encoding"]
