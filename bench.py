@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="leaf proofs per step and rank")
     ap.add_argument("--base-bits", type=int, default=13)
     ap.add_argument("--streams", type=int, default=4, help="HIP streams: 1 = both shapes on one; 2 = one per shape; 4 = two half-batches per shape")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="PCIe-inclusive variant: every step uploads its wire / quotient matrices from pinned host memory "
+                         "on the prover's stream (never the headline value; see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,13 +125,23 @@ def main():
             d_vals.append(buf)
         d_cd = cx.to_device(O.rand_field(4, SEED + 7))
         d_ph = cx.to_device(O.rand_field((nb, 4), SEED + 8 + rank + 97 * len(provers)))
-        provers.append((pr, d_vals, d_cd, d_ph))
+        staging = []
+        if args.host_inputs:
+            for buf in d_vals:
+                if buf is None:
+                    continue
+                view, hptr = cx.host_alloc(buf.nbytes)
+                view[:] = np.frombuffer(buf.download((buf.nbytes // 8,)).tobytes(), dtype=np.uint8)
+                staging.append((buf, hptr, buf.nbytes))
+        provers.append((pr, d_vals, d_cd, d_ph, cx, staging))
     n_ntt = 1 << LOG_NTT
     d_poly = ctx.to_device(O.rand_field((1, n_ntt), 0xC0FFEE02 + rank))
     d_out = ctx.alloc(n_ntt * 8)
 
     def step():
-        for pr, d_vals, d_cd, d_ph in provers:
+        for pr, d_vals, d_cd, d_ph, cx, staging in provers:
+            for buf, hptr, nbytes in staging:
+                cx.h2d_async(buf, hptr, nbytes)
             pr.prove(d_vals, d_cd, d_ph)
 
     def sync_all():
@@ -212,7 +225,7 @@ def main():
             "config": {"workload": f"configs[3]-shaped leaf proofs: base 2^{args.base_bits} + wrap 2^12 prove() PCS pipeline "
                                    "(commitments, Fiat-Shamir, openings, FRI) at standard_recursion_config; "
                                    "roofline leg = configs[1] 2^22-point NTT",
-                       "batch_per_rank": B, "streams": args.streams, "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
+                       "batch_per_rank": B, "streams": args.streams, "host_inputs": bool(args.host_inputs), "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
                        "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B"},
             "roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, both launches)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -45,6 +45,11 @@ int mp2g_dev_alloc(mp2g_ctx* ctx, size_t bytes, void** d_ptr);
 int mp2g_dev_free(mp2g_ctx* ctx, void* d_ptr);
 int mp2g_h2d(mp2g_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int mp2g_d2h(mp2g_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+/* pinned host staging memory and stream-ordered uploads (a host that feeds witness matrices from
+ * its own memory overlaps the PCIe copy of batch k+1 with the proving of batch k) */
+int mp2g_host_alloc(mp2g_ctx* ctx, size_t bytes, void** ptr);
+int mp2g_host_free(mp2g_ctx* ctx, void* ptr);
+int mp2g_h2d_async(mp2g_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 /* HIP-event stopwatch on the context's stream (used by bench.py) */
 int mp2g_timer_start(mp2g_ctx* ctx);
 int mp2g_timer_stop(mp2g_ctx* ctx, float* ms);

@@ -129,6 +129,19 @@ class Context:
         a = np.ascontiguousarray(a)
         return DeviceBuffer(self, a.nbytes).upload(a)
 
+    def host_alloc(self, nbytes):
+        """Pinned host buffer as a numpy uint8 view (freed with host_free)."""
+        ptr = ctypes.c_void_p()
+        _ck(load().mp2g_host_alloc(self.h, ctypes.c_size_t(nbytes), ctypes.byref(ptr)))
+        buf = (ctypes.c_uint8 * nbytes).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.uint8), ptr
+
+    def host_free(self, ptr):
+        _ck(load().mp2g_host_free(self.h, ptr))
+
+    def h2d_async(self, d_dst, host_ptr, nbytes, dst_offset=0):
+        _ck(load().mp2g_h2d_async(self.h, ctypes.c_void_p(d_dst.ptr.value + dst_offset), host_ptr, ctypes.c_size_t(nbytes)))
+
     def timer_start(self):
         _ck(load().mp2g_timer_start(self.h))
 

@@ -95,6 +95,22 @@ int mp2g_d2h(mp2g_ctx* c, void* dst, const void* d_src, size_t bytes) {
   CK(hipStreamSynchronize(c->stream));
   return 0;
 }
+int mp2g_host_alloc(mp2g_ctx* c, size_t bytes, void** ptr) {
+  NEED(c && ptr, "ctx/ptr");
+  CK(hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocDefault));
+  return 0;
+}
+int mp2g_host_free(mp2g_ctx* c, void* ptr) {
+  NEED(c, "ctx");
+  CK(hipStreamSynchronize(c->stream));
+  CK(hipHostFree(ptr));
+  return 0;
+}
+int mp2g_h2d_async(mp2g_ctx* c, void* d_dst, const void* src, size_t bytes) {
+  NEED(c, "ctx");
+  CK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
 int mp2g_timer_start(mp2g_ctx* c) { NEED(c, "ctx"); CK(hipEventRecord(c->ev0, c->stream)); return 0; }
 int mp2g_timer_stop(mp2g_ctx* c, float* ms) {
   NEED(c && ms, "ctx/ms");
