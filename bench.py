@@ -11,10 +11,12 @@ wrap_circuit.rs:122-148). One step = one batch of `--batch` such leaf proofs, sh
 8(d) config 3 says (base 2^13 + wrap 2^12, standard_recursion_config: 84 constants/sigmas + 135
 wires + 20 Z/partial products + 16 quotient chunks, rate 1/8, cap 16, FRI [4,4], 16-bit PoW, 28
 queries), on synthetic witness matrices that are resident in HBM before the timed region. What
-runs per proof is the commitment / permutation-argument / Fiat-Shamir / opening / FRI pipeline of
-`prove()` (HOT LOOPS 1 and 3 of SURVEY 3.1, plus the Z / partial-product polynomials); witness
-generation and gate-constraint evaluation (HOT LOOP 2, SURVEY 8(f)-1 "next") are not part of this
-round, so the wire and quotient matrices are random -- see DESIGN.md.
+runs per proof is everything `prove()` does after witness generation -- wires commitment, Z / partial
+products, quotient polynomials, their commitments, Fiat-Shamir, openings, FRI (HOT LOOPS 1-3 of
+SURVEY 3.1) -- for a satisfied circuit whose constraints are copy constraints only: the quotient
+kernel evaluates the gate-independent vanishing terms; the 26 gate types' constraint evaluators
+(SURVEY 8(f)-1 "next") are the terms still to add, and witness generation stays on the host. The
+proofs verify (FRI + the PLONK identity at zeta, tests/test_gpu_permutation.py).
 Leaf proofs shard across ranks with no data-path collective ("scaling": "weak"); the per-rank
 multiset digests meet in one 160-byte all_gather outside the per-proof path.
 
@@ -50,11 +52,13 @@ def cpu_baseline(base_bits, n_proofs=1):
     t_total = 0.0
     for k in (base_bits, 12):
         ofp = O.standard_params(k, ORACLE_W)
-        vals = [O.rand_field((w, 1 << k), SEED + i) for i, w in enumerate(ORACLE_W)]
+        sig, wires = O.copy_constraint_circuit(k, NUM_ROUTED, ORACLE_W[1], 1 << (k - 1), SEED)
+        vals = [np.concatenate([O.rand_field((ORACLE_W[0] - NUM_ROUTED, 1 << k), SEED), sig]), wires,
+                np.zeros((ORACLE_W[2], 1 << k), dtype=np.uint64), np.zeros((ORACLE_W[3], 1 << k), dtype=np.uint64)]
         cd, ph = O.rand_field(4, 1), O.rand_field(4, 2)
         t0 = time.perf_counter()
         for _ in range(n_proofs):
-            O.pcs_prove(ofp, vals, cd, ph, num_routed=NUM_ROUTED, degree=8)
+            O.pcs_prove(ofp, vals, cd, ph, num_routed=NUM_ROUTED, degree=8, quotient=True)
         t_total += time.perf_counter() - t0
     return {"value": n_proofs / t_total, "unit": "leaf proofs/s", "cores": cores, "kind": "port",
             "sample": f"{n_proofs} leaf proof(s) = base 2^{base_bits} + wrap 2^12 PCS pipelines by oracle/ (OpenMP, {cores} threads; "
@@ -109,16 +113,20 @@ def main():
         fp = mp2.standard_recursion_params(k, ORACLE_W)
         n = 1 << k
         pr = mp2.BatchedProver(cx, fp, nb)
-        pr.set_preprocessed(cx.to_device(O.rand_field((ORACLE_W[0], n), SEED + k)))
-        pr.enable_permutation(NUM_ROUTED, 8)  # Z / partial products are computed on the device from wires + sigmas
+        # a satisfied circuit whose constraints are copy constraints only: identity sigma with n/2
+        # random 3-cycles of routed cells (the witness repeats the cycle's value in its cells)
+        sig, wires_one = O.copy_constraint_circuit(k, NUM_ROUTED, ORACLE_W[1], n // 2, SEED + k)
+        pr.set_preprocessed(cx.to_device(np.concatenate([O.rand_field((ORACLE_W[0] - NUM_ROUTED, n), SEED + k), sig])))
+        pr.enable_permutation(NUM_ROUTED, 8)  # Z / partial products on the device from wires + sigmas
+        pr.enable_quotient()                  # quotient chunks on the device (gate-independent terms)
         # one random matrix per oracle, tiled over the batch (distinct public-input hashes keep
         # the transcripts, challenges and proofs distinct)
         d_vals = []
         for i, w in enumerate(ORACLE_W[1:]):
-            if i == 1:
-                d_vals.append(None)  # oracle 2: permutation argument, produced by the prover itself
+            if i >= 1:
+                d_vals.append(None)  # oracles 2 and 3: produced by the prover itself
                 continue
-            one = O.rand_field((w, n), SEED + 100 * k + i + 1000 * rank)
+            one = wires_one
             buf = cx.alloc(nb * w * n * 8)
             for b in range(nb):
                 mp2._ck(mp2.load().mp2g_h2d(cx.h, ctypes.c_void_p(buf.ptr.value + b * w * n * 8), mp2._p(one), ctypes.c_size_t(one.nbytes)))
@@ -222,8 +230,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 (Goldilocks field)", "data": "synthetic",
-            "config": {"workload": f"configs[3]-shaped leaf proofs: base 2^{args.base_bits} + wrap 2^12 prove() PCS pipeline "
-                                   "(commitments, Fiat-Shamir, openings, FRI) at standard_recursion_config; "
+            "config": {"workload": f"configs[3]-shaped leaf proofs: base 2^{args.base_bits} + wrap 2^12 prove() from the wire matrix "
+                                   "(commitments, permutation argument, quotient of the gate-independent terms, Fiat-Shamir, "
+                                   "openings, FRI) at standard_recursion_config on a copy-constraint-only circuit; "
                                    "roofline leg = configs[1] 2^22-point NTT",
                        "batch_per_rank": B, "streams": args.streams, "host_inputs": bool(args.host_inputs), "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
                        "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B"},

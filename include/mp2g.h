@@ -252,6 +252,12 @@ int mp2g_partial_products_and_zs(mp2g_ctx* ctx, const uint64_t* wires, uint32_t 
  * NULL): the sigmas are the last num_routed polynomials of the preprocessed oracle, betas/gammas
  * the challenges drawn after the wires cap. Call after mp2g_prover_set_preprocessed_dev. */
 int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_t degree);
+/* Also compute oracle 3 (the quotient chunks) on the device, as plonk/prover.rs compute_quotient_polys
+ * does for the gate-independent terms of the vanishing polynomial (Z(1) = 1 and the partial-product
+ * checks): the complete prove() of a circuit whose only constraints are copy constraints; gate
+ * constraint evaluators are the next terms to add. d_values[2] may then be NULL. Needs
+ * mp2g_prover_enable_permutation, rate_bits 3 and oracle_w[3] = zs_count * 8. */
+int mp2g_prover_enable_quotient(mp2g_prover* pr);
 
 #ifdef __cplusplus
 }

@@ -410,6 +410,11 @@ class BatchedProver:
         polynomials (prove()'s permutation argument); d_values[1] may then be None."""
         _ck(load().mp2g_prover_enable_permutation(self.h, num_routed, degree))
 
+    def enable_quotient(self):
+        """Also compute the quotient chunks on the device for the gate-independent vanishing terms
+        (complete prove() of a copy-constraint-only circuit); d_values[2] may then be None."""
+        _ck(load().mp2g_prover_enable_quotient(self.h))
+
     def prove(self, d_values, d_circuit_digest, d_pi_hash):
         """d_values: device buffers [batch][w_o][n] for oracles 1..; asynchronous."""
         ptrs = (ctypes.c_void_p * len(d_values))(*[(d.ptr.value if d is not None else None) for d in d_values])

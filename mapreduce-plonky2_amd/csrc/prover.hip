@@ -33,7 +33,8 @@ struct mp2g_prover {
   DevBuf fvals[9], flevels[8], fcoeffs[9];
   // permutation argument computed on the device (mp2g_prover_enable_permutation)
   uint32_t num_routed = 0, degree = 0;
-  DevBuf pre_values, zs_values, chunk_q;
+  bool quotient = false;
+  DevBuf pre_values, zs_values, chunk_q, bg, alphas, qvals;
 };
 
 static int params_check(const mp2g_fri_params* p) {
@@ -232,14 +233,13 @@ void mp2g_prover_free(mp2g_prover* pr) {
   (void)hipStreamSynchronize(pr->ctx->stream);
   delete pr;
 }
-// values [nb][w][n] -> coeffs, LDE values, Merkle levels of oracle o
-static hipError_t commit_oracle(mp2g_prover* pr, uint32_t o, const u64* d_values, uint32_t nb) {
+// coefficients in pr->coeffs[o] -> LDE values, Merkle levels (PolynomialBatch::from_coeffs)
+static hipError_t commit_oracle_coeffs(mp2g_prover* pr, uint32_t o, uint32_t nb) {
   mp2g_ctx* c = pr->ctx;
   const mp2g_fri_params& P = pr->P;
   const u64 n = (u64)1 << P.log_n, N = n << P.rate_bits;
   const uint32_t w = P.oracle_w[o], lg = P.log_n + P.rate_bits;
-  hipError_t e = c->ntt.run(d_values, pr->coeffs[o].p, P.log_n, nb * w, 0, n, n, true, nullptr, false);
-  if (e != hipSuccess) return e;
+  hipError_t e;
   CosetTables* pre;
   e = c->ntt.coset(P.log_n, P.rate_bits, GL_MULT_GEN, &pre);
   if (e != hipSuccess) return e;
@@ -248,6 +248,14 @@ static hipError_t commit_oracle(mp2g_prover* pr, uint32_t o, const u64* d_values
   e = leaf_hash_poly_major(c->stream, P.variant, pr->values[o].p, w, N, N, pr->levels[o].p, nb, (u64)w * N, pr->levels_words);
   if (e != hipSuccess) return e;
   return merkle_reduce(c->stream, P.variant, pr->levels[o].p, lg, P.cap_height, nb, pr->levels_words);
+}
+// values [nb][w][n] -> coeffs, LDE values, Merkle levels of oracle o (PolynomialBatch::from_values)
+static hipError_t commit_oracle(mp2g_prover* pr, uint32_t o, const u64* d_values, uint32_t nb) {
+  const mp2g_fri_params& P = pr->P;
+  const u64 n = (u64)1 << P.log_n;
+  hipError_t e = pr->ctx->ntt.run(d_values, pr->coeffs[o].p, P.log_n, nb * P.oracle_w[o], 0, n, n, true, nullptr, false);
+  if (e != hipSuccess) return e;
+  return commit_oracle_coeffs(pr, o, nb);
 }
 int mp2g_prover_set_preprocessed_dev(mp2g_prover* pr, const uint64_t* d_values) {
   NEED(pr && d_values, "prover/values");
@@ -269,7 +277,19 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
   const size_t n = (size_t)1 << P.log_n;
   CK(pr->zs_values.alloc((size_t)pr->B * P.oracle_w[2] * n * sizeof(u64)));
   CK(pr->chunk_q.alloc((size_t)pr->B * P.zs_count * (num_routed / degree) * n * sizeof(u64)));
+  CK(pr->bg.alloc((size_t)pr->B * 4 * sizeof(u64)));
+  CK(pr->alphas.alloc((size_t)pr->B * 2 * sizeof(u64)));
   pr->num_routed = num_routed; pr->degree = degree;
+  return 0;
+}
+int mp2g_prover_enable_quotient(mp2g_prover* pr) {
+  NEED(pr && pr->num_routed, "call mp2g_prover_enable_permutation first");
+  const mp2g_fri_params& P = pr->P;
+  NEED(P.n_oracles == 4 && P.rate_bits == 3, "needs the four plonky2 oracles and rate_bits 3 (quotient degree factor 8)");
+  NEED(P.oracle_w[3] == P.zs_count * 8, "oracle_w[3] must be zs_count * 8 quotient chunks");
+  NEED(P.log_n + 3 <= 24, "log_n <= 21");
+  CK(pr->qvals.alloc((size_t)pr->B * P.zs_count * ((size_t)8 << P.log_n) * sizeof(u64)));
+  pr->quotient = true;
   return 0;
 }
 }  // extern "C"
@@ -352,19 +372,35 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
   for (uint32_t o = 1; o < P.n_oracles; o++) {
     const u64* vals = (const u64*)d_values[o - 1];
     if (o == 2 && pr->num_routed) {
-      // betas = chal[0..2), gammas = chal[2..4) of every transcript (drawn after the wires cap)
+      // betas = bg[0..2), gammas = bg[2..4) of every transcript (drawn after the wires cap)
       CK(zpp_compute(s, B, (const u64*)d_values[0], (u64)P.oracle_w[1] * n, pr->pre_values.p + (u64)(P.oracle_w[0] - pr->num_routed) * n,
-                     P.log_n, pr->num_routed, pr->degree, chal, chal + 2, 8, P.zs_count, pr->chunk_q.p, pr->zs_values.p,
+                     P.log_n, pr->num_routed, pr->degree, pr->bg.p, pr->bg.p + 2, 4, P.zs_count, pr->chunk_q.p, pr->zs_values.p,
                      (u64)P.oracle_w[2] * n));
       vals = pr->zs_values.p;
     }
-    NEED(vals, "d_values[o]");
-    CK(commit_oracle(pr, o, vals, B));
+    if (o == 3 && pr->quotient) {
+      // compute_quotient_polys for the gate-independent terms: values on the coset, coset iFFT, and the
+      // 8n coefficients of each challenge are its 8 degree-n chunks, already laid out as oracle 3's coeffs
+      const u32 nc = P.zs_count;
+      CK(quotient_perm_values(s, B, pr->values[1].p, (u64)P.oracle_w[1] * N, pr->values[0].p + (u64)(P.oracle_w[0] - pr->num_routed) * N,
+                              pr->values[2].p, (u64)P.oracle_w[2] * N, P.log_n, pr->num_routed, pr->degree, pr->bg.p, 4,
+                              pr->alphas.p, 2, nc, pr->qvals.p));
+      CK(c->ntt.run(pr->qvals.p, pr->coeffs[3].p, P.log_n + 3, B * nc, 0, N, N, true, nullptr, false));
+      CK(c->ntt.scale_powers(pr->coeffs[3].p, P.log_n + 3, B * nc, gl_inv(GL_MULT_GEN), 1));
+      CK(commit_oracle_coeffs(pr, 3, B));
+    } else {
+      NEED(vals, "d_values[o]");
+      CK(commit_oracle(pr, o, vals, B));
+    }
     u64* cap_dst = (u64*)d_caps + o * capw;
     CK(copy_rows(s, B, pr->levels[o].p + LW - capw, LW, cap_dst, caps_b, (u32)capw));
     // plonk/prover.rs: wires cap -> betas, gammas (2+2); zs cap -> alphas (2); all other caps -> 0
     uint32_t n_get = o == 1 ? 4 : (o == 2 ? 2 : 0);
-    CK(challenger_step(s, V, st, B, cap_dst, caps_b, (u32)capw, chal, 8, n_get));
+    u64* dst = chal;
+    u64 dst_stride = 8;
+    if (pr->num_routed && o == 1) { dst = pr->bg.p; dst_stride = 4; }
+    if (pr->num_routed && o == 2) { dst = pr->alphas.p; dst_stride = 2; }
+    CK(challenger_step(s, V, st, B, cap_dst, caps_b, (u32)capw, dst, dst_stride, n_get));
   }
   CK(challenger_step(s, V, st, B, chal, 0, 0, pr->zeta.p, 2, 2));  // zeta
 

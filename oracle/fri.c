@@ -28,6 +28,9 @@ void orc_lde_leaves(const gl_t* coeffs, unsigned log_n, size_t w, unsigned rate_
 size_t orc_bitrev(size_t x, unsigned bits);
 void orc_partial_products_and_zs(const gl_t* wires, const gl_t* sigmas, unsigned log_n, unsigned num_routed,
                                  unsigned degree, const gl_t* betas, const gl_t* gammas, unsigned nc, gl_t* out);
+void orc_quotient_perm(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, const gl_t* zs_coeffs, unsigned log_n,
+                       unsigned num_routed, unsigned degree, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
+                       unsigned nc, gl_t* out);
 
 // ---- challenger ---------------------------------------------------------------------------
 void orc_ch_init(orc_challenger* c, int variant) { memset(c, 0, sizeof *c); c->variant = variant; }
@@ -254,8 +257,12 @@ void orc_fri_prove(const orc_fri_params* P, gl_t* const* coeffs, gl_t* const* le
 // num_routed > 0: oracle 2 (Z / partial products) is not taken from values[2] but computed from the
 // wires (values[1]), the sigma values (last num_routed polynomials of values[0]) and the betas /
 // gammas drawn after the wires cap, as prove() does; needs oracle_w[2] = zs_count * num_routed/degree.
+// quotient != 0 (needs num_routed > 0): oracle 3 is not taken from values[3] either but computed as
+// compute_quotient_polys does for a circuit without gate constraints (orc_quotient_perm); bgao, if not
+// NULL, receives betas[2], gammas[2], alphas[2], zeta[2] for the PLONK identity check.
 void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4],
-                   const gl_t pi_hash[4], unsigned num_routed, unsigned degree, gl_t* caps, gl_t* openings, gl_t* proof) {
+                   const gl_t pi_hash[4], unsigned num_routed, unsigned degree, unsigned quotient, gl_t* bgao,
+                   gl_t* caps, gl_t* openings, gl_t* proof) {
   unsigned k = P->log_n, lg = k + P->rate_bits;
   size_t n = (size_t)1 << k, N = (size_t)1 << lg;
   size_t capw = ((size_t)4) << P->cap_height;
@@ -264,7 +271,7 @@ void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_
   orc_ch_init(&ch, P->variant);
   orc_ch_observe(&ch, circuit_digest, 4);
   orc_ch_observe(&ch, pi_hash, 4);
-  gl_t bg[4] = {0, 0, 0, 0};
+  gl_t bg[4] = {0, 0, 0, 0}, al[2] = {0, 0};
   gl_t* zs_vals = NULL;
   for (uint32_t o = 0; o < P->n_oracles; o++) {
     size_t w = P->oracle_w[o];
@@ -276,8 +283,14 @@ void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_
       src = zs_vals;
     }
     coeffs[o] = malloc(w * n * sizeof(gl_t));
-    memcpy(coeffs[o], src, w * n * sizeof(gl_t));
-    for (size_t p = 0; p < w; p++) orc_fft(coeffs[o] + p * n, k, 1);
+    if (o == 3 && quotient && num_routed) {
+      // PolynomialBatch::from_coeffs: the quotient chunks are produced in coefficient form
+      orc_quotient_perm(coeffs[1], coeffs[0] + (size_t)(P->oracle_w[0] - num_routed) * n, coeffs[2], k, num_routed, degree,
+                        bg, bg + 2, al, P->zs_count, coeffs[o]);
+    } else {
+      memcpy(coeffs[o], src, w * n * sizeof(gl_t));
+      for (size_t p = 0; p < w; p++) orc_fft(coeffs[o] + p * n, k, 1);
+    }
     leaves[o] = malloc(w * N * sizeof(gl_t));
     orc_lde_leaves(coeffs[o], k, w, P->rate_bits, leaves[o]);
     levels[o] = malloc(orc_merkle_levels_len(lg, P->cap_height) * sizeof(gl_t));
@@ -287,10 +300,11 @@ void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_
     orc_ch_observe(&ch, caps + o * capw, capw);
     // wires cap -> betas[2], gammas[2]; zs cap -> alphas[2]; quotient cap -> zeta
     if (o == 1) for (int i = 0; i < 4; i++) bg[i] = orc_ch_get(&ch);
-    else if (o == 2) for (int i = 0; i < 2; i++) (void)orc_ch_get(&ch);
+    else if (o == 2) for (int i = 0; i < 2; i++) al[i] = orc_ch_get(&ch);
   }
   free(zs_vals);
   gl2_t zeta = orc_ch_get_ext(&ch);
+  if (bgao) { memcpy(bgao, bg, 32); memcpy(bgao + 4, al, 16); bgao[6] = zeta.c[0]; bgao[7] = zeta.c[1]; }
   gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(k));
   size_t oi = 0;
   for (uint32_t o = 0; o < P->n_oracles; o++)
@@ -520,4 +534,113 @@ void orc_partial_products_and_zs(const gl_t* wires, const gl_t* sigmas, unsigned
   }
   free(chunk_prod);
   free(k_is);
+}
+
+// ---- quotient polynomials for the gate-independent part of the vanishing polynomial ------------
+// [dep] plonky2 plonk/prover.rs compute_quotient_polys + plonk/vanishing_poly.rs
+// eval_vanishing_poly_base_batch / check_partial_products, with an empty gate set (a circuit whose
+// only constraints are the copy constraints): terms = [L_0(x)(Z_c(x)-1) for c] ++ [partial-product
+// checks of challenge 0, of challenge 1, ...]; per alpha: sum_k terms[k] alpha^k, divided by Z_H on
+// the coset g<w_8n>, coset-iFFT, split into 8 chunks of n coefficients per challenge.
+// wires/sigmas/zs given as coefficient vectors [.][n]; zs = [Z_0..Z_{nc-1}, pp(0), pp(1)..].
+// out: [nc * 8][n] quotient chunk coefficients (the polynomials PolynomialBatch::from_coeffs commits).
+void orc_quotient_perm(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, const gl_t* zs_coeffs, unsigned log_n,
+                       unsigned num_routed, unsigned degree, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
+                       unsigned nc, gl_t* out) {
+  const unsigned rate_bits = 3;
+  size_t n = (size_t)1 << log_n, N = n << rate_bits;
+  unsigned lg = log_n + rate_bits, chunks = num_routed / degree, num_prods = chunks - 1;
+  unsigned n_zs = nc * chunks;
+  // natural-order LDE values on g<w_N>
+  gl_t* W = malloc((size_t)num_routed * N * sizeof(gl_t));
+  gl_t* S = malloc((size_t)num_routed * N * sizeof(gl_t));
+  gl_t* Z = malloc((size_t)n_zs * N * sizeof(gl_t));
+  void orc_lde_values(const gl_t*, unsigned, size_t, unsigned, gl_t*);
+  orc_lde_values(wires_coeffs, log_n, num_routed, rate_bits, W);
+  orc_lde_values(sigma_coeffs, log_n, num_routed, rate_bits, S);
+  orc_lde_values(zs_coeffs, log_n, n_zs, rate_bits, Z);
+  gl_t* k_is = malloc(num_routed * sizeof(gl_t));
+  k_is[0] = 1;
+  for (unsigned j = 1; j < num_routed; j++) k_is[j] = gl_mul(k_is[j - 1], GL_MULT_GEN);
+  gl_t wN = gl_root_of_unity(lg), gn = gl_pow(GL_MULT_GEN, n), w8 = gl_root_of_unity(rate_bits);
+  gl_t n_field = (gl_t)n % GL_P;
+  gl_t* q = malloc((size_t)nc * N * sizeof(gl_t));
+  gl_t* terms = malloc((nc + (size_t)nc * chunks) * sizeof(gl_t));
+  for (size_t i = 0; i < N; i++) {
+    gl_t x = gl_mul(GL_MULT_GEN, gl_pow(wN, i));
+    gl_t zh = gl_sub(gl_mul(gn, gl_pow(w8, i % 8)), 1);  // x^n - 1
+    gl_t l0 = gl_mul(zh, gl_inv(gl_mul(n_field, gl_sub(x, 1))));
+    size_t inext = (i + 8) % N;
+    size_t t = 0;
+    for (unsigned c = 0; c < nc; c++) terms[t++] = gl_mul(l0, gl_sub(Z[(size_t)c * N + i], 1));
+    for (unsigned c = 0; c < nc; c++) {
+      const gl_t* pp = Z + ((size_t)nc + (size_t)c * num_prods) * N;
+      for (unsigned k = 0; k < chunks; k++) {
+        gl_t num = 1, den = 1;
+        for (unsigned j = k * degree; j < (k + 1) * degree; j++) {
+          gl_t wv = W[(size_t)j * N + i];
+          num = gl_mul(num, gl_add(gl_add(wv, gl_mul(betas[c], gl_mul(k_is[j], x))), gammas[c]));
+          den = gl_mul(den, gl_add(gl_add(wv, gl_mul(betas[c], S[(size_t)j * N + i])), gammas[c]));
+        }
+        gl_t prev = k == 0 ? Z[(size_t)c * N + i] : pp[(size_t)(k - 1) * N + i];
+        gl_t next = k == chunks - 1 ? Z[(size_t)c * N + inext] : pp[(size_t)k * N + i];
+        terms[t++] = gl_sub(gl_mul(prev, num), gl_mul(next, den));
+      }
+    }
+    gl_t zh_inv = gl_inv(zh);
+    for (unsigned a = 0; a < nc; a++) {
+      gl_t acc = 0;
+      for (size_t k = t; k-- > 0;) acc = gl_add(gl_mul(acc, alphas[a]), terms[k]);
+      q[(size_t)a * N + i] = gl_mul(acc, zh_inv);
+    }
+  }
+  void orc_coset_ifft(gl_t*, unsigned, gl_t);
+  for (unsigned a = 0; a < nc; a++) {
+    orc_coset_ifft(q + (size_t)a * N, lg, GL_MULT_GEN);
+    memcpy(out + (size_t)a * N, q + (size_t)a * N, N * sizeof(gl_t));  // 8 chunks of n, contiguous
+  }
+  free(terms); free(q); free(k_is); free(W); free(S); free(Z);
+}
+// plonk/verifier.rs: vanishing(zeta) == Z_H(zeta) * sum_i zeta^(n i) t_i(zeta) for every challenge, from
+// the opened values only (openings layout of orc_pcs_prove; num_constants = oracle_w[0] - num_routed).
+// Returns 0 when the identity holds.
+int orc_plonk_identity_check(const orc_fri_params* P, unsigned num_routed, unsigned degree, const gl_t* openings,
+                             gl2_t zeta, const gl_t* betas, const gl_t* gammas, const gl_t* alphas) {
+  unsigned k = P->log_n, nc = P->zs_count, chunks = num_routed / degree, num_prods = chunks - 1;
+  size_t n = (size_t)1 << k;
+  size_t o_sig = P->oracle_w[0] - num_routed, o_w = P->oracle_w[0], o_z = o_w + P->oracle_w[1];
+  size_t o_q = o_z + P->oracle_w[2], o_next = o_q + P->oracle_w[3];
+#define OPEN(i) ((gl2_t){{openings[2 * (i)], openings[2 * (i) + 1]}})
+  gl2_t zn = zeta;
+  for (unsigned i = 0; i < k; i++) zn = gl2_mul(zn, zn);
+  gl2_t zh = gl2_sub(zn, gl2_from(1));
+  gl2_t l0 = gl2_mul(zh, gl2_inv(gl2_scale(gl2_sub(zeta, gl2_from(1)), (gl_t)n % GL_P)));
+  gl2_t terms[64];
+  size_t t = 0;
+  for (unsigned c = 0; c < nc; c++) terms[t++] = gl2_mul(l0, gl2_sub(OPEN(o_z + c), gl2_from(1)));
+  gl_t kj = 1;
+  gl_t k_is[256];
+  for (unsigned j = 0; j < num_routed; j++) { k_is[j] = kj; kj = gl_mul(kj, GL_MULT_GEN); }
+  for (unsigned c = 0; c < nc; c++) {
+    for (unsigned ch = 0; ch < chunks; ch++) {
+      gl2_t num = gl2_from(1), den = gl2_from(1);
+      for (unsigned j = ch * degree; j < (ch + 1) * degree; j++) {
+        gl2_t wv = OPEN(o_w + j);
+        num = gl2_mul(num, gl2_add(gl2_add(wv, gl2_scale(zeta, gl_mul(betas[c], k_is[j]))), gl2_from(gammas[c])));
+        den = gl2_mul(den, gl2_add(gl2_add(wv, gl2_scale(OPEN(o_sig + j), betas[c])), gl2_from(gammas[c])));
+      }
+      gl2_t prev = ch == 0 ? OPEN(o_z + c) : OPEN(o_z + nc + (size_t)c * num_prods + ch - 1);
+      gl2_t next = ch == chunks - 1 ? OPEN(o_next + c) : OPEN(o_z + nc + (size_t)c * num_prods + ch);
+      terms[t++] = gl2_sub(gl2_mul(prev, num), gl2_mul(next, den));
+    }
+  }
+  for (unsigned a = 0; a < nc; a++) {
+    gl2_t van = gl2_from(0);
+    for (size_t i = t; i-- > 0;) van = gl2_add(gl2_scale(van, alphas[a]), terms[i]);
+    gl2_t tz = gl2_from(0);
+    for (unsigned i = 8; i-- > 0;) tz = gl2_add(gl2_mul(tz, zn), OPEN(o_q + (size_t)a * 8 + i));
+    if (!gl2_eq(van, gl2_mul(zh, tz))) return 1 + (int)a;
+  }
+#undef OPEN
+  return 0;
 }

@@ -173,7 +173,7 @@ def standard_params(log_n, oracle_w=(84, 135, 20, 16), variant=0, rate_bits=3, c
     return fp
 
 
-def pcs_prove(fp, values, circuit_digest, pi_hash, num_routed=0, degree=8):
+def pcs_prove(fp, values, circuit_digest, pi_hash, num_routed=0, degree=8, quotient=False, want_challenges=False):
     """values: list of [w_o][n] arrays. Returns (caps, openings, proof). num_routed > 0: the Z /
     partial-product oracle is computed from the wires and sigmas (values[2] is ignored)."""
     vals = [arr(v) for v in values]
@@ -183,7 +183,10 @@ def pcs_prove(fp, values, circuit_digest, pi_hash, num_routed=0, degree=8):
     openings = np.zeros((lib().orc_n_openings(ctypes.byref(fp)), 2), dtype=np.uint64)
     proof = np.zeros(lib().orc_fri_proof_words(ctypes.byref(fp)), dtype=np.uint64)
     cd, ph = arr(circuit_digest), arr(pi_hash)
-    lib().orc_pcs_prove(ctypes.byref(fp), ptrs, p(cd), p(ph), num_routed, degree, p(caps), p(openings), p(proof))
+    bgao = np.zeros(8, dtype=np.uint64)
+    lib().orc_pcs_prove(ctypes.byref(fp), ptrs, p(cd), p(ph), num_routed, degree, int(bool(quotient)), p(bgao), p(caps), p(openings), p(proof))
+    if want_challenges:
+        return caps, openings, proof, bgao
     return caps, openings, proof
 
 
@@ -200,3 +203,34 @@ def partial_products_and_zs(wires, sigmas, betas, gammas, degree=8):
     out = np.zeros((nc * (num_routed // degree), n), dtype=np.uint64)
     lib().orc_partial_products_and_zs(p(wires), p(sigmas), int(n).bit_length() - 1, num_routed, degree, p(betas), p(gammas), nc, p(out))
     return out
+
+
+def plonk_identity_check(fp, num_routed, degree, openings, bgao):
+    """plonk/verifier.rs vanishing(zeta) == Z_H(zeta) t(zeta) for a gate-less circuit; 0 = holds."""
+    o = arr(openings)
+    class G2(ctypes.Structure):
+        _fields_ = [("c", ctypes.c_uint64 * 2)]
+    z = G2()
+    z.c[0], z.c[1] = int(bgao[6]), int(bgao[7])
+    b, g, a = arr(bgao[0:2]), arr(bgao[2:4]), arr(bgao[4:6])
+    return lib().orc_plonk_identity_check(ctypes.byref(fp), num_routed, degree, p(o), z, p(b), p(g), p(a))
+
+
+def copy_constraint_circuit(log_n, num_routed, wires_w, n_cycles, seed):
+    """A satisfied copy-constraint-only circuit: identity sigma with `n_cycles` random 3-cycles of
+    routed cells forced to equal values. Returns (sigma values [num_routed][n], wires [wires_w][n])."""
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    w = pow(7277203076849721926, 1 << (32 - log_n), P)
+    xs = [pow(w, i, P) for i in range(n)]
+    ks = [pow(MULT_GEN, j, P) for j in range(num_routed)]
+    sig = np.array([[ks[j] * x % P for x in xs] for j in range(num_routed)], dtype=np.uint64)
+    wires = rand_field((wires_w, n), seed)
+    cells = rng.permutation(num_routed * n)[:3 * n_cycles].reshape(-1, 3)
+    for a, b, c in cells:
+        (ja, ia), (jb, ib), (jc, ic) = divmod(int(a), n), divmod(int(b), n), divmod(int(c), n)
+        wires[jb, ib] = wires[ja, ia]
+        wires[jc, ic] = wires[ja, ia]
+        sa, sb, sc = sig[ja, ia], sig[jb, ib], sig[jc, ic]
+        sig[ja, ia], sig[jb, ib], sig[jc, ic] = sb, sc, sa
+    return sig, wires

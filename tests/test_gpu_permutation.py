@@ -82,3 +82,62 @@ def test_prover_with_device_permutation(ctx, mp2):
     # shape errors
     with pytest.raises(mp2.Mp2gError):
         pr.enable_permutation(num_routed, 5)
+
+
+def test_complete_proof_of_copy_constraint_circuit(ctx, mp2):
+    """Wires in, proof out: Z / partial products, quotient chunks (gate-independent vanishing terms),
+    commitments, openings and FRI all on the device. Bit-exact vs the oracle, FRI verifier accepts,
+    and the PLONK identity vanishing(zeta) = Z_H(zeta) t(zeta) holds on the opened values."""
+    log_n, R, B = 6, 16, 2
+    ws = (2 + R, R + 3, 2 * (R // 8), 16)
+    ofp = O.standard_params(log_n, ws, pow_bits=4, num_queries=3)
+    fp = mp2.FriParams()
+    ctypes.memmove(ctypes.byref(fp), ctypes.byref(ofp), ctypes.sizeof(fp))
+    n = 1 << log_n
+    sig, wires0 = O.copy_constraint_circuit(log_n, R, ws[1], 20, 7)
+    # second witness for the same circuit: constrained cells must stay equal -> reuse and re-randomise free cells only
+    pre = np.concatenate([O.rand_field((2, n), 1), sig])
+    wires = [wires0, wires0.copy()]
+    wires[1][R:] = O.rand_field((ws[1] - R, n), 77)  # unrouted advice columns are free
+    cd, ph = O.rand_field(4, 2), O.rand_field((B, 4), 3)
+    pr = mp2.BatchedProver(ctx, fp, B)
+    pr.set_preprocessed(ctx.to_device(pre))
+    pr.enable_permutation(R, 8)
+    pr.enable_quotient()
+    pr.prove([ctx.to_device(np.stack(wires)), None, None], ctx.to_device(cd), ctx.to_device(ph))
+    caps, openings, proofs = pr.results()
+    d2, d3 = np.zeros((ws[2], n), dtype=np.uint64), np.zeros((ws[3], n), dtype=np.uint64)
+    for b in range(B):
+        oc, oo, op, bgao = O.pcs_prove(ofp, [pre, wires[b], d2, d3], cd, ph[b], num_routed=R, degree=8, quotient=True, want_challenges=True)
+        assert np.array_equal(caps[b], oc) and np.array_equal(openings[b], oo) and np.array_equal(proofs[b], op)
+        assert O.pcs_verify(ofp, cd, ph[b], caps[b], openings[b], proofs[b]) == 0
+        assert O.plonk_identity_check(ofp, R, 8, openings[b], bgao) == 0
+    # an unsatisfied witness still yields a FRI-valid opening proof but fails the PLONK identity
+    bad = O.rand_field(wires0.shape, 5)
+    pr.prove([ctx.to_device(np.stack([bad, bad])), None, None], ctx.to_device(cd), ctx.to_device(ph))
+    caps, openings, proofs = pr.results()
+    _, _, _, bgao = O.pcs_prove(ofp, [pre, bad, d2, d3], cd, ph[0], num_routed=R, degree=8, quotient=True, want_challenges=True)
+    assert O.plonk_identity_check(ofp, R, 8, openings[0], bgao) != 0
+
+
+def test_complete_proof_standard_shape(ctx, mp2):
+    """Same at standard_recursion_config shape: 80 routed of 135 wires, 2^12 rows."""
+    log_n, R = 12, 80
+    ws = (84, 135, 20, 16)
+    ofp = O.standard_params(log_n, ws)
+    fp = mp2.standard_recursion_params(log_n, ws)
+    n = 1 << log_n
+    sig, wires = O.copy_constraint_circuit(log_n, R, ws[1], 5000, 11)
+    pre = np.concatenate([O.rand_field((4, n), 1), sig])
+    cd, ph = O.rand_field(4, 2), O.rand_field((1, 4), 3)
+    pr = mp2.BatchedProver(ctx, fp, 1)
+    pr.set_preprocessed(ctx.to_device(pre))
+    pr.enable_permutation(R, 8)
+    pr.enable_quotient()
+    pr.prove([ctx.to_device(wires[None]), None, None], ctx.to_device(cd), ctx.to_device(ph))
+    caps, openings, proofs = pr.results()
+    d2, d3 = np.zeros((ws[2], n), dtype=np.uint64), np.zeros((ws[3], n), dtype=np.uint64)
+    oc, oo, op, bgao = O.pcs_prove(ofp, [pre, wires, d2, d3], cd, ph[0], num_routed=R, degree=8, quotient=True, want_challenges=True)
+    assert np.array_equal(caps[0], oc) and np.array_equal(openings[0], oo) and np.array_equal(proofs[0], op)
+    assert O.pcs_verify(ofp, cd, ph[0], caps[0], openings[0], proofs[0]) == 0
+    assert O.plonk_identity_check(ofp, R, 8, openings[0], bgao) == 0
