@@ -37,6 +37,14 @@ struct mp2g_prover {
   DevBuf pre_values, zs_values, chunk_q, bg, alphas, qvals;
 };
 
+namespace {
+// frees a temporary prover on every exit path of the convenience entry points
+struct ProverGuard {
+  mp2g_prover* pr = nullptr;
+  ~ProverGuard();
+};
+}  // namespace
+
 static int params_check(const mp2g_fri_params* p) {
   NEED(p, "params");
   NEED(p->variant <= 1, "variant");
@@ -228,6 +236,9 @@ static int prover_create_impl(mp2g_ctx* c, const mp2g_fri_params* params, uint32
 int mp2g_prover_create(mp2g_ctx* c, const mp2g_fri_params* params, uint32_t batch, mp2g_prover** out) {
   return prover_create_impl(c, params, batch, true, out);
 }
+}  // extern "C"
+ProverGuard::~ProverGuard() { if (pr) mp2g_prover_free(pr); }
+extern "C" {
 void mp2g_prover_free(mp2g_prover* pr) {
   if (!pr) return;
   (void)hipStreamSynchronize(pr->ctx->stream);
@@ -469,6 +480,8 @@ int mp2g_fri_prove(mp2g_ctx* c, const mp2g_fri_params* params, mp2g_batch* const
   mp2g_prover* pr;
   int rc = prover_create_impl(c, params, 1, false, &pr);
   if (rc) return rc;
+  ProverGuard guard;
+  guard.pr = pr;
   const mp2g_fri_params& P = pr->P;
   FriShape sh{};
   sh.log_n = P.log_n; sh.rate_bits = P.rate_bits; sh.cap_h = P.cap_height; sh.n_oracles = P.n_oracles;
@@ -477,7 +490,6 @@ int mp2g_fri_prove(mp2g_ctx* c, const mp2g_fri_params* params, mp2g_batch* const
     const mp2g_batch* b = oracles[o];
     if (!b || b->ctx != c || b->log_n != P.log_n || b->w != P.oracle_w[o] || b->rate_bits != P.rate_bits ||
         b->cap_h != P.cap_height || b->variant != (int)P.variant) {
-      mp2g_prover_free(pr);
       return fail("oracle %u does not match the FRI parameters", o);
     }
     OracleRef& r = sh.o[o];
@@ -487,14 +499,13 @@ int mp2g_fri_prove(mp2g_ctx* c, const mp2g_fri_params* params, mp2g_batch* const
   DevBuf dproof;
   hipError_t e = dproof.alloc(pr->proof_words * sizeof(u64));
   if (e == hipSuccess) e = hipMemcpyAsync(pr->zeta.p, zeta, 2 * sizeof(u64), hipMemcpyHostToDevice, c->stream);
-  if (e != hipSuccess) { mp2g_prover_free(pr); return fail("fri_prove setup: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) return fail("fri_prove setup: %s", hipGetErrorString(e));
   rc = fri_tail(pr, sh, (ChState*)ch->st.p, dproof.p);
   if (!rc) {
     e = hipMemcpyAsync(proof, dproof.p, pr->proof_words * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = fail("fri_prove copy-out: %s", hipGetErrorString(e));
   }
-  mp2g_prover_free(pr);
   return rc;
 }
 
@@ -504,6 +515,8 @@ int mp2g_pcs_prove(mp2g_ctx* c, const mp2g_fri_params* params, const uint64_t* c
   mp2g_prover* pr;
   int rc = mp2g_prover_create(c, params, 1, &pr);
   if (rc) return rc;
+  ProverGuard guard;
+  guard.pr = pr;
   const mp2g_fri_params& P = pr->P;
   const size_t n = (size_t)1 << P.log_n;
   DevBuf dv[8], dd, dp, dcaps, dopen, dproof;
@@ -521,7 +534,7 @@ int mp2g_pcs_prove(mp2g_ctx* c, const mp2g_fri_params* params, const uint64_t* c
   if (e == hipSuccess) e = dproof.alloc(pr->proof_words * sizeof(u64));
   if (e == hipSuccess) e = hipMemcpyAsync(dd.p, circuit_digest, 32, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(dp.p, pi_hash, 32, hipMemcpyHostToDevice, c->stream);
-  if (e != hipSuccess) { mp2g_prover_free(pr); return fail("pcs_prove setup: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) return fail("pcs_prove setup: %s", hipGetErrorString(e));
   rc = mp2g_prover_set_preprocessed_dev(pr, dv[0].p);
   if (!rc) rc = mp2g_prover_prove_dev(pr, dptr, dd.p, dp.p, dcaps.p, dopen.p, dproof.p);
   if (!rc) {
@@ -531,7 +544,6 @@ int mp2g_pcs_prove(mp2g_ctx* c, const mp2g_fri_params* params, const uint64_t* c
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = fail("pcs_prove copy-out: %s", hipGetErrorString(e));
   }
-  mp2g_prover_free(pr);
   return rc;
 }
 
