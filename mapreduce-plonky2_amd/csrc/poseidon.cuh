@@ -110,8 +110,9 @@ P2_UNROLL(P2_UNROLL_EXT)
   for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
 
-// Poseidon MDS: circulant [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,...]; all entries < 2^6,
-// so the 32-bit halves of the state accumulate in u64 without overflow and reduce once per row.
+// Poseidon (WrapC), weak-representative form like Poseidon2 above. MDS: circulant
+// [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,...]; all entries < 2^6, so the 32-bit halves of the
+// limbs accumulate in u64 without overflow (< 2^41) and reduce once per row.
 GLHD void poseidon_mds(u64 s[12]) {
   const u32 circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   u64 lo[12], hi[12];
@@ -127,10 +128,10 @@ GLHD void poseidon_mds(u64 s[12]) {
       ah += hi[(i + r) % 12] * circ[i];
     }
     if (r == 0) { al += lo[0] * 8; ah += hi[0] * 8; }
-    // value = al + ah * 2^32, al, ah < 2^42
-    u64 l = al + (ah << 32);
-    u64 h = (ah >> 32) + (l < al ? 1 : 0);
-    out[r] = gl_reduce128(l, h);
+    // value = al + ah * 2^32
+    u64 l;
+    bool c = __builtin_add_overflow(al, ah << 32, &l);
+    out[r] = gl_reduce96w(l, (ah >> 32) + (c ? 1 : 0));
   }
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = out[i];
@@ -138,16 +139,18 @@ GLHD void poseidon_mds(u64 s[12]) {
 GLHD void poseidon_perm(u64 s[12]) {
 #pragma unroll 1
   for (int r = 0; r < 30; r++) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], c_p_rc[12 * r + i]);
     if (r < 4 || r >= 26) {
 #pragma unroll
-      for (int i = 0; i < 12; i++) s[i] = gl_pow7(s[i]);
+      for (int i = 0; i < 12; i++) s[i] = p2_sbox(s[i], c_p_rc[12 * r + i]);
     } else {
-      s[0] = gl_pow7(s[0]);
+      s[0] = p2_sbox(s[0], c_p_rc[12 * r]);
+#pragma unroll
+      for (int i = 1; i < 12; i++) s[i] = gl_addw(s[i], c_p_rc[12 * r + i]);
     }
     poseidon_mds(s);
   }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
 template <int VARIANT>
 GLHD void perm(u64 s[12]) {
