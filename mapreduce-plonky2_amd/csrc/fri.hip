@@ -17,7 +17,7 @@
 //   * the proof-of-work search returns the smallest valid witness (the reference's rayon
 //     find_any returns an arbitrary one).
 #include "fri.h"
-#include "poseidon.cuh"
+#include "poseidon_wave.cuh"
 
 namespace mp2g {
 
@@ -55,6 +55,44 @@ __global__ void ch_kernel(ChState* st, u32 B, const u64* obs, u64 obs_bstride, u
   }
   st[b] = c;
 }
+// Lane-cooperative form for Poseidon2 (poseidon_wave.cuh): 16 lanes per transcript, the state limb l in
+// lane l, the pending input / squeezed output buffers in lanes 0..7. A transcript is ~110 sequential
+// permutations (64 of them absorbing the 257 openings), so permutation LATENCY is what counts here.
+__global__ void __launch_bounds__(64) ch_wave_kernel(ChState* st, u32 B, const u64* obs, u64 obs_bstride, u32 n_obs, u64* out,
+                                                     u64 out_bstride, u32 n_get) {
+  const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const u32 braw = gid >> 4, l = gid & 15;
+  const bool active = braw < B;
+  const u32 b = active ? braw : B - 1;  // idle groups shadow the last transcript (loads only)
+  ChState* c = st + b;
+  u64 x = l < 12 ? c->state[l] : 0;
+  u64 inb = l < 8 ? c->in[l] : 0, outb = l < 8 ? c->out[l] : 0;
+  u32 n_in = c->n_in, n_out = c->n_out;
+  const u64* o = obs + b * obs_bstride;
+  auto duplex = [&]() {
+    if (l < n_in) x = inb;
+    n_in = 0;
+    x = wp2_perm(x, (int)l);
+    outb = x;
+    n_out = 8;
+  };
+  for (u32 i = 0; i < n_obs; i++) {
+    u64 e = o[i];
+    n_out = 0;
+    if (l == n_in) inb = e;
+    if (++n_in == 8) duplex();
+  }
+  u64* dst = out + b * out_bstride;
+  for (u32 i = 0; i < n_get; i++) {
+    if (n_in || !n_out) duplex();
+    --n_out;
+    if (active && l == n_out) dst[i] = outb;
+  }
+  if (!active) return;
+  if (l < 12) c->state[l] = x;
+  if (l < 8) { c->in[l] = inb; c->out[l] = outb; }
+  if (l == 0) { c->n_in = n_in; c->n_out = n_out; }
+}
 __global__ void ch_init_kernel(ChState* st, u32 B) {
   u32 b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -71,7 +109,7 @@ hipError_t challenger_init(hipStream_t s, ChState* st, u32 B) {
 hipError_t challenger_step(hipStream_t s, int variant, ChState* st, u32 B, const u64* obs, u64 obs_bstride, u32 n_obs,
                            u64* out, u64 out_bstride, u32 n_get) {
   if (variant == MP2G_POSEIDON2)
-    hipLaunchKernelGGL((ch_kernel<MP2G_POSEIDON2>), dim3((B + 63) / 64), dim3(64), 0, s, st, B, obs, obs_bstride, n_obs, out, out_bstride, n_get);
+    hipLaunchKernelGGL(ch_wave_kernel, dim3((B * 16 + 63) / 64), dim3(64), 0, s, st, B, obs, obs_bstride, n_obs, out, out_bstride, n_get);
   else
     hipLaunchKernelGGL((ch_kernel<MP2G_POSEIDON>), dim3((B + 63) / 64), dim3(64), 0, s, st, B, obs, obs_bstride, n_obs, out, out_bstride, n_get);
   return hipGetLastError();

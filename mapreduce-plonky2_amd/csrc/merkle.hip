@@ -11,7 +11,7 @@
 // polynomial-major in HBM so that lane i reading limb p of leaf i is a perfectly coalesced
 // 8 B/lane stream (no transposed copy of the 8n x w matrix is ever materialised).
 #include "merkle.h"
-#include "poseidon.cuh"
+#include "poseidon_wave.cuh"
 
 namespace mp2g {
 
@@ -115,6 +115,20 @@ __global__ void __launch_bounds__(256) merkle_level_kernel(const u64* __restrict
   d[0] = make_ulonglong2(s[0], s[1]);
   d[1] = make_ulonglong2(s[2], s[3]);
 }
+// Lane-cooperative two_to_one for the small upper levels of a tree (poseidon_wave.cuh): one node per
+// 16-lane group; a level of a few thousand nodes is bound by permutation latency, not throughput.
+__global__ void __launch_bounds__(256) merkle_level_wave_kernel(const u64* __restrict__ in, u64* __restrict__ out, u64 n_out, u64 bstride) {
+  const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 iraw = gid >> 4;
+  const int l = (int)(gid & 15);
+  const bool active = iraw < n_out;
+  const u64 i = active ? iraw : n_out - 1;
+  in += blockIdx.y * bstride;
+  out += blockIdx.y * bstride;
+  u64 x = l < 8 ? in[8 * i + l] : 0;
+  x = wp2_perm(x, l);
+  if (active && l < 4) out[4 * i + l] = x;
+}
 template <int V>
 __global__ void __launch_bounds__(256) hash_no_pad_batch_kernel(const u64* __restrict__ in, u32 in_len, u64 count, u32 out_len, u64* __restrict__ out) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,7 +218,11 @@ hipError_t merkle_reduce(hipStream_t st, int variant, u64* levels, u32 log_leave
   for (u32 lv = log_leaves; lv > cap_h; lv--) {
     u64 n_in = (u64)1 << lv;
     u64* nxt = cur + 4 * n_in;
-    LAUNCH_V(merkle_level_kernel, grid1(n_in / 2, 256, batch), dim3(256), st, cur, nxt, n_in / 2, bstride);
+    // below ~2^14 nodes in flight the level is latency-bound: spread each permutation over 16 lanes
+    if (variant == MP2G_POSEIDON2 && (n_in / 2) * (u64)batch <= 16384)
+      hipLaunchKernelGGL(merkle_level_wave_kernel, grid1(n_in / 2 * 16, 256, batch), dim3(256), 0, st, cur, nxt, n_in / 2, bstride);
+    else
+      LAUNCH_V(merkle_level_kernel, grid1(n_in / 2, 256, batch), dim3(256), st, cur, nxt, n_in / 2, bstride);
     cur = nxt;
   }
   return hipGetLastError();
