@@ -259,6 +259,45 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
  * mp2g_prover_enable_permutation, rate_bits 3 and oracle_w[3] = zs_count * 8. */
 int mp2g_prover_enable_quotient(mp2g_prover* pr);
 
+/* ---- work plan: the reference's only scheduler --------------------------------------
+ * Host-side, no GPU involved. Replaces ryhope/src/storage/updatetree.rs: UpdateTree (:19-242, arena
+ * of nodes, node 0 = root, children ordered by arena index) and UpdatePlan (:422-541). Keys are u64
+ * (row / cell / block keys); a path runs root -> node. An item handed out by the plan is the unit one
+ * GPU proves locally: a single node (subtree_size == 1) or a spun-off subtree whose root proof is the
+ * only thing returned. */
+typedef struct mp2g_update_tree mp2g_update_tree;
+typedef struct mp2g_update_plan mp2g_update_plan;
+/* UpdateTree::from_paths (:80-92): paths concatenated in `keys`, path i has path_lens[i] keys.
+ * n_paths == 0 gives the empty tree. Fails where the reference panics: an empty path, a key that
+ * occurs twice at different positions, a path whose first key is not the root. */
+int mp2g_update_tree_from_paths(const uint64_t* keys, const uint32_t* path_lens, uint32_t n_paths, int64_t epoch,
+                                mp2g_update_tree** out);
+/* UpdateTree::extend_with_path (:145-151) */
+int mp2g_update_tree_extend_with_path(mp2g_update_tree* t, const uint64_t* path, uint32_t len);
+uint32_t mp2g_update_tree_size(const mp2g_update_tree* t);
+int64_t mp2g_update_tree_epoch(const mp2g_update_tree* t);
+int mp2g_update_tree_contains_key(const mp2g_update_tree* t, uint64_t k);
+/* arena dump: keys[size], parents[size] (-1 for a root), is_path_end[size]; any pointer may be NULL */
+int mp2g_update_tree_nodes(const mp2g_update_tree* t, uint64_t* keys, int32_t* parents, uint8_t* is_path_end);
+/* UpdateTree::subtree_size_i (:171-179) by key */
+int mp2g_update_tree_subtree_size(const mp2g_update_tree* t, uint64_t k, uint32_t* out);
+void mp2g_update_tree_free(mp2g_update_tree* t);
+/* into_workplan (subtree_size 1) / into_batched_workplan (:154-163); the tree is consumed (the
+ * handle stays valid only for mp2g_update_tree_free, which the plan performs). */
+int mp2g_update_plan_create(mp2g_update_tree* t, uint32_t subtree_size, mp2g_update_plan** out);
+#define MP2G_PLAN_FINISHED 0 /* Iterator::next() == None           */
+#define MP2G_PLAN_READY 1    /* Some(Next::Ready(item))            */
+#define MP2G_PLAN_NOT_YET 2  /* Some(Next::NotYet)                 */
+/* Iterator::next (:517-531). On READY *k is the item's key; with subtree_size == 1 the item is
+ * WorkplanItem::Node and *is_path_end is set (*subtree = NULL); otherwise it is
+ * WorkplanItem::Subtree and *subtree receives the spun-off tree (caller frees). Returns one of
+ * the MP2G_PLAN_* states, or -1 on invalid arguments. */
+int mp2g_update_plan_next(mp2g_update_plan* p, uint64_t* k, int* is_path_end, mp2g_update_tree** subtree);
+/* UpdatePlan::done (:449-467); unknown key -> error (RyhopeError::KeyNotFound) */
+int mp2g_update_plan_done(mp2g_update_plan* p, uint64_t k);
+int mp2g_update_plan_completed(const mp2g_update_plan* p);
+void mp2g_update_plan_free(mp2g_update_plan* p);
+
 #ifdef __cplusplus
 }
 #endif
