@@ -259,6 +259,53 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
  * mp2g_prover_enable_permutation, rate_bits 3 and oracle_w[3] = zs_count * 8. */
 int mp2g_prover_enable_quotient(mp2g_prover* pr);
 
+/* ---- gate constraints: the third part of compute_quotient_polys --------------------------------
+ * Replaces [dep] plonky2 plonk/vanishing_poly.rs evaluate_gate_constraints_base_batch and the
+ * eval_unfiltered_base of the gates below (gates the reference registers:
+ * mp2-common/src/serialization/circuit_data_serialization.rs:236-267). Not yet covered: CosetInterpolation,
+ * Lookup / LookupTable, PoseidonMds, Poseidon (original), the plonky2-u32 gates, Comparison,
+ * U32Interleave / Uninterleave. A circuit using one of those cannot be proved here yet. */
+enum {
+  MP2G_GATE_NOOP = 0,
+  MP2G_GATE_CONSTANT = 1,       /* p0 = num_consts */
+  MP2G_GATE_PUBLIC_INPUT = 2,
+  MP2G_GATE_ARITHMETIC = 3,     /* p0 = num_ops */
+  MP2G_GATE_BASE_SUM = 4,       /* p0 = num_limbs, p1 = base (BaseSumGate<B>) */
+  MP2G_GATE_ARITHMETIC_EXT = 5, /* p0 = num_ops (D = 2) */
+  MP2G_GATE_MUL_EXT = 6,        /* p0 = num_ops */
+  MP2G_GATE_POSEIDON2 = 7,
+  MP2G_GATE_EXPONENTIATION = 8, /* p0 = num_power_bits */
+  MP2G_GATE_REDUCING = 9,       /* p0 = num_coeffs */
+  MP2G_GATE_REDUCING_EXT = 10,  /* p0 = num_coeffs */
+  MP2G_GATE_RANDOM_ACCESS = 11  /* p0 = bits (<= 6), p1 = num_copies, p2 = num_extra_constants */
+};
+#define MP2G_MAX_GATES 24
+#define MP2G_MAX_GATE_CONSTRAINTS 160
+/* One entry per gate of CommonCircuitData::gates, in that order (sorted by degree). The selector
+ * fields restate SelectorsInfo (gates/selectors.rs): the gate's filter is
+ * prod_{r in [group_start, group_end), r != index} (r - s) * (num_selectors > 1 ? (u32::MAX - s) : 1)
+ * with s = local_constants[selector_index]. */
+typedef struct {
+  uint32_t kind, p0, p1, p2;
+  uint32_t selector_index, group_start, group_end;
+} mp2g_gate;
+/* Gate::num_constraints / Gate::degree of a descriptor; 0 for an unknown kind */
+uint32_t mp2g_gate_num_constraints(const mp2g_gate* g);
+uint32_t mp2g_gate_degree(const mp2g_gate* g);
+/* Give the batched prover the gate table: the quotient then carries the gate constraint terms after
+ * the permutation terms (eval_vanishing_poly_base_batch order), i.e. the complete prove() of a circuit
+ * built from the gates above. Constants are the first oracle_w[0] - num_routed polynomials of the
+ * preprocessed oracle (selectors first, then the gate constants); the public-inputs hash is the
+ * d_pi_hash of mp2g_prover_prove_dev. Needs mp2g_prover_enable_quotient. n_gates = 0 removes it. */
+int mp2g_prover_set_gates(mp2g_prover* pr, const mp2g_gate* gates, uint32_t n_gates, uint32_t num_selectors);
+/* The filtered constraints C_j = sum_gates filter_g c_{g,j} at npts arbitrary points (host pointers):
+ * consts [num_constants][npts], wires [wires_w][npts], out [max_j][npts] with max_j the largest
+ * num_constraints of the table. On the subgroup H a satisfied witness gives all zeros -- the check
+ * behind plonky2's "invalid witness" panic in prove(). */
+int mp2g_eval_gate_constraints(mp2g_ctx* ctx, const mp2g_gate* gates, uint32_t n_gates, uint32_t num_selectors,
+                               const uint64_t* consts, uint32_t num_constants, const uint64_t* wires, uint32_t wires_w,
+                               uint64_t npts, const uint64_t pi_hash[4], uint64_t* out);
+
 /* ---- work plan: the reference's only scheduler --------------------------------------
  * Host-side, no GPU involved. Replaces ryhope/src/storage/updatetree.rs: UpdateTree (:19-242, arena
  * of nodes, node 0 = root, children ordered by arena index) and UpdatePlan (:422-541). Keys are u64

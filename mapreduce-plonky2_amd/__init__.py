@@ -390,6 +390,36 @@ def pcs_prove(ctx, fp, values, circuit_digest, pi_hash):
     return caps, openings, proof
 
 
+class Gate(ctypes.Structure):
+    """mp2g_gate: one entry of CommonCircuitData::gates with its selector group."""
+    _fields_ = [("kind", ctypes.c_uint32), ("p0", ctypes.c_uint32), ("p1", ctypes.c_uint32), ("p2", ctypes.c_uint32),
+                ("selector_index", ctypes.c_uint32), ("group_start", ctypes.c_uint32), ("group_end", ctypes.c_uint32)]
+
+    @property
+    def num_constraints(self):
+        return load().mp2g_gate_num_constraints(ctypes.byref(self))
+
+    @property
+    def degree(self):
+        return load().mp2g_gate_degree(ctypes.byref(self))
+
+
+(GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_ARITHMETIC_EXT, GATE_MUL_EXT, GATE_POSEIDON2,
+ GATE_EXPONENTIATION, GATE_REDUCING, GATE_REDUCING_EXT, GATE_RANDOM_ACCESS) = range(12)
+
+
+def eval_gate_constraints(ctx, gates, num_selectors, consts, wires, pi_hash):
+    """Filtered gate constraints C_j at arbitrary points: consts [num_constants][npts], wires [w][npts]
+    -> [max_j][npts]. All zero on H for a satisfied witness (plonky2's prove() panics otherwise)."""
+    c, w, ph = _arr(consts), _arr(wires), _arr(pi_hash)
+    arr = (Gate * len(gates))(*gates)
+    max_j = max(g.num_constraints for g in gates)
+    out = np.zeros((max_j, w.shape[1]), dtype=np.uint64)
+    _ck(load().mp2g_eval_gate_constraints(ctx.h, arr, len(gates), num_selectors, _p(c), c.shape[0], _p(w), w.shape[0],
+                                          ctypes.c_uint64(w.shape[1]), _p(ph), _p(out)))
+    return out
+
+
 class BatchedProver:
     """mp2g_prover: `batch` same-shape proofs per call, device resident."""
 
@@ -414,6 +444,12 @@ class BatchedProver:
         """Also compute the quotient chunks on the device for the gate-independent vanishing terms
         (complete prove() of a copy-constraint-only circuit); d_values[2] may then be None."""
         _ck(load().mp2g_prover_enable_quotient(self.h))
+
+    def set_gates(self, gates, num_selectors):
+        """Gate table of the circuit (CommonCircuitData::gates + SelectorsInfo): the quotient then
+        includes the gate constraint terms -- prove() of a circuit built from the supported gates."""
+        arr = (Gate * len(gates))(*gates)
+        _ck(load().mp2g_prover_set_gates(self.h, arr, len(gates), num_selectors))
 
     def prove(self, d_values, d_circuit_digest, d_pi_hash):
         """d_values: device buffers [batch][w_o][n] for oracles 1..; asynchronous."""

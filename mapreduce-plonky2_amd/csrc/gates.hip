@@ -1,0 +1,338 @@
+// Gate constraint evaluation for the quotient polynomial.
+//
+// Replaces [dep] plonky2 plonk/vanishing_poly.rs evaluate_gate_constraints_base_batch, gates/gate.rs
+// eval_filtered_base_batch / compute_filter and the eval_unfiltered_base of the gates listed in
+// include/mp2g.h, as reached from compute_quotient_polys inside prove()
+// (recursion-framework/src/circuit_builder.rs:308). One lane per LDE point; the ~135 wire and the few
+// constant values of a point are 8 B/lane coalesced streams of the polynomial-major LDE matrices, read
+// on demand by the gate that needs them (L2 absorbs wires shared by several gates). plonky2 sums
+// filter_g * c_{g,j} into slot j and alpha-reduces the slots; here each gate alpha-reduces its own
+// constraints and the filter multiplies the reduced value -- the same field element with
+// (#constraints - 1) fewer multiplications per gate and challenge.
+#include "gates.h"
+#include "poseidon.cuh"
+
+namespace mp2g {
+
+u32 gate_num_constraints(const mp2g_gate& g) {
+  switch (g.kind) {
+    case MP2G_GATE_CONSTANT: return g.p0;
+    case MP2G_GATE_PUBLIC_INPUT: return 4;
+    case MP2G_GATE_ARITHMETIC: return g.p0;
+    case MP2G_GATE_BASE_SUM: return 1 + g.p0;
+    case MP2G_GATE_ARITHMETIC_EXT: case MP2G_GATE_MUL_EXT: return 2 * g.p0;
+    case MP2G_GATE_POSEIDON2: return 1 + 4 + 36 + 22 + 48 + 12;
+    case MP2G_GATE_EXPONENTIATION: return g.p0 + 1;
+    case MP2G_GATE_REDUCING: case MP2G_GATE_REDUCING_EXT: return 2 * g.p0;
+    case MP2G_GATE_RANDOM_ACCESS: return (g.p0 + 2) * g.p1 + g.p2;
+    default: return 0;
+  }
+}
+u32 gate_degree(const mp2g_gate& g) {
+  switch (g.kind) {
+    case MP2G_GATE_CONSTANT: case MP2G_GATE_PUBLIC_INPUT: return 1;
+    case MP2G_GATE_ARITHMETIC: case MP2G_GATE_ARITHMETIC_EXT: case MP2G_GATE_MUL_EXT: return 3;
+    case MP2G_GATE_BASE_SUM: return g.p1;
+    case MP2G_GATE_POSEIDON2: return 7;
+    case MP2G_GATE_EXPONENTIATION: return 4;
+    case MP2G_GATE_REDUCING: case MP2G_GATE_REDUCING_EXT: return 2;
+    case MP2G_GATE_RANDOM_ACCESS: return g.p0 + 1;
+    default: return 0;
+  }
+}
+// highest wire index + 1 and gate constants a descriptor touches
+static void gate_footprint(const mp2g_gate& g, u32& wires, u32& consts) {
+  wires = 0; consts = 0;
+  switch (g.kind) {
+    case MP2G_GATE_CONSTANT: wires = g.p0; consts = g.p0; break;
+    case MP2G_GATE_PUBLIC_INPUT: wires = 4; break;
+    case MP2G_GATE_ARITHMETIC: wires = 4 * g.p0; consts = 2; break;
+    case MP2G_GATE_BASE_SUM: wires = 1 + g.p0; break;
+    case MP2G_GATE_ARITHMETIC_EXT: wires = 8 * g.p0; consts = 2; break;
+    case MP2G_GATE_MUL_EXT: wires = 6 * g.p0; consts = 1; break;
+    case MP2G_GATE_POSEIDON2: wires = 135; break;
+    case MP2G_GATE_EXPONENTIATION: wires = 2 * g.p0 + 2; break;
+    case MP2G_GATE_REDUCING: wires = 6 + g.p0 + 2 * (g.p0 - 1); break;
+    case MP2G_GATE_REDUCING_EXT: wires = 6 + 2 * g.p0 + 2 * (g.p0 - 1); break;
+    case MP2G_GATE_RANDOM_ACCESS: wires = (2 + (1u << g.p0)) * g.p1 + g.p2 + g.p0 * g.p1; consts = g.p2; break;
+    default: break;
+  }
+}
+const char* gate_table_check(const GateTable& t, u32 num_constants, u32 wires_w) {
+  if (t.n_gates > MP2G_MAX_GATES) return "too many gates";
+  if (t.num_selectors == 0 || t.num_selectors > num_constants) return "num_selectors must be in 1..num_constants";
+  for (u32 i = 0; i < t.n_gates; i++) {
+    const mp2g_gate& g = t.g[i];
+    if (g.kind > MP2G_GATE_RANDOM_ACCESS) return "unknown gate kind";
+    if (g.kind == MP2G_GATE_BASE_SUM && (g.p1 < 2 || g.p0 < 1)) return "BaseSumGate needs base >= 2 and a limb";
+    if ((g.kind == MP2G_GATE_REDUCING || g.kind == MP2G_GATE_REDUCING_EXT || g.kind == MP2G_GATE_EXPONENTIATION) && g.p0 < 1)
+      return "gate needs at least one coefficient / power bit";
+    if (g.kind == MP2G_GATE_RANDOM_ACCESS && (g.p0 < 1 || g.p0 > 6 || g.p1 < 1)) return "RandomAccessGate needs 1..6 bits and a copy";
+    u32 w, c;
+    gate_footprint(g, w, c);
+    if (w > wires_w) return "gate needs more wires than the wires oracle has";
+    if (t.num_selectors + c > num_constants) return "gate needs more constants than the preprocessed oracle has";
+    if (g.selector_index >= t.num_selectors) return "selector_index out of range";
+    if (!(g.group_start <= i && i < g.group_end && g.group_end <= t.n_gates)) return "gate is not inside its selector group";
+    if (gate_num_constraints(g) > MP2G_MAX_GATE_CONSTRAINTS) return "gate has too many constraints";
+  }
+  return nullptr;
+}
+
+struct Alg { u64 a, b; };  // ExtensionAlgebra element over the evaluation field, X^2 = 7
+GLD Alg alg_mul(Alg x, Alg y) {
+  return Alg{gl_add(gl_mul(x.a, y.a), gl_mul_small(gl_mul(x.b, y.b), 7)), gl_add(gl_mul(x.a, y.b), gl_mul(x.b, y.a))};
+}
+GLD Alg alg_add(Alg x, Alg y) { return Alg{gl_add(x.a, y.a), gl_add(x.b, y.b)}; }
+GLD Alg alg_sub(Alg x, Alg y) { return Alg{gl_sub(x.a, y.a), gl_sub(x.b, y.b)}; }
+GLD Alg alg_scale(Alg x, u64 c) { return Alg{gl_mul(x.a, c), gl_mul(x.b, c)}; }
+
+// eval_unfiltered_base of one gate: wire(j) / cst(j) fetch local wire j / gate constant j (after the
+// selector prefix), emit(c) receives the constraints in plonky2's order (canonical values).
+template <class WireF, class ConstF, class Emit>
+__device__ __noinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF cst, const u64* __restrict__ pih, Emit emit) {
+  switch (g.kind) {
+    case MP2G_GATE_CONSTANT:
+      for (u32 i = 0; i < g.p0; i++) emit(gl_sub(cst(i), wire(i)));
+      break;
+    case MP2G_GATE_PUBLIC_INPUT:
+      for (u32 i = 0; i < 4; i++) emit(gl_sub(wire(i), pih[i]));
+      break;
+    case MP2G_GATE_ARITHMETIC: {
+      const u64 c0 = cst(0), c1 = cst(1);
+      for (u32 i = 0; i < g.p0; i++) {
+        u64 m0 = wire(4 * i), m1 = wire(4 * i + 1), ad = wire(4 * i + 2), o = wire(4 * i + 3);
+        emit(gl_sub(o, gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1))));
+      }
+      break;
+    }
+    case MP2G_GATE_BASE_SUM: {
+      u64 acc = 0;
+      for (u32 i = g.p0; i-- > 0;) acc = gl_add(gl_mul_small(acc, g.p1), wire(1 + i));
+      emit(gl_sub(acc, wire(0)));
+      for (u32 i = 0; i < g.p0; i++) {
+        const u64 limb = wire(1 + i);
+        u64 pr = limb;  // k = 0 factor
+        for (u32 k = 1; k < g.p1; k++) pr = gl_mul(pr, gl_sub(limb, k));
+        emit(pr);
+      }
+      break;
+    }
+    case MP2G_GATE_ARITHMETIC_EXT: {
+      const u64 c0 = cst(0), c1 = cst(1);
+      for (u32 i = 0; i < g.p0; i++) {
+        const u32 b = 8 * i;
+        Alg m0{wire(b), wire(b + 1)}, m1{wire(b + 2), wire(b + 3)}, ad{wire(b + 4), wire(b + 5)}, o{wire(b + 6), wire(b + 7)};
+        Alg d = alg_sub(o, alg_add(alg_scale(alg_mul(m0, m1), c0), alg_scale(ad, c1)));
+        emit(d.a); emit(d.b);
+      }
+      break;
+    }
+    case MP2G_GATE_MUL_EXT: {
+      const u64 c0 = cst(0);
+      for (u32 i = 0; i < g.p0; i++) {
+        const u32 b = 6 * i;
+        Alg m0{wire(b), wire(b + 1)}, m1{wire(b + 2), wire(b + 3)}, o{wire(b + 4), wire(b + 5)};
+        Alg d = alg_sub(o, alg_scale(alg_mul(m0, m1), c0));
+        emit(d.a); emit(d.b);
+      }
+      break;
+    }
+    case MP2G_GATE_POSEIDON2: {
+      // wires: input 0..11, output 12..23, swap 24, delta 25..28, S-box inputs 29..64 (full rounds 1..3),
+      // 65..86 (partial rounds), 87..134 (second full rounds). The state runs in weak form between the
+      // wire substitutions (poseidon.cuh) and is canonicalised where it meets a wire.
+      const u64 swap = wire(24);
+      emit(gl_mul(swap, gl_sub(swap, 1)));
+      u64 s[12];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        u64 lhs = wire(i), rhs = wire(i + 4), delta = wire(25 + i);
+        emit(gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), delta));
+        s[i] = gl_add(lhs, delta);
+        s[i + 4] = gl_sub(rhs, delta);
+      }
+#pragma unroll
+      for (int i = 8; i < 12; i++) s[i] = wire(i);
+      p2_external(s);
+#pragma unroll 1
+      for (int r = 0; r < 4; r++) {
+        if (r != 0) {
+#pragma unroll
+          for (int i = 0; i < 12; i++) {
+            u64 in = wire(29 + 12 * (r - 1) + i);
+            emit(gl_sub(gl_add(gl_canon(s[i]), c_p2_ext[12 * r + i]), in));
+            s[i] = p2_sbox(in, 0);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 12; i++) s[i] = p2_sbox(s[i], c_p2_ext[i]);
+        }
+        p2_external(s);
+      }
+#pragma unroll 1
+      for (int r = 0; r < 22; r++) {
+        u64 in = wire(65 + r);
+        emit(gl_sub(gl_add(gl_canon(s[0]), c_p2_int[r]), in));
+        s[0] = p2_sbox(in, 0);
+        p2_internal(s);
+      }
+#pragma unroll 1
+      for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+          u64 in = wire(87 + 12 * r + i);
+          emit(gl_sub(gl_add(gl_canon(s[i]), c_p2_ext[12 * (4 + r) + i]), in));
+          s[i] = p2_sbox(in, 0);
+        }
+        p2_external(s);
+      }
+#pragma unroll
+      for (int i = 0; i < 12; i++) emit(gl_sub(gl_canon(s[i]), wire(12 + i)));
+      break;
+    }
+    case MP2G_GATE_EXPONENTIATION: {
+      const u32 nb = g.p0;
+      const u64 base = wire(0);
+      u64 prev_int = 1;
+      for (u32 i = 0; i < nb; i++) {
+        u64 prev = i == 0 ? 1 : gl_mul(prev_int, prev_int);
+        u64 bit = wire(1 + (nb - 1 - i));
+        u64 mulby = gl_add(gl_mul(bit, base), gl_sub(1, bit));
+        u64 cur = wire(nb + 2 + i);
+        emit(gl_sub(gl_mul(prev, mulby), cur));
+        prev_int = cur;
+      }
+      emit(gl_sub(wire(nb + 1), prev_int));
+      break;
+    }
+    case MP2G_GATE_REDUCING:
+    case MP2G_GATE_REDUCING_EXT: {
+      const u32 n = g.p0;
+      const bool ext = g.kind == MP2G_GATE_REDUCING_EXT;
+      const u32 start_accs = 6 + (ext ? 2 * n : n);
+      Alg alpha{wire(2), wire(3)}, acc{wire(4), wire(5)};
+      for (u32 i = 0; i < n; i++) {
+        Alg coeff = ext ? Alg{wire(6 + 2 * i), wire(7 + 2 * i)} : Alg{wire(6 + i), 0};
+        Alg nxt = i == n - 1 ? Alg{wire(0), wire(1)} : Alg{wire(start_accs + 2 * i), wire(start_accs + 2 * i + 1)};
+        Alg d = alg_sub(alg_add(alg_mul(acc, alpha), coeff), nxt);
+        emit(d.a); emit(d.b);
+        acc = nxt;
+      }
+      break;
+    }
+    case MP2G_GATE_RANDOM_ACCESS: {
+      const u32 bits = g.p0, copies = g.p1, extra = g.p2, vs = 1u << bits;
+      const u32 routed = (2 + vs) * copies + extra;
+      u64 items[32];
+      for (u32 c = 0; c < copies; c++) {
+        const u32 w0 = (2 + vs) * c, b0 = routed + c * bits;
+        for (u32 i = 0; i < bits; i++) {
+          u64 b = wire(b0 + i);
+          emit(gl_mul(b, gl_sub(b, 1)));
+        }
+        u64 idx = 0;
+        for (u32 i = bits; i-- > 0;) idx = gl_add(gl_add(idx, idx), wire(b0 + i));
+        emit(gl_sub(idx, wire(w0)));
+        {  // first fold straight from the wires
+          const u64 b = wire(b0);
+          for (u32 k = 0; k < vs / 2; k++) {
+            u64 x = wire(w0 + 2 + 2 * k), y = wire(w0 + 3 + 2 * k);
+            items[k] = gl_add(x, gl_mul(b, gl_sub(y, x)));
+          }
+        }
+        for (u32 i = 1, len = vs / 2; i < bits; i++, len >>= 1) {
+          const u64 b = wire(b0 + i);
+          for (u32 k = 0; k < len / 2; k++) items[k] = gl_add(items[2 * k], gl_mul(b, gl_sub(items[2 * k + 1], items[2 * k])));
+        }
+        emit(gl_sub(items[0], wire(w0 + 1)));
+      }
+      for (u32 i = 0; i < extra; i++) emit(gl_sub(cst(i), wire((2 + vs) * copies + i)));
+      break;
+    }
+    default: break;
+  }
+}
+
+// gates/gate.rs compute_filter
+template <class ConstAll>
+GLD u64 gate_filter(const GateTable& t, u32 gi, ConstAll call) {
+  const mp2g_gate& g = t.g[gi];
+  const u64 s = call(g.selector_index);
+  u64 f = 1;
+  for (u32 r = g.group_start; r < g.group_end; r++)
+    if (r != gi) f = gl_mul(f, gl_sub(r, s));
+  if (t.num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
+  return f;
+}
+
+__global__ void __launch_bounds__(256) gate_constraints_lde_kernel(GateTable t, const u64* __restrict__ C, const u64* __restrict__ W,
+                                                                   u64 w_bstride, u32 lg, const u64* __restrict__ alphas,
+                                                                   u64 al_bstride, u32 nc, const u64* __restrict__ pi_hash,
+                                                                   u64* __restrict__ q) {
+  const u64 N = (u64)1 << lg;
+  const u32 p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (p >= N) return;
+  const u64* w = W + b * w_bstride + p;
+  const u64* c = C + p;
+  const u64* pih = pi_hash + 4 * b;
+  u64 al[2] = {0, 0}, gsum[2] = {0, 0};
+  for (u32 a = 0; a < nc; a++) al[a] = alphas[b * al_bstride + a];
+  auto wire = [&](u32 j) { return w[(u64)j << lg]; };
+  auto call = [&](u32 j) { return c[(u64)j << lg]; };
+  const u32 ns = t.num_selectors;
+  auto cst = [&](u32 j) { return c[(u64)(ns + j) << lg]; };
+  for (u32 gi = 0; gi < t.n_gates; gi++) {
+    if (t.g[gi].kind == MP2G_GATE_NOOP) continue;
+    const u64 f = gate_filter(t, gi, call);
+    u64 cacc[2] = {0, 0}, cpow[2] = {1, 1};
+    eval_gate(t.g[gi], wire, cst, pih, [&](u64 v) {
+      for (u32 a = 0; a < nc; a++) {
+        cacc[a] = gl_add(cacc[a], gl_mul(v, cpow[a]));
+        cpow[a] = gl_mul(cpow[a], al[a]);
+      }
+    });
+    for (u32 a = 0; a < nc; a++) gsum[a] = gl_add(gsum[a], gl_mul(f, cacc[a]));
+  }
+  const u32 i = bitrev32(p, lg);
+  for (u32 a = 0; a < nc; a++) q[(((u64)b * nc + a) << lg) + i] = gsum[a];
+}
+
+__global__ void __launch_bounds__(256) gate_constraints_points_kernel(GateTable t, const u64* __restrict__ consts,
+                                                                      const u64* __restrict__ wires, u64 npts, u32 max_j,
+                                                                      const u64* __restrict__ pih, u64* __restrict__ out) {
+  const u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npts) return;
+  auto wire = [&](u32 j) { return wires[(u64)j * npts + p]; };
+  auto call = [&](u32 j) { return consts[(u64)j * npts + p]; };
+  const u32 ns = t.num_selectors;
+  auto cst = [&](u32 j) { return consts[(u64)(ns + j) * npts + p]; };
+  for (u32 j = 0; j < max_j; j++) out[(u64)j * npts + p] = 0;
+  for (u32 gi = 0; gi < t.n_gates; gi++) {
+    if (t.g[gi].kind == MP2G_GATE_NOOP) continue;
+    const u64 f = gate_filter(t, gi, call);
+    u32 j = 0;
+    eval_gate(t.g[gi], wire, cst, pih, [&](u64 v) {
+      u64* o = out + (u64)j * npts + p;
+      *o = gl_add(*o, gl_mul(f, v));
+      j++;
+    });
+  }
+}
+
+hipError_t gate_constraints_lde(hipStream_t s, u32 B, const GateTable& t, const u64* C, const u64* W, u64 w_bstride, u32 lg,
+                                const u64* alphas, u64 al_bstride, u32 nc, const u64* pi_hash, u64* q) {
+  if (nc < 1 || nc > 2) return hipErrorInvalidValue;
+  const u64 N = (u64)1 << lg;
+  hipLaunchKernelGGL(gate_constraints_lde_kernel, dim3((u32)((N + 255) / 256), B), dim3(256), 0, s, t, C, W, w_bstride, lg, alphas,
+                     al_bstride, nc, pi_hash, q);
+  return hipGetLastError();
+}
+hipError_t gate_constraints_points(hipStream_t s, const GateTable& t, const u64* consts, const u64* wires, u64 npts, u32 max_j,
+                                   const u64* pi_hash, u64* out) {
+  if (!npts) return hipSuccess;
+  hipLaunchKernelGGL(gate_constraints_points_kernel, dim3((u32)((npts + 255) / 256)), dim3(256), 0, s, t, consts, wires, npts, max_j,
+                     pi_hash, out);
+  return hipGetLastError();
+}
+}  // namespace mp2g

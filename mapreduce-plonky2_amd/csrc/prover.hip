@@ -7,6 +7,7 @@
 #include "ctx.h"
 #include "fri.h"
 #include "zperm.h"
+#include "gates.h"
 #include <new>
 #include <vector>
 
@@ -35,6 +36,8 @@ struct mp2g_prover {
   uint32_t num_routed = 0, degree = 0;
   bool quotient = false;
   DevBuf pre_values, zs_values, chunk_q, bg, alphas, qvals;
+  // gate constraints (mp2g_prover_set_gates)
+  GateTable gates{};
 };
 
 namespace {
@@ -303,6 +306,25 @@ int mp2g_prover_enable_quotient(mp2g_prover* pr) {
   pr->quotient = true;
   return 0;
 }
+int mp2g_prover_set_gates(mp2g_prover* pr, const mp2g_gate* gates, uint32_t n_gates, uint32_t num_selectors) {
+  NEED(pr && pr->quotient, "call mp2g_prover_enable_quotient first");
+  NEED(n_gates <= MP2G_MAX_GATES, "at most MP2G_MAX_GATES gates");
+  GateTable t{};
+  t.n_gates = n_gates; t.num_selectors = num_selectors;
+  if (n_gates) {
+    NEED(gates, "gates");
+    for (uint32_t i = 0; i < n_gates; i++) t.g[i] = gates[i];
+    const char* msg = gate_table_check(t, pr->P.oracle_w[0] - pr->num_routed, pr->P.oracle_w[1]);
+    if (msg) return fail("invalid gate table: %s", msg);
+    // Sum of filter degree and gate degree must fit the quotient degree factor (gates/selectors.rs)
+    for (uint32_t i = 0; i < n_gates; i++) {
+      uint32_t fdeg = t.g[i].group_end - t.g[i].group_start - 1 + (num_selectors > 1 ? 1 : 0);
+      if (fdeg + gate_degree(t.g[i]) > 8) return fail("invalid gate table: filtered degree of gate %u exceeds the quotient degree factor 8", i);
+    }
+  }
+  pr->gates = t;
+  return 0;
+}
 }  // extern "C"
 
 // fri/oracle.rs prove_openings + fri/prover.rs fri_proof for B transcripts: alpha, batch composition,
@@ -393,9 +415,12 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
       // compute_quotient_polys for the gate-independent terms: values on the coset, coset iFFT, and the
       // 8n coefficients of each challenge are its 8 degree-n chunks, already laid out as oracle 3's coeffs
       const u32 nc = P.zs_count;
+      if (pr->gates.n_gates)
+        CK(gate_constraints_lde(s, B, pr->gates, pr->values[0].p, pr->values[1].p, (u64)P.oracle_w[1] * N, P.log_n + 3, pr->alphas.p, 2,
+                                nc, (const u64*)d_pi_hash, pr->qvals.p));
       CK(quotient_perm_values(s, B, pr->values[1].p, (u64)P.oracle_w[1] * N, pr->values[0].p + (u64)(P.oracle_w[0] - pr->num_routed) * N,
                               pr->values[2].p, (u64)P.oracle_w[2] * N, P.log_n, pr->num_routed, pr->degree, pr->bg.p, 4,
-                              pr->alphas.p, 2, nc, pr->qvals.p));
+                              pr->alphas.p, 2, nc, pr->gates.n_gates != 0, pr->qvals.p));
       CK(c->ntt.run(pr->qvals.p, pr->coeffs[3].p, P.log_n + 3, B * nc, 0, N, N, true, nullptr, false));
       CK(c->ntt.scale_powers(pr->coeffs[3].p, P.log_n + 3, B * nc, gl_inv(GL_MULT_GEN), 1));
       CK(commit_oracle_coeffs(pr, 3, B));
@@ -450,6 +475,39 @@ int mp2g_partial_products_and_zs(mp2g_ctx* c, const uint64_t* wires, uint32_t wi
   CK(hipMemcpyAsync(dc.p + nc, gammas, nc * sizeof(u64), hipMemcpyHostToDevice, c->stream));
   CK(zpp_compute(c->stream, 1, dw.p, 0, ds.p, log_n, num_routed, degree, dc.p, dc.p + nc, 0, nc, dq.p, dout.p, 0));
   CK(hipMemcpyAsync(out, dout.p, nc * chunks * n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+uint32_t mp2g_gate_num_constraints(const mp2g_gate* g) { return g ? gate_num_constraints(*g) : 0; }
+uint32_t mp2g_gate_degree(const mp2g_gate* g) { return g ? gate_degree(*g) : 0; }
+int mp2g_eval_gate_constraints(mp2g_ctx* c, const mp2g_gate* gates, uint32_t n_gates, uint32_t num_selectors, const uint64_t* consts,
+                               uint32_t num_constants, const uint64_t* wires, uint32_t wires_w, uint64_t npts,
+                               const uint64_t pi_hash[4], uint64_t* out) {
+  NEED(c && gates && consts && wires && pi_hash && out, "ctx/pointers");
+  NEED(n_gates >= 1 && n_gates <= MP2G_MAX_GATES, "1..MP2G_MAX_GATES gates");
+  NEED(npts >= 1 && npts <= ((uint64_t)1 << 28), "npts");
+  GateTable t{};
+  t.n_gates = n_gates; t.num_selectors = num_selectors;
+  uint32_t max_j = 0;
+  for (uint32_t i = 0; i < n_gates; i++) {
+    t.g[i] = gates[i];
+    uint32_t k = gate_num_constraints(gates[i]);
+    if (k > max_j) max_j = k;
+  }
+  const char* msg = gate_table_check(t, num_constants, wires_w);
+  if (msg) return fail("invalid gate table: %s", msg);
+  if (!max_j) return 0;
+  DevBuf dc, dw, dp, dout;
+  CK(dc.alloc((size_t)num_constants * npts * sizeof(u64)));
+  CK(dw.alloc((size_t)wires_w * npts * sizeof(u64)));
+  CK(dp.alloc(4 * sizeof(u64)));
+  CK(dout.alloc((size_t)max_j * npts * sizeof(u64)));
+  CK(hipMemcpyAsync(dc.p, consts, (size_t)num_constants * npts * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(hipMemcpyAsync(dw.p, wires, (size_t)wires_w * npts * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(hipMemcpyAsync(dp.p, pi_hash, 4 * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  CK(gate_constraints_points(c->stream, t, dc.p, dw.p, npts, max_j, dp.p, dout.p));
+  CK(hipMemcpyAsync(out, dout.p, (size_t)max_j * npts * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
   return 0;
 }

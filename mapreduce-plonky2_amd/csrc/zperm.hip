@@ -100,7 +100,8 @@ __global__ void __launch_bounds__(1024) zpp_scan_kernel(const u64* __restrict__ 
 __global__ void __launch_bounds__(256) quotient_perm_kernel(const u64* __restrict__ W, u64 w_bstride, const u64* __restrict__ S,
                                                             const u64* __restrict__ Z, u64 z_bstride, u32 log_n, u32 num_routed,
                                                             u32 degree, const u64* __restrict__ bg, u64 bg_bstride,
-                                                            const u64* __restrict__ alphas, u64 al_bstride, u32 nc, u64* __restrict__ q) {
+                                                            const u64* __restrict__ alphas, u64 al_bstride, u32 nc, bool gates,
+                                                            u64* __restrict__ q) {
   const u32 lg = log_n + 3;
   const u64 N = (u64)1 << lg;
   const u32 p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
@@ -150,15 +151,18 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(const u64* __restric
       prev = next;
     }
   }
+  // gate constraint terms follow (gates.hip left sum_j alpha^j C_j(x) in this lane's slot)
+  if (gates)
+    for (u32 a = 0; a < nc; a++) acc[a] = gl_add(acc[a], gl_mul(apow[a], q[(((u64)b * nc + a) << lg) + i]));
   for (u32 a = 0; a < nc; a++) q[(((u64)b * nc + a) << lg) + i] = gl_mul(acc[a], zh_inv[i & 7]);
 }
 hipError_t quotient_perm_values(hipStream_t s, u32 B, const u64* W, u64 w_bstride, const u64* S, const u64* Z, u64 z_bstride,
                                 u32 log_n, u32 num_routed, u32 degree, const u64* bg, u64 bg_bstride, const u64* alphas,
-                                u64 al_bstride, u32 nc, u64* q) {
+                                u64 al_bstride, u32 nc, bool gates, u64* q) {
   if (nc < 1 || nc > 2 || !degree || num_routed % degree) return hipErrorInvalidValue;
   const u64 N = (u64)8 << log_n;
   hipLaunchKernelGGL(quotient_perm_kernel, dim3((u32)((N + 255) / 256), B), dim3(256), 0, s, W, w_bstride, S, Z, z_bstride, log_n,
-                     num_routed, degree, bg, bg_bstride, alphas, al_bstride, nc, q);
+                     num_routed, degree, bg, bg_bstride, alphas, al_bstride, nc, gates, q);
   return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@
 // Called from the reference at recursion-framework/src/circuit_builder.rs:308 and
 // universal_verifier_gadget/wrap_circuit.rs:143 (`prove`).
 #include "fri.h"
+#include "gates.h"
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -31,6 +32,16 @@ void orc_partial_products_and_zs(const gl_t* wires, const gl_t* sigmas, unsigned
 void orc_quotient_perm(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, const gl_t* zs_coeffs, unsigned log_n,
                        unsigned num_routed, unsigned degree, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
                        unsigned nc, gl_t* out);
+// the gate part of a circuit: descriptors, the constant polynomials (selectors first) and the wire count
+typedef struct {
+  const orc_gate* gates;
+  unsigned n_gates, num_selectors, num_constants, wires_w;
+  const gl_t* const_coeffs;  // [num_constants][n]
+  const gl_t* pi_hash;       // [4]
+} orc_gate_ctx;
+void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, const gl_t* zs_coeffs, unsigned log_n,
+                        unsigned num_routed, unsigned degree, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
+                        unsigned nc, const orc_gate_ctx* G, gl_t* out);
 
 // ---- challenger ---------------------------------------------------------------------------
 void orc_ch_init(orc_challenger* c, int variant) { memset(c, 0, sizeof *c); c->variant = variant; }
@@ -260,9 +271,10 @@ void orc_fri_prove(const orc_fri_params* P, gl_t* const* coeffs, gl_t* const* le
 // quotient != 0 (needs num_routed > 0): oracle 3 is not taken from values[3] either but computed as
 // compute_quotient_polys does for a circuit without gate constraints (orc_quotient_perm); bgao, if not
 // NULL, receives betas[2], gammas[2], alphas[2], zeta[2] for the PLONK identity check.
-void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4],
-                   const gl_t pi_hash[4], unsigned num_routed, unsigned degree, unsigned quotient, gl_t* bgao,
-                   gl_t* caps, gl_t* openings, gl_t* proof) {
+static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4],
+                           const gl_t pi_hash[4], unsigned num_routed, unsigned degree, unsigned quotient,
+                           const orc_gate* gates, unsigned n_gates, unsigned num_selectors, gl_t* bgao,
+                           gl_t* caps, gl_t* openings, gl_t* proof) {
   unsigned k = P->log_n, lg = k + P->rate_bits;
   size_t n = (size_t)1 << k, N = (size_t)1 << lg;
   size_t capw = ((size_t)4) << P->cap_height;
@@ -285,8 +297,9 @@ void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_
     coeffs[o] = malloc(w * n * sizeof(gl_t));
     if (o == 3 && quotient && num_routed) {
       // PolynomialBatch::from_coeffs: the quotient chunks are produced in coefficient form
-      orc_quotient_perm(coeffs[1], coeffs[0] + (size_t)(P->oracle_w[0] - num_routed) * n, coeffs[2], k, num_routed, degree,
-                        bg, bg + 2, al, P->zs_count, coeffs[o]);
+      orc_gate_ctx G = {gates, n_gates, num_selectors, P->oracle_w[0] - num_routed, P->oracle_w[1], coeffs[0], pi_hash};
+      orc_quotient_polys(coeffs[1], coeffs[0] + (size_t)(P->oracle_w[0] - num_routed) * n, coeffs[2], k, num_routed, degree,
+                         bg, bg + 2, al, P->zs_count, n_gates ? &G : NULL, coeffs[o]);
     } else {
       memcpy(coeffs[o], src, w * n * sizeof(gl_t));
       for (size_t p = 0; p < w; p++) orc_fft(coeffs[o] + p * n, k, 1);
@@ -319,6 +332,21 @@ void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_
   orc_ch_observe(&ch, openings, 2 * oi);
   orc_fri_prove(P, coeffs, leaves, levels, zeta, &ch, proof);
   for (uint32_t o = 0; o < P->n_oracles; o++) { free(coeffs[o]); free(leaves[o]); free(levels[o]); }
+}
+
+void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4],
+                   const gl_t pi_hash[4], unsigned num_routed, unsigned degree, unsigned quotient, gl_t* bgao,
+                   gl_t* caps, gl_t* openings, gl_t* proof) {
+  pcs_prove_impl(P, values, circuit_digest, pi_hash, num_routed, degree, quotient, NULL, 0, 0, bgao, caps, openings, proof);
+}
+// prove() of a circuit with gates: as orc_pcs_prove(quotient = 1) with the gate constraints as further
+// terms of the vanishing polynomial. The constants are the first oracle_w[0] - num_routed polynomials of
+// values[0], selectors first.
+void orc_pcs_prove_gates(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4],
+                         const gl_t pi_hash[4], unsigned num_routed, unsigned degree, const orc_gate* gates,
+                         unsigned n_gates, unsigned num_selectors, gl_t* bgao, gl_t* caps, gl_t* openings, gl_t* proof) {
+  pcs_prove_impl(P, values, circuit_digest, pi_hash, num_routed, degree, 1, gates, n_gates, num_selectors, bgao, caps, openings,
+                 proof);
 }
 
 // ---- verifier -----------------------------------------------------------------------------
@@ -547,17 +575,34 @@ void orc_partial_products_and_zs(const gl_t* wires, const gl_t* sigmas, unsigned
 void orc_quotient_perm(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, const gl_t* zs_coeffs, unsigned log_n,
                        unsigned num_routed, unsigned degree, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
                        unsigned nc, gl_t* out) {
+  orc_quotient_polys(wires_coeffs, sigma_coeffs, zs_coeffs, log_n, num_routed, degree, betas, gammas, alphas, nc, NULL, out);
+}
+// With G != NULL the gate constraints C_j(x) = sum_gates filter_g(x) c_{g,j}(x) follow the permutation
+// terms in the alpha-reduction (vanishing_poly.rs eval_vanishing_poly_base_batch: z_1 terms, partial
+// product terms, gate constraint terms); wires_coeffs must then hold all G->wires_w wire polynomials.
+void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, const gl_t* zs_coeffs, unsigned log_n,
+                        unsigned num_routed, unsigned degree, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
+                        unsigned nc, const orc_gate_ctx* G, gl_t* out) {
   const unsigned rate_bits = 3;
   size_t n = (size_t)1 << log_n, N = n << rate_bits;
   unsigned lg = log_n + rate_bits, chunks = num_routed / degree, num_prods = chunks - 1;
   unsigned n_zs = nc * chunks;
   // natural-order LDE values on g<w_N>
-  gl_t* W = malloc((size_t)num_routed * N * sizeof(gl_t));
+  unsigned wires_w = G ? G->wires_w : num_routed;
+  gl_t* W = malloc((size_t)wires_w * N * sizeof(gl_t));
   gl_t* S = malloc((size_t)num_routed * N * sizeof(gl_t));
+  gl_t* C = NULL;
+  gl_t *lc = NULL, *lw = NULL;
   gl_t* Z = malloc((size_t)n_zs * N * sizeof(gl_t));
   void orc_lde_values(const gl_t*, unsigned, size_t, unsigned, gl_t*);
-  orc_lde_values(wires_coeffs, log_n, num_routed, rate_bits, W);
+  orc_lde_values(wires_coeffs, log_n, wires_w, rate_bits, W);
   orc_lde_values(sigma_coeffs, log_n, num_routed, rate_bits, S);
+  if (G) {
+    C = malloc((size_t)G->num_constants * N * sizeof(gl_t));
+    orc_lde_values(G->const_coeffs, log_n, G->num_constants, rate_bits, C);
+    lc = malloc((G->num_constants + 1) * sizeof(gl_t));
+    lw = malloc(wires_w * sizeof(gl_t));
+  }
   orc_lde_values(zs_coeffs, log_n, n_zs, rate_bits, Z);
   gl_t* k_is = malloc(num_routed * sizeof(gl_t));
   k_is[0] = 1;
@@ -565,7 +610,7 @@ void orc_quotient_perm(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, const
   gl_t wN = gl_root_of_unity(lg), gn = gl_pow(GL_MULT_GEN, n), w8 = gl_root_of_unity(rate_bits);
   gl_t n_field = (gl_t)n % GL_P;
   gl_t* q = malloc((size_t)nc * N * sizeof(gl_t));
-  gl_t* terms = malloc((nc + (size_t)nc * chunks) * sizeof(gl_t));
+  gl_t* terms = malloc((nc + (size_t)nc * chunks + ORC_MAX_GATE_CONSTRAINTS) * sizeof(gl_t));
   for (size_t i = 0; i < N; i++) {
     gl_t x = gl_mul(GL_MULT_GEN, gl_pow(wN, i));
     gl_t zh = gl_sub(gl_mul(gn, gl_pow(w8, i % 8)), 1);  // x^n - 1
@@ -587,6 +632,11 @@ void orc_quotient_perm(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, const
         terms[t++] = gl_sub(gl_mul(prev, num), gl_mul(next, den));
       }
     }
+    if (G) {
+      for (unsigned j = 0; j < G->num_constants; j++) lc[j] = C[(size_t)j * N + i];
+      for (unsigned j = 0; j < wires_w; j++) lw[j] = W[(size_t)j * N + i];
+      t += orc_gates_eval_base(G->gates, G->n_gates, G->num_selectors, lc, lw, G->pi_hash, terms + t);
+    }
     gl_t zh_inv = gl_inv(zh);
     for (unsigned a = 0; a < nc; a++) {
       gl_t acc = 0;
@@ -599,13 +649,23 @@ void orc_quotient_perm(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, const
     orc_coset_ifft(q + (size_t)a * N, lg, GL_MULT_GEN);
     memcpy(out + (size_t)a * N, q + (size_t)a * N, N * sizeof(gl_t));  // 8 chunks of n, contiguous
   }
-  free(terms); free(q); free(k_is); free(W); free(S); free(Z);
+  free(terms); free(q); free(k_is); free(W); free(S); free(Z); free(C); free(lc); free(lw);
 }
 // plonk/verifier.rs: vanishing(zeta) == Z_H(zeta) * sum_i zeta^(n i) t_i(zeta) for every challenge, from
 // the opened values only (openings layout of orc_pcs_prove; num_constants = oracle_w[0] - num_routed).
 // Returns 0 when the identity holds.
+int orc_plonk_identity_check_gates(const orc_fri_params* P, unsigned num_routed, unsigned degree, const gl_t* openings,
+                                   gl2_t zeta, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
+                                   const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* pi_hash);
 int orc_plonk_identity_check(const orc_fri_params* P, unsigned num_routed, unsigned degree, const gl_t* openings,
                              gl2_t zeta, const gl_t* betas, const gl_t* gammas, const gl_t* alphas) {
+  return orc_plonk_identity_check_gates(P, num_routed, degree, openings, zeta, betas, gammas, alphas, NULL, 0, 0, NULL);
+}
+// with gates: the gate constraints evaluated over the extension field on the opened constants / wires
+// (plonk/vanishing_poly.rs eval_vanishing_poly) follow the permutation terms
+int orc_plonk_identity_check_gates(const orc_fri_params* P, unsigned num_routed, unsigned degree, const gl_t* openings,
+                                   gl2_t zeta, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
+                                   const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* pi_hash) {
   unsigned k = P->log_n, nc = P->zs_count, chunks = num_routed / degree, num_prods = chunks - 1;
   size_t n = (size_t)1 << k;
   size_t o_sig = P->oracle_w[0] - num_routed, o_w = P->oracle_w[0], o_z = o_w + P->oracle_w[1];
@@ -615,7 +675,7 @@ int orc_plonk_identity_check(const orc_fri_params* P, unsigned num_routed, unsig
   for (unsigned i = 0; i < k; i++) zn = gl2_mul(zn, zn);
   gl2_t zh = gl2_sub(zn, gl2_from(1));
   gl2_t l0 = gl2_mul(zh, gl2_inv(gl2_scale(gl2_sub(zeta, gl2_from(1)), (gl_t)n % GL_P)));
-  gl2_t terms[64];
+  gl2_t terms[64 + ORC_MAX_GATE_CONSTRAINTS];
   size_t t = 0;
   for (unsigned c = 0; c < nc; c++) terms[t++] = gl2_mul(l0, gl2_sub(OPEN(o_z + c), gl2_from(1)));
   gl_t kj = 1;
@@ -633,6 +693,13 @@ int orc_plonk_identity_check(const orc_fri_params* P, unsigned num_routed, unsig
       gl2_t next = ch == chunks - 1 ? OPEN(o_next + c) : OPEN(o_z + nc + (size_t)c * num_prods + ch);
       terms[t++] = gl2_sub(gl2_mul(prev, num), gl2_mul(next, den));
     }
+  }
+  if (n_gates) {
+    gl2_t lc[64], lw[256], ph[4];
+    for (size_t j = 0; j < o_sig; j++) lc[j] = OPEN(j);
+    for (size_t j = 0; j < P->oracle_w[1]; j++) lw[j] = OPEN(o_w + j);
+    for (int j = 0; j < 4; j++) ph[j] = gl2_from(pi_hash[j]);
+    t += orc_gates_eval_ext(gates, n_gates, num_selectors, lc, lw, ph, terms + t);
   }
   for (unsigned a = 0; a < nc; a++) {
     gl2_t van = gl2_from(0);

@@ -1,0 +1,87 @@
+// TEST INFRASTRUCTURE -- CPU oracle (see gl.h header).
+// Gate constraint evaluation: the third part of plonky2's compute_quotient_polys (after the Z(1) = 1 and
+// partial-product terms), [dep] plonky2/src/plonk/vanishing_poly.rs + plonky2/src/gates/*.rs. PARITY
+// UNPINNED: restated from the published source; the checks available here are self-consistency ones (a
+// satisfied witness vanishes on H, the verifier identity holds at zeta, an unsatisfied witness fails).
+#include "gates.h"
+#include "constants.h"
+#include <stdlib.h>
+
+#define F gl_t
+#define F_ADD gl_add
+#define F_SUB gl_sub
+#define F_MUL gl_mul
+#define F_CONST(x) ((gl_t)(x))
+#define FN(n) b_##n
+#include "gates_body.inc"
+#undef F
+#undef F_ADD
+#undef F_SUB
+#undef F_MUL
+#undef F_CONST
+#undef FN
+
+#define F gl2_t
+#define F_ADD gl2_add
+#define F_SUB gl2_sub
+#define F_MUL gl2_mul
+#define F_CONST(x) gl2_from((gl_t)(x))
+#define FN(n) e_##n
+#include "gates_body.inc"
+
+unsigned orc_gates_eval_base(const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* consts,
+                             const gl_t* wires, const gl_t* pih, gl_t* acc) {
+  return b_eval_gate_constraints(gates, n_gates, num_selectors, consts, wires, pih, acc);
+}
+unsigned orc_gates_eval_ext(const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl2_t* consts,
+                            const gl2_t* wires, const gl2_t* pih, gl2_t* acc) {
+  return e_eval_gate_constraints(gates, n_gates, num_selectors, consts, wires, pih, acc);
+}
+unsigned orc_gate_num_constraints(const orc_gate* g) {
+  switch (g->kind) {
+    case ORC_GATE_CONSTANT: return g->p0;
+    case ORC_GATE_PUBLIC_INPUT: return 4;
+    case ORC_GATE_ARITHMETIC: return g->p0;
+    case ORC_GATE_BASE_SUM: return 1 + g->p0;
+    case ORC_GATE_ARITHMETIC_EXT: case ORC_GATE_MUL_EXT: return 2 * g->p0;
+    case ORC_GATE_POSEIDON2: return 1 + 4 + 36 + 22 + 48 + 12;
+    case ORC_GATE_EXPONENTIATION: return g->p0 + 1;
+    case ORC_GATE_REDUCING: case ORC_GATE_REDUCING_EXT: return 2 * g->p0;
+    case ORC_GATE_RANDOM_ACCESS: return (g->p0 + 2) * g->p1 + g->p2;
+    default: return 0;
+  }
+}
+// Gate::degree()
+unsigned orc_gate_degree(const orc_gate* g) {
+  switch (g->kind) {
+    case ORC_GATE_CONSTANT: case ORC_GATE_PUBLIC_INPUT: return 1;
+    case ORC_GATE_ARITHMETIC: case ORC_GATE_ARITHMETIC_EXT: case ORC_GATE_MUL_EXT: return 3;
+    case ORC_GATE_BASE_SUM: return g->p1;
+    case ORC_GATE_POSEIDON2: return 7;
+    case ORC_GATE_EXPONENTIATION: return 4;
+    case ORC_GATE_REDUCING: case ORC_GATE_REDUCING_EXT: return 2;
+    case ORC_GATE_RANDOM_ACCESS: return g->p0 + 1;
+    default: return 0;
+  }
+}
+// C_j at `npts` arbitrary points: consts [num_constants][npts], wires [wires_w][npts] (point-minor), out [maxc][npts].
+// On the subgroup H with a satisfied witness every C_j is zero (the prover-side witness check).
+unsigned orc_gates_eval_points(const orc_gate* gates, unsigned n_gates, unsigned num_selectors, unsigned num_constants,
+                               const gl_t* consts, unsigned wires_w, const gl_t* wires, size_t npts, const gl_t* pih, gl_t* out) {
+  unsigned maxc = 0;
+  for (unsigned g = 0; g < n_gates; g++) {
+    unsigned c = orc_gate_num_constraints(&gates[g]);
+    if (c > maxc) maxc = c;
+  }
+  gl_t* lc = malloc((num_constants + wires_w + 1) * sizeof(gl_t));
+  gl_t* lw = lc + num_constants;
+  gl_t acc[ORC_MAX_GATE_CONSTRAINTS];
+  for (size_t i = 0; i < npts; i++) {
+    for (unsigned j = 0; j < num_constants; j++) lc[j] = consts[(size_t)j * npts + i];
+    for (unsigned j = 0; j < wires_w; j++) lw[j] = wires[(size_t)j * npts + i];
+    orc_gates_eval_base(gates, n_gates, num_selectors, lc, lw, pih, acc);
+    for (unsigned j = 0; j < maxc; j++) out[(size_t)j * npts + i] = acc[j];
+  }
+  free(lc);
+  return maxc;
+}

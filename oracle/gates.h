@@ -1,0 +1,33 @@
+// TEST INFRASTRUCTURE -- CPU oracle (see gl.h header).
+// Gate descriptors for the constraint evaluators of gates.c. Same meaning, field for field, as mp2g_gate in
+// include/mp2g.h (separate definition: the product never includes oracle headers).
+#ifndef MP2_ORACLE_GATES_H
+#define MP2_ORACLE_GATES_H
+#include "gl.h"
+enum {
+  ORC_GATE_NOOP = 0,
+  ORC_GATE_CONSTANT = 1,        // p0 = num_consts
+  ORC_GATE_PUBLIC_INPUT = 2,
+  ORC_GATE_ARITHMETIC = 3,      // p0 = num_ops
+  ORC_GATE_BASE_SUM = 4,        // p0 = num_limbs, p1 = base
+  ORC_GATE_ARITHMETIC_EXT = 5,  // p0 = num_ops
+  ORC_GATE_MUL_EXT = 6,         // p0 = num_ops
+  ORC_GATE_POSEIDON2 = 7,
+  ORC_GATE_EXPONENTIATION = 8,  // p0 = num_power_bits
+  ORC_GATE_REDUCING = 9,        // p0 = num_coeffs
+  ORC_GATE_REDUCING_EXT = 10,   // p0 = num_coeffs
+  ORC_GATE_RANDOM_ACCESS = 11,  // p0 = bits, p1 = num_copies, p2 = num_extra_constants
+};
+#define ORC_MAX_GATE_CONSTRAINTS 160
+typedef struct {
+  uint32_t kind, p0, p1, p2;
+  uint32_t selector_index;            // which selector polynomial filters this gate
+  uint32_t group_start, group_end;    // gate indices sharing that selector (gates/selectors.rs groups)
+} orc_gate;
+unsigned orc_gate_num_constraints(const orc_gate* g);
+unsigned orc_gate_degree(const orc_gate* g);
+unsigned orc_gates_eval_base(const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* consts,
+                             const gl_t* wires, const gl_t* pih, gl_t* acc);
+unsigned orc_gates_eval_ext(const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl2_t* consts,
+                            const gl2_t* wires, const gl2_t* pih, gl2_t* acc);
+#endif

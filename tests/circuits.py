@@ -1,0 +1,313 @@
+"""Small gate-level circuits with satisfied witnesses for the gate-constraint tests.
+
+Test infrastructure: a stand-in for what plonky2's CircuitBuilder + witness generators would hand to
+prove() -- constants (selectors first), sigma polynomials, the wire matrix and the gate table. Follows
+[dep] plonky2 gates/selectors.rs selector_polynomials for the selector layout and gates/*.rs for the
+wire layouts (see oracle/gates_body.inc). Pure Python over ints mod p; sized for 2^5..2^8 rows.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+import oracle as O
+
+P = O.P
+NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, BASE_SUM, ARITHMETIC_EXT, MUL_EXT, POSEIDON2, EXPONENTIATION, REDUCING, REDUCING_EXT, RANDOM_ACCESS = range(12)
+UNUSED_SELECTOR = 0xFFFFFFFF
+NUM_WIRES, NUM_ROUTED, MAX_DEGREE = 135, 80, 8
+
+
+class Gate(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint32), ("p0", ctypes.c_uint32), ("p1", ctypes.c_uint32), ("p2", ctypes.c_uint32),
+                ("selector_index", ctypes.c_uint32), ("group_start", ctypes.c_uint32), ("group_end", ctypes.c_uint32)]
+
+
+def gate_degree(g):
+    return O.lib().orc_gate_degree(ctypes.byref(g))
+
+
+def gate_num_constraints(g):
+    return O.lib().orc_gate_num_constraints(ctypes.byref(g))
+
+
+_consts = None
+
+
+def poseidon2_constants():
+    global _consts
+    if _consts is None:
+        src = open(os.path.join(O.ORACLE_DIR, "constants.h")).read()
+        out = {}
+        for name in ("POSEIDON2_RC_EXT", "POSEIDON2_RC_INT", "POSEIDON2_DIAG_M1"):
+            body = re.search(name + r"\[\d+\] = \{(.*?)\};", src, re.S).group(1)
+            out[name] = [int(x.rstrip("ULu"), 0) for x in re.findall(r"0x[0-9a-fA-F]+U?L*|\d+U?L*", body)]
+        _consts = out
+    return _consts
+
+
+M4 = ((5, 7, 1, 3), (4, 6, 1, 1), (1, 3, 5, 7), (1, 1, 4, 6))
+
+
+def p2_external(s):
+    t = [sum(s[4 * c + j] * M4[i][j] for j in range(4)) % P for c in range(3) for i in range(4)]
+    sums = [(t[i] + t[4 + i] + t[8 + i]) % P for i in range(4)]
+    return [(t[4 * c + i] + sums[i]) % P for c in range(3) for i in range(4)]
+
+
+def p2_internal(s):
+    d = poseidon2_constants()["POSEIDON2_DIAG_M1"]
+    tot = sum(s) % P
+    return [(s[i] * d[i] + tot) % P for i in range(12)]
+
+
+def ext_mul(a, b):
+    return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def ext_add(a, b):
+    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+
+
+def fill_row(g, w, consts, inp, rng, pi_hash):
+    """Write a satisfying assignment of gate `g` into the wire list `w` (length NUM_WIRES).
+    inp(col) yields the value of a free routed input cell (random, or copied from an earlier cell)."""
+    k = g.kind
+    rnd = lambda: int(rng.integers(0, P, dtype=np.uint64))
+    if k == CONSTANT:
+        for i in range(g.p0):
+            w[i] = consts[i]
+    elif k == PUBLIC_INPUT:
+        for i in range(4):
+            w[i] = int(pi_hash[i])
+    elif k == ARITHMETIC:
+        for i in range(g.p0):
+            m0, m1, ad = inp(4 * i), inp(4 * i + 1), inp(4 * i + 2)
+            w[4 * i], w[4 * i + 1], w[4 * i + 2] = m0, m1, ad
+            w[4 * i + 3] = (m0 * m1 % P * consts[0] + ad * consts[1]) % P
+    elif k == BASE_SUM:
+        limbs = [int(rng.integers(0, g.p1)) for _ in range(g.p0)]
+        w[0] = sum(l * g.p1 ** i for i, l in enumerate(limbs)) % P
+        w[1:1 + g.p0] = limbs
+    elif k in (ARITHMETIC_EXT, MUL_EXT):
+        per = 8 if k == ARITHMETIC_EXT else 6
+        for i in range(g.p0):
+            b = per * i
+            for c in range(per - 2):
+                w[b + c] = inp(b + c)
+            prod = ext_mul((w[b], w[b + 1]), (w[b + 2], w[b + 3]))
+            o = (prod[0] * consts[0] % P, prod[1] * consts[0] % P)
+            if k == ARITHMETIC_EXT:
+                o = ext_add(o, (w[b + 4] * consts[1] % P, w[b + 5] * consts[1] % P))
+            w[b + per - 2], w[b + per - 1] = o
+    elif k == POSEIDON2:
+        C = poseidon2_constants()
+        for i in range(12):
+            w[i] = inp(i)
+        swap = int(rng.integers(0, 2))
+        w[24] = swap
+        s = [0] * 12
+        for i in range(4):
+            delta = swap * (w[i + 4] - w[i]) % P
+            w[25 + i] = delta
+            s[i], s[i + 4] = (w[i] + delta) % P, (w[i + 4] - delta) % P
+        s[8:12] = w[8:12]
+        s = p2_external(s)
+        for r in range(4):
+            s = [(s[i] + C["POSEIDON2_RC_EXT"][12 * r + i]) % P for i in range(12)]
+            if r:
+                w[29 + 12 * (r - 1):29 + 12 * r] = s
+            s = p2_external([pow(x, 7, P) for x in s])
+        for r in range(22):
+            s[0] = (s[0] + C["POSEIDON2_RC_INT"][r]) % P
+            w[65 + r] = s[0]
+            s[0] = pow(s[0], 7, P)
+            s = p2_internal(s)
+        for r in range(4):
+            s = [(s[i] + C["POSEIDON2_RC_EXT"][12 * (4 + r) + i]) % P for i in range(12)]
+            w[87 + 12 * r:87 + 12 * (r + 1)] = s
+            s = p2_external([pow(x, 7, P) for x in s])
+        w[12:24] = s
+    elif k == EXPONENTIATION:
+        nb = g.p0
+        base = inp(0)
+        bits = [int(rng.integers(0, 2)) for _ in range(nb)]
+        w[0] = base
+        w[1:1 + nb] = bits
+        cur = 1
+        for i in range(nb):
+            prev = 1 if i == 0 else cur * cur % P
+            cur = prev * (base if bits[nb - 1 - i] else 1) % P
+            w[nb + 2 + i] = cur
+        w[nb + 1] = cur
+    elif k in (REDUCING, REDUCING_EXT):
+        nc, ext = g.p0, k == REDUCING_EXT
+        start_accs = 6 + (2 * nc if ext else nc)
+        for c in range(2, 6):
+            w[c] = inp(c)
+        alpha, acc = (w[2], w[3]), (w[4], w[5])
+        for i in range(nc):
+            if ext:
+                w[6 + 2 * i], w[7 + 2 * i] = inp(6 + 2 * i), inp(7 + 2 * i)
+                coeff = (w[6 + 2 * i], w[7 + 2 * i])
+            else:
+                w[6 + i] = inp(6 + i)
+                coeff = (w[6 + i], 0)
+            acc = ext_add(ext_mul(acc, alpha), coeff)
+            if i == nc - 1:
+                w[0], w[1] = acc
+            else:
+                w[start_accs + 2 * i], w[start_accs + 2 * i + 1] = acc
+    elif k == RANDOM_ACCESS:
+        bits, copies, extra = g.p0, g.p1, g.p2
+        vs = 1 << bits
+        routed = (2 + vs) * copies + extra
+        for c in range(copies):
+            b = (2 + vs) * c
+            idx = int(rng.integers(0, vs))
+            for i in range(vs):
+                w[b + 2 + i] = inp(b + 2 + i)
+            w[b], w[b + 1] = idx, w[b + 2 + idx]
+            for i in range(bits):
+                w[routed + c * bits + i] = (idx >> i) & 1
+        for i in range(extra):
+            w[(2 + vs) * copies + i] = consts[i]
+    for i in range(NUM_WIRES):
+        if w[i] is None:
+            w[i] = rnd()  # unused cells are unconstrained
+
+
+def selector_polynomials(gates, instances, max_degree=MAX_DEGREE):
+    """gates/selectors.rs selector_polynomials: `gates` sorted by degree; instances[row] = gate index.
+    Returns (selector columns, selector_indices, groups)."""
+    n, num_gates = len(instances), len(gates)
+    degs = [gate_degree(g) for g in gates]
+    if max(degs) + num_gates - 1 <= max_degree:
+        return [[i for i in instances]], [0] * num_gates, [(0, num_gates)]
+    groups, start = [], 0
+    while start < num_gates:
+        size = 0
+        while start + size < num_gates and size + degs[start + size] < max_degree:
+            size += 1
+        groups.append((start, start + size))
+        start += size
+    sel_idx = [next(j for j, (a, b) in enumerate(groups) if a <= i < b) for i in range(num_gates)]
+    cols = [[(g if a <= g < b else UNUSED_SELECTOR) for g in instances] for (a, b) in groups]
+    return cols, sel_idx, groups
+
+
+class Circuit:
+    """gates: list of Gate with selector fields filled; pre = constants ‖ sigmas [num_constants + 80][n];
+    wires [135][n]; num_selectors; pi_hash."""
+
+
+def build(log_n, kinds, seed, copy_prob=0.35):
+    """A random satisfied circuit using every gate kind in `kinds` (list of (kind, p0, p1, p2)), rows dealt
+    round-robin (row 0 = PublicInput when present), with random copy constraints between routed cells."""
+    n = 1 << log_n
+    rng = np.random.default_rng(seed)
+    gates = [Gate(k, p0, p1, p2, 0, 0, 0) for (k, p0, p1, p2) in kinds]
+    gates.sort(key=lambda g: (gate_degree(g), g.kind, g.p0))  # CircuitBuilder sorts gates by (degree, id)
+    order = list(range(len(gates)))
+    instances = [order[i % len(order)] for i in range(n)]
+    rng.shuffle(instances)
+    pi_rows = [i for i, g in enumerate(gates) if g.kind == PUBLIC_INPUT]
+    if pi_rows:
+        instances[0] = pi_rows[0]
+        instances = [instances[0]] + [g if g != pi_rows[0] else order[(r + 1) % len(order)] if gates[order[(r + 1) % len(order)]].kind != PUBLIC_INPUT else order[0]
+                                      for r, g in enumerate(instances[1:], 1)]
+    cols, sel_idx, groups = selector_polynomials(gates, instances)
+    for i, g in enumerate(gates):
+        g.selector_index, (g.group_start, g.group_end) = sel_idx[i], groups[sel_idx[i]]
+    num_selectors = len(cols)
+    pi_hash = O.rand_field(4, seed + 1)
+    gate_consts = [[int(x) for x in O.rand_field(2, seed * 1000 + r)] for r in range(n)]
+    wires = [[None] * NUM_WIRES for _ in range(n)]
+    parent = {}
+
+    def find(c):
+        while parent.get(c, c) != c:
+            c = parent[c]
+        return c
+
+    filled = []  # routed cells (row, col) with a value
+    for r in range(n):
+        g = gates[instances[r]]
+        w = wires[r]
+
+        def inp(col, r=r, w=w):
+            if col < NUM_ROUTED and filled and rng.random() < copy_prob:
+                rr, cc = filled[int(rng.integers(0, len(filled)))]
+                parent[find((r, col))] = find((rr, cc))
+                return wires[rr][cc]
+            return int(rng.integers(0, P, dtype=np.uint64))
+
+        fill_row(g, w, gate_consts[r], inp, rng, pi_hash)
+        filled += [(r, c) for c in range(0, NUM_ROUTED, 7)]
+    # sigma: identity with each equivalence class of copy-constrained cells rotated by one
+    wN = pow(7277203076849721926, 1 << (32 - log_n), P)
+    xs = [pow(wN, i, P) for i in range(n)]
+    ks = [pow(O.MULT_GEN, j, P) for j in range(NUM_ROUTED)]
+    sig = [[ks[j] * xs[i] % P for i in range(n)] for j in range(NUM_ROUTED)]
+    classes = {}
+    for c in list(parent):
+        classes.setdefault(find(c), set()).add(c)
+    for root, members in classes.items():
+        cells = sorted(members | {root})
+        vals = {wires[r][c] for r, c in cells}
+        assert len(vals) == 1
+        ids = [ks[c] * xs[r] % P for r, c in cells]
+        for (r, c), v in zip(cells, ids[1:] + ids[:1]):
+            sig[c][r] = v
+    consts = np.array(cols + [[gate_consts[r][k] for r in range(n)] for k in range(2)], dtype=np.uint64)
+    ckt = Circuit()
+    ckt.log_n, ckt.gates, ckt.num_selectors, ckt.pi_hash = log_n, gates, num_selectors, pi_hash
+    ckt.pre = np.concatenate([consts, np.array(sig, dtype=np.uint64)])
+    ckt.wires = np.array(wires, dtype=np.uint64).T.copy()
+    ckt.num_constants = consts.shape[0]
+    ckt.instances = instances
+    ckt.gate_array = (Gate * len(gates))(*gates)
+    return ckt
+
+
+ALL_KINDS = [(NOOP, 0, 0, 0), (CONSTANT, 2, 0, 0), (PUBLIC_INPUT, 0, 0, 0), (ARITHMETIC, 20, 0, 0), (BASE_SUM, 63, 2, 0),
+             (BASE_SUM, 20, 4, 0), (ARITHMETIC_EXT, 10, 0, 0), (MUL_EXT, 13, 0, 0), (POSEIDON2, 0, 0, 0),
+             (EXPONENTIATION, 66, 0, 0), (REDUCING, 43, 0, 0), (REDUCING_EXT, 32, 0, 0), (RANDOM_ACCESS, 4, 4, 2)]
+
+
+def eval_on_points(ckt, consts, wires):
+    """C_j at the given points: consts [num_constants][npts], wires [135][npts] -> [maxc][npts]"""
+    consts, wires = O.arr(consts), O.arr(wires)
+    npts = wires.shape[1]
+    maxc = max(gate_num_constraints(g) for g in ckt.gates)
+    out = np.zeros((maxc, npts), dtype=np.uint64)
+    ph = O.arr(ckt.pi_hash)
+    O.lib().orc_gates_eval_points(ckt.gate_array, len(ckt.gates), ckt.num_selectors, consts.shape[0], O.p(consts), wires.shape[0],
+                                  O.p(wires), O.sz(npts), O.p(ph), O.p(out))
+    return out
+
+
+def prove(ckt, fp, circuit_digest):
+    """oracle prove() of the circuit; returns (caps, openings, proof, bgao)"""
+    n = 1 << ckt.log_n
+    vals = [O.arr(ckt.pre), O.arr(ckt.wires), np.zeros((fp.oracle_w[2], n), dtype=np.uint64), np.zeros((fp.oracle_w[3], n), dtype=np.uint64)]
+    ptrs = (ctypes.c_void_p * 4)(*[v.ctypes.data for v in vals])
+    capw = 4 << fp.cap_height
+    caps = np.zeros((fp.n_oracles, capw), dtype=np.uint64)
+    openings = np.zeros((O.lib().orc_n_openings(ctypes.byref(fp)), 2), dtype=np.uint64)
+    proof = np.zeros(O.lib().orc_fri_proof_words(ctypes.byref(fp)), dtype=np.uint64)
+    cd, ph, bgao = O.arr(circuit_digest), O.arr(ckt.pi_hash), np.zeros(8, dtype=np.uint64)
+    O.lib().orc_pcs_prove_gates(ctypes.byref(fp), ptrs, O.p(cd), O.p(ph), NUM_ROUTED, 8, ckt.gate_array, len(ckt.gates),
+                                ckt.num_selectors, O.p(bgao), O.p(caps), O.p(openings), O.p(proof))
+    return caps, openings, proof, bgao
+
+
+def identity_check(ckt, fp, openings, bgao):
+    class G2(ctypes.Structure):
+        _fields_ = [("c", ctypes.c_uint64 * 2)]
+    z = G2()
+    z.c[0], z.c[1] = int(bgao[6]), int(bgao[7])
+    o, b, g, a, ph = O.arr(openings), O.arr(bgao[0:2]), O.arr(bgao[2:4]), O.arr(bgao[4:6]), O.arr(ckt.pi_hash)
+    return O.lib().orc_plonk_identity_check_gates(ctypes.byref(fp), NUM_ROUTED, 8, O.p(o), z, O.p(b), O.p(g), O.p(a), ckt.gate_array,
+                                                  len(ckt.gates), ckt.num_selectors, O.p(ph))

@@ -1,0 +1,117 @@
+"""Gate constraint evaluators on the GPU vs the oracle: per-constraint values at
+arbitrary points, the witness check on H, and the complete prove() of gate-level circuits, bit-exact
+against the oracle's proof, accepted by the oracle's verifier (FRI + PLONK identity with gate terms)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import circuits as C
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+P = O.P
+
+
+def gpu_gates(mp2, ckt):
+    return [mp2.Gate(g.kind, g.p0, g.p1, g.p2, g.selector_index, g.group_start, g.group_end) for g in ckt.gates]
+
+
+def params(mp2, ckt, log_n, **kw):
+    ws = (ckt.num_constants + C.NUM_ROUTED, C.NUM_WIRES, 20, 16)
+    ofp = O.standard_params(log_n, ws, **kw)
+    fp = mp2.FriParams()
+    ctypes.memmove(ctypes.byref(fp), ctypes.byref(ofp), ctypes.sizeof(fp))
+    return ofp, fp
+
+
+@pytest.mark.parametrize("kinds", [[k] for k in C.ALL_KINDS if k[0] != C.NOOP] + [C.ALL_KINDS])
+def test_constraints_match_oracle_at_random_points(ctx, mp2, kinds):
+    ckt = C.build(5, [(C.NOOP, 0, 0, 0)] + [k for k in kinds if k[0] != C.NOOP], 21)
+    npts = 300
+    consts = O.rand_field((ckt.num_constants, npts), 1)
+    # selectors hit real gate indices on some points so that filters are exercised at zero and non-zero values
+    consts[:ckt.num_selectors, :100] = np.arange(100, dtype=np.uint64)[None, :] % np.uint64(len(ckt.gates) + 1)
+    wires = O.rand_field((C.NUM_WIRES, npts), 2)
+    got = mp2.eval_gate_constraints(ctx, gpu_gates(mp2, ckt), ckt.num_selectors, consts, wires, ckt.pi_hash)
+    want = C.eval_on_points(ckt, consts, wires)
+    assert np.array_equal(got, want)
+    assert got.any()
+
+
+def test_witness_check_on_h(ctx, mp2):
+    ckt = C.build(6, C.ALL_KINDS, 4)
+    gates = gpu_gates(mp2, ckt)
+    out = mp2.eval_gate_constraints(ctx, gates, ckt.num_selectors, ckt.pre[:ckt.num_constants], ckt.wires, ckt.pi_hash)
+    assert not out.any()
+    bad = ckt.wires.copy()
+    row = ckt.instances.index(next(i for i, g in enumerate(ckt.gates) if g.kind == C.POSEIDON2))
+    bad[70, row] ^= np.uint64(1)  # one partial-round S-box input
+    out = mp2.eval_gate_constraints(ctx, gates, ckt.num_selectors, ckt.pre[:ckt.num_constants], bad, ckt.pi_hash)
+    assert out[:, row].any() and not np.delete(out, row, axis=1).any()
+
+
+def test_gate_descriptor_queries(mp2):
+    for k in C.ALL_KINDS:
+        og = C.Gate(*k, 0, 0, 0)
+        g = mp2.Gate(*k, 0, 0, 0)
+        assert g.num_constraints == C.gate_num_constraints(og) and g.degree == C.gate_degree(og)
+
+
+@pytest.mark.parametrize("kinds,log_n,B", [([(C.NOOP, 0, 0, 0), (C.CONSTANT, 2, 0, 0), (C.PUBLIC_INPUT, 0, 0, 0), (C.ARITHMETIC, 20, 0, 0)], 5, 2),
+                                            (C.ALL_KINDS, 6, 2), ([(C.NOOP, 0, 0, 0), (C.POSEIDON2, 0, 0, 0), (C.ARITHMETIC, 20, 0, 0)], 8, 1)])
+def test_complete_proof_with_gates(ctx, mp2, kinds, log_n, B):
+    ckt = C.build(log_n, kinds, 5)
+    ofp, fp = params(mp2, ckt, log_n, pow_bits=4, num_queries=3)
+    cd = O.rand_field(4, 9)
+    # the batch proves the same witness under different public-input hashes only when no PublicInput gate binds
+    # them; here every proof of the batch uses the circuit's hash
+    ph = np.stack([ckt.pi_hash] * B)
+    pr = mp2.BatchedProver(ctx, fp, B)
+    pr.set_preprocessed(ctx.to_device(ckt.pre))
+    pr.enable_permutation(C.NUM_ROUTED, 8)
+    pr.enable_quotient()
+    pr.set_gates(gpu_gates(mp2, ckt), ckt.num_selectors)
+    pr.prove([ctx.to_device(np.stack([ckt.wires] * B)), None, None], ctx.to_device(cd), ctx.to_device(ph))
+    caps, openings, proofs = pr.results()
+    oc, oo, op, bgao = C.prove(ckt, ofp, cd)
+    for b in range(B):
+        assert np.array_equal(caps[b], oc) and np.array_equal(openings[b], oo) and np.array_equal(proofs[b], op)
+    assert O.pcs_verify(ofp, cd, ckt.pi_hash, caps[0], openings[0], proofs[0]) == 0
+    assert C.identity_check(ckt, ofp, openings[0], bgao) == 0
+    # a witness violating one gate: still bit-exact with the oracle, FRI opens, the identity fails
+    gi = next(i for i, g in enumerate(ckt.gates) if g.kind == C.ARITHMETIC)
+    row = ckt.instances.index(gi)
+    ckt.wires[3, row] = (int(ckt.wires[3, row]) + 1) % P
+    pr.prove([ctx.to_device(np.stack([ckt.wires] * B)), None, None], ctx.to_device(cd), ctx.to_device(ph))
+    caps, openings, proofs = pr.results()
+    oc, oo, op, bgao = C.prove(ckt, ofp, cd)
+    assert np.array_equal(caps[0], oc) and np.array_equal(openings[0], oo) and np.array_equal(proofs[0], op)
+    assert C.identity_check(ckt, ofp, openings[0], bgao) != 0
+    # removing the table returns to the copy-constraint-only quotient
+    pr.set_gates([], 1)
+    pr.free()
+
+
+def test_gate_table_validation(ctx, mp2):
+    ckt = C.build(5, C.ALL_KINDS, 3)
+    ofp, fp = params(mp2, ckt, 5, pow_bits=2, num_queries=2)
+    pr = mp2.BatchedProver(ctx, fp, 1)
+    pr.set_preprocessed(ctx.to_device(ckt.pre))
+    with pytest.raises(mp2.Mp2gError):
+        pr.set_gates(gpu_gates(mp2, ckt), ckt.num_selectors)  # needs enable_quotient first
+    pr.enable_permutation(C.NUM_ROUTED, 8)
+    pr.enable_quotient()
+    good = gpu_gates(mp2, ckt)
+    pr.set_gates(good, ckt.num_selectors)
+    for mutate in (lambda g: setattr(g[0], "kind", 99), lambda g: setattr(g[1], "selector_index", 9),
+                   lambda g: setattr(g[2], "group_end", g[2].group_start), lambda g: setattr(next(x for x in g if x.kind == mp2.GATE_ARITHMETIC), "p0", 40)):
+        bad = gpu_gates(mp2, ckt)
+        mutate(bad)
+        with pytest.raises(mp2.Mp2gError):
+            pr.set_gates(bad, ckt.num_selectors)
+    with pytest.raises(mp2.Mp2gError):
+        pr.set_gates(good, 0)
+    big = [mp2.Gate(mp2.GATE_ARITHMETIC, 40, 0, 0, 0, 0, 1)]  # 160 routed wires > 135
+    with pytest.raises(mp2.Mp2gError):
+        pr.set_gates(big, 1)
