@@ -8,15 +8,18 @@ Workload. The metric is quoted on the 2^20-row table build (configs[3]); its uni
 framework leaf proof, which the recursion framework always produces as one base `prove()` plus
 one wrap `prove()` down to 2^12 rows (recursion-framework/src/circuit_builder.rs:286-311,
 wrap_circuit.rs:122-148). One step = one batch of `--batch` such leaf proofs, shaped as SURVEY
-8(d) config 3 says (base 2^13 + wrap 2^12, standard_recursion_config: 84 constants/sigmas + 135
-wires + 20 Z/partial products + 16 quotient chunks, rate 1/8, cap 16, FRI [4,4], 16-bit PoW, 28
+8(d) config 3 says (base 2^13 + wrap 2^12, standard_recursion_config: 7 constants + 80 sigmas,
+135 wires, 20 Z/partial products, 16 quotient chunks, rate 1/8, cap 16, FRI [4,4], 16-bit PoW, 28
 queries), on synthetic witness matrices that are resident in HBM before the timed region. What
 runs per proof is everything `prove()` does after witness generation -- wires commitment, Z / partial
-products, quotient polynomials, their commitments, Fiat-Shamir, openings, FRI (HOT LOOPS 1-3 of
-SURVEY 3.1) -- for a satisfied circuit whose constraints are copy constraints only: the quotient
-kernel evaluates the gate-independent vanishing terms; the 26 gate types' constraint evaluators
-(SURVEY 8(f)-1 "next") are the terms still to add, and witness generation stays on the host. The
-proofs verify (FRI + the PLONK identity at zeta, tests/test_gpu_permutation.py).
+products, quotient polynomials (permutation terms and the gate constraints), their commitments,
+Fiat-Shamir, openings, FRI (HOT LOOPS 1-3 of SURVEY 3.1) -- for a satisfied synthetic circuit that
+uses every gate kind the library evaluates (tests/circuits.py ALL_KINDS: Noop, Constant, PublicInput,
+Arithmetic, BaseSum<2>, BaseSum<4>, ArithmeticExtension, MulExtension, Poseidon2, Poseidon,
+PoseidonMds, Exponentiation, Reducing, ReducingExtension, RandomAccess; as in plonky2 every gate is
+evaluated at every LDE point, so the cost depends on the gate set, not on the row mix) with random
+copy constraints. Witness generation stays on the host. The proofs verify (FRI + the PLONK identity
+at zeta with the gate terms, tests/test_gpu_gates.py).
 Leaf proofs shard across ranks with no data-path collective ("scaling": "weak"); the per-rank
 multiset digests meet in one 160-byte all_gather outside the per-proof path.
 
@@ -39,7 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 LOG_NTT = 22
-ORACLE_W = (84, 135, 20, 16)
+ORACLE_W = (87, 135, 20, 16)  # 5 selectors + 2 gate constants + 80 sigmas | wires | Z, partial products | quotient chunks
 NUM_ROUTED = 80  # standard_recursion_config: 80 routed wires, quotient_degree_factor 8 => 2 x (1 + 9) Z / partial products
 SEED = 0xC0FFEE03
 
@@ -47,22 +50,21 @@ SEED = 0xC0FFEE03
 def cpu_baseline(base_bits, n_proofs=1):
     """The CPU oracle (our restatement of the same pipeline; kind 'port'), OpenMP over
     polynomials / leaves on all host cores, on a bounded sample of the same workload."""
+    import circuits as C
     import oracle as O
     cores = os.cpu_count() or 1
     t_total = 0.0
     for k in (base_bits, 12):
         ofp = O.standard_params(k, ORACLE_W)
-        sig, wires = O.copy_constraint_circuit(k, NUM_ROUTED, ORACLE_W[1], 1 << (k - 1), SEED)
-        vals = [np.concatenate([O.rand_field((ORACLE_W[0] - NUM_ROUTED, 1 << k), SEED), sig]), wires,
-                np.zeros((ORACLE_W[2], 1 << k), dtype=np.uint64), np.zeros((ORACLE_W[3], 1 << k), dtype=np.uint64)]
-        cd, ph = O.rand_field(4, 1), O.rand_field(4, 2)
+        ckt = C.build(k, C.ALL_KINDS, SEED + k)
+        cd = O.rand_field(4, 1)
         t0 = time.perf_counter()
         for _ in range(n_proofs):
-            O.pcs_prove(ofp, vals, cd, ph, num_routed=NUM_ROUTED, degree=8, quotient=True)
+            C.prove(ckt, ofp, cd)
         t_total += time.perf_counter() - t0
     return {"value": n_proofs / t_total, "unit": "leaf proofs/s", "cores": cores, "kind": "port",
-            "sample": f"{n_proofs} leaf proof(s) = base 2^{base_bits} + wrap 2^12 PCS pipelines by oracle/ (OpenMP, {cores} threads; "
-                      "FRI composition and transcript are single-threaded)"}
+            "sample": f"{n_proofs} leaf proof(s) = base 2^{base_bits} + wrap 2^12 prove() of the same gate-level circuits by oracle/ "
+                      f"(OpenMP over polynomials / leaves, {cores} threads; quotient evaluation, FRI composition and transcript are single-threaded)"}
 
 
 def main():
@@ -91,7 +93,8 @@ def main():
 
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
-    import oracle as O  # synthetic input stream + cpu_baseline leg only
+    import circuits as C  # synthetic circuit + witness generator (pure Python)
+    import oracle as O  # rand_field (SplitMix64 stream); the oracle library itself is used by the cpu_baseline leg only
     # two contexts = two HIP streams on the same GPU: the base and the wrap prover run concurrently, so
     # the latency-bound stretches of one (transcript, top Merkle levels) hide under the other's sponges
     ctx = mp2.Context(local_rank)
@@ -109,30 +112,38 @@ def main():
 
     # ---- synthetic inputs, resident in HBM before the timed region -----------------------------
     provers = []
+    circuits = {}
     for k, cx, nb in plan:
         fp = mp2.standard_recursion_params(k, ORACLE_W)
         n = 1 << k
         pr = mp2.BatchedProver(cx, fp, nb)
-        # a satisfied circuit whose constraints are copy constraints only: identity sigma with n/2
-        # random 3-cycles of routed cells (the witness repeats the cycle's value in its cells)
-        sig, wires_one = O.copy_constraint_circuit(k, NUM_ROUTED, ORACLE_W[1], n // 2, SEED + k)
-        pr.set_preprocessed(cx.to_device(np.concatenate([O.rand_field((ORACLE_W[0] - NUM_ROUTED, n), SEED + k), sig])))
+        # a satisfied gate-level circuit: rows dealt over every supported gate kind, random copy constraints
+        if k not in circuits:
+            circuits[k] = C.build(k, C.ALL_KINDS, SEED + k)
+        ckt = circuits[k]
+        assert ckt.pre.shape[0] == ORACLE_W[0]
+        pr.set_preprocessed(cx.to_device(ckt.pre))
         pr.enable_permutation(NUM_ROUTED, 8)  # Z / partial products on the device from wires + sigmas
-        pr.enable_quotient()                  # quotient chunks on the device (gate-independent terms)
-        # one random matrix per oracle, tiled over the batch (distinct public-input hashes keep
-        # the transcripts, challenges and proofs distinct)
+        pr.enable_quotient()                  # quotient chunks on the device
+        pr.set_gates([mp2.Gate(g.kind, g.p0, g.p1, g.p2, g.selector_index, g.group_start, g.group_end) for g in ckt.gates],
+                     ckt.num_selectors)       # ... including the gate constraint terms
+        # the witness, tiled over the batch; the unrouted cells of one Noop row are free, so re-drawing
+        # them per proof keeps the commitments, transcripts and proofs of the batch distinct
+        wires_one = ckt.wires
+        noop_row = ckt.instances.index(next(i for i, g in enumerate(ckt.gates) if g.kind == C.NOOP))
         d_vals = []
         for i, w in enumerate(ORACLE_W[1:]):
             if i >= 1:
                 d_vals.append(None)  # oracles 2 and 3: produced by the prover itself
                 continue
-            one = wires_one
+            one = wires_one.copy()
             buf = cx.alloc(nb * w * n * 8)
             for b in range(nb):
+                one[NUM_ROUTED:, noop_row] = O.rand_field(w - NUM_ROUTED, SEED + 1000 * len(provers) + 31 * rank + b)
                 mp2._ck(mp2.load().mp2g_h2d(cx.h, ctypes.c_void_p(buf.ptr.value + b * w * n * 8), mp2._p(one), ctypes.c_size_t(one.nbytes)))
             d_vals.append(buf)
         d_cd = cx.to_device(O.rand_field(4, SEED + 7))
-        d_ph = cx.to_device(O.rand_field((nb, 4), SEED + 8 + rank + 97 * len(provers)))
+        d_ph = cx.to_device(np.stack([ckt.pi_hash] * nb))  # bound to the wires by the PublicInput gate
         staging = []
         if args.host_inputs:
             for buf in d_vals:
@@ -231,8 +242,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 (Goldilocks field)", "data": "synthetic",
             "config": {"workload": f"configs[3]-shaped leaf proofs: base 2^{args.base_bits} + wrap 2^12 prove() from the wire matrix "
-                                   "(commitments, permutation argument, quotient of the gate-independent terms, Fiat-Shamir, "
-                                   "openings, FRI) at standard_recursion_config on a copy-constraint-only circuit; "
+                                   "(commitments, permutation argument, quotient with gate constraints, Fiat-Shamir, openings, FRI) at "
+                                   "standard_recursion_config on a synthetic circuit using all 15 supported gate kinds; "
                                    "roofline leg = configs[1] 2^22-point NTT",
                        "batch_per_rank": B, "streams": args.streams, "host_inputs": bool(args.host_inputs), "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
                        "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B"},

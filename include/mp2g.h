@@ -263,7 +263,7 @@ int mp2g_prover_enable_quotient(mp2g_prover* pr);
  * Replaces [dep] plonky2 plonk/vanishing_poly.rs evaluate_gate_constraints_base_batch and the
  * eval_unfiltered_base of the gates below (gates the reference registers:
  * mp2-common/src/serialization/circuit_data_serialization.rs:236-267). Not yet covered: CosetInterpolation,
- * Lookup / LookupTable, PoseidonMds, Poseidon (original), the plonky2-u32 gates, Comparison,
+ * Lookup / LookupTable, the plonky2-u32 gates, Comparison,
  * U32Interleave / Uninterleave. A circuit using one of those cannot be proved here yet. */
 enum {
   MP2G_GATE_NOOP = 0,
@@ -277,7 +277,9 @@ enum {
   MP2G_GATE_EXPONENTIATION = 8, /* p0 = num_power_bits */
   MP2G_GATE_REDUCING = 9,       /* p0 = num_coeffs */
   MP2G_GATE_REDUCING_EXT = 10,  /* p0 = num_coeffs */
-  MP2G_GATE_RANDOM_ACCESS = 11  /* p0 = bits (<= 6), p1 = num_copies, p2 = num_extra_constants */
+  MP2G_GATE_RANDOM_ACCESS = 11, /* p0 = bits (<= 6), p1 = num_copies, p2 = num_extra_constants */
+  MP2G_GATE_POSEIDON = 12,      /* the original Poseidon permutation gate (wrap circuits) */
+  MP2G_GATE_POSEIDON_MDS = 13
 };
 #define MP2G_MAX_GATES 24
 #define MP2G_MAX_GATE_CONSTRAINTS 160

@@ -21,7 +21,8 @@ u32 gate_num_constraints(const mp2g_gate& g) {
     case MP2G_GATE_ARITHMETIC: return g.p0;
     case MP2G_GATE_BASE_SUM: return 1 + g.p0;
     case MP2G_GATE_ARITHMETIC_EXT: case MP2G_GATE_MUL_EXT: return 2 * g.p0;
-    case MP2G_GATE_POSEIDON2: return 1 + 4 + 36 + 22 + 48 + 12;
+    case MP2G_GATE_POSEIDON2: case MP2G_GATE_POSEIDON: return 1 + 4 + 36 + 22 + 48 + 12;
+    case MP2G_GATE_POSEIDON_MDS: return 24;
     case MP2G_GATE_EXPONENTIATION: return g.p0 + 1;
     case MP2G_GATE_REDUCING: case MP2G_GATE_REDUCING_EXT: return 2 * g.p0;
     case MP2G_GATE_RANDOM_ACCESS: return (g.p0 + 2) * g.p1 + g.p2;
@@ -33,7 +34,8 @@ u32 gate_degree(const mp2g_gate& g) {
     case MP2G_GATE_CONSTANT: case MP2G_GATE_PUBLIC_INPUT: return 1;
     case MP2G_GATE_ARITHMETIC: case MP2G_GATE_ARITHMETIC_EXT: case MP2G_GATE_MUL_EXT: return 3;
     case MP2G_GATE_BASE_SUM: return g.p1;
-    case MP2G_GATE_POSEIDON2: return 7;
+    case MP2G_GATE_POSEIDON2: case MP2G_GATE_POSEIDON: return 7;
+    case MP2G_GATE_POSEIDON_MDS: return 1;
     case MP2G_GATE_EXPONENTIATION: return 4;
     case MP2G_GATE_REDUCING: case MP2G_GATE_REDUCING_EXT: return 2;
     case MP2G_GATE_RANDOM_ACCESS: return g.p0 + 1;
@@ -50,7 +52,8 @@ static void gate_footprint(const mp2g_gate& g, u32& wires, u32& consts) {
     case MP2G_GATE_BASE_SUM: wires = 1 + g.p0; break;
     case MP2G_GATE_ARITHMETIC_EXT: wires = 8 * g.p0; consts = 2; break;
     case MP2G_GATE_MUL_EXT: wires = 6 * g.p0; consts = 1; break;
-    case MP2G_GATE_POSEIDON2: wires = 135; break;
+    case MP2G_GATE_POSEIDON2: case MP2G_GATE_POSEIDON: wires = 135; break;
+    case MP2G_GATE_POSEIDON_MDS: wires = 48; break;
     case MP2G_GATE_EXPONENTIATION: wires = 2 * g.p0 + 2; break;
     case MP2G_GATE_REDUCING: wires = 6 + g.p0 + 2 * (g.p0 - 1); break;
     case MP2G_GATE_REDUCING_EXT: wires = 6 + 2 * g.p0 + 2 * (g.p0 - 1); break;
@@ -63,7 +66,7 @@ const char* gate_table_check(const GateTable& t, u32 num_constants, u32 wires_w)
   if (t.num_selectors == 0 || t.num_selectors > num_constants) return "num_selectors must be in 1..num_constants";
   for (u32 i = 0; i < t.n_gates; i++) {
     const mp2g_gate& g = t.g[i];
-    if (g.kind > MP2G_GATE_RANDOM_ACCESS) return "unknown gate kind";
+    if (g.kind > MP2G_GATE_POSEIDON_MDS) return "unknown gate kind";
     if (g.kind == MP2G_GATE_BASE_SUM && (g.p1 < 2 || g.p0 < 1)) return "BaseSumGate needs base >= 2 and a limb";
     if ((g.kind == MP2G_GATE_REDUCING || g.kind == MP2G_GATE_REDUCING_EXT || g.kind == MP2G_GATE_EXPONENTIATION) && g.p0 < 1)
       return "gate needs at least one coefficient / power bit";
@@ -87,10 +90,20 @@ GLD Alg alg_add(Alg x, Alg y) { return Alg{gl_add(x.a, y.a), gl_add(x.b, y.b)}; 
 GLD Alg alg_sub(Alg x, Alg y) { return Alg{gl_sub(x.a, y.a), gl_sub(x.b, y.b)}; }
 GLD Alg alg_scale(Alg x, u64 c) { return Alg{gl_mul(x.a, c), gl_mul(x.b, c)}; }
 
+// a - b for any u64 a and canonical b, as some u64 representative
+GLD u64 gl_subw(u64 a, u64 b) {
+  u64 r;
+  bool br = __builtin_sub_overflow(a, b, &r);  // borrow: r = a - b + 2^64 >= 2^32, so -EPS cannot borrow again
+  return r - (br ? GL_EPS : 0);
+}
 // eval_unfiltered_base of one gate: wire(j) / cst(j) fetch local wire j / gate constant j (after the
-// selector prefix), emit(c) receives the constraints in plonky2's order (canonical values).
-template <class WireF, class ConstF, class Emit>
-__device__ __noinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF cst, const u64* __restrict__ pih, Emit emit) {
+// selector prefix), emit(c) receives the constraints in plonky2's order. WEAK = true lets the Poseidon
+// gates hand over un-canonicalised representatives (the lazy accumulator of the LDE kernel takes any u64).
+template <bool WEAK, class WireF, class ConstF, class Emit>
+__device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF cst, const u64* __restrict__ pih, Emit emit) {
+  // state limb + round constant - wire
+  auto diff = [](u64 s, u64 rc, u64 in) { return WEAK ? gl_subw(gl_addw(s, rc), in) : gl_sub(gl_add(gl_canon(s), rc), in); };
+  auto diff0 = [](u64 s, u64 in) { return WEAK ? gl_subw(s, in) : gl_sub(gl_canon(s), in); };
   switch (g.kind) {
     case MP2G_GATE_CONSTANT:
       for (u32 i = 0; i < g.p0; i++) emit(gl_sub(cst(i), wire(i)));
@@ -161,7 +174,7 @@ __device__ __noinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF cst
 #pragma unroll
           for (int i = 0; i < 12; i++) {
             u64 in = wire(29 + 12 * (r - 1) + i);
-            emit(gl_sub(gl_add(gl_canon(s[i]), c_p2_ext[12 * r + i]), in));
+            emit(diff(s[i], c_p2_ext[12 * r + i], in));
             s[i] = p2_sbox(in, 0);
           }
         } else {
@@ -173,7 +186,7 @@ __device__ __noinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF cst
 #pragma unroll 1
       for (int r = 0; r < 22; r++) {
         u64 in = wire(65 + r);
-        emit(gl_sub(gl_add(gl_canon(s[0]), c_p2_int[r]), in));
+        emit(diff(s[0], c_p2_int[r], in));
         s[0] = p2_sbox(in, 0);
         p2_internal(s);
       }
@@ -182,13 +195,69 @@ __device__ __noinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF cst
 #pragma unroll
         for (int i = 0; i < 12; i++) {
           u64 in = wire(87 + 12 * r + i);
-          emit(gl_sub(gl_add(gl_canon(s[i]), c_p2_ext[12 * (4 + r) + i]), in));
+          emit(diff(s[i], c_p2_ext[12 * (4 + r) + i], in));
           s[i] = p2_sbox(in, 0);
         }
         p2_external(s);
       }
 #pragma unroll
-      for (int i = 0; i < 12; i++) emit(gl_sub(gl_canon(s[i]), wire(12 + i)));
+      for (int i = 0; i < 12; i++) emit(diff0(s[i], wire(12 + i)));
+      break;
+    }
+    case MP2G_GATE_POSEIDON: {
+      // gates/poseidon.rs: same wire layout as Poseidon2Gate. plonky2 evaluates the partial rounds in the
+      // "fast" factorisation; that is an exact linear identity for arbitrary S-box outputs, so the
+      // constraint polynomials equal those of the plain round structure used here.
+      const u64 swap = wire(24);
+      emit(gl_mul(swap, gl_sub(swap, 1)));
+      u64 s[12];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        u64 lhs = wire(i), rhs = wire(i + 4), delta = wire(25 + i);
+        emit(gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), delta));
+        s[i] = gl_add(lhs, delta);
+        s[i + 4] = gl_sub(rhs, delta);
+      }
+#pragma unroll
+      for (int i = 8; i < 12; i++) s[i] = wire(i);
+#pragma unroll 1
+      for (int r = 0; r < 30; r++) {
+        if (r >= 4 && r < 26) {
+          u64 in = wire(65 + (r - 4));
+          emit(diff(s[0], c_p_rc[12 * r], in));
+          s[0] = p2_sbox(in, 0);
+#pragma unroll
+          for (int i = 1; i < 12; i++) s[i] = gl_addw(s[i], c_p_rc[12 * r + i]);
+        } else if (r == 0) {
+#pragma unroll
+          for (int i = 0; i < 12; i++) s[i] = p2_sbox(s[i], c_p_rc[i]);
+        } else {
+          const int base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26);
+#pragma unroll
+          for (int i = 0; i < 12; i++) {
+            u64 in = wire(base + i);
+            emit(diff(s[i], c_p_rc[12 * r + i], in));
+            s[i] = p2_sbox(in, 0);
+          }
+        }
+        poseidon_mds(s);
+      }
+#pragma unroll
+      for (int i = 0; i < 12; i++) emit(diff0(s[i], wire(12 + i)));
+      break;
+    }
+    case MP2G_GATE_POSEIDON_MDS: {
+      // 12 extension inputs (wires 2i, 2i+1), outputs at 24 + 2i; constraints limb-major, D components each
+      u64 s0[12], s1[12];
+#pragma unroll
+      for (int i = 0; i < 12; i++) { s0[i] = wire(2 * i); s1[i] = wire(2 * i + 1); }
+      poseidon_mds(s0);
+      poseidon_mds(s1);
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        emit(gl_sub(wire(24 + 2 * i), gl_canon(s0[i])));
+        emit(gl_sub(wire(25 + 2 * i), gl_canon(s1[i])));
+      }
       break;
     }
     case MP2G_GATE_EXPONENTIATION: {
@@ -266,36 +335,63 @@ GLD u64 gate_filter(const GateTable& t, u32 gi, ConstAll call) {
   return f;
 }
 
-__global__ void __launch_bounds__(256) gate_constraints_lde_kernel(GateTable t, const u64* __restrict__ C, const u64* __restrict__ W,
+// One launch per gate of the table, specialised on the gate kind (the generic switch needs ~250 VGPRs
+// and runs at 2 waves/SIMD; a specialised body keeps only its own live state). The alpha powers of the
+// block's proof sit in LDS, and a gate's constraints accumulate un-reduced, sum_j c_j alpha^j as a 136-bit
+// integer (lo, hi, top), reduced once: per constraint and challenge one 64x64 multiply and a carry chain
+// instead of two modular multiplications. q[b][a][i] is written by the first launch and added to by the rest.
+template <u32 KIND>
+__global__ void __launch_bounds__(256) gate_constraints_lde_kernel(mp2g_gate g, u32 gi, u32 num_selectors, u32 n_cons,
+                                                                   const u64* __restrict__ C, const u64* __restrict__ W,
                                                                    u64 w_bstride, u32 lg, const u64* __restrict__ alphas,
                                                                    u64 al_bstride, u32 nc, const u64* __restrict__ pi_hash,
-                                                                   u64* __restrict__ q) {
+                                                                   u64* __restrict__ q, int first) {
+  __shared__ u64 apw[2][MP2G_MAX_GATE_CONSTRAINTS];
   const u64 N = (u64)1 << lg;
   const u32 p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  for (u32 j = threadIdx.x; j < 2 * n_cons; j += 256) {
+    const u32 a = j >= n_cons ? 1 : 0, e = j - a * n_cons;
+    apw[a][e] = a < nc ? gl_pow(alphas[b * al_bstride + a], e) : 0;
+  }
+  __syncthreads();
   if (p >= N) return;
+  g.kind = KIND;
   const u64* w = W + b * w_bstride + p;
   const u64* c = C + p;
   const u64* pih = pi_hash + 4 * b;
-  u64 al[2] = {0, 0}, gsum[2] = {0, 0};
-  for (u32 a = 0; a < nc; a++) al[a] = alphas[b * al_bstride + a];
   auto wire = [&](u32 j) { return w[(u64)j << lg]; };
-  auto call = [&](u32 j) { return c[(u64)j << lg]; };
-  const u32 ns = t.num_selectors;
-  auto cst = [&](u32 j) { return c[(u64)(ns + j) << lg]; };
-  for (u32 gi = 0; gi < t.n_gates; gi++) {
-    if (t.g[gi].kind == MP2G_GATE_NOOP) continue;
-    const u64 f = gate_filter(t, gi, call);
-    u64 cacc[2] = {0, 0}, cpow[2] = {1, 1};
-    eval_gate(t.g[gi], wire, cst, pih, [&](u64 v) {
-      for (u32 a = 0; a < nc; a++) {
-        cacc[a] = gl_add(cacc[a], gl_mul(v, cpow[a]));
-        cpow[a] = gl_mul(cpow[a], al[a]);
-      }
-    });
-    for (u32 a = 0; a < nc; a++) gsum[a] = gl_add(gsum[a], gl_mul(f, cacc[a]));
+  auto cst = [&](u32 j) { return c[(u64)(num_selectors + j) << lg]; };
+  // gates/gate.rs compute_filter
+  u64 f = 1;
+  {
+    const u64 s = c[(u64)g.selector_index << lg];
+    for (u32 r = g.group_start; r < g.group_end; r++)
+      if (r != gi) f = gl_mul(f, gl_sub(r, s));
+    if (num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
   }
+  u64 lo[2] = {0, 0}, hi[2] = {0, 0};
+  u32 top[2] = {0, 0};
+  u32 j = 0;
+  eval_gate<true>(g, wire, cst, pih, [&](u64 v) {
+#pragma unroll
+    for (u32 a = 0; a < 2; a++) {
+      u64 pl, ph;
+      gl_mul_wide(v, apw[a][j], pl, ph);
+      bool c0 = __builtin_add_overflow(lo[a], pl, &lo[a]);
+      bool c1 = __builtin_add_overflow(hi[a], ph, &hi[a]);
+      bool c2 = __builtin_add_overflow(hi[a], (u64)(c0 ? 1 : 0), &hi[a]);
+      top[a] += (c1 ? 1 : 0) + (c2 ? 1 : 0);
+    }
+    j++;
+  });
   const u32 i = bitrev32(p, lg);
-  for (u32 a = 0; a < nc; a++) q[(((u64)b * nc + a) << lg) + i] = gsum[a];
+  for (u32 a = 0; a < nc; a++) {
+    // lo + hi 2^64 + top 2^128, 2^128 = -2^32 (mod p)
+    u64 r = gl_sub(gl_reduce128(lo[a], hi[a]), (u64)top[a] << 32);
+    r = gl_mul(f, r);
+    u64* dst = q + (((u64)b * nc + a) << lg) + i;
+    *dst = first ? r : gl_add(*dst, r);
+  }
 }
 
 __global__ void __launch_bounds__(256) gate_constraints_points_kernel(GateTable t, const u64* __restrict__ consts,
@@ -312,7 +408,7 @@ __global__ void __launch_bounds__(256) gate_constraints_points_kernel(GateTable 
     if (t.g[gi].kind == MP2G_GATE_NOOP) continue;
     const u64 f = gate_filter(t, gi, call);
     u32 j = 0;
-    eval_gate(t.g[gi], wire, cst, pih, [&](u64 v) {
+    eval_gate<false>(t.g[gi], wire, cst, pih, [&](u64 v) {
       u64* o = out + (u64)j * npts + p;
       *o = gl_add(*o, gl_mul(f, v));
       j++;
@@ -324,8 +420,37 @@ hipError_t gate_constraints_lde(hipStream_t s, u32 B, const GateTable& t, const 
                                 const u64* alphas, u64 al_bstride, u32 nc, const u64* pi_hash, u64* q) {
   if (nc < 1 || nc > 2) return hipErrorInvalidValue;
   const u64 N = (u64)1 << lg;
-  hipLaunchKernelGGL(gate_constraints_lde_kernel, dim3((u32)((N + 255) / 256), B), dim3(256), 0, s, t, C, W, w_bstride, lg, alphas,
-                     al_bstride, nc, pi_hash, q);
+  const dim3 grid((u32)((N + 255) / 256), B), block(256);
+  int first = 1;
+  for (u32 gi = 0; gi < t.n_gates; gi++) {
+    const mp2g_gate& g = t.g[gi];
+    const u32 n_cons = gate_num_constraints(g);
+    if (!n_cons) continue;
+#define GATE_CASE(K)                                                                                                        \
+  case K:                                                                                                                   \
+    hipLaunchKernelGGL(gate_constraints_lde_kernel<K>, grid, block, 0, s, g, gi, t.num_selectors, n_cons, C, W, w_bstride, lg, \
+                       alphas, al_bstride, nc, pi_hash, q, first);                                                          \
+    break;
+    switch (g.kind) {
+      GATE_CASE(MP2G_GATE_CONSTANT)
+      GATE_CASE(MP2G_GATE_PUBLIC_INPUT)
+      GATE_CASE(MP2G_GATE_ARITHMETIC)
+      GATE_CASE(MP2G_GATE_BASE_SUM)
+      GATE_CASE(MP2G_GATE_ARITHMETIC_EXT)
+      GATE_CASE(MP2G_GATE_MUL_EXT)
+      GATE_CASE(MP2G_GATE_POSEIDON2)
+      GATE_CASE(MP2G_GATE_EXPONENTIATION)
+      GATE_CASE(MP2G_GATE_REDUCING)
+      GATE_CASE(MP2G_GATE_REDUCING_EXT)
+      GATE_CASE(MP2G_GATE_RANDOM_ACCESS)
+      GATE_CASE(MP2G_GATE_POSEIDON)
+      GATE_CASE(MP2G_GATE_POSEIDON_MDS)
+      default: return hipErrorInvalidValue;
+    }
+#undef GATE_CASE
+    first = 0;
+  }
+  if (first) return hipMemsetAsync(q, 0, (size_t)B * nc * N * sizeof(u64), s);  // a table of Noops only
   return hipGetLastError();
 }
 hipError_t gate_constraints_points(hipStream_t s, const GateTable& t, const u64* consts, const u64* wires, u64 npts, u32 max_j,

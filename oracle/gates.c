@@ -44,7 +44,8 @@ unsigned orc_gate_num_constraints(const orc_gate* g) {
     case ORC_GATE_ARITHMETIC: return g->p0;
     case ORC_GATE_BASE_SUM: return 1 + g->p0;
     case ORC_GATE_ARITHMETIC_EXT: case ORC_GATE_MUL_EXT: return 2 * g->p0;
-    case ORC_GATE_POSEIDON2: return 1 + 4 + 36 + 22 + 48 + 12;
+    case ORC_GATE_POSEIDON2: case ORC_GATE_POSEIDON: return 1 + 4 + 36 + 22 + 48 + 12;
+    case ORC_GATE_POSEIDON_MDS: return 24;
     case ORC_GATE_EXPONENTIATION: return g->p0 + 1;
     case ORC_GATE_REDUCING: case ORC_GATE_REDUCING_EXT: return 2 * g->p0;
     case ORC_GATE_RANDOM_ACCESS: return (g->p0 + 2) * g->p1 + g->p2;
@@ -57,7 +58,8 @@ unsigned orc_gate_degree(const orc_gate* g) {
     case ORC_GATE_CONSTANT: case ORC_GATE_PUBLIC_INPUT: return 1;
     case ORC_GATE_ARITHMETIC: case ORC_GATE_ARITHMETIC_EXT: case ORC_GATE_MUL_EXT: return 3;
     case ORC_GATE_BASE_SUM: return g->p1;
-    case ORC_GATE_POSEIDON2: return 7;
+    case ORC_GATE_POSEIDON2: case ORC_GATE_POSEIDON: return 7;
+    case ORC_GATE_POSEIDON_MDS: return 1;
     case ORC_GATE_EXPONENTIATION: return 4;
     case ORC_GATE_REDUCING: case ORC_GATE_REDUCING_EXT: return 2;
     case ORC_GATE_RANDOM_ACCESS: return g->p0 + 1;

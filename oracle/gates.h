@@ -17,6 +17,8 @@ enum {
   ORC_GATE_REDUCING = 9,        // p0 = num_coeffs
   ORC_GATE_REDUCING_EXT = 10,   // p0 = num_coeffs
   ORC_GATE_RANDOM_ACCESS = 11,  // p0 = bits, p1 = num_copies, p2 = num_extra_constants
+  ORC_GATE_POSEIDON = 12,
+  ORC_GATE_POSEIDON_MDS = 13,
 };
 #define ORC_MAX_GATE_CONSTRAINTS 160
 typedef struct {

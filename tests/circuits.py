@@ -14,7 +14,8 @@ import numpy as np
 import oracle as O
 
 P = O.P
-NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, BASE_SUM, ARITHMETIC_EXT, MUL_EXT, POSEIDON2, EXPONENTIATION, REDUCING, REDUCING_EXT, RANDOM_ACCESS = range(12)
+(NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, BASE_SUM, ARITHMETIC_EXT, MUL_EXT, POSEIDON2, EXPONENTIATION, REDUCING, REDUCING_EXT,
+ RANDOM_ACCESS, POSEIDON, POSEIDON_MDS) = range(14)
 UNUSED_SELECTOR = 0xFFFFFFFF
 NUM_WIRES, NUM_ROUTED, MAX_DEGREE = 135, 80, 8
 
@@ -25,11 +26,16 @@ class Gate(ctypes.Structure):
 
 
 def gate_degree(g):
-    return O.lib().orc_gate_degree(ctypes.byref(g))
+    """Gate::degree()"""
+    return {NOOP: 0, CONSTANT: 1, PUBLIC_INPUT: 1, ARITHMETIC: 3, BASE_SUM: g.p1, ARITHMETIC_EXT: 3, MUL_EXT: 3, POSEIDON2: 7,
+            EXPONENTIATION: 4, REDUCING: 2, REDUCING_EXT: 2, RANDOM_ACCESS: g.p0 + 1, POSEIDON: 7, POSEIDON_MDS: 1}[g.kind]
 
 
 def gate_num_constraints(g):
-    return O.lib().orc_gate_num_constraints(ctypes.byref(g))
+    """Gate::num_constraints()"""
+    return {NOOP: 0, CONSTANT: g.p0, PUBLIC_INPUT: 4, ARITHMETIC: g.p0, BASE_SUM: 1 + g.p0, ARITHMETIC_EXT: 2 * g.p0, MUL_EXT: 2 * g.p0,
+            POSEIDON2: 123, EXPONENTIATION: g.p0 + 1, REDUCING: 2 * g.p0, REDUCING_EXT: 2 * g.p0,
+            RANDOM_ACCESS: (g.p0 + 2) * g.p1 + g.p2, POSEIDON: 123, POSEIDON_MDS: 24}[g.kind]
 
 
 _consts = None
@@ -38,9 +44,10 @@ _consts = None
 def poseidon2_constants():
     global _consts
     if _consts is None:
-        src = open(os.path.join(O.ORACLE_DIR, "constants.h")).read()
+        # the generated constant tables (tools/gen_constants.py writes the same numbers for product and oracle)
+        src = open(os.path.join(O.ROOT, "mapreduce-plonky2_amd", "csrc", "perm_constants.h")).read()
         out = {}
-        for name in ("POSEIDON2_RC_EXT", "POSEIDON2_RC_INT", "POSEIDON2_DIAG_M1"):
+        for name in ("POSEIDON2_RC_EXT", "POSEIDON2_RC_INT", "POSEIDON2_DIAG_M1", "POSEIDON_RC", "POSEIDON_MDS_CIRC", "POSEIDON_MDS_DIAG"):
             body = re.search(name + r"\[\d+\] = \{(.*?)\};", src, re.S).group(1)
             out[name] = [int(x.rstrip("ULu"), 0) for x in re.findall(r"0x[0-9a-fA-F]+U?L*|\d+U?L*", body)]
         _consts = out
@@ -60,6 +67,12 @@ def p2_internal(s):
     d = poseidon2_constants()["POSEIDON2_DIAG_M1"]
     tot = sum(s) % P
     return [(s[i] * d[i] + tot) % P for i in range(12)]
+
+
+def poseidon_mds(s):
+    C = poseidon2_constants()
+    circ, diag = C["POSEIDON_MDS_CIRC"], C["POSEIDON_MDS_DIAG"]
+    return [(sum(s[(i + r) % 12] * circ[i] for i in range(12)) + s[r] * diag[r]) % P for r in range(12)]
 
 
 def ext_mul(a, b):
@@ -129,6 +142,37 @@ def fill_row(g, w, consts, inp, rng, pi_hash):
             w[87 + 12 * r:87 + 12 * (r + 1)] = s
             s = p2_external([pow(x, 7, P) for x in s])
         w[12:24] = s
+    elif k == POSEIDON:
+        C = poseidon2_constants()
+        for i in range(12):
+            w[i] = inp(i)
+        swap = int(rng.integers(0, 2))
+        w[24] = swap
+        s = [0] * 12
+        for i in range(4):
+            delta = swap * (w[i + 4] - w[i]) % P
+            w[25 + i] = delta
+            s[i], s[i + 4] = (w[i] + delta) % P, (w[i + 4] - delta) % P
+        s[8:12] = w[8:12]
+        for r in range(30):
+            s = [(s[i] + C["POSEIDON_RC"][12 * r + i]) % P for i in range(12)]
+            if 4 <= r < 26:
+                w[65 + r - 4] = s[0]
+                s[0] = pow(s[0], 7, P)
+            else:
+                if r:
+                    base = 29 + 12 * (r - 1) if r < 4 else 87 + 12 * (r - 26)
+                    w[base:base + 12] = s
+                s = [pow(x, 7, P) for x in s]
+            s = poseidon_mds(s)
+        w[12:24] = s
+    elif k == POSEIDON_MDS:
+        for i in range(24):
+            w[i] = inp(i)
+        for c in range(2):
+            o = poseidon_mds([w[2 * i + c] for i in range(12)])
+            for i in range(12):
+                w[24 + 2 * i + c] = o[i]
     elif k == EXPONENTIATION:
         nb = g.p0
         base = inp(0)
@@ -273,7 +317,8 @@ def build(log_n, kinds, seed, copy_prob=0.35):
 
 ALL_KINDS = [(NOOP, 0, 0, 0), (CONSTANT, 2, 0, 0), (PUBLIC_INPUT, 0, 0, 0), (ARITHMETIC, 20, 0, 0), (BASE_SUM, 63, 2, 0),
              (BASE_SUM, 20, 4, 0), (ARITHMETIC_EXT, 10, 0, 0), (MUL_EXT, 13, 0, 0), (POSEIDON2, 0, 0, 0),
-             (EXPONENTIATION, 66, 0, 0), (REDUCING, 43, 0, 0), (REDUCING_EXT, 32, 0, 0), (RANDOM_ACCESS, 4, 4, 2)]
+             (EXPONENTIATION, 66, 0, 0), (REDUCING, 43, 0, 0), (REDUCING_EXT, 32, 0, 0), (RANDOM_ACCESS, 4, 4, 2),
+             (POSEIDON, 0, 0, 0), (POSEIDON_MDS, 0, 0, 0)]
 
 
 def eval_on_points(ckt, consts, wires):

@@ -32,6 +32,14 @@ def test_satisfied_witness_vanishes_on_h(kinds):
         assert out[:, row].any() and not np.delete(out, row, axis=1).any(), g.kind
 
 
+def test_descriptor_tables_agree():
+    import ctypes
+    for k in C.ALL_KINDS:
+        g = C.Gate(*k, 0, 0, 0)
+        assert O.lib().orc_gate_degree(ctypes.byref(g)) == C.gate_degree(g)
+        assert O.lib().orc_gate_num_constraints(ctypes.byref(g)) == C.gate_num_constraints(g)
+
+
 def test_selector_groups():
     ckt = C.build(5, C.ALL_KINDS, 3)
     degs = [C.gate_degree(g) for g in ckt.gates]
