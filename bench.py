@@ -8,7 +8,7 @@ Workload. The metric is quoted on the 2^20-row table build (configs[3]); its uni
 framework leaf proof, which the recursion framework always produces as one base `prove()` plus
 one wrap `prove()` down to 2^12 rows (recursion-framework/src/circuit_builder.rs:286-311,
 wrap_circuit.rs:122-148). One step = one batch of `--batch` such leaf proofs, shaped as SURVEY
-8(d) config 3 says (base 2^13 + wrap 2^12, standard_recursion_config: 7 constants + 80 sigmas,
+8(d) config 3 says (base 2^13 + wrap 2^12, standard_recursion_config: 8 constants + 80 sigmas,
 135 wires, 20 Z/partial products, 16 quotient chunks, rate 1/8, cap 16, FRI [4,4], 16-bit PoW, 28
 queries), on synthetic witness matrices that are resident in HBM before the timed region. What
 runs per proof is everything `prove()` does after witness generation -- wires commitment, Z / partial
@@ -16,7 +16,7 @@ products, quotient polynomials (permutation terms and the gate constraints), the
 Fiat-Shamir, openings, FRI (HOT LOOPS 1-3 of SURVEY 3.1) -- for a satisfied synthetic circuit that
 uses every gate kind the library evaluates (tests/circuits.py ALL_KINDS: Noop, Constant, PublicInput,
 Arithmetic, BaseSum<2>, BaseSum<4>, ArithmeticExtension, MulExtension, Poseidon2, Poseidon,
-PoseidonMds, Exponentiation, Reducing, ReducingExtension, RandomAccess; as in plonky2 every gate is
+PoseidonMds, Exponentiation, Reducing, ReducingExtension, RandomAccess, CosetInterpolation; as in plonky2 every gate is
 evaluated at every LDE point, so the cost depends on the gate set, not on the row mix) with random
 copy constraints. Witness generation stays on the host. The proofs verify (FRI + the PLONK identity
 at zeta with the gate terms, tests/test_gpu_gates.py).
@@ -42,7 +42,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 LOG_NTT = 22
-ORACLE_W = (87, 135, 20, 16)  # 5 selectors + 2 gate constants + 80 sigmas | wires | Z, partial products | quotient chunks
+ORACLE_W = (88, 135, 20, 16)  # 6 selectors + 2 gate constants + 80 sigmas | wires | Z, partial products | quotient chunks
 NUM_ROUTED = 80  # standard_recursion_config: 80 routed wires, quotient_degree_factor 8 => 2 x (1 + 9) Z / partial products
 SEED = 0xC0FFEE03
 
@@ -243,7 +243,7 @@ def main():
             "dtype": "u64 (Goldilocks field)", "data": "synthetic",
             "config": {"workload": f"configs[3]-shaped leaf proofs: base 2^{args.base_bits} + wrap 2^12 prove() from the wire matrix "
                                    "(commitments, permutation argument, quotient with gate constraints, Fiat-Shamir, openings, FRI) at "
-                                   "standard_recursion_config on a synthetic circuit using all 15 supported gate kinds; "
+                                   "standard_recursion_config on a synthetic circuit using all 16 supported gate kinds (15 plonky2 gate types); "
                                    "roofline leg = configs[1] 2^22-point NTT",
                        "batch_per_rank": B, "streams": args.streams, "host_inputs": bool(args.host_inputs), "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
                        "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B"},

@@ -262,7 +262,7 @@ int mp2g_prover_enable_quotient(mp2g_prover* pr);
 /* ---- gate constraints: the third part of compute_quotient_polys --------------------------------
  * Replaces [dep] plonky2 plonk/vanishing_poly.rs evaluate_gate_constraints_base_batch and the
  * eval_unfiltered_base of the gates below (gates the reference registers:
- * mp2-common/src/serialization/circuit_data_serialization.rs:236-267). Not yet covered: CosetInterpolation,
+ * mp2-common/src/serialization/circuit_data_serialization.rs:236-267). Not yet covered:
  * Lookup / LookupTable, the plonky2-u32 gates, Comparison,
  * U32Interleave / Uninterleave. A circuit using one of those cannot be proved here yet. */
 enum {
@@ -279,7 +279,8 @@ enum {
   MP2G_GATE_REDUCING_EXT = 10,  /* p0 = num_coeffs */
   MP2G_GATE_RANDOM_ACCESS = 11, /* p0 = bits (<= 6), p1 = num_copies, p2 = num_extra_constants */
   MP2G_GATE_POSEIDON = 12,      /* the original Poseidon permutation gate (wrap circuits) */
-  MP2G_GATE_POSEIDON_MDS = 13
+  MP2G_GATE_POSEIDON_MDS = 13,
+  MP2G_GATE_COSET_INTERPOLATION = 14 /* p0 = subgroup_bits (2..5), p1 = degree (CosetInterpolationGate::degree) */
 };
 #define MP2G_MAX_GATES 24
 #define MP2G_MAX_GATE_CONSTRAINTS 160

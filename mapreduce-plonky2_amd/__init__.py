@@ -405,7 +405,8 @@ class Gate(ctypes.Structure):
 
 
 (GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_ARITHMETIC_EXT, GATE_MUL_EXT, GATE_POSEIDON2,
- GATE_EXPONENTIATION, GATE_REDUCING, GATE_REDUCING_EXT, GATE_RANDOM_ACCESS, GATE_POSEIDON, GATE_POSEIDON_MDS) = range(14)
+ GATE_EXPONENTIATION, GATE_REDUCING, GATE_REDUCING_EXT, GATE_RANDOM_ACCESS, GATE_POSEIDON, GATE_POSEIDON_MDS,
+ GATE_COSET_INTERPOLATION) = range(15)
 
 
 def eval_gate_constraints(ctx, gates, num_selectors, consts, wires, pi_hash):

@@ -23,6 +23,7 @@ u32 gate_num_constraints(const mp2g_gate& g) {
     case MP2G_GATE_ARITHMETIC_EXT: case MP2G_GATE_MUL_EXT: return 2 * g.p0;
     case MP2G_GATE_POSEIDON2: case MP2G_GATE_POSEIDON: return 1 + 4 + 36 + 22 + 48 + 12;
     case MP2G_GATE_POSEIDON_MDS: return 24;
+    case MP2G_GATE_COSET_INTERPOLATION: return 4 + 4 * (((1u << g.p0) - 2) / (g.p1 - 1));
     case MP2G_GATE_EXPONENTIATION: return g.p0 + 1;
     case MP2G_GATE_REDUCING: case MP2G_GATE_REDUCING_EXT: return 2 * g.p0;
     case MP2G_GATE_RANDOM_ACCESS: return (g.p0 + 2) * g.p1 + g.p2;
@@ -36,6 +37,7 @@ u32 gate_degree(const mp2g_gate& g) {
     case MP2G_GATE_BASE_SUM: return g.p1;
     case MP2G_GATE_POSEIDON2: case MP2G_GATE_POSEIDON: return 7;
     case MP2G_GATE_POSEIDON_MDS: return 1;
+    case MP2G_GATE_COSET_INTERPOLATION: return g.p1;
     case MP2G_GATE_EXPONENTIATION: return 4;
     case MP2G_GATE_REDUCING: case MP2G_GATE_REDUCING_EXT: return 2;
     case MP2G_GATE_RANDOM_ACCESS: return g.p0 + 1;
@@ -54,6 +56,7 @@ static void gate_footprint(const mp2g_gate& g, u32& wires, u32& consts) {
     case MP2G_GATE_MUL_EXT: wires = 6 * g.p0; consts = 1; break;
     case MP2G_GATE_POSEIDON2: case MP2G_GATE_POSEIDON: wires = 135; break;
     case MP2G_GATE_POSEIDON_MDS: wires = 48; break;
+    case MP2G_GATE_COSET_INTERPOLATION: wires = 1 + 2 * (1u << g.p0) + 6 + 4 * (((1u << g.p0) - 2) / (g.p1 - 1)); break;
     case MP2G_GATE_EXPONENTIATION: wires = 2 * g.p0 + 2; break;
     case MP2G_GATE_REDUCING: wires = 6 + g.p0 + 2 * (g.p0 - 1); break;
     case MP2G_GATE_REDUCING_EXT: wires = 6 + 2 * g.p0 + 2 * (g.p0 - 1); break;
@@ -66,7 +69,9 @@ const char* gate_table_check(const GateTable& t, u32 num_constants, u32 wires_w)
   if (t.num_selectors == 0 || t.num_selectors > num_constants) return "num_selectors must be in 1..num_constants";
   for (u32 i = 0; i < t.n_gates; i++) {
     const mp2g_gate& g = t.g[i];
-    if (g.kind > MP2G_GATE_POSEIDON_MDS) return "unknown gate kind";
+    if (g.kind > MP2G_GATE_COSET_INTERPOLATION) return "unknown gate kind";
+    if (g.kind == MP2G_GATE_COSET_INTERPOLATION && (g.p0 < 2 || g.p0 > 5 || g.p1 < 2 || g.p1 > (1u << g.p0)))
+      return "CosetInterpolationGate needs 2..5 subgroup bits and 2 <= degree <= 2^bits";
     if (g.kind == MP2G_GATE_BASE_SUM && (g.p1 < 2 || g.p0 < 1)) return "BaseSumGate needs base >= 2 and a limb";
     if ((g.kind == MP2G_GATE_REDUCING || g.kind == MP2G_GATE_REDUCING_EXT || g.kind == MP2G_GATE_EXPONENTIATION) && g.p0 < 1)
       return "gate needs at least one coefficient / power bit";
@@ -260,6 +265,40 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
       }
       break;
     }
+    case MP2G_GATE_COSET_INTERPOLATION: {
+      // gates/coset_interpolation.rs: barycentric interpolation over the 2^p0-point subgroup in chunks of
+      // `degree` (then degree - 1) points; the running (eval, prod) pair is checked against intermediate
+      // wires between chunks. For a two-adic subgroup the weights are w_i = x_i / n.
+      const u32 npts = 1u << g.p0, deg = g.p1, nint = (npts - 2) / (deg - 1);
+      const u32 w_pt = 1 + 2 * npts, w_val = w_pt + 2, w_int = w_val + 2, w_sh = w_int + 4 * nint;
+      const Alg pt{wire(w_pt), wire(w_pt + 1)}, sh{wire(w_sh), wire(w_sh + 1)};
+      Alg d0 = alg_sub(pt, alg_scale(sh, wire(0)));
+      emit(d0.a); emit(d0.b);
+      const u64 om = gl_root_of_unity(g.p0), ninv = gl_inv(npts);
+      u64 xi = 1;
+      Alg ev{0, 0}, pr{1, 0};
+      u32 start = 0, end = deg;
+      for (u32 c = 0; c <= nint; c++) {
+        for (u32 i = start; i < end; i++) {
+          Alg val = alg_scale(Alg{wire(1 + 2 * i), wire(2 + 2 * i)}, gl_mul(xi, ninv));
+          Alg term{gl_sub(sh.a, xi), sh.b};
+          Alg nev = alg_add(alg_mul(ev, term), alg_mul(val, pr));
+          pr = alg_mul(pr, term);
+          ev = nev;
+          xi = gl_mul(xi, om);
+        }
+        if (c == nint) break;
+        Alg iev{wire(w_int + 2 * c), wire(w_int + 2 * c + 1)}, ipr{wire(w_int + 2 * (nint + c)), wire(w_int + 2 * (nint + c) + 1)};
+        Alg d1 = alg_sub(iev, ev), d2 = alg_sub(ipr, pr);
+        emit(d1.a); emit(d1.b); emit(d2.a); emit(d2.b);
+        ev = iev; pr = ipr;
+        start = 1 + (deg - 1) * (c + 1);
+        end = start + deg - 1 < npts ? start + deg - 1 : npts;
+      }
+      Alg d3 = alg_sub(Alg{wire(w_val), wire(w_val + 1)}, ev);
+      emit(d3.a); emit(d3.b);
+      break;
+    }
     case MP2G_GATE_EXPONENTIATION: {
       const u32 nb = g.p0;
       const u64 base = wire(0);
@@ -448,6 +487,7 @@ hipError_t gate_constraints_lde(hipStream_t s, u32 B, const GateTable& t, const 
       GATE_CASE(MP2G_GATE_RANDOM_ACCESS)
       GATE_CASE(MP2G_GATE_POSEIDON)
       GATE_CASE(MP2G_GATE_POSEIDON_MDS)
+      GATE_CASE(MP2G_GATE_COSET_INTERPOLATION)
       default: return hipErrorInvalidValue;
     }
 #undef GATE_CASE

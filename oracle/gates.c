@@ -7,6 +7,18 @@
 #include "constants.h"
 #include <stdlib.h>
 
+void orc_barycentric_weights(unsigned bits, gl_t* domain, gl_t* weights) {
+  unsigned n = 1u << bits;
+  gl_t w = gl_root_of_unity(bits), x = 1;
+  for (unsigned i = 0; i < n; i++) { domain[i] = x; x = gl_mul(x, w); }
+  for (unsigned i = 0; i < n; i++) {
+    gl_t p = 1;
+    for (unsigned j = 0; j < n; j++)
+      if (j != i) p = gl_mul(p, gl_sub(domain[i], domain[j]));
+    weights[i] = gl_inv(p);
+  }
+}
+
 #define F gl_t
 #define F_ADD gl_add
 #define F_SUB gl_sub
@@ -46,6 +58,7 @@ unsigned orc_gate_num_constraints(const orc_gate* g) {
     case ORC_GATE_ARITHMETIC_EXT: case ORC_GATE_MUL_EXT: return 2 * g->p0;
     case ORC_GATE_POSEIDON2: case ORC_GATE_POSEIDON: return 1 + 4 + 36 + 22 + 48 + 12;
     case ORC_GATE_POSEIDON_MDS: return 24;
+    case ORC_GATE_COSET_INTERPOLATION: return 4 + 4 * (((1u << g->p0) - 2) / (g->p1 - 1));
     case ORC_GATE_EXPONENTIATION: return g->p0 + 1;
     case ORC_GATE_REDUCING: case ORC_GATE_REDUCING_EXT: return 2 * g->p0;
     case ORC_GATE_RANDOM_ACCESS: return (g->p0 + 2) * g->p1 + g->p2;
@@ -60,6 +73,7 @@ unsigned orc_gate_degree(const orc_gate* g) {
     case ORC_GATE_BASE_SUM: return g->p1;
     case ORC_GATE_POSEIDON2: case ORC_GATE_POSEIDON: return 7;
     case ORC_GATE_POSEIDON_MDS: return 1;
+    case ORC_GATE_COSET_INTERPOLATION: return g->p1;
     case ORC_GATE_EXPONENTIATION: return 4;
     case ORC_GATE_REDUCING: case ORC_GATE_REDUCING_EXT: return 2;
     case ORC_GATE_RANDOM_ACCESS: return g->p0 + 1;

@@ -19,6 +19,7 @@ enum {
   ORC_GATE_RANDOM_ACCESS = 11,  // p0 = bits, p1 = num_copies, p2 = num_extra_constants
   ORC_GATE_POSEIDON = 12,
   ORC_GATE_POSEIDON_MDS = 13,
+  ORC_GATE_COSET_INTERPOLATION = 14,  // p0 = subgroup_bits (<= 5), p1 = degree
 };
 #define ORC_MAX_GATE_CONSTRAINTS 160
 typedef struct {
@@ -26,6 +27,8 @@ typedef struct {
   uint32_t selector_index;            // which selector polynomial filters this gate
   uint32_t group_start, group_end;    // gate indices sharing that selector (gates/selectors.rs groups)
 } orc_gate;
+// two_adic_subgroup(bits) and its barycentric weights w_i = 1 / prod_{j != i} (x_i - x_j)
+void orc_barycentric_weights(unsigned bits, gl_t* domain, gl_t* weights);
 unsigned orc_gate_num_constraints(const orc_gate* g);
 unsigned orc_gate_degree(const orc_gate* g);
 unsigned orc_gates_eval_base(const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* consts,

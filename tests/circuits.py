@@ -15,7 +15,7 @@ import oracle as O
 
 P = O.P
 (NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, BASE_SUM, ARITHMETIC_EXT, MUL_EXT, POSEIDON2, EXPONENTIATION, REDUCING, REDUCING_EXT,
- RANDOM_ACCESS, POSEIDON, POSEIDON_MDS) = range(14)
+ RANDOM_ACCESS, POSEIDON, POSEIDON_MDS, COSET_INTERPOLATION) = range(15)
 UNUSED_SELECTOR = 0xFFFFFFFF
 NUM_WIRES, NUM_ROUTED, MAX_DEGREE = 135, 80, 8
 
@@ -28,14 +28,15 @@ class Gate(ctypes.Structure):
 def gate_degree(g):
     """Gate::degree()"""
     return {NOOP: 0, CONSTANT: 1, PUBLIC_INPUT: 1, ARITHMETIC: 3, BASE_SUM: g.p1, ARITHMETIC_EXT: 3, MUL_EXT: 3, POSEIDON2: 7,
-            EXPONENTIATION: 4, REDUCING: 2, REDUCING_EXT: 2, RANDOM_ACCESS: g.p0 + 1, POSEIDON: 7, POSEIDON_MDS: 1}[g.kind]
+            EXPONENTIATION: 4, REDUCING: 2, REDUCING_EXT: 2, RANDOM_ACCESS: g.p0 + 1, POSEIDON: 7, POSEIDON_MDS: 1, COSET_INTERPOLATION: g.p1}[g.kind]
 
 
 def gate_num_constraints(g):
     """Gate::num_constraints()"""
     return {NOOP: 0, CONSTANT: g.p0, PUBLIC_INPUT: 4, ARITHMETIC: g.p0, BASE_SUM: 1 + g.p0, ARITHMETIC_EXT: 2 * g.p0, MUL_EXT: 2 * g.p0,
             POSEIDON2: 123, EXPONENTIATION: g.p0 + 1, REDUCING: 2 * g.p0, REDUCING_EXT: 2 * g.p0,
-            RANDOM_ACCESS: (g.p0 + 2) * g.p1 + g.p2, POSEIDON: 123, POSEIDON_MDS: 24}[g.kind]
+            RANDOM_ACCESS: (g.p0 + 2) * g.p1 + g.p2, POSEIDON: 123, POSEIDON_MDS: 24,
+            COSET_INTERPOLATION: 4 + 4 * (((1 << g.p0) - 2) // max(g.p1 - 1, 1))}[g.kind]
 
 
 _consts = None
@@ -77,6 +78,17 @@ def poseidon_mds(s):
 
 def ext_mul(a, b):
     return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def ext_sub(a, b):
+    return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+
+
+def coset_interpolation_degree(subgroup_bits, max_degree=MAX_DEGREE):
+    """CosetInterpolationGate::with_max_degree: the smallest degree that needs no more intermediates"""
+    n_points = 1 << subgroup_bits
+    n_intermediates = (n_points - 2) // (max_degree - 1)
+    return (n_points - 2) // (n_intermediates + 1) + 2
 
 
 def ext_add(a, b):
@@ -173,6 +185,42 @@ def fill_row(g, w, consts, inp, rng, pi_hash):
             o = poseidon_mds([w[2 * i + c] for i in range(12)])
             for i in range(12):
                 w[24 + 2 * i + c] = o[i]
+    elif k == COSET_INTERPOLATION:
+        npts, deg = 1 << g.p0, g.p1
+        nint = (npts - 2) // (deg - 1)
+        w_pt, w_val = 1 + 2 * npts, 3 + 2 * npts
+        w_int = w_val + 2
+        w_sh = w_int + 4 * nint
+        om = pow(7277203076849721926, 1 << (32 - g.p0), P)
+        dom = [pow(om, i, P) for i in range(npts)]
+        bw = []
+        for i in range(npts):
+            pr = 1
+            for j in range(npts):
+                if j != i:
+                    pr = pr * (dom[i] - dom[j]) % P
+            bw.append(pow(pr, P - 2, P))
+        shift = inp(0)
+        w[0] = shift
+        for c in range(1, 1 + 2 * npts):
+            w[c] = inp(c)
+        sh = (inp(w_sh) if w_sh < NUM_ROUTED else rnd(), rnd())  # shifted point: not routed
+        w[w_sh], w[w_sh + 1] = sh
+        w[w_pt], w[w_pt + 1] = sh[0] * shift % P, sh[1] * shift % P
+        ev, pr = (0, 0), (1, 0)
+        start, end = 0, deg
+        for c in range(nint + 1):
+            for i in range(start, end):
+                val = (w[1 + 2 * i] * bw[i] % P, w[2 + 2 * i] * bw[i] % P)
+                term = ((sh[0] - dom[i]) % P, sh[1])
+                ev, pr = ext_add(ext_mul(ev, term), ext_mul(val, pr)), ext_mul(pr, term)
+            if c == nint:
+                break
+            w[w_int + 2 * c], w[w_int + 2 * c + 1] = ev
+            w[w_int + 2 * (nint + c)], w[w_int + 2 * (nint + c) + 1] = pr
+            start = 1 + (deg - 1) * (c + 1)
+            end = min(start + deg - 1, npts)
+        w[w_val], w[w_val + 1] = ev
     elif k == EXPONENTIATION:
         nb = g.p0
         base = inp(0)
@@ -318,7 +366,7 @@ def build(log_n, kinds, seed, copy_prob=0.35):
 ALL_KINDS = [(NOOP, 0, 0, 0), (CONSTANT, 2, 0, 0), (PUBLIC_INPUT, 0, 0, 0), (ARITHMETIC, 20, 0, 0), (BASE_SUM, 63, 2, 0),
              (BASE_SUM, 20, 4, 0), (ARITHMETIC_EXT, 10, 0, 0), (MUL_EXT, 13, 0, 0), (POSEIDON2, 0, 0, 0),
              (EXPONENTIATION, 66, 0, 0), (REDUCING, 43, 0, 0), (REDUCING_EXT, 32, 0, 0), (RANDOM_ACCESS, 4, 4, 2),
-             (POSEIDON, 0, 0, 0), (POSEIDON_MDS, 0, 0, 0)]
+             (POSEIDON, 0, 0, 0), (POSEIDON_MDS, 0, 0, 0), (COSET_INTERPOLATION, 4, coset_interpolation_degree(4), 0)]
 
 
 def eval_on_points(ckt, consts, wires):
