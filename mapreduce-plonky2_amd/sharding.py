@@ -106,3 +106,58 @@ def exchange_bytes(dist, payload, src, dst, device=None):
         dist.recv(body, src)
         return bytes(body.cpu().numpy())
     return None
+
+
+def all_gather_bytes(dist, payload, device=None):
+    """all_gather of one variable-length byte string per rank (serialized root proofs of a wave):
+    lengths first, then bodies padded to the longest. Returns [bytes per rank]."""
+    import torch
+    world = dist.get_world_size()
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    lens = [int(x.item()) for x in lens]
+    cap = max(max(lens), 1)
+    body = torch.zeros(cap, dtype=torch.uint8)
+    body[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8) if payload else body[:0]
+    if device is not None:
+        body = body.to(device)
+    out = [torch.empty_like(body) for _ in range(world)]
+    dist.all_gather(out, body)
+    return [bytes(o.cpu().numpy()[:ln]) for o, ln in zip(out, lens)]
+
+
+def run_workplan(dist, plan, prove_item, device=None):
+    """Drive an UpdatePlan (workplan.py) over the ranks of `dist` (None = single process).
+
+    Every rank holds the same plan. Per wave: drain the Ready items, deal them to ranks
+    (`workplan.assign_subtrees`, deterministic), each rank proves its items with
+    `prove_item(item, child_results) -> bytes` -- an item is one node or one spun-off subtree proved
+    bottom-up locally, only its root result leaves the rank -- then one all_gather per wave publishes the
+    root results, and every rank marks the wave's items done. `child_results` maps the keys of already
+    finished items to their results (what a parent above the subtree boundary needs). Returns
+    {key: result} of every item; the last one is the tree root's. Children-before-parents is the plan's
+    own guarantee (ryhope/src/storage/updatetree.rs:449-531); the collective is one small all_gather per
+    wave, latency-bound, outside the per-proof path."""
+    import struct
+    from . import workplan as wp
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    results = {}
+    while True:
+        wave = wp.drain_wave(plan)
+        if not wave:
+            if not plan.completed():
+                raise RuntimeError("work plan stalled: items not marked done")
+            return results
+        owners = wp.assign_subtrees(wave, world)
+        mine = [(it.k, prove_item(it, results)) for it, o in zip(wave, owners) if o == rank]
+        blob = b"".join(struct.pack("<QQ", k, len(r)) + r for k, r in mine)
+        for part in (all_gather_bytes(dist, blob, device) if dist is not None else [blob]):
+            off = 0
+            while off < len(part):
+                k, ln = struct.unpack_from("<QQ", part, off)
+                results[k] = part[off + 16:off + 16 + ln]
+                off += 16 + ln
+        for it in wave:
+            plan.done(it.k)

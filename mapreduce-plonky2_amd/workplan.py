@@ -209,12 +209,19 @@ class UpdatePlan:
 
 def drain_wave(plan):
     """All items that are Ready right now (the reference harness's inner `while let Some(Next::Ready)`,
-    mp2-v1/tests/common/celltree.rs:54-189)."""
-    out = []
+    mp2-v1/tests/common/celltree.rs:54-189). A batched plan that is drained without `done` in between
+    hands out the same subtree once per leaf anchor it contains (the anchors of a spun-off subtree stay
+    queued until its root is done: updatetree.rs:481-515); those repeats are dropped here."""
+    out, seen = [], set()
     while True:
         n = plan.next()
         if n is None or not n.ready:
             return out
+        if n.item.k in seen:
+            if n.item.subtree is not None:
+                n.item.subtree.free()
+            continue
+        seen.add(n.item.k)
         out.append(n.item)
 
 

@@ -100,6 +100,25 @@ def test_mt_creation_staggered():
     assert whole.k == 1 and len(whole.subtree) == n
 
 
+def test_wave_draining_of_a_batched_plan_has_no_repeats():
+    """without done() in between, the reference yields the same subtree once per leaf anchor inside it"""
+    plan = make_tree().into_batched_workplan(3)
+    first = plan.next().item
+    again = [plan.next().item for _ in range(3)]
+    assert first.k == 43 and [a.k for a in again] == [9, 89, 9]  # 9 = {9, 0, 10} comes back for its second leaf
+    plan2 = make_tree().into_batched_workplan(3)
+    seen = []
+    while True:
+        wave = wp.drain_wave(plan2)
+        if not wave:
+            break
+        assert len({it.k for it in wave}) == len(wave)
+        for it in wave:
+            seen += it.subtree.nodes()
+            plan2.done(it.k)
+    assert sorted(seen) == sorted(make_tree().nodes()) and plan2.completed()
+
+
 def test_not_yet_until_done():
     plan = make_tree().into_workplan()
     wave = wp.drain_wave(plan)
