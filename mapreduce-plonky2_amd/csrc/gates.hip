@@ -412,9 +412,6 @@ __global__ void __launch_bounds__(256) gate_constraints_lde_kernel(mp2g_gate g, 
   u32 top[2] = {0, 0};
   u32 j = 0;
   eval_gate<true>(g, wire, cst, pih, [&](u64 v) {
-#ifdef MP2G_GATE_DBG_NOEMIT
-    lo[0] ^= v; return;
-#endif
 #pragma unroll
     for (u32 a = 0; a < 2; a++) {
       u64 pl, ph;

@@ -115,3 +115,30 @@ def test_gate_table_validation(ctx, mp2):
     big = [mp2.Gate(mp2.GATE_ARITHMETIC, 40, 0, 0, 0, 0, 1)]  # 160 routed wires > 135
     with pytest.raises(mp2.Mp2gError):
         pr.set_gates(big, 1)
+
+
+def test_gate_parameter_fuzz(ctx, mp2):
+    """random gate parameters (op counts, limb counts, bases, bit widths) at random points vs the oracle"""
+    rng = np.random.default_rng(2024)
+    for it in range(12):
+        kinds = [(C.NOOP, 0, 0, 0), (C.CONSTANT, int(rng.integers(1, 3)), 0, 0), (C.ARITHMETIC, int(rng.integers(1, 21)), 0, 0),
+                 (C.BASE_SUM, int(rng.integers(1, 64)), int(rng.integers(2, 6)), 0), (C.ARITHMETIC_EXT, int(rng.integers(1, 11)), 0, 0),
+                 (C.MUL_EXT, int(rng.integers(1, 14)), 0, 0), (C.EXPONENTIATION, int(rng.integers(1, 67)), 0, 0),
+                 (C.REDUCING, int(rng.integers(1, 44)), 0, 0), (C.REDUCING_EXT, int(rng.integers(1, 33)), 0, 0)]
+        bits = int(rng.integers(1, 6))
+        copies = int(rng.integers(1, max(2, min(78 // (2 + (1 << bits)), (135 - 80) // bits) + 1)))
+        kinds.append((C.RANDOM_ACCESS, bits, copies, int(rng.integers(0, 3))))
+        sb = int(rng.integers(2, 6))
+        deg = int(rng.integers(2, min(1 << sb, 7) + 1))
+        if 1 + 2 * (1 << sb) + 6 + 4 * (((1 << sb) - 2) // (deg - 1)) <= 135:
+            kinds.append((C.COSET_INTERPOLATION, sb, deg, 0))
+        pick = [kinds[0]] + [kinds[i] for i in sorted(rng.choice(np.arange(1, len(kinds)), size=int(rng.integers(1, 6)), replace=False))]
+        ckt = C.build(4, pick, 100 + it)
+        out = C.eval_on_points(ckt, ckt.pre[:ckt.num_constants], ckt.wires)
+        assert not out.any(), pick  # the witness generator and the oracle agree on every parameterisation
+        npts = 200
+        consts = O.rand_field((ckt.num_constants, npts), it)
+        consts[:ckt.num_selectors, :64] = np.arange(64, dtype=np.uint64)[None, :] % np.uint64(len(ckt.gates) + 1)
+        wires = O.rand_field((C.NUM_WIRES, npts), 50 + it)
+        got = mp2.eval_gate_constraints(ctx, gpu_gates(mp2, ckt), ckt.num_selectors, consts, wires, ckt.pi_hash)
+        assert np.array_equal(got, C.eval_on_points(ckt, consts, wires)), pick
