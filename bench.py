@@ -47,6 +47,17 @@ NUM_ROUTED = 80  # standard_recursion_config: 80 routed wires, quotient_degree_f
 SEED = 0xC0FFEE03
 
 
+def gpu_clocks(device):
+    """rocm-smi's current clocks of the device (state the measured clocks with every report)"""
+    import subprocess
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+        return {k.strip(): v for k, v in card.items() if "clock" in k.lower() and ("sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower())}
+    except Exception as e:  # no rocm-smi / no permission: say so instead of guessing
+        return {"error": str(e)[:80]}
+
+
 def cpu_baseline(base_bits, n_proofs=1):
     """The CPU oracle (our restatement of the same pipeline; kind 'port'), OpenMP over
     polynomials / leaves on all host cores, on a bounded sample of the same workload."""
@@ -207,6 +218,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # per-stage split of one batch per shape, each prover alone on the GPU (outside the timed region)
+    stages = {}
+    if rank == 0:
+        seen_shapes = set()
+        for (k, cx, nb), (pr, d_vals, d_cd, d_ph, _, _) in zip(plan, provers):
+            if k in seen_shapes:
+                continue
+            seen_shapes.add(k)
+            sync_all()
+            pr.enable_timing(True)
+            pr.prove(d_vals, d_cd, d_ph)
+            ms = pr.stage_ms()
+            pr.enable_timing(False)
+            stages[f"2^{k} x {nb}"] = {s: round(v, 3) for s, v in ms.items()}
+
     # the per-rank multiset digest (2^16 rows x 4 value columns, device resident) meets in one
     # all_gather of one encoded point per rank, outside the per-proof path
     rows, n_cols = 1 << 16, 4
@@ -253,6 +279,8 @@ def main():
                          "launch_ms": ntt_s * 1e3, "algorithmic_bytes": 16 * n_ntt},
             "ntt_batched_2p12": {"transforms": nb12, "GBps": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9,
                                  "frac_of_hbm_peak": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9 / HBM_PEAK_GBPS},
+            "stage_ms": stages,
+            "clocks": gpu_clocks(local_rank),
             "digest_rows_per_s": rows / digest_s,
             "digest_check": [int(x) for x in w],
         }

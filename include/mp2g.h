@@ -259,6 +259,16 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
  * mp2g_prover_enable_permutation, rate_bits 3 and oracle_w[3] = zs_count * 8. */
 int mp2g_prover_enable_quotient(mp2g_prover* pr);
 
+/* Stage timing of the batched prover (measurement aid; plonky2 prints the same split through its
+ * `timed!` macro inside prove()). With timing on, every mp2g_prover_prove_dev records HIP events on
+ * the prover's stream at the phase boundaries; mp2g_prover_stage_ms synchronises and returns the
+ * milliseconds of the last call: 0 wires commitment, 1 Z / partial products + commitment, 2 quotient
+ * polynomials + commitment, 3 openings, 4 FRI batch composition + commit phase, 5 proof of work,
+ * 6 query rounds. */
+#define MP2G_N_STAGES 7
+int mp2g_prover_enable_timing(mp2g_prover* pr, int on);
+int mp2g_prover_stage_ms(mp2g_prover* pr, float out[MP2G_N_STAGES]);
+
 /* ---- gate constraints: the third part of compute_quotient_polys --------------------------------
  * Replaces [dep] plonky2 plonk/vanishing_poly.rs evaluate_gate_constraints_base_batch and the
  * eval_unfiltered_base of the gates below (gates the reference registers:

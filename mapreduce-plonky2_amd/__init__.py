@@ -452,6 +452,17 @@ class BatchedProver:
         arr = (Gate * len(gates))(*gates)
         _ck(load().mp2g_prover_set_gates(self.h, arr, len(gates), num_selectors))
 
+    STAGES = ("wires_commit", "z_partial_products", "quotient", "openings", "fri_commit_phase", "proof_of_work", "fri_queries")
+
+    def enable_timing(self, on=True):
+        _ck(load().mp2g_prover_enable_timing(self.h, int(on)))
+
+    def stage_ms(self):
+        """{stage: milliseconds} of the last prove() (HIP events on the prover's stream); synchronises."""
+        out = (ctypes.c_float * len(self.STAGES))()
+        _ck(load().mp2g_prover_stage_ms(self.h, out))
+        return dict(zip(self.STAGES, [float(x) for x in out]))
+
     def prove(self, d_values, d_circuit_digest, d_pi_hash):
         """d_values: device buffers [batch][w_o][n] for oracles 1..; asynchronous."""
         ptrs = (ctypes.c_void_p * len(d_values))(*[(d.ptr.value if d is not None else None) for d in d_values])

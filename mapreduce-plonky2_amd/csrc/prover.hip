@@ -38,7 +38,15 @@ struct mp2g_prover {
   DevBuf pre_values, zs_values, chunk_q, bg, alphas, qvals;
   // gate constraints (mp2g_prover_set_gates)
   GateTable gates{};
+  // stage timing (mp2g_prover_enable_timing): events at the phase boundaries of the last prove
+  bool timing = false;
+  hipEvent_t ev[MP2G_N_STAGES + 1] = {};
+  ~mp2g_prover() {
+    for (hipEvent_t e : ev)
+      if (e) (void)hipEventDestroy(e);
+  }
 };
+#define STAGE_MARK(pr, i) do { if ((pr)->timing) CK(hipEventRecord((pr)->ev[i], (pr)->ctx->stream)); } while (0)
 
 namespace {
 // frees a temporary prover on every exit path of the convenience entry points
@@ -372,7 +380,9 @@ static int fri_tail(mp2g_prover* pr, const FriShape& sh, ChState* st, u64* d_pro
   }
   if (P.n_layers == 0) CK(fri_soa_to_aos(s, B, (u32)n, pr->final_poly.p, 2 * n, (u32)n, proof + pr->final_off, pr->proof_words));
   CK(challenger_step(s, V, st, B, proof + pr->final_off, pr->proof_words, (u32)(2 * pr->final_len), chal, 8, 0));
+  STAGE_MARK(pr, 5);  // FRI batch composition + commit phase
   CK(fri_pow(s, V, st, B, P.pow_bits, pr->witness.p));
+  STAGE_MARK(pr, 6);  // proof of work
   CK(copy_rows(s, B, pr->witness.p, FRI_POW_STRIDE, proof + pr->final_off + 2 * pr->final_len, pr->proof_words, 1));
   CK(challenger_step(s, V, st, B, pr->witness.p, FRI_POW_STRIDE, 1, chal, 8, 1));  // observe witness, draw pow response
   if (P.num_queries) {
@@ -398,6 +408,7 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
   u64* chal = pr->chal.p;
   const u64 caps_b = P.n_oracles * capw;
 
+  STAGE_MARK(pr, 0);
   CK(challenger_init(s, st, B));
   CK(challenger_step(s, V, st, B, (const u64*)d_circuit_digest, 0, 4, chal, 8, 0));
   CK(challenger_step(s, V, st, B, (const u64*)d_pi_hash, 4, 4, chal, 8, 0));
@@ -437,7 +448,9 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
     if (pr->num_routed && o == 1) { dst = pr->bg.p; dst_stride = 4; }
     if (pr->num_routed && o == 2) { dst = pr->alphas.p; dst_stride = 2; }
     CK(challenger_step(s, V, st, B, cap_dst, caps_b, (u32)capw, dst, dst_stride, n_get));
+    if (o <= 3) STAGE_MARK(pr, o);  // 1: wires committed, 2: Z / partial products, 3: quotient
   }
+  if (P.n_oracles < 4) for (uint32_t o = P.n_oracles; o <= 3; o++) STAGE_MARK(pr, o);
   CK(challenger_step(s, V, st, B, chal, 0, 0, pr->zeta.p, 2, 2));  // zeta
 
   FriShape sh{};
@@ -453,7 +466,26 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
   }
   CK(fri_openings(s, sh, B, pr->zeta.p, 2, (u64*)d_openings));
   CK(challenger_step(s, V, st, B, (const u64*)d_openings, 2 * pr->n_open, (u32)(2 * pr->n_open), chal, 8, 0));
-  return fri_tail(pr, sh, st, (u64*)d_proof);
+  STAGE_MARK(pr, 4);  // openings
+  int rc = fri_tail(pr, sh, st, (u64*)d_proof);
+  if (rc) return rc;
+  STAGE_MARK(pr, 7);
+  return 0;
+}
+int mp2g_prover_enable_timing(mp2g_prover* pr, int on) {
+  NEED(pr, "prover");
+  if (on)
+    for (hipEvent_t& e : pr->ev)
+      if (!e) CK(hipEventCreate(&e));
+  pr->timing = on != 0;
+  return 0;
+}
+int mp2g_prover_stage_ms(mp2g_prover* pr, float out[MP2G_N_STAGES]) {
+  NEED(pr && out, "prover/out");
+  NEED(pr->timing, "call mp2g_prover_enable_timing first");
+  CK(hipStreamSynchronize(pr->ctx->stream));
+  for (int i = 0; i < MP2G_N_STAGES; i++) CK(hipEventElapsedTime(&out[i], pr->ev[i], pr->ev[i + 1]));
+  return 0;
 }
 
 int mp2g_partial_products_and_zs(mp2g_ctx* c, const uint64_t* wires, uint32_t wires_w, const uint64_t* sigmas, uint32_t log_n,
