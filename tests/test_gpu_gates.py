@@ -142,3 +142,31 @@ def test_gate_parameter_fuzz(ctx, mp2):
         wires = O.rand_field((C.NUM_WIRES, npts), 50 + it)
         got = mp2.eval_gate_constraints(ctx, gpu_gates(mp2, ckt), ckt.num_selectors, consts, wires, ckt.pi_hash)
         assert np.array_equal(got, C.eval_on_points(ckt, consts, wires)), pick
+
+
+def test_complete_proof_standard_shape_with_gates(ctx, mp2):
+    """standard_recursion_config shape (2^12 rows, 135 wires, 80 routed, cap 16, 16-bit PoW, 28 queries) with
+    every supported gate: bit-exact vs the oracle, FRI verifier accepts, PLONK identity holds; and the
+    device-side witness check is clean on H at full size."""
+    log_n = 12
+    ckt = C.build(log_n, C.ALL_KINDS, 0xC0FFEE03)
+    ofp, fp = params(mp2, ckt, log_n)
+    gates = gpu_gates(mp2, ckt)
+    assert not mp2.eval_gate_constraints(ctx, gates, ckt.num_selectors, ckt.pre[:ckt.num_constants], ckt.wires, ckt.pi_hash).any()
+    cd = O.rand_field(4, 9)
+    pr = mp2.BatchedProver(ctx, fp, 1)
+    pr.set_preprocessed(ctx.to_device(ckt.pre))
+    pr.enable_permutation(C.NUM_ROUTED, 8)
+    pr.enable_quotient()
+    pr.set_gates(gates, ckt.num_selectors)
+    pr.prove([ctx.to_device(ckt.wires[None]), None, None], ctx.to_device(cd), ctx.to_device(ckt.pi_hash[None]))
+    caps, openings, proofs = pr.results()
+    oc, oo, op, bgao = C.prove(ckt, ofp, cd)
+    assert np.array_equal(caps[0], oc) and np.array_equal(openings[0], oo) and np.array_equal(proofs[0], op)
+    assert O.pcs_verify(ofp, cd, ckt.pi_hash, caps[0], openings[0], proofs[0]) == 0
+    assert C.identity_check(ckt, ofp, openings[0], bgao) == 0
+    # the proof survives the wire format
+    blob = mp2.serialize_proof(fp, ckt.num_constants, caps[0], openings[0], proofs[0], ckt.pi_hash)
+    c2, o2, p2, pi2 = mp2.deserialize_proof(fp, ckt.num_constants, blob, 4)
+    assert np.array_equal(c2[1:], caps[0][1:]) and np.array_equal(o2, openings[0]) and np.array_equal(p2, proofs[0])
+    pr.free()
