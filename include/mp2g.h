@@ -259,6 +259,11 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
  * mp2g_prover_enable_permutation, rate_bits 3 and oracle_w[3] = zs_count * 8. */
 int mp2g_prover_enable_quotient(mp2g_prover* pr);
 
+/* Replay the prover's launch sequence (several hundred small kernels per call) as a hipGraph: the
+ * first call after enabling runs normally (it creates the cached twiddle tables), the second is captured,
+ * later calls with the same buffer addresses launch the instantiated graph. A call with different
+ * addresses re-captures. Cuts the launch-bound latency of small batches; results are identical. */
+int mp2g_prover_enable_graph(mp2g_prover* pr, int on);
 /* Stage timing of the batched prover (measurement aid; plonky2 prints the same split through its
  * `timed!` macro inside prove()). With timing on, every mp2g_prover_prove_dev records HIP events on
  * the prover's stream at the phase boundaries; mp2g_prover_stage_ms synchronises and returns the

@@ -452,6 +452,10 @@ class BatchedProver:
         arr = (Gate * len(gates))(*gates)
         _ck(load().mp2g_prover_set_gates(self.h, arr, len(gates), num_selectors))
 
+    def enable_graph(self, on=True):
+        """Replay the launch sequence as a hipGraph from the third prove() with the same buffers on."""
+        _ck(load().mp2g_prover_enable_graph(self.h, int(on)))
+
     STAGES = ("wires_commit", "z_partial_products", "quotient", "openings", "fri_commit_phase", "proof_of_work", "fri_queries")
 
     def enable_timing(self, on=True):
