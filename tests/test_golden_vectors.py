@@ -39,6 +39,49 @@ def test_oracle_reproduces_golden():
     assert fnv(proof) == G["pcs_prove_2p6"]["proof_fnv1a"] and int(proof[-1]) == G["pcs_prove_2p6"]["pow_witness"]
 
 
+def golden_gate_circuit():
+    import circuits as C
+    ckt = C.build(5, C.ALL_KINDS, 77)
+    g = G["gate_constraints_5pts"]
+    assert [[x.kind, x.p0, x.p1, x.p2, x.selector_index, x.group_start, x.group_end] for x in ckt.gates] == g["gates"]
+    assert ckt.pi_hash.tolist() == g["pi_hash"] and ckt.num_selectors == g["num_selectors"]
+    consts, wires = O.rand_field((ckt.num_constants, 5), 11), O.rand_field((C.NUM_WIRES, 5), 12)
+    consts[:ckt.num_selectors, :] = np.arange(5, dtype=np.uint64)[None, :] + np.arange(ckt.num_selectors, dtype=np.uint64)[:, None] * np.uint64(3)
+    return C, ckt, consts, wires
+
+
+def test_oracle_reproduces_golden_gates():
+    C, ckt, consts, wires = golden_gate_circuit()
+    ev = C.eval_on_points(ckt, consts, wires)
+    g = G["gate_constraints_5pts"]
+    assert ev[0].tolist() == g["c0"] and ev[1].tolist() == g["c1"] and fnv(ev) == g["all_fnv1a"]
+    p = G["gate_level_proof_2p5"]
+    assert fnv(ckt.wires) == p["wires_fnv1a"] and fnv(ckt.pre) == p["pre_fnv1a"]  # the witness generator is frozen too
+    ofp = O.standard_params(5, (ckt.num_constants + C.NUM_ROUTED, C.NUM_WIRES, 20, 16), pow_bits=5, num_queries=3)
+    gc, go, gp, _ = C.prove(ckt, ofp, O.rand_field(4, 3))
+    assert fnv(gc) == p["caps_fnv1a"] and fnv(go) == p["openings_fnv1a"] and fnv(gp) == p["proof_fnv1a"]
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_gates(ctx, mp2):
+    C, ckt, consts, wires = golden_gate_circuit()
+    gates = [mp2.Gate(*row) for row in G["gate_constraints_5pts"]["gates"]]
+    ev = mp2.eval_gate_constraints(ctx, gates, ckt.num_selectors, consts, wires, ckt.pi_hash)
+    g = G["gate_constraints_5pts"]
+    assert ev[0].tolist() == g["c0"] and ev[1].tolist() == g["c1"] and fnv(ev) == g["all_fnv1a"]
+    p = G["gate_level_proof_2p5"]
+    fp = mp2.standard_recursion_params(5, (ckt.num_constants + C.NUM_ROUTED, C.NUM_WIRES, 20, 16), pow_bits=5, num_queries=3)
+    pr = mp2.BatchedProver(ctx, fp, 1)
+    pr.set_preprocessed(ctx.to_device(ckt.pre))
+    pr.enable_permutation(C.NUM_ROUTED, 8)
+    pr.enable_quotient()
+    pr.set_gates(gates, ckt.num_selectors)
+    pr.prove([ctx.to_device(ckt.wires[None]), None, None], ctx.to_device(O.rand_field(4, 3)), ctx.to_device(ckt.pi_hash[None]))
+    caps, openings, proofs = pr.results()
+    assert fnv(caps[0]) == p["caps_fnv1a"] and fnv(openings[0]) == p["openings_fnv1a"] and fnv(proofs[0]) == p["proof_fnv1a"]
+    pr.free()
+
+
 @pytest.mark.gpu
 def test_hip_reproduces_golden(ctx, mp2):
     x = O.rand_field((4, 9), 0xC0FFEE04)

@@ -54,6 +54,20 @@ def main():
     dw = np.zeros(5, dtype=np.uint64)
     O.lib().orc_row_digest_batch(0, O.p(col_ids), O.sz(4), O.p(O.arr(values, np.uint32)), O.p(O.arr(unique, np.uint32)), O.sz(1), O.sz(10), O.p(dw), None)
     out["row_digest_10x4"] = {"numpy_default_rng": 20, "col_id_seed": "0xC0FFEE04", "unique": "first value column", "encoding": dw.tolist()}
+    # gate constraint evaluators: every kind at 5 fixed random points (first filtered constraint values + a
+    # checksum of all), and the fingerprint of one complete gate-level proof
+    import circuits as C
+    ckt = C.build(5, C.ALL_KINDS, 77)
+    consts, wires = O.rand_field((ckt.num_constants, 5), 11), O.rand_field((C.NUM_WIRES, 5), 12)
+    consts[:ckt.num_selectors, :] = np.arange(5, dtype=np.uint64)[None, :] + np.arange(ckt.num_selectors, dtype=np.uint64)[:, None] * np.uint64(3)
+    ev = C.eval_on_points(ckt, consts, wires)
+    gates = [[g.kind, g.p0, g.p1, g.p2, g.selector_index, g.group_start, g.group_end] for g in ckt.gates]
+    out["gate_constraints_5pts"] = {"circuit_seed": 77, "const_seed": 11, "wire_seed": 12, "gates": gates, "num_selectors": ckt.num_selectors,
+                                    "pi_hash": ckt.pi_hash.tolist(), "c0": ev[0].tolist(), "c1": ev[1].tolist(), "all_fnv1a": fnv(ev)}
+    ofp = O.standard_params(5, (ckt.num_constants + C.NUM_ROUTED, C.NUM_WIRES, 20, 16), pow_bits=5, num_queries=3)
+    gc, go, gp, _ = C.prove(ckt, ofp, O.rand_field(4, 3))
+    out["gate_level_proof_2p5"] = {"circuit_seed": 77, "digest_seed": 3, "pow_bits": 5, "num_queries": 3, "wires_fnv1a": fnv(ckt.wires),
+                                   "pre_fnv1a": fnv(ckt.pre), "caps_fnv1a": fnv(gc), "openings_fnv1a": fnv(go), "proof_fnv1a": fnv(gp)}
     path = os.path.join(ROOT, "tests", "golden", "oracle_vectors.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
