@@ -65,8 +65,32 @@ GLHD u64 gl_addw(u64 a, u64 b) {
   return gl_mk(t0, t1);
 }
 // hi*2^64 + lo -> some u64 congruent to it (2^64 = EPS, 2^96 = -1 mod p); any lo, hi.
-// (Measured: this 64-bit formulation, 17.7 issue slots, beats a 32-bit carry-chain one, 20.4.)
+// With hi = hh 2^32 + hl: x = lo + hl EPS - hh. Device code spells the sequence out: one
+// v_mad_u64_u32 forms t = hl EPS + lo and hands its carry c over in an SGPR pair, the subtract chain
+// leaves the borrow b of t - hh in vcc, and r = t - hh + (c - b) EPS (mod 2^64) is exact:
+//   c = 1, b = 0: t <= 2^64 - 2^33, so + EPS cannot wrap;  c = 0, b = 1: t - hh + 2^64 >= 2^64 - 2^32 + 1, so
+//   - EPS cannot wrap;  c = b: the two corrections cancel mod 2^64.
+// What the compiler makes of the portable form below re-derives carry and borrow with two v_cmp_*_u64
+// (~4 issue slots each): 23 % slower per reduction, 12 % per multiply (tools/ubench, profiles/r01/ubench_alu.txt).
 GLHD u64 gl_reduce128w(u64 lo, u64 hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u32 hl = (u32)hi, hh = (u32)(hi >> 32);
+  u64 t, c;
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(hl), "v"(lo));
+  u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mb, mc;
+  asm("v_sub_co_u32 %0, vcc, %4, %6\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_cndmask_b32 %3, 0, -1, %7\n\t"
+      "v_add_co_u32 %0, vcc, %0, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(mb), "=&v"(mc)
+      : "v"(t0), "v"(t1), "v"(hh), "s"(c)
+      : "vcc");
+  return gl_mk(r0, r1);
+#else
   u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
   u64 t0;
   bool b = __builtin_sub_overflow(lo, hi_hi, &t0);  // borrow => t0 >= 2^64 - 2^32 + 1, so -EPS cannot borrow again
@@ -75,13 +99,27 @@ GLHD u64 gl_reduce128w(u64 lo, u64 hi) {
   u64 r;
   bool c = __builtin_add_overflow(t0, t1, &r);      // carry => r <= 2^64 - 2^33, so +EPS cannot carry again
   return r + (c ? GL_EPS : 0);
+#endif
 }
 // hi*2^64 + lo with hi < 2^32
 GLHD u64 gl_reduce96w(u64 lo, u64 hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 t, c;
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"((u32)hi), "v"(lo));
+  u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mc;
+  asm("v_cndmask_b32 %2, 0, -1, %5\n\t"
+      "v_add_co_u32 %0, vcc, %3, %2\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %4, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(mc)
+      : "v"(t0), "v"(t1), "s"(c)
+      : "vcc");
+  return gl_mk(r0, r1);
+#else
   u64 t1 = (hi << 32) - hi;
   u64 r;
   bool c = __builtin_add_overflow(lo, t1, &r);
   return r + (c ? GL_EPS : 0);
+#endif
 }
 GLHD u64 gl_reduce128(u64 lo, u64 hi) { return gl_canon(gl_reduce128w(lo, hi)); }
 GLHD void gl_mul_wide(u64 a, u64 b, u64& lo, u64& hi) {

@@ -19,6 +19,47 @@ GLD u64 red64(u64 lo, u64 hi) {
 GLD u64 mulw64(u64 a, u64 b) { u64 lo, hi; gl_mul_wide(a, b, lo, hi); return red64(lo, hi); }
 GLD u64 add64c(u64 a, u64 b) { u32 c0, c1; u32 s0 = __builtin_addc((u32)a, (u32)b, 0u, &c0); u32 s1 = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c0, &c1); return gl_mk(s0, s1 + c1); }
 
+// asm formulation: the multiply-add's own carry-out and the subtract chain's borrow drive the two EPS
+// corrections (no 64-bit compares)
+GLD u64 red_asm(u64 lo, u64 hi) {
+  u32 hl = (u32)hi, hh = (u32)(hi >> 32);
+  u64 t, c;
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(hl), "v"(lo));
+  u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mb, mc;
+  asm("v_sub_co_u32 %0, vcc, %4, %6\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_cndmask_b32 %3, 0, -1, %7\n\t"
+      "v_add_co_u32 %0, vcc, %0, %3\n\t"
+      "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+      "v_sub_co_u32 %0, vcc, %0, %2\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %1, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(mb), "=&v"(mc)
+      : "v"(t0), "v"(t1), "v"(hh), "s"(c)
+      : "vcc");
+  return gl_mk(r0, r1);
+}
+GLD u64 mulw_asm(u64 a, u64 b) { u64 lo, hi; gl_mul_wide(a, b, lo, hi); return red_asm(lo, hi); }
+// merged corrections: r += (c - b) * EPS as one signed 64-bit addend
+GLD u64 red_asm2(u64 lo, u64 hi) {
+  u32 hl = (u32)hi, hh = (u32)(hi >> 32);
+  u64 t, c;
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(hl), "v"(lo));
+  u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mb, mc;
+  asm("v_sub_co_u32 %0, vcc, %4, %6\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
+      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_cndmask_b32 %3, 0, -1, %7\n\t"
+      "v_sub_co_u32 %3, vcc, %3, %2\n\t"          // d0 = mc - mb, borrow when c = 0, b = 1
+      "v_subb_co_u32 %2, vcc, 0, 0, vcc\n\t"      // d1 = -borrow
+      "v_add_co_u32 %0, vcc, %0, %3\n\t"
+      "v_addc_co_u32 %1, vcc, %1, %2, vcc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(mb), "=&v"(mc)
+      : "v"(t0), "v"(t1), "v"(hh), "s"(c)
+      : "vcc");
+  return gl_mk(r0, r1);
+}
+
 template <int OP>
 __global__ void __launch_bounds__(256) k(u64* out, u64 seed) {
   u64 a[8];
@@ -46,6 +87,9 @@ __global__ void __launch_bounds__(256) k(u64* out, u64 seed) {
       if (OP == 15) a[i] = gl_reduce128w(a[i], a[(i + 1) & 7]);
       if (OP == 16) a[i] = gl_sub(a[i], a[(i + 1) & 7]);
       if (OP == 17) a[i] = gl_addw(a[i], a[(i + 1) & 7]);
+      if (OP == 18) a[i] = mulw_asm(a[i], a[(i + 1) & 7]);
+      if (OP == 19) a[i] = red_asm(a[i], a[(i + 1) & 7]);
+      if (OP == 20) a[i] = red_asm2(a[i], a[(i + 1) & 7]);
     }
   }
   u64 r = 0;
@@ -57,6 +101,21 @@ __global__ void __launch_bounds__(256) kperm(u64* out, u64 seed, int reps) {
   for (int i = 0; i < 12; i++) s[i] = (seed * (threadIdx.x + 1 + i * 977) + blockIdx.x) % GL_P;
   for (int r = 0; r < reps; r++) poseidon2_perm(s);
   out[blockIdx.x * blockDim.x + threadIdx.x] = s[0];
+}
+__global__ void kcheck(u64* bad, u64 seed) {
+  u64 x = seed * (blockIdx.x * 256 + threadIdx.x + 1), y = x * 0xD1342543DE82EF95ull + 12345;
+  for (int it = 0; it < 64; it++) {
+    x = x * 6364136223846793005ull + 1442695040888963407ull; y = y * 6364136223846793005ull + x;
+    u64 lo = x, hi = y;
+    if (it % 8 == 0) hi |= 0xFFFFFFFF00000000ull;
+    if (it % 8 == 1) lo = 0;
+    if (it % 8 == 2) { lo = ~0ull; hi = ~0ull - 0xFFFFFFFFull; }  // largest product hi
+    if (it % 8 == 3) hi &= 0xFFFFFFFFull;
+    u64 hmax = 0xFFFFFFFE00000001ull;  // (2^64-1)^2 >> 64
+    if (hi > hmax) hi = hmax;
+    u64 want = gl_canon(gl_reduce128w(lo, hi));
+    if (gl_canon(red_asm(lo, hi)) != want || gl_canon(red_asm2(lo, hi)) != want) atomicAdd((unsigned long long*)bad, 1ull);
+  }
 }
 template <class F>
 float timeit(F f) {
@@ -76,11 +135,17 @@ int main() {
   const int blocks = 256 * 16, threads = 256;
   u64* d;
   hipMalloc(&d, sizeof(u64) * blocks * threads);
-  const char* names[] = {"gl_mul", "v_mad_u64_u32", "add64", "cmp+sel+add64", "mul_lo_u32", "mul_hi_u32", "gl_add", "add32", "gl_mul_small", "add_co+addc", "cmp32+sel", "mulw(64bit)", "mulw(32chain)", "mul_wide", "red(64bit)", "red(32chain)", "gl_sub", "gl_addw"};
+  {
+    u64* bad; hipMalloc(&bad, 8); hipMemset(bad, 0, 8);
+    hipLaunchKernelGGL(kcheck, dim3(4096), dim3(256), 0, 0, bad, 0x9E3779B97F4A7C15ull);
+    u64 h = 1; hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
+    printf("asm reduce mismatches: %llu\n", (unsigned long long)h);
+  }
+  const char* names[] = {"gl_mul", "v_mad_u64_u32", "add64", "cmp+sel+add64", "mul_lo_u32", "mul_hi_u32", "gl_add", "add32", "gl_mul_small", "add_co+addc", "cmp32+sel", "mulw(64bit)", "mulw(32chain)", "mul_wide", "red(64bit)", "red(32chain)", "gl_sub", "gl_addw", "mulw(asm red)", "red(asm)", "red(asm2)"};
   double ops = (double)blocks * threads * ITERS * 8;
 #define RUN(N) { float ms = timeit([&] { hipLaunchKernelGGL(k<N>, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull); }); \
     printf("%-14s %8.3f ms  %8.2f Gop/s (lane-ops)\n", names[N], ms, ops / ms / 1e6); }
-  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17)
+  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20)
   {
     int reps = 64;
     float ms = timeit([&] { hipLaunchKernelGGL(kperm, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull, reps); });
