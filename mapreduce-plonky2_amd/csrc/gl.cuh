@@ -78,9 +78,13 @@ GLHD u64 gl_reduce128w(u64 lo, u64 hi) {
   u64 t, c;
   asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(hl), "v"(lo));
   u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mb, mc;
+  // Hazard discipline (gfx90a+: a VALU-written SGPR / VCC needs 2 wait states before another VALU reads it
+  // as an explicit operand; the compiler cannot see inside asm): VCC is only consumed through the implicit
+  // carry-in of VOP2 forms, the borrow mask is made by u0 - u0 - borrow, and the mad's carry pair %7 is
+  // first read three VALU instructions into this block.
   asm("v_sub_co_u32 %0, vcc, %4, %6\n\t"
       "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
-      "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %0, %0, vcc\n\t"
       "v_cndmask_b32 %3, 0, -1, %7\n\t"
       "v_add_co_u32 %0, vcc, %0, %3\n\t"
       "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
@@ -107,7 +111,8 @@ GLHD u64 gl_reduce96w(u64 lo, u64 hi) {
   u64 t, c;
   asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"((u32)hi), "v"(lo));
   u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mc;
-  asm("v_cndmask_b32 %2, 0, -1, %5\n\t"
+  asm("s_nop 1\n\t"  // 2 wait states between the mad's SGPR carry and its first VALU reader
+      "v_cndmask_b32 %2, 0, -1, %5\n\t"
       "v_add_co_u32 %0, vcc, %3, %2\n\t"
       "v_addc_co_u32 %1, vcc, 0, %4, vcc"
       : "=&v"(r0), "=&v"(r1), "=&v"(mc)

@@ -60,6 +60,26 @@ GLD u64 red_asm2(u64 lo, u64 hi) {
   return gl_mk(r0, r1);
 }
 
+// corrections as one 64-bit addend built without carry-writing instructions
+GLD u64 red_asm3(u64 lo, u64 hi) {
+  u32 hl = (u32)hi, hh = (u32)(hi >> 32);
+  u64 t, c;
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(hl), "v"(lo));
+  u32 t0 = (u32)t, t1 = (u32)(t >> 32), u0, u1, d0, d1;
+  asm("v_sub_co_u32 %0, vcc, %4, %6\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
+      "v_cndmask_b32 %3, 0, -1, vcc\n\t"          // mb
+      "v_cndmask_b32 %2, 0, -1, %7\n\t"           // mc
+      "v_sub_u32 %2, %2, %3\n\t"                   // d0 = mc - mb
+      "s_andn2_b64 vcc, vcc, %7\n\t"               // b and not c
+      "v_cndmask_b32 %3, 0, -1, vcc"                 // d1
+      : "=&v"(u0), "=&v"(u1), "=&v"(d0), "=&v"(d1)
+      : "v"(t0), "v"(t1), "v"(hh), "s"(c)
+      : "vcc");
+  return gl_mk(u0, u1) + gl_mk(d0, d1);
+}
+GLD u64 mulw_asm3(u64 a, u64 b) { u64 lo, hi; gl_mul_wide(a, b, lo, hi); return red_asm3(lo, hi); }
+
 template <int OP>
 __global__ void __launch_bounds__(256) k(u64* out, u64 seed) {
   u64 a[8];
@@ -90,6 +110,8 @@ __global__ void __launch_bounds__(256) k(u64* out, u64 seed) {
       if (OP == 18) a[i] = mulw_asm(a[i], a[(i + 1) & 7]);
       if (OP == 19) a[i] = red_asm(a[i], a[(i + 1) & 7]);
       if (OP == 20) a[i] = red_asm2(a[i], a[(i + 1) & 7]);
+      if (OP == 21) a[i] = red_asm3(a[i], a[(i + 1) & 7]);
+      if (OP == 22) a[i] = mulw_asm3(a[i], a[(i + 1) & 7]);
     }
   }
   u64 r = 0;
@@ -113,8 +135,11 @@ __global__ void kcheck(u64* bad, u64 seed) {
     if (it % 8 == 3) hi &= 0xFFFFFFFFull;
     u64 hmax = 0xFFFFFFFE00000001ull;  // (2^64-1)^2 >> 64
     if (hi > hmax) hi = hmax;
-    u64 want = gl_canon(gl_reduce128w(lo, hi));
-    if (gl_canon(red_asm(lo, hi)) != want || gl_canon(red_asm2(lo, hi)) != want) atomicAdd((unsigned long long*)bad, 1ull);
+    u64 want = gl_canon(red64(lo, hi));  // portable formulation
+    u64 h32 = hi & 0xFFFFFFFFull;
+    if (gl_canon(gl_reduce128w(lo, hi)) != want || gl_canon(gl_reduce96w(lo, h32)) != gl_canon(red64(lo, h32)) ||
+        gl_canon(red_asm(lo, hi)) != want || gl_canon(red_asm2(lo, hi)) != want || gl_canon(red_asm3(lo, hi)) != want)
+      atomicAdd((unsigned long long*)bad, 1ull);
   }
 }
 template <class F>
@@ -141,11 +166,11 @@ int main() {
     u64 h = 1; hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
     printf("asm reduce mismatches: %llu\n", (unsigned long long)h);
   }
-  const char* names[] = {"gl_mul", "v_mad_u64_u32", "add64", "cmp+sel+add64", "mul_lo_u32", "mul_hi_u32", "gl_add", "add32", "gl_mul_small", "add_co+addc", "cmp32+sel", "mulw(64bit)", "mulw(32chain)", "mul_wide", "red(64bit)", "red(32chain)", "gl_sub", "gl_addw", "mulw(asm red)", "red(asm)", "red(asm2)"};
+  const char* names[] = {"gl_mul", "v_mad_u64_u32", "add64", "cmp+sel+add64", "mul_lo_u32", "mul_hi_u32", "gl_add", "add32", "gl_mul_small", "add_co+addc", "cmp32+sel", "mulw(64bit)", "mulw(32chain)", "mul_wide", "red(64bit)", "red(32chain)", "gl_sub", "gl_addw", "mulw(asm red)", "red(asm)", "red(asm2)", "red(asm3)", "mulw(asm3)"};
   double ops = (double)blocks * threads * ITERS * 8;
 #define RUN(N) { float ms = timeit([&] { hipLaunchKernelGGL(k<N>, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull); }); \
     printf("%-14s %8.3f ms  %8.2f Gop/s (lane-ops)\n", names[N], ms, ops / ms / 1e6); }
-  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20)
+  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20) RUN(21) RUN(22)
   {
     int reps = 64;
     float ms = timeit([&] { hipLaunchKernelGGL(kperm, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull, reps); });
