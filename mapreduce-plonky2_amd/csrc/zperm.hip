@@ -15,12 +15,20 @@
 namespace mp2g {
 
 #define ZP_MAX_CHUNKS 16
+#define ZP_MAX_ROUTED 256
+// k_j = g^j (cosets.rs get_unique_coset_shifts) for the block, in LDS
+__device__ __forceinline__ void fill_k_is(u64* kis, u32 num_routed) {
+  for (u32 j = threadIdx.x; j < num_routed; j += blockDim.x) kis[j] = gl_pow(GL_MULT_GEN, j);
+  __syncthreads();
+}
 
 // chunk_q[((b*nc + c)*chunks + k)*n + i] = prod_{j in chunk k} (w_j + beta k_j x + gamma) / (w_j + beta sigma_j + gamma)
 __global__ void __launch_bounds__(256) zpp_chunk_kernel(const u64* __restrict__ wires, u64 wires_bstride, const u64* __restrict__ sigmas,
                                                         u32 log_n, u32 num_routed, u32 degree, const u64* __restrict__ betas,
                                                         const u64* __restrict__ gammas, u64 chal_bstride, u32 nc, u64* __restrict__ chunk_q) {
   const u32 n = 1u << log_n, i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+  __shared__ u64 kis[ZP_MAX_ROUTED];
+  fill_k_is(kis, num_routed);
   if (i >= n) return;
   const u32 chunks = num_routed / degree;
   const u64 beta = betas[b * chal_bstride + c], gamma = gammas[b * chal_bstride + c];
@@ -28,17 +36,17 @@ __global__ void __launch_bounds__(256) zpp_chunk_kernel(const u64* __restrict__ 
   const u64* w = wires + b * wires_bstride + i;
   const u64* sg = sigmas + i;
   u64 num[ZP_MAX_CHUNKS], den[ZP_MAX_CHUNKS];
-  u64 kj = 1;  // k_j = g^j
   u32 j = 0;
   for (u32 k = 0; k < chunks; k++) {
+    // the running products stay weak representatives (gl.cuh); only the denominator, which is tested
+    // against zero, is canonicalised
     u64 pn = 1, pd = 1;
     for (u32 t = 0; t < degree; t++, j++) {
       u64 wv = w[(u64)j << log_n];
-      pn = gl_mul(pn, gl_add(gl_add(wv, gl_mul(bx, kj)), gamma));
-      pd = gl_mul(pd, gl_add(gl_add(wv, gl_mul(beta, sg[(u64)j << log_n])), gamma));
-      kj = gl_mul(kj, GL_MULT_GEN);
+      pn = gl_mulw(pn, gl_addw(gl_addw(gl_mulw(bx, kis[j]), wv), gamma));
+      pd = gl_mulw(pd, gl_addw(gl_addw(gl_mulw(beta, sg[(u64)j << log_n]), wv), gamma));
     }
-    num[k] = pn; den[k] = pd;
+    num[k] = pn; den[k] = gl_canon(pd);
   }
   // Montgomery batch inversion of the chunk denominators (0 -> 0, as inverse_or_zero would)
   u64 pre[ZP_MAX_CHUNKS];
@@ -107,6 +115,8 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(const u64* __restric
   const u32 p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   const u32 i = bitrev32(p, lg);
   __shared__ u64 zh_inv[8];
+  __shared__ u64 kis[ZP_MAX_ROUTED];
+  fill_k_is(kis, num_routed);
   if (threadIdx.x < 8) {
     u64 gn = gl_pow(GL_MULT_GEN, (u64)1 << log_n);
     zh_inv[threadIdx.x] = gl_inv(gl_sub(gl_mul(gn, gl_pow(gl_root_of_unity(3), threadIdx.x)), 1));
@@ -135,16 +145,14 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(const u64* __restric
     const u64 beta = bg[b * bg_bstride + c], gamma = bg[b * bg_bstride + nc + c];
     const u64 bx = gl_mul(beta, x);
     const u64* pp = z + ((u64)(nc + c * num_prods) << lg);
-    u64 kj = 1;
     u32 j = 0;
     u64 prev = z[((u64)c << lg) + p];
     for (u32 k = 0; k < chunks; k++) {
       u64 num = 1, den = 1;
       for (u32 t = 0; t < degree; t++, j++) {
         u64 wv = w[(u64)j << lg];
-        num = gl_mul(num, gl_add(gl_add(wv, gl_mul(bx, kj)), gamma));
-        den = gl_mul(den, gl_add(gl_add(wv, gl_mul(beta, sg[(u64)j << lg])), gamma));
-        kj = gl_mul(kj, GL_MULT_GEN);
+        num = gl_mulw(num, gl_addw(gl_addw(gl_mulw(bx, kis[j]), wv), gamma));  // weak running products
+        den = gl_mulw(den, gl_addw(gl_addw(gl_mulw(beta, sg[(u64)j << lg]), wv), gamma));
       }
       u64 next = k == chunks - 1 ? z[((u64)c << lg) + pn] : pp[((u64)k << lg) + p];
       push(gl_sub(gl_mul(prev, num), gl_mul(next, den)));
@@ -159,7 +167,7 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(const u64* __restric
 hipError_t quotient_perm_values(hipStream_t s, u32 B, const u64* W, u64 w_bstride, const u64* S, const u64* Z, u64 z_bstride,
                                 u32 log_n, u32 num_routed, u32 degree, const u64* bg, u64 bg_bstride, const u64* alphas,
                                 u64 al_bstride, u32 nc, bool gates, u64* q) {
-  if (nc < 1 || nc > 2 || !degree || num_routed % degree) return hipErrorInvalidValue;
+  if (nc < 1 || nc > 2 || !degree || num_routed % degree || num_routed > ZP_MAX_ROUTED) return hipErrorInvalidValue;
   const u64 N = (u64)8 << log_n;
   hipLaunchKernelGGL(quotient_perm_kernel, dim3((u32)((N + 255) / 256), B), dim3(256), 0, s, W, w_bstride, S, Z, z_bstride, log_n,
                      num_routed, degree, bg, bg_bstride, alphas, al_bstride, nc, gates, q);
@@ -169,7 +177,8 @@ hipError_t quotient_perm_values(hipStream_t s, u32 B, const u64* W, u64 w_bstrid
 hipError_t zpp_compute(hipStream_t s, u32 B, const u64* wires, u64 wires_bstride, const u64* sigmas, u32 log_n, u32 num_routed,
                        u32 degree, const u64* betas, const u64* gammas, u64 chal_bstride, u32 nc, u64* chunk_q, u64* out,
                        u64 out_bstride) {
-  if (!degree || num_routed % degree || num_routed / degree > ZP_MAX_CHUNKS || num_routed / degree < 1) return hipErrorInvalidValue;
+  if (!degree || num_routed % degree || num_routed / degree > ZP_MAX_CHUNKS || num_routed / degree < 1 || num_routed > ZP_MAX_ROUTED)
+    return hipErrorInvalidValue;
   const u32 n = 1u << log_n, chunks = num_routed / degree;
   hipLaunchKernelGGL(zpp_chunk_kernel, dim3((n + 255) / 256, nc, B), dim3(256), 0, s, wires, wires_bstride, sigmas, log_n, num_routed,
                      degree, betas, gammas, chal_bstride, nc, chunk_q);
