@@ -75,7 +75,7 @@ def cpu_baseline(base_bits, n_proofs=1):
         t_total += time.perf_counter() - t0
     return {"value": n_proofs / t_total, "unit": "leaf proofs/s", "cores": cores, "kind": "port",
             "sample": f"{n_proofs} leaf proof(s) = base 2^{base_bits} + wrap 2^12 prove() of the same gate-level circuits by oracle/ "
-                      f"(OpenMP over polynomials / leaves, {cores} threads; quotient evaluation, FRI composition and transcript are single-threaded)"}
+                      f"(OpenMP over polynomials, leaves, quotient points and PoW candidates, {cores} threads; FRI composition and transcript are single-threaded)"}
 
 
 def main():

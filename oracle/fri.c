@@ -220,13 +220,20 @@ void orc_fri_prove(const orc_fri_params* P, gl_t* const* coeffs, gl_t* const* le
     memcpy(st, ch->state, sizeof st);
     memcpy(st, ch->in, ch->n_in * sizeof(gl_t));
     unsigned pos = ch->n_in;
+    // plonky2 searches with rayon (find_any); here chunks of candidates are tried in parallel and the
+    // smallest hit of the first chunk that has one is kept (= the smallest witness overall)
     gl_t wit = 0;
-    for (;; wit++) {
-      gl_t t[12];
-      memcpy(t, st, sizeof t);
-      t[pos] = wit;
-      orc_perm(P->variant, t);
-      if (P->pow_bits == 0 || (t[7] >> (64 - P->pow_bits)) == 0) break;
+    for (gl_t base = 0;; base += 4096) {
+      gl_t best = ~(gl_t)0;
+#pragma omp parallel for schedule(static) reduction(min : best)
+      for (long k = 0; k < 4096; k++) {
+        gl_t t[12];
+        memcpy(t, st, sizeof t);
+        t[pos] = base + (gl_t)k;
+        orc_perm(P->variant, t);
+        if ((P->pow_bits == 0 || (t[7] >> (64 - P->pow_bits)) == 0) && base + (gl_t)k < best) best = base + (gl_t)k;
+      }
+      if (best != ~(gl_t)0) { wit = best; break; }
     }
     out_final[2 * final_len] = wit;
     orc_ch_observe(ch, &wit, 1);
@@ -592,7 +599,6 @@ void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, cons
   gl_t* W = malloc((size_t)wires_w * N * sizeof(gl_t));
   gl_t* S = malloc((size_t)num_routed * N * sizeof(gl_t));
   gl_t* C = NULL;
-  gl_t *lc = NULL, *lw = NULL;
   gl_t* Z = malloc((size_t)n_zs * N * sizeof(gl_t));
   void orc_lde_values(const gl_t*, unsigned, size_t, unsigned, gl_t*);
   orc_lde_values(wires_coeffs, log_n, wires_w, rate_bits, W);
@@ -600,8 +606,6 @@ void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, cons
   if (G) {
     C = malloc((size_t)G->num_constants * N * sizeof(gl_t));
     orc_lde_values(G->const_coeffs, log_n, G->num_constants, rate_bits, C);
-    lc = malloc((G->num_constants + 1) * sizeof(gl_t));
-    lw = malloc(wires_w * sizeof(gl_t));
   }
   orc_lde_values(zs_coeffs, log_n, n_zs, rate_bits, Z);
   gl_t* k_is = malloc(num_routed * sizeof(gl_t));
@@ -610,7 +614,13 @@ void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, cons
   gl_t wN = gl_root_of_unity(lg), gn = gl_pow(GL_MULT_GEN, n), w8 = gl_root_of_unity(rate_bits);
   gl_t n_field = (gl_t)n % GL_P;
   gl_t* q = malloc((size_t)nc * N * sizeof(gl_t));
+  // plonky2 evaluates the coset points in parallel batches (rayon); OpenMP over the points here
+#pragma omp parallel
+  {
   gl_t* terms = malloc((nc + (size_t)nc * chunks + ORC_MAX_GATE_CONSTRAINTS) * sizeof(gl_t));
+  gl_t* lc = G ? malloc((G->num_constants + 1) * sizeof(gl_t)) : NULL;
+  gl_t* lw = G ? malloc(wires_w * sizeof(gl_t)) : NULL;
+#pragma omp for schedule(static)
   for (size_t i = 0; i < N; i++) {
     gl_t x = gl_mul(GL_MULT_GEN, gl_pow(wN, i));
     gl_t zh = gl_sub(gl_mul(gn, gl_pow(w8, i % 8)), 1);  // x^n - 1
@@ -644,12 +654,14 @@ void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, cons
       q[(size_t)a * N + i] = gl_mul(acc, zh_inv);
     }
   }
+  free(terms); free(lc); free(lw);
+  }
   void orc_coset_ifft(gl_t*, unsigned, gl_t);
   for (unsigned a = 0; a < nc; a++) {
     orc_coset_ifft(q + (size_t)a * N, lg, GL_MULT_GEN);
     memcpy(out + (size_t)a * N, q + (size_t)a * N, N * sizeof(gl_t));  // 8 chunks of n, contiguous
   }
-  free(terms); free(q); free(k_is); free(W); free(S); free(Z); free(C); free(lc); free(lw);
+  free(q); free(k_is); free(W); free(S); free(Z); free(C);
 }
 // plonk/verifier.rs: vanishing(zeta) == Z_H(zeta) * sum_i zeta^(n i) t_i(zeta) for every challenge, from
 // the opened values only (openings layout of orc_pcs_prove; num_constants = oracle_w[0] - num_routed).
