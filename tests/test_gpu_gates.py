@@ -201,3 +201,50 @@ def test_graph_replay_is_identical(ctx, mp2):
     pr.prove([d_w, None, None], d_cd_other, d_ph)
     assert all(np.array_equal(a, b) for a, b in zip(ref1, pr.results()))
     pr.free()
+
+
+def test_noop_only_table_and_distinct_witnesses(ctx, mp2):
+    """(i) a gate table holding only NoopGate gives the copy-constraint-only quotient; (ii) the proofs of one
+    batch are independent: different witnesses (free cells re-drawn) and public-input hashes per proof."""
+    log_n, B = 6, 3
+    kinds = [(C.NOOP, 0, 0, 0), (C.ARITHMETIC, 20, 0, 0), (C.POSEIDON2, 0, 0, 0), (C.BASE_SUM, 63, 2, 0)]  # no PublicInput gate
+    ckt = C.build(log_n, kinds, 31)
+    ofp, fp = params(mp2, ckt, log_n, pow_bits=4, num_queries=3)
+    cd = O.rand_field(4, 9)
+    noop_rows = [r for r, g in enumerate(ckt.instances) if ckt.gates[g].kind == C.NOOP]
+    wires = []
+    for b in range(B):
+        w = ckt.wires.copy()
+        w[C.NUM_ROUTED:, noop_rows] = O.rand_field((C.NUM_WIRES - C.NUM_ROUTED, len(noop_rows)), 500 + b)
+        wires.append(w)
+    ph = O.rand_field((B, 4), 77)
+    pr = mp2.BatchedProver(ctx, fp, B)
+    pr.set_preprocessed(ctx.to_device(ckt.pre))
+    pr.enable_permutation(C.NUM_ROUTED, 8)
+    pr.enable_quotient()
+    pr.set_gates(gpu_gates(mp2, ckt), ckt.num_selectors)
+    pr.prove([ctx.to_device(np.stack(wires)), None, None], ctx.to_device(cd), ctx.to_device(ph))
+    caps, openings, proofs = pr.results()
+    good = ckt.wires
+    for b in range(B):
+        ckt.wires, ckt.pi_hash = wires[b], ph[b]
+        oc, oo, op, bgao = C.prove(ckt, ofp, cd)
+        assert np.array_equal(caps[b], oc) and np.array_equal(openings[b], oo) and np.array_equal(proofs[b], op)
+        assert O.pcs_verify(ofp, cd, ph[b], caps[b], openings[b], proofs[b]) == 0
+        assert C.identity_check(ckt, ofp, openings[b], bgao) == 0
+    assert not np.array_equal(proofs[0], proofs[1])
+    ckt.wires = good
+    # Noop-only table == no table
+    sig, w0 = O.copy_constraint_circuit(log_n, C.NUM_ROUTED, C.NUM_WIRES, 40, 7)
+    pre = np.concatenate([O.rand_field((ckt.num_constants, 1 << log_n), 1), sig])
+    pr.set_preprocessed(ctx.to_device(pre))
+    res = []
+    for table in ([mp2.Gate(mp2.GATE_NOOP, 0, 0, 0, 0, 0, 1)], []):
+        pr.set_gates(table, 1)
+        pr.prove([ctx.to_device(np.stack([w0] * B)), None, None], ctx.to_device(cd), ctx.to_device(ph))
+        res.append(pr.results())
+    assert all(np.array_equal(a, b) for a, b in zip(*res))
+    oc, oo, op = O.pcs_prove(ofp, [pre, w0, np.zeros((20, 1 << log_n), np.uint64), np.zeros((16, 1 << log_n), np.uint64)], cd, ph[0],
+                             num_routed=C.NUM_ROUTED, degree=8, quotient=True)
+    assert np.array_equal(res[0][2][0], op)
+    pr.free()
