@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="PCIe-inclusive variant: every step uploads its wire / quotient matrices from pinned host memory "
                          "on the prover's stream (never the headline value; see DESIGN.md)")
+    ap.add_argument("--witness-check", action="store_true",
+                    help="also run the device-side witness check (gate + copy constraints on H) inside every prove, "
+                         "as plonky2's prove() does before it panics on a bad witness")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -138,6 +141,8 @@ def main():
         pr.enable_quotient()                  # quotient chunks on the device
         pr.set_gates([mp2.Gate(g.kind, g.p0, g.p1, g.p2, g.selector_index, g.group_start, g.group_end) for g in ckt.gates],
                      ckt.num_selectors)       # ... including the gate constraint terms
+        if args.witness_check:
+            pr.enable_witness_check()
         # the witness, tiled over the batch; the unrouted cells of one Noop row are free, so re-drawing
         # them per proof keeps the commitments, transcripts and proofs of the batch distinct
         wires_one = ckt.wires
@@ -218,6 +223,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if args.witness_check:
+        for pr, *_ in provers:
+            pr.witness_status()  # raises on a violated constraint
     # per-stage split of one batch per shape, each prover alone on the GPU (outside the timed region)
     stages = {}
     if rank == 0:
@@ -271,7 +279,7 @@ def main():
                                    "(commitments, permutation argument, quotient with gate constraints, Fiat-Shamir, openings, FRI) at "
                                    "standard_recursion_config on a synthetic circuit using all 16 supported gate kinds (15 plonky2 gate types); "
                                    "roofline leg = configs[1] 2^22-point NTT",
-                       "batch_per_rank": B, "streams": args.streams, "host_inputs": bool(args.host_inputs), "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
+                       "batch_per_rank": B, "streams": args.streams, "witness_check": bool(args.witness_check), "host_inputs": bool(args.host_inputs), "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
                        "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B"},
             "roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, both launches)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

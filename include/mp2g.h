@@ -259,6 +259,14 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
  * mp2g_prover_enable_permutation, rate_bits 3 and oracle_w[3] = zs_count * 8. */
 int mp2g_prover_enable_quotient(mp2g_prover* pr);
 
+/* plonky2's prove() panics on a witness that violates a constraint (the reference's tests depend on it:
+ * recursion-framework/src/framework.rs:694-700). With the check on, every mp2g_prover_prove_dev also
+ * evaluates, per proof, the gate constraints on the subgroup (needs mp2g_prover_set_gates) and the
+ * wrap-around of the permutation product; mp2g_prover_witness_status synchronises and returns non-zero with
+ * a message naming the first offending proof. flags (may be NULL) receives one word per proof: bit 0 a
+ * copy constraint, bit 1 a gate constraint. The proof itself is still produced (it does not verify). */
+int mp2g_prover_enable_witness_check(mp2g_prover* pr, int on);
+int mp2g_prover_witness_status(mp2g_prover* pr, uint32_t* flags);
 /* Replay the prover's launch sequence (several hundred small kernels per call) as a hipGraph: the
  * first call after enabling runs normally (it creates the cached twiddle tables), the second is captured,
  * later calls with the same buffer addresses launch the instantiated graph. A call with different

@@ -452,6 +452,21 @@ class BatchedProver:
         arr = (Gate * len(gates))(*gates)
         _ck(load().mp2g_prover_set_gates(self.h, arr, len(gates), num_selectors))
 
+    def enable_witness_check(self, on=True):
+        """Check gate and copy constraints of every witness on the device (plonky2 panics on a bad one)."""
+        _ck(load().mp2g_prover_enable_witness_check(self.h, int(on)))
+
+    def witness_status(self):
+        """Per-proof flags of the last prove() (bit 0 copy constraint, bit 1 gate constraint); raises
+        Mp2gError naming the first bad proof, like prove()'s panic in the reference."""
+        flags = np.zeros(self.batch, dtype=np.uint32)
+        rc = load().mp2g_prover_witness_status(self.h, _p(flags))
+        if rc:
+            err = Mp2gError(load().mp2g_last_error().decode())
+            err.flags = flags
+            raise err
+        return flags
+
     def enable_graph(self, on=True):
         """Replay the launch sequence as a hipGraph from the third prove() with the same buffers on."""
         _ck(load().mp2g_prover_enable_graph(self.h, int(on)))

@@ -19,4 +19,8 @@ hipError_t gate_constraints_lde(hipStream_t s, u32 B, const GateTable& t, const 
 // out[j][p] = C_j at point p (device pointers; consts [.][npts], wires [.][npts])
 hipError_t gate_constraints_points(hipStream_t s, const GateTable& t, const u64* consts, const u64* wires, u64 npts, u32 max_j,
                                    const u64* pi_hash, u64* out);
+// flags[b] |= 2 where a gate constraint of proof b is non-zero on the subgroup: consts [.][npts] (shared),
+// wires [B][.][npts] with batch stride w_bstride, pi_hash [B][4]
+hipError_t gate_check(hipStream_t s, u32 B, const GateTable& t, const u64* consts, const u64* wires, u64 w_bstride, u64 npts,
+                      const u64* pi_hash, u32* flags);
 }  // namespace mp2g

@@ -455,6 +455,35 @@ __global__ void __launch_bounds__(256) gate_constraints_points_kernel(GateTable 
   }
 }
 
+// Witness check on the subgroup H (what makes plonky2's prove() panic on an unsatisfied witness): on a row
+// of H only the row's own gate has a non-zero filter, so a violated constraint cannot cancel against another
+// gate's. flags[b] |= 2 when any gate constraint of proof b is non-zero somewhere.
+__global__ void __launch_bounds__(256) gate_check_kernel(GateTable t, const u64* __restrict__ consts, const u64* __restrict__ wires,
+                                                         u64 w_bstride, u64 npts, const u64* __restrict__ pi_hash, u32* __restrict__ flags) {
+  const u64 p = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u32 b = blockIdx.y;
+  if (p >= npts) return;
+  const u64* w = wires + b * w_bstride;
+  auto wire = [&](u32 j) { return w[(u64)j * npts + p]; };
+  auto call = [&](u32 j) { return consts[(u64)j * npts + p]; };
+  const u32 ns = t.num_selectors;
+  auto cst = [&](u32 j) { return consts[(u64)(ns + j) * npts + p]; };
+  bool bad = false;
+  for (u32 gi = 0; gi < t.n_gates; gi++) {
+    if (t.g[gi].kind == MP2G_GATE_NOOP) continue;
+    if (gate_filter(t, gi, call) == 0) continue;  // not this row's gate
+    eval_gate<false>(t.g[gi], wire, cst, pi_hash + 4 * b, [&](u64 v) { bad |= v != 0; });
+  }
+  if (bad) atomicOr(&flags[b], 2u);
+}
+hipError_t gate_check(hipStream_t s, u32 B, const GateTable& t, const u64* consts, const u64* wires, u64 w_bstride, u64 npts,
+                      const u64* pi_hash, u32* flags) {
+  if (!npts || !B) return hipSuccess;
+  hipLaunchKernelGGL(gate_check_kernel, dim3((u32)((npts + 255) / 256), B), dim3(256), 0, s, t, consts, wires, w_bstride, npts, pi_hash,
+                     flags);
+  return hipGetLastError();
+}
+
 hipError_t gate_constraints_lde(hipStream_t s, u32 B, const GateTable& t, const u64* C, const u64* W, u64 w_bstride, u32 lg,
                                 const u64* alphas, u64 al_bstride, u32 nc, const u64* pi_hash, u64* q) {
   if (nc < 1 || nc > 2) return hipErrorInvalidValue;

@@ -39,6 +39,9 @@ struct mp2g_prover {
   DevBuf pre_values, zs_values, chunk_q, bg, alphas, qvals;
   // gate constraints (mp2g_prover_set_gates)
   GateTable gates{};
+  // witness check (mp2g_prover_enable_witness_check): bit 0 copy constraints, bit 1 gate constraints
+  bool wcheck = false;
+  DevBuf wflags;
   // stage timing (mp2g_prover_enable_timing): events at the phase boundaries of the last prove
   bool timing = false;
   hipEvent_t ev[MP2G_N_STAGES + 1] = {};
@@ -463,6 +466,12 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
   const u64 caps_b = P.n_oracles * capw;
 
   STAGE_MARK(pr, 0);
+  if (pr->wcheck) {
+    CK(hipMemsetAsync(pr->wflags.p, 0, B * sizeof(u32), s));
+    if (pr->gates.n_gates)
+      CK(gate_check(s, B, pr->gates, pr->pre_values.p, (const u64*)d_values[0], (u64)P.oracle_w[1] * n, n, (const u64*)d_pi_hash,
+                    (u32*)pr->wflags.p));
+  }
   CK(challenger_init(s, st, B));
   CK(challenger_step(s, V, st, B, (const u64*)d_circuit_digest, 0, 4, chal, 8, 0));
   CK(challenger_step(s, V, st, B, (const u64*)d_pi_hash, 4, 4, chal, 8, 0));
@@ -475,6 +484,9 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
                      P.log_n, pr->num_routed, pr->degree, pr->bg.p, pr->bg.p + 2, 4, P.zs_count, pr->chunk_q.p, pr->zs_values.p,
                      (u64)P.oracle_w[2] * n));
       vals = pr->zs_values.p;
+      if (pr->wcheck)
+        CK(zpp_wrap_check(s, B, pr->chunk_q.p, pr->zs_values.p, (u64)P.oracle_w[2] * n, P.log_n, pr->num_routed / pr->degree, P.zs_count,
+                          (u32*)pr->wflags.p));
     }
     if (o == 3 && pr->quotient) {
       // compute_quotient_polys for the gate-independent terms: values on the coset, coset iFFT, and the
@@ -524,6 +536,25 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
   int rc = fri_tail(pr, sh, st, (u64*)d_proof);
   if (rc) return rc;
   STAGE_MARK(pr, 7);
+  return 0;
+}
+int mp2g_prover_enable_witness_check(mp2g_prover* pr, int on) {
+  NEED(pr && pr->num_routed, "call mp2g_prover_enable_permutation first");
+  if (on && !pr->wflags.p) CK(pr->wflags.alloc((size_t)pr->B * sizeof(u32)));
+  pr->wcheck = on != 0;
+  pr->drop_graph();
+  return 0;
+}
+int mp2g_prover_witness_status(mp2g_prover* pr, uint32_t* flags) {
+  NEED(pr && pr->wcheck, "call mp2g_prover_enable_witness_check first");
+  std::vector<uint32_t> h(pr->B);
+  CK(hipMemcpyAsync(h.data(), pr->wflags.p, pr->B * sizeof(u32), hipMemcpyDeviceToHost, pr->ctx->stream));
+  CK(hipStreamSynchronize(pr->ctx->stream));
+  if (flags) memcpy(flags, h.data(), pr->B * sizeof(u32));
+  for (uint32_t b = 0; b < pr->B; b++)
+    if (h[b])
+      return fail("invalid witness: proof %u of the batch violates %s%s%s", b, (h[b] & 1) ? "a copy constraint" : "",
+                  h[b] == 3 ? " and " : "", (h[b] & 2) ? "a gate constraint" : "");
   return 0;
 }
 int mp2g_prover_enable_timing(mp2g_prover* pr, int on) {

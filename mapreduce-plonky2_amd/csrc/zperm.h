@@ -13,4 +13,8 @@ hipError_t zpp_compute(hipStream_t s, u32 B, const u64* wires, u64 wires_bstride
 hipError_t quotient_perm_values(hipStream_t s, u32 B, const u64* W, u64 w_bstride, const u64* S, const u64* Z, u64 z_bstride,
                                 u32 log_n, u32 num_routed, u32 degree, const u64* bg, u64 bg_bstride, const u64* alphas,
                                 u64 al_bstride, u32 nc, bool gates, u64* q);
+// flags[b] |= 1 when the permutation product of proof b does not wrap to one (a violated copy constraint);
+// chunk_q / zs as produced by zpp_compute
+hipError_t zpp_wrap_check(hipStream_t s, u32 B, const u64* chunk_q, const u64* zs, u64 zs_bstride, u32 log_n, u32 chunks, u32 nc,
+                          u32* flags);
 }  // namespace mp2g

@@ -174,6 +174,24 @@ hipError_t quotient_perm_values(hipStream_t s, u32 B, const u64* W, u64 w_bstrid
   return hipGetLastError();
 }
 
+// Copy constraints hold iff the running product returns to one: Z(g^(n-1)) times the last row's chunk
+// quotients must be 1 for every challenge (w.h.p. over beta, gamma). flags[b] |= 1 otherwise.
+__global__ void zpp_wrap_check_kernel(const u64* __restrict__ chunk_q, const u64* __restrict__ zs, u64 zs_bstride, u32 log_n, u32 chunks,
+                                      u32 nc, u32 B, u32* __restrict__ flags) {
+  const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * nc) return;
+  const u32 b = t / nc, c = t % nc, last = (1u << log_n) - 1;
+  u64 acc = zs[b * zs_bstride + ((u64)c << log_n) + last];
+  const u64* q = chunk_q + ((u64)(b * nc + c) * chunks << log_n);
+  for (u32 k = 0; k < chunks; k++) acc = gl_mul(acc, q[((u64)k << log_n) + last]);
+  if (acc != 1) atomicOr(&flags[b], 1u);
+}
+hipError_t zpp_wrap_check(hipStream_t s, u32 B, const u64* chunk_q, const u64* zs, u64 zs_bstride, u32 log_n, u32 chunks, u32 nc,
+                          u32* flags) {
+  hipLaunchKernelGGL(zpp_wrap_check_kernel, dim3((B * nc + 63) / 64), dim3(64), 0, s, chunk_q, zs, zs_bstride, log_n, chunks, nc, B, flags);
+  return hipGetLastError();
+}
+
 hipError_t zpp_compute(hipStream_t s, u32 B, const u64* wires, u64 wires_bstride, const u64* sigmas, u32 log_n, u32 num_routed,
                        u32 degree, const u64* betas, const u64* gammas, u64 chal_bstride, u32 nc, u64* chunk_q, u64* out,
                        u64 out_bstride) {

@@ -248,3 +248,46 @@ def test_noop_only_table_and_distinct_witnesses(ctx, mp2):
                              num_routed=C.NUM_ROUTED, degree=8, quotient=True)
     assert np.array_equal(res[0][2][0], op)
     pr.free()
+
+
+def test_device_witness_check(ctx, mp2):
+    """mp2g_prover_enable_witness_check: a satisfied batch is clean; a violated gate, a violated copy constraint
+    and both are reported per proof, with an error naming the first offender (prove() panics in the reference)."""
+    log_n, B = 6, 4
+    ckt = C.build(log_n, C.ALL_KINDS, 12)
+    ofp, fp = params(mp2, ckt, log_n, pow_bits=3, num_queries=2)
+    n = 1 << log_n
+    wN = pow(7277203076849721926, 1 << (32 - log_n), P)
+    ident = lambda col, row: pow(O.MULT_GEN, col, P) * pow(wN, row, P) % P
+    sig = ckt.pre[ckt.num_constants:]
+    noop = next(i for i, g in enumerate(ckt.gates) if g.kind == C.NOOP)
+    copy_cell = next((col, row) for row in range(n) if ckt.instances[row] == noop for col in range(C.NUM_ROUTED)
+                     if int(sig[col, row]) != ident(col, row))
+    arith_row = ckt.instances.index(next(i for i, g in enumerate(ckt.gates) if g.kind == C.ARITHMETIC))
+    wires = [ckt.wires.copy() for _ in range(B)]
+    wires[1][3, arith_row] ^= np.uint64(1)                      # gate violation (an output that is not routed anywhere)
+    wires[2][copy_cell] = (int(wires[2][copy_cell]) + 1) % P    # copy violation in a Noop row
+    wires[3][3, arith_row] ^= np.uint64(1)
+    wires[3][copy_cell] = (int(wires[3][copy_cell]) + 1) % P
+    pr = mp2.BatchedProver(ctx, fp, B)
+    pr.set_preprocessed(ctx.to_device(ckt.pre))
+    with pytest.raises(mp2.Mp2gError):
+        pr.enable_witness_check()  # needs the permutation argument configured first
+    pr.enable_permutation(C.NUM_ROUTED, 8)
+    pr.enable_quotient()
+    pr.set_gates(gpu_gates(mp2, ckt), ckt.num_selectors)
+    with pytest.raises(mp2.Mp2gError):
+        pr.witness_status()  # not enabled yet
+    pr.enable_witness_check()
+    d_cd, d_ph = ctx.to_device(O.rand_field(4, 1)), ctx.to_device(np.stack([ckt.pi_hash] * B))
+    pr.prove([ctx.to_device(np.stack([ckt.wires] * B)), None, None], d_cd, d_ph)
+    assert pr.witness_status().tolist() == [0] * B
+    ref = pr.results()
+    pr.prove([ctx.to_device(np.stack(wires)), None, None], d_cd, d_ph)
+    with pytest.raises(mp2.Mp2gError, match="proof 1 of the batch violates a gate constraint") as e:
+        pr.witness_status()
+    assert e.value.flags.tolist() == [0, 2, 1, 3]
+    got = pr.results()
+    assert np.array_equal(got[2][0], ref[2][0]) and not np.array_equal(got[2][1], ref[2][1])  # the good proof of the batch is unaffected
+    pr.enable_witness_check(False)
+    pr.free()
