@@ -253,9 +253,9 @@ int mp2g_partial_products_and_zs(mp2g_ctx* ctx, const uint64_t* wires, uint32_t 
  * the challenges drawn after the wires cap. Call after mp2g_prover_set_preprocessed_dev. */
 int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_t degree);
 /* Also compute oracle 3 (the quotient chunks) on the device, as plonk/prover.rs compute_quotient_polys
- * does for the gate-independent terms of the vanishing polynomial (Z(1) = 1 and the partial-product
- * checks): the complete prove() of a circuit whose only constraints are copy constraints; gate
- * constraint evaluators are the next terms to add. d_values[2] may then be NULL. Needs
+ * does: the vanishing terms Z(1) = 1 and the partial-product checks, plus the gate constraints once
+ * mp2g_prover_set_gates has given the gate table (without a table: the complete prove() of a circuit whose
+ * only constraints are copy constraints). d_values[2] may then be NULL. Needs
  * mp2g_prover_enable_permutation, rate_bits 3 and oracle_w[3] = zs_count * 8. */
 int mp2g_prover_enable_quotient(mp2g_prover* pr);
 

@@ -442,8 +442,8 @@ class BatchedProver:
         _ck(load().mp2g_prover_enable_permutation(self.h, num_routed, degree))
 
     def enable_quotient(self):
-        """Also compute the quotient chunks on the device for the gate-independent vanishing terms
-        (complete prove() of a copy-constraint-only circuit); d_values[2] may then be None."""
+        """Also compute the quotient chunks on the device: permutation terms, plus the gate constraints
+        once set_gates() has given the gate table; d_values[2] may then be None."""
         _ck(load().mp2g_prover_enable_quotient(self.h))
 
     def set_gates(self, gates, num_selectors):

@@ -489,7 +489,7 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
                           (u32*)pr->wflags.p));
     }
     if (o == 3 && pr->quotient) {
-      // compute_quotient_polys for the gate-independent terms: values on the coset, coset iFFT, and the
+      // compute_quotient_polys (gate constraints first, then folded into the permutation terms): values on the coset, coset iFFT, and the
       // 8n coefficients of each challenge are its 8 degree-n chunks, already laid out as oracle 3's coeffs
       const u32 nc = P.zs_count;
       if (pr->gates.n_gates)

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(1024) zpp_scan_kernel(const u64* __restrict__ 
   }
 }
 
-// ---- quotient values for the gate-independent vanishing terms ---------------------------------
+// ---- quotient values: the permutation terms (+ the gate term left in q by gates.hip) -----------
 // plonk/prover.rs compute_quotient_polys + vanishing_poly.rs eval_vanishing_poly_base_batch with no
 // gate constraints: terms = [L_0(x)(Z_c(x) - 1)]_c ++ [prev * prod(num) - next * prod(den)] per chunk and
 // challenge; q_a(x) = sum_k terms[k] alpha_a^k / Z_H(x) on the coset g<w_N>, N = 8n.
