@@ -6,7 +6,7 @@ mp2 = importlib.import_module("mapreduce-plonky2_amd")
 import oracle as O
 ctx = mp2.Context(0)
 L = mp2.load()
-rows, n_cols, n_unique = 1 << 16, 4, 1
+rows, n_cols, n_unique = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 16), 4, 1
 rng = np.random.default_rng(1)
 d_ids = ctx.to_device(O.rand_field(n_cols, 3))
 d_vals = ctx.to_device(rng.integers(0, 1 << 32, size=(rows, n_cols, 8), dtype=np.uint32))
