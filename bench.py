@@ -102,8 +102,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # MP2G_BENCH_BACKEND=gloo runs the multi-rank code path on a box with fewer GPUs than ranks (ranks share
+        # devices round-robin; collectives go through host tensors) -- a plumbing check, not a measurement
+        backend = os.environ.get("MP2G_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
@@ -219,7 +227,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -253,7 +261,7 @@ def main():
     w = mp2.compute_table_row_digest_dev(ctx, d_ids, n_cols, d_values, d_unique, 1, rows)
     digest_s = time.perf_counter() - t1
     if dist is not None:
-        allw = sharding.all_gather_words(dist, w, device=torch.device("cuda", local_rank))
+        allw = sharding.all_gather_words(dist, w, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None)
         w = mp2.curve_sum(ctx, allw)
 
     if rank == 0:
