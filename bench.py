@@ -8,18 +8,20 @@ Workload. The metric is quoted on the 2^20-row table build (configs[3]); its uni
 framework leaf proof, which the recursion framework always produces as one base `prove()` plus
 one wrap `prove()` down to 2^12 rows (recursion-framework/src/circuit_builder.rs:286-311,
 wrap_circuit.rs:122-148). One step = one batch of `--batch` such leaf proofs, shaped as SURVEY
-8(d) config 3 says (base 2^13 + wrap 2^12, standard_recursion_config: 8 constants + 80 sigmas,
+8(d) config 3 says (base 2^13 + wrap 2^12, standard_recursion_config: constants + 80 sigmas,
 135 wires, 20 Z/partial products, 16 quotient chunks, rate 1/8, cap 16, FRI [4,4], 16-bit PoW, 28
 queries), on synthetic witness matrices that are resident in HBM before the timed region. What
 runs per proof is everything `prove()` does after witness generation -- wires commitment, Z / partial
 products, quotient polynomials (permutation terms and the gate constraints), their commitments,
-Fiat-Shamir, openings, FRI (HOT LOOPS 1-3 of SURVEY 3.1) -- for a satisfied synthetic circuit that
-uses every gate kind the library evaluates (tests/circuits.py ALL_KINDS: Noop, Constant, PublicInput,
-Arithmetic, BaseSum<2>, BaseSum<4>, ArithmeticExtension, MulExtension, Poseidon2, Poseidon,
-PoseidonMds, Exponentiation, Reducing, ReducingExtension, RandomAccess, CosetInterpolation; as in plonky2 every gate is
-evaluated at every LDE point, so the cost depends on the gate set, not on the row mix) with random
-copy constraints. Witness generation stays on the host. The proofs verify (FRI + the PLONK identity
-at zeta with the gate terms, tests/test_gpu_gates.py).
+Fiat-Shamir, openings, FRI (HOT LOOPS 1-3 of SURVEY 3.1) -- for satisfied synthetic circuits composed as the reference composes them
+(tests/circuits.py): the wrap circuit has the gate set of plonky2's recursive verifier (Noop, Constant,
+PublicInput, Arithmetic, ArithmeticExtension, MulExtension, BaseSum<2>, Exponentiation, Reducing,
+ReducingExtension, RandomAccess, CosetInterpolation, Poseidon2: 13 gates), the base (leaf) circuit adds
+the user-logic gates (BaseSum<4>, U32Arithmetic, U32RangeCheck, U32Subtraction, U32AddMany, Comparison:
+19 gates); as in plonky2 every gate of a circuit is evaluated at every LDE point, so the cost depends on
+the gate set, not on the row mix. Rows are dealt over the gates with random copy constraints. Witness
+generation stays on the host. The proofs verify (FRI + the PLONK identity at zeta with the gate terms,
+tests/test_gpu_gates.py).
 Leaf proofs shard across ranks with no data-path collective ("scaling": "weak"); the per-rank
 multiset digests meet in one 160-byte all_gather outside the per-proof path.
 
@@ -42,7 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 LOG_NTT = 22
-ORACLE_W = (88, 135, 20, 16)  # 6 selectors + 2 gate constants + 80 sigmas | wires | Z, partial products | quotient chunks
+ORACLE_W = (None, 135, 20, 16)  # constants (selectors + 2) + 80 sigmas: from the circuit | wires | Z, partial products | quotient chunks
 NUM_ROUTED = 80  # standard_recursion_config: 80 routed wires, quotient_degree_factor 8 => 2 x (1 + 9) Z / partial products
 SEED = 0xC0FFEE03
 
@@ -58,13 +60,21 @@ def gpu_clocks(device):
         return {"error": str(e)[:80]}
 
 
+def build_circuit(C, role, k):
+    """the synthetic circuit of a role: base = leaf gate set (verifier gadget + u32 logic), wrap = verifier gate set"""
+    return C.build(k, C.LEAF_KINDS if role == "base" else C.VERIFIER_KINDS, SEED + k + (0 if role == "base" else 100))
+
+
 def cpu_baseline(base_bits, budget_s=15.0):
     """The CPU oracle (our restatement of the same pipeline; kind 'port'), OpenMP on all host cores, on a
     bounded sample of the same workload: whole leaf proofs until ~budget_s seconds are spent (1..6)."""
     import circuits as C
     import oracle as O
     cores = os.cpu_count() or 1
-    shapes = [(O.standard_params(k, ORACLE_W), C.build(k, C.ALL_KINDS, SEED + k)) for k in (base_bits, 12)]
+    shapes = []
+    for role, k in (("base", base_bits), ("wrap", 12)):
+        ckt = build_circuit(C, role, k)
+        shapes.append((O.standard_params(k, (ckt.pre.shape[0],) + ORACLE_W[1:]), ckt))
     cd = O.rand_field(4, 1)
     t_total, n_proofs = 0.0, 0
     while n_proofs < 6 and (n_proofs == 0 or t_total * (n_proofs + 1) / n_proofs < budget_s):
@@ -126,24 +136,25 @@ def main():
     # provers: (shape, context, share of the batch). 1 stream: both shapes on it; 2: one each;
     # 4: every shape split into two half-batches
     if n_ctx >= 4:
-        plan = [(args.base_bits, ctxs[0], B // 2), (12, ctxs[1], B // 2), (args.base_bits, ctxs[2], B - B // 2), (12, ctxs[3], B - B // 2)]
+        plan = [("base", args.base_bits, ctxs[0], B // 2), ("wrap", 12, ctxs[1], B // 2), ("base", args.base_bits, ctxs[2], B - B // 2),
+                ("wrap", 12, ctxs[3], B - B // 2)]
     elif n_ctx >= 2:
-        plan = [(args.base_bits, ctxs[0], B), (12, ctxs[1], B)]
+        plan = [("base", args.base_bits, ctxs[0], B), ("wrap", 12, ctxs[1], B)]
     else:
-        plan = [(args.base_bits, ctx, B), (12, ctx, B)]
+        plan = [("base", args.base_bits, ctx, B), ("wrap", 12, ctx, B)]
 
     # ---- synthetic inputs, resident in HBM before the timed region -----------------------------
     provers = []
     circuits = {}
-    for k, cx, nb in plan:
-        fp = mp2.standard_recursion_params(k, ORACLE_W)
+    for role, k, cx, nb in plan:
         n = 1 << k
+        # a satisfied gate-level circuit of the role's gate set: rows dealt over the gates, random copy constraints
+        if role not in circuits:
+            circuits[role] = build_circuit(C, role, k)
+        ckt = circuits[role]
+        oracle_w = (ckt.pre.shape[0],) + ORACLE_W[1:]
+        fp = mp2.standard_recursion_params(k, oracle_w)
         pr = mp2.BatchedProver(cx, fp, nb)
-        # a satisfied gate-level circuit: rows dealt over every supported gate kind, random copy constraints
-        if k not in circuits:
-            circuits[k] = C.build(k, C.ALL_KINDS, SEED + k)
-        ckt = circuits[k]
-        assert ckt.pre.shape[0] == ORACLE_W[0]
         pr.set_preprocessed(cx.to_device(ckt.pre))
         pr.enable_permutation(NUM_ROUTED, 8)  # Z / partial products on the device from wires + sigmas
         pr.enable_quotient()                  # quotient chunks on the device
@@ -156,7 +167,7 @@ def main():
         wires_one = ckt.wires
         noop_row = ckt.instances.index(next(i for i, g in enumerate(ckt.gates) if g.kind == C.NOOP))
         d_vals = []
-        for i, w in enumerate(ORACLE_W[1:]):
+        for i, w in enumerate(oracle_w[1:]):
             if i >= 1:
                 d_vals.append(None)  # oracles 2 and 3: produced by the prover itself
                 continue
@@ -238,16 +249,16 @@ def main():
     stages = {}
     if rank == 0:
         seen_shapes = set()
-        for (k, cx, nb), (pr, d_vals, d_cd, d_ph, _, _) in zip(plan, provers):
-            if k in seen_shapes:
+        for (role, k, cx, nb), (pr, d_vals, d_cd, d_ph, _, _) in zip(plan, provers):
+            if role in seen_shapes:
                 continue
-            seen_shapes.add(k)
+            seen_shapes.add(role)
             sync_all()
             pr.enable_timing(True)
             pr.prove(d_vals, d_cd, d_ph)
             ms = pr.stage_ms()
             pr.enable_timing(False)
-            stages[f"2^{k} x {nb}"] = {s: round(v, 3) for s, v in ms.items()}
+            stages[f"{role} 2^{k} x {nb}"] = {s: round(v, 3) for s, v in ms.items()}
 
     # the per-rank multiset digest (2^16 rows x 4 value columns, device resident) meets in one
     # all_gather of one encoded point per rank, outside the per-proof path
@@ -285,9 +296,11 @@ def main():
             "dtype": "u64 (Goldilocks field)", "data": "synthetic",
             "config": {"workload": f"configs[3]-shaped leaf proofs: base 2^{args.base_bits} + wrap 2^12 prove() from the wire matrix "
                                    "(commitments, permutation argument, quotient with gate constraints, Fiat-Shamir, openings, FRI) at "
-                                   "standard_recursion_config on a synthetic circuit using all 16 supported gate kinds (15 plonky2 gate types); "
+                                   "standard_recursion_config; base circuit = 19 gates (recursive-verifier set + u32 / comparison logic), wrap circuit = the 13 "
+                                   "gates of plonky2's recursive verifier; "
                                    "roofline leg = configs[1] 2^22-point NTT",
-                       "batch_per_rank": B, "streams": args.streams, "witness_check": bool(args.witness_check), "host_inputs": bool(args.host_inputs), "oracle_polys": list(ORACLE_W), "hasher": "Poseidon2",
+                       "batch_per_rank": B, "streams": args.streams, "witness_check": bool(args.witness_check), "host_inputs": bool(args.host_inputs), "oracle_polys": {r: [int(c.pre.shape[0])] + list(ORACLE_W[1:]) for r, c in circuits.items()},
+                       "gates": {r: len(c.gates) for r, c in circuits.items()}, "hasher": "Poseidon2",
                        "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B"},
             "roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, both launches)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -286,8 +286,7 @@ int mp2g_prover_stage_ms(mp2g_prover* pr, float out[MP2G_N_STAGES]);
  * Replaces [dep] plonky2 plonk/vanishing_poly.rs evaluate_gate_constraints_base_batch and the
  * eval_unfiltered_base of the gates below (gates the reference registers:
  * mp2-common/src/serialization/circuit_data_serialization.rs:236-267). Not yet covered:
- * Lookup / LookupTable, the plonky2-u32 gates, Comparison,
- * U32Interleave / Uninterleave. A circuit using one of those cannot be proved here yet. */
+ * Lookup / LookupTable, U32Interleave / UninterleaveToB32 / UninterleaveToU32. A circuit using one of those cannot be proved here yet. */
 enum {
   MP2G_GATE_NOOP = 0,
   MP2G_GATE_CONSTANT = 1,       /* p0 = num_consts */
@@ -303,7 +302,13 @@ enum {
   MP2G_GATE_RANDOM_ACCESS = 11, /* p0 = bits (<= 6), p1 = num_copies, p2 = num_extra_constants */
   MP2G_GATE_POSEIDON = 12,      /* the original Poseidon permutation gate (wrap circuits) */
   MP2G_GATE_POSEIDON_MDS = 13,
-  MP2G_GATE_COSET_INTERPOLATION = 14 /* p0 = subgroup_bits (2..5), p1 = degree (CosetInterpolationGate::degree) */
+  MP2G_GATE_COSET_INTERPOLATION = 14, /* p0 = subgroup_bits (2..5), p1 = degree (CosetInterpolationGate::degree) */
+  /* plonky2-u32 (restated from memory of the published crate, like everything here that is not in the tree) */
+  MP2G_GATE_U32_ARITHMETIC = 15,  /* p0 = num_ops */
+  MP2G_GATE_U32_RANGE_CHECK = 16, /* p0 = num_input_limbs */
+  MP2G_GATE_U32_SUBTRACTION = 17, /* p0 = num_ops */
+  MP2G_GATE_U32_ADD_MANY = 18,    /* p0 = num_addends (<= 16), p1 = num_ops */
+  MP2G_GATE_COMPARISON = 19       /* p0 = num_bits, p1 = num_chunks (chunks of at most 4 bits) */
 };
 #define MP2G_MAX_GATES 24
 #define MP2G_MAX_GATE_CONSTRAINTS 160

@@ -406,7 +406,8 @@ class Gate(ctypes.Structure):
 
 (GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_ARITHMETIC_EXT, GATE_MUL_EXT, GATE_POSEIDON2,
  GATE_EXPONENTIATION, GATE_REDUCING, GATE_REDUCING_EXT, GATE_RANDOM_ACCESS, GATE_POSEIDON, GATE_POSEIDON_MDS,
- GATE_COSET_INTERPOLATION) = range(15)
+ GATE_COSET_INTERPOLATION, GATE_U32_ARITHMETIC, GATE_U32_RANGE_CHECK, GATE_U32_SUBTRACTION, GATE_U32_ADD_MANY,
+ GATE_COMPARISON) = range(20)
 
 
 def eval_gate_constraints(ctx, gates, num_selectors, consts, wires, pi_hash):

@@ -24,6 +24,11 @@ u32 gate_num_constraints(const mp2g_gate& g) {
     case MP2G_GATE_POSEIDON2: case MP2G_GATE_POSEIDON: return 1 + 4 + 36 + 22 + 48 + 12;
     case MP2G_GATE_POSEIDON_MDS: return 24;
     case MP2G_GATE_COSET_INTERPOLATION: return 4 + 4 * (((1u << g.p0) - 2) / (g.p1 - 1));
+    case MP2G_GATE_U32_ARITHMETIC: return 36 * g.p0;
+    case MP2G_GATE_U32_RANGE_CHECK: return 17 * g.p0;
+    case MP2G_GATE_U32_SUBTRACTION: return 19 * g.p0;
+    case MP2G_GATE_U32_ADD_MANY: return 21 * g.p1;
+    case MP2G_GATE_COMPARISON: return g.p1 ? 6 + 5 * g.p1 + (g.p0 + g.p1 - 1) / g.p1 : 0;
     case MP2G_GATE_EXPONENTIATION: return g.p0 + 1;
     case MP2G_GATE_REDUCING: case MP2G_GATE_REDUCING_EXT: return 2 * g.p0;
     case MP2G_GATE_RANDOM_ACCESS: return (g.p0 + 2) * g.p1 + g.p2;
@@ -38,6 +43,8 @@ u32 gate_degree(const mp2g_gate& g) {
     case MP2G_GATE_POSEIDON2: case MP2G_GATE_POSEIDON: return 7;
     case MP2G_GATE_POSEIDON_MDS: return 1;
     case MP2G_GATE_COSET_INTERPOLATION: return g.p1;
+    case MP2G_GATE_U32_ARITHMETIC: case MP2G_GATE_U32_RANGE_CHECK: case MP2G_GATE_U32_SUBTRACTION: case MP2G_GATE_U32_ADD_MANY: return 4;
+    case MP2G_GATE_COMPARISON: return g.p1 ? 1u << ((g.p0 + g.p1 - 1) / g.p1) : 0;
     case MP2G_GATE_EXPONENTIATION: return 4;
     case MP2G_GATE_REDUCING: case MP2G_GATE_REDUCING_EXT: return 2;
     case MP2G_GATE_RANDOM_ACCESS: return g.p0 + 1;
@@ -57,6 +64,11 @@ static void gate_footprint(const mp2g_gate& g, u32& wires, u32& consts) {
     case MP2G_GATE_POSEIDON2: case MP2G_GATE_POSEIDON: wires = 135; break;
     case MP2G_GATE_POSEIDON_MDS: wires = 48; break;
     case MP2G_GATE_COSET_INTERPOLATION: wires = 1 + 2 * (1u << g.p0) + 6 + 4 * (((1u << g.p0) - 2) / (g.p1 - 1)); break;
+    case MP2G_GATE_U32_ARITHMETIC: wires = 38 * g.p0; break;
+    case MP2G_GATE_U32_RANGE_CHECK: wires = 17 * g.p0; break;
+    case MP2G_GATE_U32_SUBTRACTION: wires = 21 * g.p0; break;
+    case MP2G_GATE_U32_ADD_MANY: wires = (g.p0 + 3 + 18) * g.p1; break;
+    case MP2G_GATE_COMPARISON: wires = g.p1 ? 4 + 5 * g.p1 + (g.p0 + g.p1 - 1) / g.p1 + 1 : 0; break;
     case MP2G_GATE_EXPONENTIATION: wires = 2 * g.p0 + 2; break;
     case MP2G_GATE_REDUCING: wires = 6 + g.p0 + 2 * (g.p0 - 1); break;
     case MP2G_GATE_REDUCING_EXT: wires = 6 + 2 * g.p0 + 2 * (g.p0 - 1); break;
@@ -69,7 +81,12 @@ const char* gate_table_check(const GateTable& t, u32 num_constants, u32 wires_w)
   if (t.num_selectors == 0 || t.num_selectors > num_constants) return "num_selectors must be in 1..num_constants";
   for (u32 i = 0; i < t.n_gates; i++) {
     const mp2g_gate& g = t.g[i];
-    if (g.kind > MP2G_GATE_COSET_INTERPOLATION) return "unknown gate kind";
+    if (g.kind > MP2G_GATE_COMPARISON) return "unknown gate kind";
+    if ((g.kind == MP2G_GATE_U32_ARITHMETIC || g.kind == MP2G_GATE_U32_RANGE_CHECK || g.kind == MP2G_GATE_U32_SUBTRACTION) && g.p0 < 1)
+      return "u32 gate needs at least one operation";
+    if (g.kind == MP2G_GATE_U32_ADD_MANY && (g.p0 < 1 || g.p0 > 16 || g.p1 < 1)) return "U32AddManyGate needs 1..16 addends and an operation";
+    if (g.kind == MP2G_GATE_COMPARISON && (g.p1 < 1 || g.p0 < g.p1 || (g.p0 + g.p1 - 1) / g.p1 > 4))
+      return "ComparisonGate needs num_chunks >= 1 and chunks of at most 4 bits";
     if (g.kind == MP2G_GATE_COSET_INTERPOLATION && (g.p0 < 2 || g.p0 > 5 || g.p1 < 2 || g.p1 > (1u << g.p0)))
       return "CosetInterpolationGate needs 2..5 subgroup bits and 2 <= degree <= 2^bits";
     if (g.kind == MP2G_GATE_BASE_SUM && (g.p1 < 2 || g.p0 < 1)) return "BaseSumGate needs base >= 2 and a limb";
@@ -299,6 +316,116 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
       emit(d3.a); emit(d3.b);
       break;
     }
+    case MP2G_GATE_U32_ARITHMETIC: {
+      // plonky2-u32 arithmetic_u32.rs: per op m0, m1, addend, output_low, output_high, inverse (routed), then 32
+      // two-bit limbs of the 64-bit output
+      const u32 ops = g.p0;
+      for (u32 i = 0; i < ops; i++) {
+        const u32 b = 6 * i;
+        const u64 computed = gl_add(gl_mul(wire(b), wire(b + 1)), wire(b + 2));
+        const u64 lo = wire(b + 3), hi = wire(b + 4), inv = wire(b + 5);
+        const u64 hi_not_max = gl_sub(gl_mul(inv, gl_sub(0xFFFFFFFFull, hi)), 1);
+        emit(gl_mul(hi_not_max, lo));
+        emit(gl_sub(gl_add(gl_mul(hi, (u64)1 << 32), lo), computed));
+        u64 clo = 0, chi = 0;
+        for (u32 j = 32; j-- > 0;) {
+          const u64 limb = wire(6 * ops + 32 * i + j);
+          u64 pr = limb;
+          for (u32 x = 1; x < 4; x++) pr = gl_mul(pr, gl_sub(limb, x));
+          emit(pr);
+          if (j < 16) clo = gl_add(gl_mul_small(clo, 4), limb); else chi = gl_add(gl_mul_small(chi, 4), limb);
+        }
+        emit(gl_sub(clo, lo));
+        emit(gl_sub(chi, hi));
+      }
+      break;
+    }
+    case MP2G_GATE_U32_RANGE_CHECK: {
+      const u32 k = g.p0;
+      for (u32 i = 0; i < k; i++) {
+        u64 acc = 0;
+        for (u32 j = 16; j-- > 0;) acc = gl_add(gl_mul_small(acc, 4), wire(k + 16 * i + j));
+        emit(gl_sub(acc, wire(i)));
+        for (u32 j = 0; j < 16; j++) {
+          const u64 limb = wire(k + 16 * i + j);
+          u64 pr = limb;
+          for (u32 x = 1; x < 4; x++) pr = gl_mul(pr, gl_sub(limb, x));
+          emit(pr);
+        }
+      }
+      break;
+    }
+    case MP2G_GATE_U32_SUBTRACTION: {
+      const u32 ops = g.p0;
+      for (u32 i = 0; i < ops; i++) {
+        const u32 b = 5 * i;
+        const u64 initial = gl_sub(gl_sub(wire(b), wire(b + 1)), wire(b + 2));
+        const u64 res = wire(b + 3), bo = wire(b + 4);
+        emit(gl_sub(res, gl_add(initial, gl_mul((u64)1 << 32, bo))));
+        u64 comb = 0;
+        for (u32 j = 16; j-- > 0;) {
+          const u64 limb = wire(5 * ops + 16 * i + j);
+          u64 pr = limb;
+          for (u32 x = 1; x < 4; x++) pr = gl_mul(pr, gl_sub(limb, x));
+          emit(pr);
+          comb = gl_add(gl_mul_small(comb, 4), limb);
+        }
+        emit(gl_sub(comb, res));
+        emit(gl_mul(bo, gl_sub(1, bo)));
+      }
+      break;
+    }
+    case MP2G_GATE_U32_ADD_MANY: {
+      const u32 na = g.p0, ops = g.p1, per = na + 3;
+      for (u32 i = 0; i < ops; i++) {
+        const u32 b = per * i;
+        u64 computed = wire(b + na);
+        for (u32 j = 0; j < na; j++) computed = gl_add(computed, wire(b + j));
+        const u64 res = wire(b + na + 1), co = wire(b + na + 2);
+        emit(gl_sub(gl_add(gl_mul(co, (u64)1 << 32), res), computed));
+        u64 cres = 0, ccar = 0;
+        for (u32 j = 18; j-- > 0;) {
+          const u64 limb = wire(per * ops + 18 * i + j);
+          u64 pr = limb;
+          for (u32 x = 1; x < 4; x++) pr = gl_mul(pr, gl_sub(limb, x));
+          emit(pr);
+          if (j < 16) cres = gl_add(gl_mul_small(cres, 4), limb); else ccar = gl_add(gl_mul_small(ccar, 4), limb);
+        }
+        emit(gl_sub(cres, res));
+        emit(gl_sub(ccar, co));
+      }
+      break;
+    }
+    case MP2G_GATE_COMPARISON: {
+      // plonky2-u32 comparison.rs: first <= second over p0 bits in p1 chunks
+      const u32 nch = g.p1, cb = (g.p0 + nch - 1) / nch, cs = 1u << cb;
+      const u32 o_fc = 4, o_sc = 4 + nch, o_ed = 4 + 2 * nch, o_ce = 4 + 3 * nch, o_iv = 4 + 4 * nch, o_bits = 4 + 5 * nch;
+      u64 a1 = 0, a2 = 0;
+      for (u32 i = nch; i-- > 0;) { a1 = gl_add(gl_mul_small(a1, cs), wire(o_fc + i)); a2 = gl_add(gl_mul_small(a2, cs), wire(o_sc + i)); }
+      emit(gl_sub(a1, wire(0)));
+      emit(gl_sub(a2, wire(1)));
+      u64 msd = 0;
+      for (u32 i = 0; i < nch; i++) {
+        const u64 f = wire(o_fc + i), sc = wire(o_sc + i), ce = wire(o_ce + i), iv = wire(o_iv + i);
+        u64 p1 = f, p2 = sc;
+        for (u32 x = 1; x < cs; x++) { p1 = gl_mul(p1, gl_sub(f, x)); p2 = gl_mul(p2, gl_sub(sc, x)); }
+        emit(p1);
+        emit(p2);
+        const u64 diff = gl_sub(sc, f);
+        emit(gl_sub(gl_mul(diff, wire(o_ed + i)), gl_sub(1, ce)));
+        emit(gl_mul(ce, diff));
+        emit(gl_sub(iv, gl_mul(ce, msd)));
+        msd = gl_add(iv, gl_mul(gl_sub(1, ce), diff));
+      }
+      const u64 msd_w = wire(3);
+      emit(gl_sub(msd_w, msd));
+      u64 bc = 0;
+      for (u32 i = cb + 1; i-- > 0;) bc = gl_add(gl_add(bc, bc), wire(o_bits + i));
+      for (u32 i = 0; i <= cb; i++) { const u64 bit = wire(o_bits + i); emit(gl_mul(bit, gl_sub(1, bit))); }
+      emit(gl_sub(gl_add(cs, msd_w), bc));
+      emit(gl_sub(wire(2), wire(o_bits + cb)));
+      break;
+    }
     case MP2G_GATE_EXPONENTIATION: {
       const u32 nb = g.p0;
       const u64 base = wire(0);
@@ -514,6 +641,11 @@ hipError_t gate_constraints_lde(hipStream_t s, u32 B, const GateTable& t, const 
       GATE_CASE(MP2G_GATE_POSEIDON)
       GATE_CASE(MP2G_GATE_POSEIDON_MDS)
       GATE_CASE(MP2G_GATE_COSET_INTERPOLATION)
+      GATE_CASE(MP2G_GATE_U32_ARITHMETIC)
+      GATE_CASE(MP2G_GATE_U32_RANGE_CHECK)
+      GATE_CASE(MP2G_GATE_U32_SUBTRACTION)
+      GATE_CASE(MP2G_GATE_U32_ADD_MANY)
+      GATE_CASE(MP2G_GATE_COMPARISON)
       default: return hipErrorInvalidValue;
     }
 #undef GATE_CASE

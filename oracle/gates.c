@@ -59,6 +59,11 @@ unsigned orc_gate_num_constraints(const orc_gate* g) {
     case ORC_GATE_POSEIDON2: case ORC_GATE_POSEIDON: return 1 + 4 + 36 + 22 + 48 + 12;
     case ORC_GATE_POSEIDON_MDS: return 24;
     case ORC_GATE_COSET_INTERPOLATION: return 4 + 4 * (((1u << g->p0) - 2) / (g->p1 - 1));
+    case ORC_GATE_U32_ARITHMETIC: return 36 * g->p0;
+    case ORC_GATE_U32_RANGE_CHECK: return 17 * g->p0;
+    case ORC_GATE_U32_SUBTRACTION: return 19 * g->p0;
+    case ORC_GATE_U32_ADD_MANY: return 21 * g->p1;
+    case ORC_GATE_COMPARISON: return 6 + 5 * g->p1 + (g->p0 + g->p1 - 1) / g->p1;
     case ORC_GATE_EXPONENTIATION: return g->p0 + 1;
     case ORC_GATE_REDUCING: case ORC_GATE_REDUCING_EXT: return 2 * g->p0;
     case ORC_GATE_RANDOM_ACCESS: return (g->p0 + 2) * g->p1 + g->p2;
@@ -74,6 +79,8 @@ unsigned orc_gate_degree(const orc_gate* g) {
     case ORC_GATE_POSEIDON2: case ORC_GATE_POSEIDON: return 7;
     case ORC_GATE_POSEIDON_MDS: return 1;
     case ORC_GATE_COSET_INTERPOLATION: return g->p1;
+    case ORC_GATE_U32_ARITHMETIC: case ORC_GATE_U32_RANGE_CHECK: case ORC_GATE_U32_SUBTRACTION: case ORC_GATE_U32_ADD_MANY: return 4;
+    case ORC_GATE_COMPARISON: return 1u << ((g->p0 + g->p1 - 1) / g->p1);
     case ORC_GATE_EXPONENTIATION: return 4;
     case ORC_GATE_REDUCING: case ORC_GATE_REDUCING_EXT: return 2;
     case ORC_GATE_RANDOM_ACCESS: return g->p0 + 1;

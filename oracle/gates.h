@@ -20,6 +20,11 @@ enum {
   ORC_GATE_POSEIDON = 12,
   ORC_GATE_POSEIDON_MDS = 13,
   ORC_GATE_COSET_INTERPOLATION = 14,  // p0 = subgroup_bits (<= 5), p1 = degree
+  ORC_GATE_U32_ARITHMETIC = 15,       // p0 = num_ops
+  ORC_GATE_U32_RANGE_CHECK = 16,      // p0 = num_input_limbs
+  ORC_GATE_U32_SUBTRACTION = 17,      // p0 = num_ops
+  ORC_GATE_U32_ADD_MANY = 18,         // p0 = num_addends, p1 = num_ops
+  ORC_GATE_COMPARISON = 19,           // p0 = num_bits, p1 = num_chunks
 };
 #define ORC_MAX_GATE_CONSTRAINTS 160
 typedef struct {

@@ -15,7 +15,8 @@ import oracle as O
 
 P = O.P
 (NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, BASE_SUM, ARITHMETIC_EXT, MUL_EXT, POSEIDON2, EXPONENTIATION, REDUCING, REDUCING_EXT,
- RANDOM_ACCESS, POSEIDON, POSEIDON_MDS, COSET_INTERPOLATION) = range(15)
+ RANDOM_ACCESS, POSEIDON, POSEIDON_MDS, COSET_INTERPOLATION, U32_ARITHMETIC, U32_RANGE_CHECK, U32_SUBTRACTION, U32_ADD_MANY,
+ COMPARISON) = range(20)
 UNUSED_SELECTOR = 0xFFFFFFFF
 NUM_WIRES, NUM_ROUTED, MAX_DEGREE = 135, 80, 8
 
@@ -28,7 +29,9 @@ class Gate(ctypes.Structure):
 def gate_degree(g):
     """Gate::degree()"""
     return {NOOP: 0, CONSTANT: 1, PUBLIC_INPUT: 1, ARITHMETIC: 3, BASE_SUM: g.p1, ARITHMETIC_EXT: 3, MUL_EXT: 3, POSEIDON2: 7,
-            EXPONENTIATION: 4, REDUCING: 2, REDUCING_EXT: 2, RANDOM_ACCESS: g.p0 + 1, POSEIDON: 7, POSEIDON_MDS: 1, COSET_INTERPOLATION: g.p1}[g.kind]
+            EXPONENTIATION: 4, REDUCING: 2, REDUCING_EXT: 2, RANDOM_ACCESS: g.p0 + 1, POSEIDON: 7, POSEIDON_MDS: 1, COSET_INTERPOLATION: g.p1,
+            U32_ARITHMETIC: 4, U32_RANGE_CHECK: 4, U32_SUBTRACTION: 4, U32_ADD_MANY: 4,
+            COMPARISON: 1 << ((g.p0 + max(g.p1, 1) - 1) // max(g.p1, 1))}[g.kind]
 
 
 def gate_num_constraints(g):
@@ -36,7 +39,9 @@ def gate_num_constraints(g):
     return {NOOP: 0, CONSTANT: g.p0, PUBLIC_INPUT: 4, ARITHMETIC: g.p0, BASE_SUM: 1 + g.p0, ARITHMETIC_EXT: 2 * g.p0, MUL_EXT: 2 * g.p0,
             POSEIDON2: 123, EXPONENTIATION: g.p0 + 1, REDUCING: 2 * g.p0, REDUCING_EXT: 2 * g.p0,
             RANDOM_ACCESS: (g.p0 + 2) * g.p1 + g.p2, POSEIDON: 123, POSEIDON_MDS: 24,
-            COSET_INTERPOLATION: 4 + 4 * (((1 << g.p0) - 2) // max(g.p1 - 1, 1))}[g.kind]
+            COSET_INTERPOLATION: 4 + 4 * (((1 << g.p0) - 2) // max(g.p1 - 1, 1)),
+            U32_ARITHMETIC: 36 * g.p0, U32_RANGE_CHECK: 17 * g.p0, U32_SUBTRACTION: 19 * g.p0, U32_ADD_MANY: 21 * g.p1,
+            COMPARISON: 6 + 5 * g.p1 + (g.p0 + max(g.p1, 1) - 1) // max(g.p1, 1)}[g.kind]
 
 
 _consts = None
@@ -221,6 +226,76 @@ def fill_row(g, w, consts, inp, rng, pi_hash):
             start = 1 + (deg - 1) * (c + 1)
             end = min(start + deg - 1, npts)
         w[w_val], w[w_val + 1] = ev
+    elif k == U32_ARITHMETIC:
+        ops = g.p0
+        for i in range(ops):
+            b = 6 * i
+            # u32 operands (a copied cell may hold a field element: reduce it so the row stays a valid u32 op)
+            m0, m1, ad = [int(rng.integers(0, 1 << 32)) for _ in range(3)]
+            if i == 0 and rng.random() < 0.5:
+                m0 = m1 = ad = (1 << 32) - 1  # largest product: output_high = 2^32 - 1, output_low = 0 ... exercised below
+            out = m0 * m1 + ad
+            lo, hi = out & 0xFFFFFFFF, out >> 32
+            w[b:b + 5] = [m0, m1, ad, lo, hi]
+            diff = (0xFFFFFFFF - hi) % P
+            w[b + 5] = pow(diff, P - 2, P) if diff else rnd()
+            for j in range(32):
+                w[6 * ops + 32 * i + j] = (out >> (2 * j)) & 3
+    elif k == U32_RANGE_CHECK:
+        kk = g.p0
+        for i in range(kk):
+            v = int(rng.integers(0, 1 << 32))
+            w[i] = v
+            for j in range(16):
+                w[kk + 16 * i + j] = (v >> (2 * j)) & 3
+    elif k == U32_SUBTRACTION:
+        ops = g.p0
+        for i in range(ops):
+            x, y, bi = int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32)), int(rng.integers(0, 2))
+            r = x - y - bi
+            bo = 1 if r < 0 else 0
+            r += bo << 32
+            w[5 * i:5 * i + 5] = [x, y, bi, r, bo]
+            for j in range(16):
+                w[5 * ops + 16 * i + j] = (r >> (2 * j)) & 3
+    elif k == U32_ADD_MANY:
+        na, ops = g.p0, g.p1
+        per = na + 3
+        for i in range(ops):
+            adds = [int(rng.integers(0, 1 << 32)) for _ in range(na)]
+            ci = int(rng.integers(0, 1 << 4))
+            tot = sum(adds) + ci
+            res, co = tot & 0xFFFFFFFF, tot >> 32
+            w[per * i:per * i + per] = adds + [ci, res, co]
+            for j in range(16):
+                w[per * ops + 18 * i + j] = (res >> (2 * j)) & 3
+            for j in range(2):
+                w[per * ops + 18 * i + 16 + j] = (co >> (2 * j)) & 3
+    elif k == COMPARISON:
+        nb, nch = g.p0, g.p1
+        cb = (nb + nch - 1) // nch
+        cs = 1 << cb
+        a, b = int(rng.integers(0, 1 << nb, dtype=np.uint64)), int(rng.integers(0, 1 << nb, dtype=np.uint64))
+        if rng.random() < 0.3:
+            b = a
+        w[0], w[1] = a, b
+        fc = [(a >> (cb * i)) & (cs - 1) for i in range(nch)]
+        sc = [(b >> (cb * i)) & (cs - 1) for i in range(nch)]
+        msd = 0
+        for i in range(nch):
+            diff = (sc[i] - fc[i]) % P
+            eq = 1 if diff == 0 else 0
+            w[4 + i], w[4 + nch + i] = fc[i], sc[i]
+            w[4 + 2 * nch + i] = rnd() if eq else pow(diff, P - 2, P)  # equality dummy: inverse of the difference
+            w[4 + 3 * nch + i] = eq
+            iv = eq * msd % P
+            w[4 + 4 * nch + i] = iv
+            msd = (iv + (1 - eq) * diff) % P
+        w[3] = msd
+        val = (cs + msd) % P  # 2^chunk_bits + most significant difference, in [1, 2^(cb+1))
+        for i in range(cb + 1):
+            w[4 + 5 * nch + i] = (val >> i) & 1
+        w[2] = (val >> cb) & 1
     elif k == EXPONENTIATION:
         nb = g.p0
         base = inp(0)
@@ -366,7 +441,21 @@ def build(log_n, kinds, seed, copy_prob=0.35):
 ALL_KINDS = [(NOOP, 0, 0, 0), (CONSTANT, 2, 0, 0), (PUBLIC_INPUT, 0, 0, 0), (ARITHMETIC, 20, 0, 0), (BASE_SUM, 63, 2, 0),
              (BASE_SUM, 20, 4, 0), (ARITHMETIC_EXT, 10, 0, 0), (MUL_EXT, 13, 0, 0), (POSEIDON2, 0, 0, 0),
              (EXPONENTIATION, 66, 0, 0), (REDUCING, 43, 0, 0), (REDUCING_EXT, 32, 0, 0), (RANDOM_ACCESS, 4, 4, 2),
-             (POSEIDON, 0, 0, 0), (POSEIDON_MDS, 0, 0, 0), (COSET_INTERPOLATION, 4, coset_interpolation_degree(4), 0)]
+             (POSEIDON, 0, 0, 0), (POSEIDON_MDS, 0, 0, 0), (COSET_INTERPOLATION, 4, coset_interpolation_degree(4), 0),
+             (U32_ARITHMETIC, 3, 0, 0), (U32_RANGE_CHECK, 7, 0, 0), (U32_SUBTRACTION, 6, 0, 0), (U32_ADD_MANY, 3, 5, 0),
+             (COMPARISON, 32, 16, 0)]
+
+
+# Gate sets as the reference composes its circuits. A wrap circuit (recursion-framework/src/universal_verifier_gadget/
+# wrap_circuit.rs) is plonky2's recursive verifier and nothing else; a leaf circuit of the table build (cells / rows tree,
+# values extraction) adds the user logic: u32 / u256 arithmetic and comparisons next to the verifier gadget. Poseidon
+# (original) and PoseidonMds only occur under the Poseidon config of the final wrap (verifiable-db/src/api.rs:148).
+VERIFIER_KINDS = [(NOOP, 0, 0, 0), (CONSTANT, 2, 0, 0), (PUBLIC_INPUT, 0, 0, 0), (ARITHMETIC, 20, 0, 0), (BASE_SUM, 63, 2, 0),
+                  (ARITHMETIC_EXT, 10, 0, 0), (MUL_EXT, 13, 0, 0), (POSEIDON2, 0, 0, 0), (EXPONENTIATION, 66, 0, 0),
+                  (REDUCING, 43, 0, 0), (REDUCING_EXT, 32, 0, 0), (RANDOM_ACCESS, 4, 4, 2),
+                  (COSET_INTERPOLATION, 4, coset_interpolation_degree(4), 0)]
+LEAF_KINDS = VERIFIER_KINDS + [(BASE_SUM, 20, 4, 0), (U32_ARITHMETIC, 3, 0, 0), (U32_RANGE_CHECK, 7, 0, 0), (U32_SUBTRACTION, 6, 0, 0),
+                               (U32_ADD_MANY, 3, 5, 0), (COMPARISON, 32, 16, 0)]
 
 
 def eval_on_points(ckt, consts, wires):

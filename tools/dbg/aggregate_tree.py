@@ -11,7 +11,7 @@ import oracle as O  # rand_field only
 mp2 = importlib.import_module("mapreduce-plonky2_amd")
 n_leaves = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-KINDS = [k for k in C.ALL_KINDS if k[0] != C.PUBLIC_INPUT]  # public inputs enter through the hash only
+KINDS = [k for k in C.VERIFIER_KINDS if k[0] != C.PUBLIC_INPUT]  # aggregation nodes are verifier circuits; public inputs enter through the hash only
 ctxs = {13: mp2.Context(0), 12: mp2.Context(0)}  # base and wrap on their own streams
 ckts = {k: C.build(k, KINDS, 0xC0FFEE03 + k) for k in (13, 12)}
 fps = {k: mp2.standard_recursion_params(k, (ckts[k].num_constants + 80, 135, 20, 16)) for k in (13, 12)}
