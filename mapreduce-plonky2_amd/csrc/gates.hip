@@ -126,6 +126,8 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
   // state limb + round constant - wire
   auto diff = [](u64 s, u64 rc, u64 in) { return WEAK ? gl_subw(gl_addw(s, rc), in) : gl_sub(gl_add(gl_canon(s), rc), in); };
   auto diff0 = [](u64 s, u64 in) { return WEAK ? gl_subw(s, in) : gl_sub(gl_canon(s), in); };
+  // product that only feeds further products or emit(): a weak representative is enough there
+  auto mulx = [](u64 a, u64 b) { return WEAK ? gl_mulw(a, b) : gl_mul(a, b); };
   switch (g.kind) {
     case MP2G_GATE_CONSTANT:
       for (u32 i = 0; i < g.p0; i++) emit(gl_sub(cst(i), wire(i)));
@@ -148,7 +150,7 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
       for (u32 i = 0; i < g.p0; i++) {
         const u64 limb = wire(1 + i);
         u64 pr = limb;  // k = 0 factor
-        for (u32 k = 1; k < g.p1; k++) pr = gl_mul(pr, gl_sub(limb, k));
+        for (u32 k = 1; k < g.p1; k++) pr = mulx(pr, gl_sub(limb, k));
         emit(pr);
       }
       break;
@@ -331,7 +333,7 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         for (u32 j = 32; j-- > 0;) {
           const u64 limb = wire(6 * ops + 32 * i + j);
           u64 pr = limb;
-          for (u32 x = 1; x < 4; x++) pr = gl_mul(pr, gl_sub(limb, x));
+          for (u32 x = 1; x < 4; x++) pr = mulx(pr, gl_sub(limb, x));
           emit(pr);
           if (j < 16) clo = gl_add(gl_mul_small(clo, 4), limb); else chi = gl_add(gl_mul_small(chi, 4), limb);
         }
@@ -349,7 +351,7 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         for (u32 j = 0; j < 16; j++) {
           const u64 limb = wire(k + 16 * i + j);
           u64 pr = limb;
-          for (u32 x = 1; x < 4; x++) pr = gl_mul(pr, gl_sub(limb, x));
+          for (u32 x = 1; x < 4; x++) pr = mulx(pr, gl_sub(limb, x));
           emit(pr);
         }
       }
@@ -366,7 +368,7 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         for (u32 j = 16; j-- > 0;) {
           const u64 limb = wire(5 * ops + 16 * i + j);
           u64 pr = limb;
-          for (u32 x = 1; x < 4; x++) pr = gl_mul(pr, gl_sub(limb, x));
+          for (u32 x = 1; x < 4; x++) pr = mulx(pr, gl_sub(limb, x));
           emit(pr);
           comb = gl_add(gl_mul_small(comb, 4), limb);
         }
@@ -387,7 +389,7 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         for (u32 j = 18; j-- > 0;) {
           const u64 limb = wire(per * ops + 18 * i + j);
           u64 pr = limb;
-          for (u32 x = 1; x < 4; x++) pr = gl_mul(pr, gl_sub(limb, x));
+          for (u32 x = 1; x < 4; x++) pr = mulx(pr, gl_sub(limb, x));
           emit(pr);
           if (j < 16) cres = gl_add(gl_mul_small(cres, 4), limb); else ccar = gl_add(gl_mul_small(ccar, 4), limb);
         }
@@ -408,7 +410,7 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
       for (u32 i = 0; i < nch; i++) {
         const u64 f = wire(o_fc + i), sc = wire(o_sc + i), ce = wire(o_ce + i), iv = wire(o_iv + i);
         u64 p1 = f, p2 = sc;
-        for (u32 x = 1; x < cs; x++) { p1 = gl_mul(p1, gl_sub(f, x)); p2 = gl_mul(p2, gl_sub(sc, x)); }
+        for (u32 x = 1; x < cs; x++) { p1 = mulx(p1, gl_sub(f, x)); p2 = mulx(p2, gl_sub(sc, x)); }
         emit(p1);
         emit(p2);
         const u64 diff = gl_sub(sc, f);
