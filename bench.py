@@ -287,7 +287,7 @@ def main():
         ntt_s = float(np.median(ntt_ms)) / 1e3
         achieved = 16.0 * n_ntt / ntt_s / 1e9
         out = {
-            "metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak",
+            "metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build, 1/2/4/8 GPU",
             "value": world * args.steps * B / dt,
             "unit": "leaf proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
