@@ -224,6 +224,18 @@ def main():
     ntt12_ms = ctx.timer_stop()
     d_b12.free()
 
+    # the sponge, the kernel that takes half of a step: 2^21 leaves of 136 limbs (17 permutations each), the rate
+    # of the instruction-bound Poseidon2 permutation; reported beside the roofline leg
+    n_hash, limbs = 1 << 21, 136
+    d_hin = ctx.alloc(n_hash * limbs * 8)
+    d_hout = ctx.alloc(n_hash * 4 * 8)
+    hargs = (ctx.h, 0, d_hin.ptr, limbs, n_hash, 4, d_hout.ptr)
+    mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
+    ctx.timer_start()
+    mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
+    hash_ms = ctx.timer_stop()
+    d_hin.free(); d_hout.free()
+
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -308,6 +320,8 @@ def main():
                          "launch_ms": ntt_s * 1e3, "algorithmic_bytes": 16 * n_ntt},
             "ntt_batched_2p12": {"transforms": nb12, "GBps": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9,
                                  "frac_of_hbm_peak": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9 / HBM_PEAK_GBPS},
+            "poseidon2_sponge": {"permutations_per_s": n_hash * (limbs // 8) / (hash_ms / 1e3), "bound": "VALU issue (integer ALU)",
+                                 "input": f"{n_hash} x {limbs} limbs, hash_no_pad, resident"},
             "stage_ms": stages,
             "clocks": gpu_clocks(local_rank),
             "digest_rows_per_s": rows / digest_s,
