@@ -11,10 +11,13 @@
 //     dimension for a tile of 2^LC adjacent columns (>= 32..128 B contiguous per row), multiplies
 //     by w_n^(i2*k1) (streamed from a precomputed table: one multiply per point) and leaves row j
 //     in DIF order; pass B transforms contiguous rows in place.
-//   * inside a block every lane keeps 8 points in registers (radix-8 = three DIF stages) between
-//     LDS exchanges -- radix-16 halves the LDS round trips but also the waves per tile and measured
-//     15 % slower; LDS indices are padded by 1/16 so the strided rounds are bank-conflict free;
-//     twiddles for the inner DFT are staged in LDS once per block.
+//   * inside a block every lane keeps 8 points in registers between LDS exchanges and runs a true radix-8
+//     DIF butterfly on them: the twiddles inside the 8-point DFT are powers of w_8 = 2^24 (plonky2's
+//     POWER_OF_TWO_GENERATOR gives w_64 = 8), i.e. shifts plus a short reduction instead of general
+//     multiplications, and the 7 general twiddles w^(E r) are applied once per output; the last round
+//     has no general twiddle at all. (radix-16 halves the LDS round trips but also the waves per tile
+//     and measured 15 % slower.) LDS indices are padded by 1/16 so the strided rounds are bank-conflict
+//     free; the twiddles of all rounds but the first are staged in LDS once per block.
 //   * LDE: the 2^r cosets of the blown-up domain are 2^r independent size-n transforms of the
 //     same coefficients scaled by (g w_{N}^j)^i; outputs land bit-reversed, i.e. already in
 //     Merkle-leaf order, so there is no separate transpose / bit-reverse pass.
@@ -40,6 +43,7 @@ struct NttArgs {
   const u64* pre_full;   // [K][n]: s_j^i; null -> pre_lo * pre_hi
   u64 post;              // scalar multiplied on the final store (n^-1 for inverse), 0 = none
   u32 bitrev_out;
+  u32 inverse;           // tables hold powers of the inverse root: the w_8 constants inside a butterfly follow
 };
 
 // lanes per block: one radix-2^NTT_RMAX item per lane and round
@@ -50,21 +54,41 @@ template <int LT, int LW> struct NttGeom {
   static constexpr int E = (1 << LT) << LW;
   static constexpr int NT = (E >> NTT_RMAX) < 64 ? 64 : ((E >> NTT_RMAX) > 1024 ? 1024 : (E >> NTT_RMAX));
 };
-// Twiddles of the inner DFT are stored stage-compact: stage s (butterflies on bit LT-1-s) uses
-// w_T^(v << s), v < 2^(LT-1-s), kept contiguously at offset 2^LT - 2^(LT-s). Lanes of a wave walk
-// consecutive v, so both the LDS copy (stages >= TWS) and the global table (first TWS stages, through
-// L1) are read conflict-free / coalesced; a single strided w_T^k table cost up to 32-way LDS bank
-// conflicts in the later stages (SQ_LDS_BANK_CONFLICT was 0.5-0.67 of SQ_LDS_IDX_ACTIVE).
-// TWS keeps the LDS footprint at 8192 points + 8 KB (T = 2^11) and 4096 points + 4 KB (T = 2^12).
-template <int LT> struct NttTw {
-  static constexpr int TWS = LT >= 12 ? 3 : (LT == 11 ? 1 : 0);
-  static constexpr int off(int s) { return (1 << LT) - (1 << (LT - s)); }
-  static constexpr int LDS_WORDS = (1 << (LT - TWS)) - 1;  // stages TWS .. LT-1
+// Twiddles of the inner DFT, one table per radix-8 round. Round rho works on index bits HI = LT-1-3 rho
+// .. HI-2 of the transform; a lane's 8 points share the low bits `below` (< 2^LO, LO = HI-2), and output m
+// of its butterfly needs w_T^(E r), E = below << (3 rho), r = bitrev3(m) = 1..7. Table rho holds
+// [r-1][below] at offset off(rho); rounds with LO = 0 (the last one) need none. Lanes of a wave walk
+// consecutive `below`, so both the LDS copy and the global table of round 0 (read through L1 for
+// T >= 2^11, where LDS is needed for the points) are conflict-free / coalesced.
+template <int LT> struct R8Tw {
+  static constexpr int lo(int rho) { return LT - 3 - 3 * rho; }
+  static constexpr int n_tables() { int r = 0; while (lo(r) >= 1) r++; return r; }
+  static constexpr int off(int rho) { int o = 0; for (int q = 0; q < rho; q++) o += 7 << lo(q); return o; }
+  static constexpr int TOTAL = off(n_tables());
+  static constexpr int GLOBAL_ROUNDS = (LT >= 11 && n_tables() >= 1) ? 1 : 0;
+  static constexpr int LDS_OFF = off(GLOBAL_ROUNDS);
+  static constexpr int LDS_WORDS = TOTAL - LDS_OFF;
 };
+// x * 2^24, 2^48, 2^72 (= w_8, w_8^2, w_8^3), canonical in and out
+__device__ __forceinline__ u64 gl_mul_2p24(u64 x) { return gl_canon(gl_reduce96w(x << 24, x >> 40)); }
+__device__ __forceinline__ u64 gl_mul_2p48(u64 x) { return gl_reduce128(x << 48, x >> 16); }
+__device__ __forceinline__ u64 gl_mul_2p72(u64 x) {
+  // x 2^72 = (x << 8) 2^64 with x << 8 = t_hi 2^64 + t_lo, and 2^128 = -2^32 (mod p)
+  return gl_sub(gl_reduce128(0, x << 8), (x >> 56) << 32);
+}
+template <int K> __device__ __forceinline__ u64 gl_mul_w8(u64 x) {  // x * w_8^K, K = 1..3
+  return K == 1 ? gl_mul_2p24(x) : (K == 2 ? gl_mul_2p48(x) : gl_mul_2p72(x));
+}
+// (u - v) * w_8^K for the forward transform, (u - v) * w_8^-K = (v - u) * w_8^(4-K) for the inverse (w_8^4 = -1)
+template <int K> __device__ __forceinline__ u64 bfly_lo(u64 u, u64 v, bool inverse) {
+  return inverse ? gl_mul_w8<4 - K>(gl_sub(v, u)) : gl_mul_w8<K>(gl_sub(u, v));
+}
 template <int LT, int HI, int R, bool COLS, int LW, int NTT_THREADS>
-__device__ __forceinline__ void dif_round(u64* s, const u64* tw, const u64* __restrict__ twg, int tid) {
+__device__ __forceinline__ void dif_round(u64* s, const u64* tw, const u64* __restrict__ twg, int tid, bool inverse) {
   constexpr int T = 1 << LT, LO = HI - R + 1, W = 1 << LW;
   constexpr int ITEMS = W << (LT - R);
+  constexpr int RHO = (LT - 1 - HI) / 3;
+  static_assert(R == 3 || LO == 0, "a partial round can only be the last one");
   for (int item = tid; item < ITEMS; item += NTT_THREADS) {
     int c, rest;
     if (COLS) { c = item & (W - 1); rest = item >> LW; }
@@ -77,27 +101,38 @@ __device__ __forceinline__ void dif_round(u64* s, const u64* tw, const u64* __re
       int j = j0 + (m << LO);
       x[m] = s[lds_pad(COLS ? (j << LW) + c : (c << LT) + j)];
     }
+    if constexpr (R == 3) {
+      // stage 0: pairs (m, m + 4), lower output times w_8^m
+      { u64 u = x[0], v = x[4]; x[0] = gl_add(u, v); x[4] = gl_sub(u, v); }
+      { u64 u = x[1], v = x[5]; x[1] = gl_add(u, v); x[5] = bfly_lo<1>(u, v, inverse); }
+      { u64 u = x[2], v = x[6]; x[2] = gl_add(u, v); x[6] = bfly_lo<2>(u, v, inverse); }
+      { u64 u = x[3], v = x[7]; x[3] = gl_add(u, v); x[7] = bfly_lo<3>(u, v, inverse); }
+      // stage 1: pairs (m, m + 2) inside each half, lower output times w_4^(m & 1)
 #pragma unroll
-    for (int t = 0; t < R; t++) {
-      constexpr int dummy = 0; (void)dummy;
-      const int half = 1 << (R - 1 - t);
-      const int b = HI - t;  // bit of j handled by this stage
-#pragma unroll
-      for (int m = 0; m < (1 << R); m++) {
-        if (m & half) continue;
-        int m_low = m & (half - 1);
-        u64 u = x[m], v = x[m + half];
-        x[m] = gl_add(u, v);
-        u64 d = gl_sub(u, v);
-        if (b > 0) {
-          constexpr int dummy2 = 0; (void)dummy2;
-          const int st = LT - 1 - b;  // stage index
-          const int v = (m_low << LO) + below;
-          u64 w = st >= NttTw<LT>::TWS ? tw[NttTw<LT>::off(st) - NttTw<LT>::off(NttTw<LT>::TWS) + v] : twg[NttTw<LT>::off(st) + v];
-          d = gl_mul(d, w);
-        }
-        x[m + half] = d;
+      for (int h = 0; h < 8; h += 4) {
+        { u64 u = x[h], v = x[h + 2]; x[h] = gl_add(u, v); x[h + 2] = gl_sub(u, v); }
+        { u64 u = x[h + 1], v = x[h + 3]; x[h + 1] = gl_add(u, v); x[h + 3] = bfly_lo<2>(u, v, inverse); }
       }
+      // stage 2: pairs (m, m + 1)
+#pragma unroll
+      for (int m = 0; m < 8; m += 2) { u64 u = x[m], v = x[m + 1]; x[m] = gl_add(u, v); x[m + 1] = gl_sub(u, v); }
+      // general twiddles w^(E r), r = bitrev3(m)
+      if constexpr (LO > 0) {
+        const u64* tab = RHO < R8Tw<LT>::GLOBAL_ROUNDS ? twg + R8Tw<LT>::off(RHO) : tw + (R8Tw<LT>::off(RHO) - R8Tw<LT>::LDS_OFF);
+#pragma unroll
+        for (int m = 1; m < 8; m++) {
+          constexpr int dummy = 0; (void)dummy;
+          const int r = ((m & 1) << 2) | (m & 2) | (m >> 2);
+          x[m] = gl_mul(x[m], tab[((r - 1) << LO) + below]);
+        }
+      }
+    } else if constexpr (R == 2) {
+      { u64 u = x[0], v = x[2]; x[0] = gl_add(u, v); x[2] = gl_sub(u, v); }
+      { u64 u = x[1], v = x[3]; x[1] = gl_add(u, v); x[3] = bfly_lo<2>(u, v, inverse); }
+      { u64 u = x[0], v = x[1]; x[0] = gl_add(u, v); x[1] = gl_sub(u, v); }
+      { u64 u = x[2], v = x[3]; x[2] = gl_add(u, v); x[3] = gl_sub(u, v); }
+    } else {
+      u64 u = x[0], v = x[1]; x[0] = gl_add(u, v); x[1] = gl_sub(u, v);
     }
 #pragma unroll
     for (int m = 0; m < (1 << R); m++) {
@@ -107,12 +142,12 @@ __device__ __forceinline__ void dif_round(u64* s, const u64* tw, const u64* __re
   }
 }
 template <int LT, int HI, bool COLS, int LW, int NTT_THREADS>
-__device__ __forceinline__ void dif_all(u64* s, const u64* tw, const u64* __restrict__ twg, int tid) {
+__device__ __forceinline__ void dif_all(u64* s, const u64* tw, const u64* __restrict__ twg, int tid, bool inverse) {
   if constexpr (HI >= 0) {
-    constexpr int R = (HI + 1 >= NTT_RMAX) ? NTT_RMAX : HI + 1;
-    dif_round<LT, HI, R, COLS, LW, NTT_THREADS>(s, tw, twg, tid);
+    constexpr int R = (HI + 1 >= 3) ? 3 : HI + 1;
+    dif_round<LT, HI, R, COLS, LW, NTT_THREADS>(s, tw, twg, tid, inverse);
     __syncthreads();
-    dif_all<LT, HI - R, COLS, LW, NTT_THREADS>(s, tw, twg, tid);
+    dif_all<LT, HI - R, COLS, LW, NTT_THREADS>(s, tw, twg, tid, inverse);
   }
 }
 
@@ -136,7 +171,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_kernel(NttArgs
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < NttTw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[NttTw<LT>::off(NttTw<LT>::TWS) + i];
+  for (int i = tid; i < R8Tw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[R8Tw<LT>::LDS_OFF + i];
   const u32 n1 = 1u << a.log_n1;
   const u64 total_rows = (u64)a.batch << a.log_n1;
   const u64 row0 = (u64)blockIdx.x << LW;
@@ -157,7 +192,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_kernel(NttArgs
     s[lds_pad(e)] = v;
   }
   __syncthreads();
-  dif_all<LT, LT - 1, false, LW, NT>(s, tw, a.tw, tid);
+  dif_all<LT, LT - 1, false, LW, NT>(s, tw, a.tw, tid, a.inverse != 0);
   for (int e = tid; e < E; e += NT) {
     int r = e >> LT, p = e & (T - 1);
     u64 g = row0 + r;
@@ -178,7 +213,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_nat_kernel(Ntt
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < NttTw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[NttTw<LT>::off(NttTw<LT>::TWS) + i];
+  for (int i = tid; i < R8Tw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[R8Tw<LT>::LDS_OFF + i];
   const u32 lo_bits = a.log_n1 - LW;
   const u32 tile = blockIdx.x;
   const u32 b = tile >> lo_bits, jr_lo = tile & ((1u << lo_bits) - 1);
@@ -188,7 +223,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_nat_kernel(Ntt
     s[lds_pad(e)] = src[((u64)jr << LT) + (e & (T - 1))];
   }
   __syncthreads();
-  dif_all<LT, LT - 1, false, LW, NT>(s, tw, a.tw, tid);
+  dif_all<LT, LT - 1, false, LW, NT>(s, tw, a.tw, tid, a.inverse != 0);
   u64* dst = out_base(a, b);
   const u32 k1_hi = bitrev32(jr_lo, lo_bits) << LW;
   for (int e = tid; e < E; e += NT) {
@@ -208,7 +243,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
   const int tid = threadIdx.x;
-  for (int i = tid; i < NttTw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[NttTw<LT>::off(NttTw<LT>::TWS) + i];
+  for (int i = tid; i < R8Tw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[R8Tw<LT>::LDS_OFF + i];
   const u32 tiles_per = 1u << (a.log_n2 - LW);
   // XCD-aware order: blocks i and i+8 land on one XCD (round-robin dispatch, speed only), so give
   // each XCD a contiguous run of column tiles -- neighbouring tiles share 128-B lines and L2 sets
@@ -229,7 +264,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
     s[lds_pad(e)] = v;
   }
   __syncthreads();
-  dif_all<LT, LT - 1, true, LW, NT>(s, tw, a.tw, tid);
+  dif_all<LT, LT - 1, true, LW, NT>(s, tw, a.tw, tid, a.inverse != 0);
   // row j holds k1 = bitrev(j); multiply by w_n^(i2*k1) and leave it at row j
   u64* dst = dst_dense ? dst_dense + (u64)b * ((u64)1 << a.log_n) : out_base(a, b);
   for (int e = tid; e < E; e += NT) {
@@ -247,15 +282,12 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
   }
 }
 
-// out[2^lt - 2^(lt-s) + v] = w^(v << s) for s < lt, v < 2^(lt-1-s)   (stage-compact twiddles)
-__global__ void stage_twiddles_kernel(u64* out, u64 w, u32 lt) {
+// table of one radix-8 round: out[(r-1) << lo | below] = w^((below << shift) * r), r = 1..7, below < 2^lo
+__global__ void r8_round_twiddles_kernel(u64* out, u64 w, u32 lo, u32 shift) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i + 1 >= (1u << lt)) return;
-  // stage s covers offsets [2^lt - 2^(lt-s), 2^lt - 2^(lt-s-1)): s = number of leading ones of i in lt bits
-  u32 s = 0;
-  while (i >= (1u << lt) - (1u << (lt - s - 1))) s++;
-  u32 v = i - ((1u << lt) - (1u << (lt - s)));
-  out[i] = gl_pow(w, (u64)v << s);
+  if (i >= (7u << lo)) return;
+  u32 r = (i >> lo) + 1, below = i & ((1u << lo) - 1);
+  out[i] = gl_pow(w, ((u64)below << shift) * r);
 }
 __global__ void powers_kernel(u64* out, u64 base, u64 first, u64 stride_exp, u32 count) {
   // out[i] = first * base^(i * stride_exp)
@@ -323,11 +355,17 @@ hipError_t NttEngine::plan(u32 log_n, bool inverse, NttPlan** out) {
   };
   // inner DFT roots: w_{n2}^k (pass B) and w_{n1}^k (pass A)
   u64 w2 = gl_pow(wn, (u64)1 << p->log_n1), w1 = gl_pow(wn, (u64)1 << p->log_n2);
+  // per-round twiddle tables of the radix-8 butterflies (R8Tw): round rho has LO = lt-3-3 rho, E = below << 3 rho
   auto stage_tw = [&](u64** dst, u64 base, u32 lt) -> hipError_t {
-    u32 count = (1u << lt);
-    HIPCHK(dev_alloc(dst, count));
-    hipLaunchKernelGGL(stage_twiddles_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, *dst, base, lt);
-    return hipGetLastError();
+    HIPCHK(dev_alloc(dst, (size_t)1 << lt));
+    u32 off = 0;
+    for (u32 rho = 0; (int)lt - 3 - 3 * (int)rho >= 1; rho++) {
+      u32 lo = lt - 3 - 3 * rho, count = 7u << lo;
+      hipLaunchKernelGGL(r8_round_twiddles_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, *dst + off, base, lo, 3 * rho);
+      HIPCHK(hipGetLastError());
+      off += count;
+    }
+    return hipSuccess;
   };
   HIPCHK(stage_tw(&p->tw_b, w2, p->log_n2));
   if (p->log_n1) {
@@ -389,7 +427,7 @@ template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : (LT == 
 template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : 12 - LT; }
 template <int LT, int LW> static size_t lds_bytes() {
   int e = (1 << LT) << LW;
-  return (size_t)(e + (e >> 4) + 1 + NttTw<LT>::LDS_WORDS + 1) * sizeof(u64);
+  return (size_t)(e + (e >> 4) + 1 + R8Tw<LT>::LDS_WORDS + 1) * sizeof(u64);
 }
 
 template <int LT>
@@ -450,6 +488,7 @@ hipError_t NttEngine::run(const u64* in, u64* out, u32 log_n, u32 polys, u32 log
   a.pre_lo = pre ? pre->lo : nullptr; a.pre_hi = pre ? pre->hi : nullptr; a.pre_full = pre ? pre->full : nullptr;
   a.post = p->n_inv;
   a.bitrev_out = bitrev_out ? 1 : 0;
+  a.inverse = inverse ? 1 : 0;
   if (p->log_n1 == 0) {
     a.tw = p->tw_b;
     return dispatch_rows(p->log_n2, a, false, stream);

@@ -80,6 +80,10 @@ GLD u64 red_asm3(u64 lo, u64 hi) {
 }
 GLD u64 mulw_asm3(u64 a, u64 b) { u64 lo, hi; gl_mul_wide(a, b, lo, hi); return red_asm3(lo, hi); }
 
+GLD u64 m2p24(u64 x) { return gl_canon(gl_reduce96w(x << 24, x >> 40)); }
+GLD u64 m2p48(u64 x) { return gl_reduce128(x << 48, x >> 16); }
+GLD u64 m2p72(u64 x) { return gl_sub(gl_reduce128(0, x << 8), (x >> 56) << 32); }
+
 template <int OP>
 __global__ void __launch_bounds__(256) k(u64* out, u64 seed) {
   u64 a[8];
@@ -111,6 +115,10 @@ __global__ void __launch_bounds__(256) k(u64* out, u64 seed) {
       if (OP == 19) a[i] = red_asm(a[i], a[(i + 1) & 7]);
       if (OP == 20) a[i] = red_asm2(a[i], a[(i + 1) & 7]);
       if (OP == 21) a[i] = red_asm3(a[i], a[(i + 1) & 7]);
+      if (OP == 23) a[i] = m2p24(a[i]) ^ a[(i + 1) & 7];
+      if (OP == 24) a[i] = m2p48(a[i]) ^ a[(i + 1) & 7];
+      if (OP == 25) a[i] = m2p72(a[i]) ^ a[(i + 1) & 7];
+      if (OP == 26) a[i] = gl_canon(a[i] + a[(i + 1) & 7]);
       if (OP == 22) a[i] = mulw_asm3(a[i], a[(i + 1) & 7]);
     }
   }
@@ -166,11 +174,11 @@ int main() {
     u64 h = 1; hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
     printf("asm reduce mismatches: %llu\n", (unsigned long long)h);
   }
-  const char* names[] = {"gl_mul", "v_mad_u64_u32", "add64", "cmp+sel+add64", "mul_lo_u32", "mul_hi_u32", "gl_add", "add32", "gl_mul_small", "add_co+addc", "cmp32+sel", "mulw(64bit)", "mulw(32chain)", "mul_wide", "red(64bit)", "red(32chain)", "gl_sub", "gl_addw", "mulw(asm red)", "red(asm)", "red(asm2)", "red(asm3)", "mulw(asm3)"};
+  const char* names[] = {"gl_mul", "v_mad_u64_u32", "add64", "cmp+sel+add64", "mul_lo_u32", "mul_hi_u32", "gl_add", "add32", "gl_mul_small", "add_co+addc", "cmp32+sel", "mulw(64bit)", "mulw(32chain)", "mul_wide", "red(64bit)", "red(32chain)", "gl_sub", "gl_addw", "mulw(asm red)", "red(asm)", "red(asm2)", "red(asm3)", "mulw(asm3)", "mul 2^24", "mul 2^48", "mul 2^72", "gl_canon"};
   double ops = (double)blocks * threads * ITERS * 8;
 #define RUN(N) { float ms = timeit([&] { hipLaunchKernelGGL(k<N>, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull); }); \
     printf("%-14s %8.3f ms  %8.2f Gop/s (lane-ops)\n", names[N], ms, ops / ms / 1e6); }
-  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20) RUN(21) RUN(22)
+  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26)
   {
     int reps = 64;
     float ms = timeit([&] { hipLaunchKernelGGL(kperm, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull, reps); });
