@@ -65,7 +65,7 @@ def build_circuit(C, role, k):
     return C.build(k, C.LEAF_KINDS if role == "base" else C.VERIFIER_KINDS, SEED + k + (0 if role == "base" else 100))
 
 
-def cpu_baseline(base_bits, budget_s=15.0):
+def cpu_baseline(base_bits, budget_s=15.0, variant=0):
     """The CPU oracle (our restatement of the same pipeline; kind 'port'), OpenMP on all host cores, on a
     bounded sample of the same workload: whole leaf proofs until ~budget_s seconds are spent (1..6)."""
     import circuits as C
@@ -74,7 +74,7 @@ def cpu_baseline(base_bits, budget_s=15.0):
     shapes = []
     for role, k in (("base", base_bits), ("wrap", 12)):
         ckt = build_circuit(C, role, k)
-        shapes.append((O.standard_params(k, (ckt.pre.shape[0],) + ORACLE_W[1:]), ckt))
+        shapes.append((O.standard_params(k, (ckt.pre.shape[0],) + ORACLE_W[1:], variant=variant), ckt))
     cd = O.rand_field(4, 1)
     t_total, n_proofs = 0.0, 0
     while n_proofs < 6 and (n_proofs == 0 or t_total * (n_proofs + 1) / n_proofs < budget_s):
@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--host-inputs", action="store_true",
                     help="PCIe-inclusive variant: every step uploads its wire / quotient matrices from pinned host memory "
                          "on the prover's stream (never the headline value; see DESIGN.md)")
+    ap.add_argument("--hasher", choices=("poseidon2", "poseidon"), default="poseidon2",
+                    help="poseidon2 = the reference's default config (Poseidon2GoldilocksConfig); poseidon = its "
+                         "`original_poseidon` feature (mp2-common/src/lib.rs:37-40), the variant pinned against the reference")
     ap.add_argument("--witness-check", action="store_true",
                     help="also run the device-side witness check (gate + copy constraints on H) inside every prove, "
                          "as plonky2's prove() does before it panics on a bad witness")
@@ -123,6 +126,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    VARIANT = 0 if args.hasher == "poseidon2" else 1
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
     import circuits as C  # synthetic circuit + witness generator (pure Python)
@@ -153,7 +157,7 @@ def main():
             circuits[role] = build_circuit(C, role, k)
         ckt = circuits[role]
         oracle_w = (ckt.pre.shape[0],) + ORACLE_W[1:]
-        fp = mp2.standard_recursion_params(k, oracle_w)
+        fp = mp2.standard_recursion_params(k, oracle_w, variant=VARIANT)
         pr = mp2.BatchedProver(cx, fp, nb)
         pr.set_preprocessed(cx.to_device(ckt.pre))
         pr.enable_permutation(NUM_ROUTED, 8)  # Z / partial products on the device from wires + sigmas
@@ -229,7 +233,7 @@ def main():
     n_hash, limbs = 1 << 21, 136
     d_hin = ctx.alloc(n_hash * limbs * 8)
     d_hout = ctx.alloc(n_hash * 4 * 8)
-    hargs = (ctx.h, 0, d_hin.ptr, limbs, n_hash, 4, d_hout.ptr)
+    hargs = (ctx.h, VARIANT, d_hin.ptr, limbs, n_hash, 4, d_hout.ptr)
     mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
     ctx.timer_start()
     mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
@@ -312,7 +316,7 @@ def main():
                                    "gates of plonky2's recursive verifier; "
                                    "roofline leg = configs[1] 2^22-point NTT",
                        "batch_per_rank": B, "streams": args.streams, "witness_check": bool(args.witness_check), "host_inputs": bool(args.host_inputs), "oracle_polys": {r: [int(c.pre.shape[0])] + list(ORACLE_W[1:]) for r, c in circuits.items()},
-                       "gates": {r: len(c.gates) for r, c in circuits.items()}, "hasher": "Poseidon2",
+                       "gates": {r: len(c.gates) for r, c in circuits.items()}, "hasher": "Poseidon2" if VARIANT == 0 else "Poseidon (original_poseidon feature)",
                        "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B"},
             "roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, both launches)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -320,7 +324,7 @@ def main():
                          "launch_ms": ntt_s * 1e3, "algorithmic_bytes": 16 * n_ntt},
             "ntt_batched_2p12": {"transforms": nb12, "GBps": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9,
                                  "frac_of_hbm_peak": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9 / HBM_PEAK_GBPS},
-            "poseidon2_sponge": {"permutations_per_s": n_hash * (limbs // 8) / (hash_ms / 1e3), "bound": "VALU issue (integer ALU)",
+            "sponge": {"hasher": args.hasher, "permutations_per_s": n_hash * (limbs // 8) / (hash_ms / 1e3), "bound": "VALU issue (integer ALU)",
                                  "input": f"{n_hash} x {limbs} limbs, hash_no_pad, resident"},
             "stage_ms": stages,
             "clocks": gpu_clocks(local_rank),
@@ -328,7 +332,7 @@ def main():
             "digest_check": [int(x) for x in w],
         }
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args.base_bits)
+            out["cpu_baseline"] = cpu_baseline(args.base_bits, variant=VARIANT)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
