@@ -33,3 +33,25 @@ def test_eight_leaves_two_to_one(ctx, mp2):
     # a parent proof does not verify under a sibling's public inputs
     pi1, caps1, op1, pr1 = levels[1]
     assert O.pcs_verify(ofp, cd, pi1[1], caps1[0], op1[0], pr1[0]) != 0
+
+
+def test_two_ranks_prove_an_update_tree():
+    """N > 1 end to end on the GPU box: two ranks share the GPU, split a batched work plan over a 14-node update
+    tree (sharding.run_workplan), prove every node for real (gate-level circuit, witness check on) and exchange
+    only root results; the root fingerprint equals the single-process one and every node is proved once."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(here, "_dist_gpu_worker.py")
+    spec = importlib.util.spec_from_file_location("_dist_gpu_worker", worker)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want_root, n_proved, n_nodes = mod.run(None)
+    assert n_proved == n_nodes == 14
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", worker]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert f"root={want_root} proved=14" in r.stdout, r.stdout[-2000:]
