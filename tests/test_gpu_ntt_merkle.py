@@ -33,6 +33,30 @@ def test_ntt_inverse_and_coset(ctx, log_n):
     assert np.array_equal(ctx.ntt(ctx.ntt(a), inverse=True), a)
 
 
+@pytest.mark.parametrize("log_n", list(range(1, 25)))
+def test_ntt_every_size_both_directions(ctx, log_n):
+    """Every tile shape of the radix-8 kernels (single pass 2^1..2^12, two-pass 2^13..2^24), forward and inverse:
+    size-independent properties -- inverse(forward(a)) = a, a delta transforms to all ones, linearity on a point
+    sample, the coset transform of the inverse is the inverse of the coset transform -- plus the oracle where it
+    is quick."""
+    n = 1 << log_n
+    a = O.rand_field((1, n), 900 + log_n)
+    f = ctx.ntt(a)
+    assert np.array_equal(ctx.ntt(f, inverse=True), a)
+    assert np.array_equal(ctx.ntt(ctx.ntt(a, inverse=True, coset_shift=O.MULT_GEN), coset_shift=O.MULT_GEN), a)
+    delta = np.zeros((1, n), dtype=np.uint64)
+    delta[0, 0] = 1
+    assert (ctx.ntt(delta) == 1).all()
+    b = O.rand_field((1, n), 1900 + log_n)
+    s = ((a.astype(object) + b.astype(object)) % P).astype(np.uint64)
+    fs, fb = ctx.ntt(s), ctx.ntt(b)
+    idx = np.unique(np.concatenate([[0, n - 1, n // 2], np.random.default_rng(log_n).integers(0, n, 64)]))
+    assert all((int(f[0, i]) + int(fb[0, i])) % P == int(fs[0, i]) for i in idx)
+    if log_n <= 17:
+        assert np.array_equal(f, O.fft(a))
+        assert np.array_equal(ctx.ntt(a, inverse=True), O.fft(a, inverse=True))
+
+
 def test_ntt_edge_values(ctx):
     n = 1 << 10
     for fill in (0, 1, P - 1):
