@@ -118,3 +118,51 @@ def test_cell_values_digest_is_additive(ctx, mp2):
     ins = np.concatenate([ids.reshape(4, 1), vals.astype(np.uint64)], axis=1)
     w = mp2.map_to_curve_batch(ctx, ins)
     assert np.array_equal(mp2.curve_sum(ctx, w), mp2.curve_sum(ctx, w[::-1]))
+
+
+def test_split_digest_point(ctx, mp2):
+    """mp2-common/src/digest.rs SplitDigestPoint over the C ABI vs the same composition of oracle primitives."""
+    import importlib
+    dg = importlib.import_module("mapreduce-plonky2_amd.digest")
+    L = O.lib()
+    pts = mp2.map_to_curve_batch(ctx, O.rand_field((4, 9), 321))
+
+    def o_sum(ws):
+        w, wei = np.zeros(5, dtype=np.uint64), np.zeros(11, dtype=np.uint64)
+        assert L.orc_curve_sum(O.p(O.arr(np.stack(ws))), O.sz(len(ws)), O.p(w), O.p(wei))
+        return w, wei
+
+    def o_map(fields):
+        w = np.zeros((1, 5), dtype=np.uint64)
+        L.orc_map_to_curve_batch(0, O.p(O.arr(fields).reshape(1, -1)), O.sz(len(fields)), O.sz(1), O.p(w), None)
+        return w[0]
+
+    def o_hashed_mul(inputs, base):
+        w, wei = np.zeros(5, dtype=np.uint64), np.zeros(11, dtype=np.uint64)
+        assert L.orc_field_hashed_scalar_mul(0, O.p(O.arr(inputs)), O.sz(len(inputs)), O.p(O.arr(base)), O.p(w), O.p(wei))
+        return w
+
+    a = dg.SplitDigestPoint.from_single_digest_point(ctx, pts[0], False)
+    b = dg.SplitDigestPoint.from_single_digest_point(ctx, pts[1], True)
+    c = dg.SplitDigestPoint.from_single_digest_point(ctx, pts[2], False)
+    d = dg.SplitDigestPoint.from_single_digest_point(ctx, pts[3], True)
+    assert not a.is_merge_case() and b.is_merge_case()
+    # simple case: no multiplier -> the row digest is map_to_curve(individual.to_fields())
+    ac = a.accumulate(c)
+    assert np.array_equal(ac.individual, o_sum([pts[0], pts[2]])[0]) and not ac.multiplier.any()
+    assert np.array_equal(ac.cond_combine_to_row_digest(), o_map(o_sum([pts[0], pts[2]])[1]))
+    # merge case: HashToInt(map(multiplier).to_fields()) * map(individual)
+    s = a.accumulate(b).accumulate(c).accumulate(d)
+    ind, ind_wei = o_sum([pts[0], pts[2]])
+    mul, mul_wei = o_sum([pts[1], pts[3]])
+    assert np.array_equal(s.individual, ind) and np.array_equal(s.multiplier, mul) and s.is_merge_case()
+    base, mult = o_map(ind_wei), o_map(mul_wei)
+    want = o_hashed_mul(o_sum([mult])[1], base)
+    assert np.array_equal(s.cond_combine_to_row_digest(), want)
+    assert np.array_equal(s.combine_to_row_digest(), o_hashed_mul(mul_wei, ind))
+    # accumulation is commutative and associative
+    t = d.accumulate(c).accumulate(b).accumulate(a)
+    assert np.array_equal(t.individual, s.individual) and np.array_equal(t.multiplier, s.multiplier)
+    # NEUTRAL is the identity of accumulate
+    e = dg.SplitDigestPoint(ctx)
+    assert np.array_equal(e.accumulate(a).individual, pts[0]) and not e.accumulate(a).multiplier.any()
