@@ -52,3 +52,33 @@ class SplitDigestPoint:
 
     def combine_to_row_digest(self):
         return field_hashed_scalar_mul(self.ctx, point_to_fields(self.ctx, self.multiplier), self.individual, self.variant)[0]
+
+
+# ---- the scalar side of the table digest (row ids, index digests) ---------------------------------------------
+def hash_to_int_value(h):
+    """mp2-common/src/poseidon.rs:120-133: the 128-bit integer e0 + e1 * 2^64 of the two low hash limbs"""
+    return int(h[0]) | (int(h[1]) << 64)
+
+
+def row_unique_data(ctx, columns_u32be, variant=POSEIDON2):
+    """mp2-v1/src/values_extraction/mod.rs:499-510: H(left_pad32(column).pack(Big) for every column), 4 limbs.
+    columns_u32be: uint32 [n_unique][8], most significant word first (the packing of `u256_to_limbs`)."""
+    limbs = np.asarray(columns_u32be, dtype=np.uint32).reshape(1, -1).astype(np.uint64)
+    return ctx.hash_no_pad_batch(limbs, 4, variant)[0]
+
+
+def compute_row_id(ctx, unique_hash, num_actual_columns, variant=POSEIDON2):
+    """values_extraction/mod.rs:512-523: H2int(row_unique_data || num_actual_columns) as a python int < 2^128"""
+    inputs = np.concatenate([np.asarray(unique_hash, dtype=np.uint64), [np.uint64(num_actual_columns)]]).reshape(1, -1)
+    return hash_to_int_value(ctx.hash_no_pad_batch(inputs, 4, variant)[0])
+
+
+def compute_index_digest(ctx, inputs, digest_w, variant=POSEIDON2):
+    """verifiable-db/src/block_tree/mod.rs:49-54: H2int(inputs) * digest (the same map as field_hashed_scalar_mul)"""
+    return field_hashed_scalar_mul(ctx, np.asarray(inputs, dtype=np.uint64), digest_w, variant)[0]
+
+
+def add_primary_index_to_digest(ctx, primary_index_id, index_value_u32be, digest_w, variant=POSEIDON2):
+    """block_tree/mod.rs:36-46: inputs = id || index_value.to_fields() (8 big-endian u32 words)"""
+    inputs = np.concatenate([[np.uint64(primary_index_id)], np.asarray(index_value_u32be, dtype=np.uint32).astype(np.uint64)])
+    return compute_index_digest(ctx, inputs, digest_w, variant)

@@ -166,3 +166,28 @@ def test_split_digest_point(ctx, mp2):
     # NEUTRAL is the identity of accumulate
     e = dg.SplitDigestPoint(ctx)
     assert np.array_equal(e.accumulate(a).individual, pts[0]) and not e.accumulate(a).multiplier.any()
+
+
+def test_row_id_helpers_agree_with_the_fused_digest(ctx, mp2):
+    """row_unique_data / compute_row_id / Cell::values_digest composed on the host reproduce the fused
+    compute_table_row_digest kernel for a single row; compute_index_digest matches the oracle."""
+    import importlib
+    dg = importlib.import_module("mapreduce-plonky2_amd.digest")
+    rng = np.random.default_rng(5)
+    n_cols = 3
+    col_ids = O.rand_field(n_cols, 41)
+    values = rng.integers(0, 1 << 32, size=(1, n_cols, 8), dtype=np.uint32)
+    unique = values[:, :2, :].copy()
+    fused, _ = mp2.compute_table_row_digest(ctx, col_ids, values, unique)
+    # sum over the cells of map_to_curve(id || value limbs), times the row id
+    cells = np.concatenate([col_ids.reshape(n_cols, 1), values[0].astype(np.uint64)], axis=1)
+    row_digest = mp2.curve_sum(ctx, mp2.map_to_curve_batch(ctx, cells))
+    uh = dg.row_unique_data(ctx, unique[0])
+    row_id = dg.compute_row_id(ctx, uh, n_cols)
+    assert row_id < 1 << 128
+    assert np.array_equal(mp2.scalar_mul_batch(ctx, row_digest.reshape(1, 5), [row_id])[0], fused)
+    # index digest
+    inputs = np.concatenate([[np.uint64(77)], values[0, 0].astype(np.uint64)])
+    w = np.zeros(5, dtype=np.uint64)
+    assert O.lib().orc_field_hashed_scalar_mul(0, O.p(O.arr(inputs)), O.sz(inputs.size), O.p(O.arr(fused)), O.p(w), None)
+    assert np.array_equal(dg.add_primary_index_to_digest(ctx, 77, values[0, 0], fused), w)
