@@ -45,3 +45,24 @@ def test_cells_tree_root_and_empty_hash(ctx, mp2):
             return [0, 0, 0, 0]
         return [int(x) for x in O.hash_n_to_m_no_pad(node(2 * i + 1) + node(2 * i + 2) + [ids[i]] + limbs(vals[i]), 4)]
     assert [int(x) for x in root] == node(0)
+
+
+def test_column_identifiers(ctx, mp2):
+    """values_extraction column ids over the C ABI vs the oracle sponge on the same byte strings"""
+    import importlib
+    ids = importlib.import_module("mapreduce-plonky2_amd.identifiers")
+    addr, chain = bytes(range(1, 21)), 31337
+
+    def want(data, variant):
+        return int(O.hash_n_to_m_no_pad(np.frombuffer(data, dtype=np.uint8).astype(np.uint64), 4, variant)[0])
+
+    for variant in (0, 1):
+        assert ids.identifier_block_column(ctx, variant) == want(b"BLOCK_NUMBER", variant)
+        assert ids.identifier_offchain_column(ctx, "t", "col", variant) == want(b"OFFCHAIN_TABLEtcol", variant)
+        extra = addr + chain.to_bytes(8, "big") + b"x"
+        assert ids.identifier_for_value_column(ctx, 3, 4, 128, 1, addr, chain, b"x", variant) == \
+            want(bytes([3]) + (4).to_bytes(8, "big") + (128).to_bytes(8, "big") + (1).to_bytes(4, "big") + extra, variant)
+        assert ids.identifier_for_mapping_key_column(ctx, 7, addr, chain, b"x", variant) == want(b"\0KEY" + bytes([7]) + extra, variant)
+        assert ids.identifier_for_outer_mapping_key_column(ctx, 7, addr, chain, b"x", variant) == want(b"\0OUT_KEY" + bytes([7]) + extra, variant)
+        assert ids.identifier_for_inner_mapping_key_column(ctx, 7, addr, chain, b"x", variant) == want(b"\0\0IN_KEY" + bytes([7]) + extra, variant)
+    assert ids.identifier_block_column(ctx, 0) != ids.identifier_block_column(ctx, 1)
