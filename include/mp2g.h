@@ -350,6 +350,11 @@ typedef struct mp2g_update_plan mp2g_update_plan;
  * occurs twice at different positions, a path whose first key is not the root. */
 int mp2g_update_tree_from_paths(const uint64_t* keys, const uint32_t* path_lens, uint32_t n_paths, int64_t epoch,
                                 mp2g_update_tree** out);
+/* UpdateTree::from_map (:296-331): the hierarchy described by a map key -> NodeContext {left, right} (arrays of n
+ * entries; has_left / has_right say whether the option is Some), walked pre-order from root. Child keys missing
+ * from the map are skipped; is_path_end = NodeContext::is_leaf. A key reached twice is the reference's panic. */
+int mp2g_update_tree_from_map(const uint64_t* keys, const uint64_t* left, const uint64_t* right, const uint8_t* has_left,
+                              const uint8_t* has_right, uint32_t n, uint64_t root, int64_t epoch, mp2g_update_tree** out);
 /* UpdateTree::extend_with_path (:145-151) */
 int mp2g_update_tree_extend_with_path(mp2g_update_tree* t, const uint64_t* path, uint32_t len);
 uint32_t mp2g_update_tree_size(const mp2g_update_tree* t);

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <set>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 #include "ctx.h"
 
@@ -98,6 +99,33 @@ int mp2g_update_tree_from_paths(const uint64_t* keys, const uint32_t* path_lens,
     if (i == 0 && path_lens[0] == 0) { delete t; return fail("empty path"); }
     if (t->extend(p, path_lens[i])) { delete t; return 1; }
     p += path_lens[i];
+  }
+  *out = t;
+  return 0;
+}
+// UpdateTree::from_map (:296-331): pre-order walk from `root` over a map key -> (left, right); a child key that
+// is not in the map is skipped; is_path_end = the node's context has no children at all (NodeContext::is_leaf)
+int mp2g_update_tree_from_map(const uint64_t* keys, const uint64_t* left, const uint64_t* right, const uint8_t* has_left,
+                              const uint8_t* has_right, uint32_t n, uint64_t root, int64_t epoch, mp2g_update_tree** out) {
+  if (!out || (n && (!keys || !left || !right || !has_left || !has_right))) return fail("invalid argument: null pointer");
+  std::unordered_map<uint64_t, uint32_t> ctx;
+  for (uint32_t i = 0; i < n; i++) ctx.emplace(keys[i], i);
+  auto* t = new (std::nothrow) mp2g_update_tree;
+  if (!t) return fail("out of memory");
+  t->epoch = epoch;
+  // explicit stack: (key, parent arena index); children pushed right first so that left is visited first
+  std::vector<std::pair<uint64_t, int32_t>> stack{{root, -1}};
+  while (!stack.empty()) {
+    auto [k, parent] = stack.back();
+    stack.pop_back();
+    auto it = ctx.find(k);
+    if (it == ctx.end()) continue;
+    const uint32_t c = it->second, cur = (uint32_t)t->nodes.size();
+    if (!t->idx.emplace(k, cur).second) { delete t; return fail("duplicated key found"); }
+    t->nodes.push_back(UtNode{parent, {}, k, !has_left[c] && !has_right[c]});
+    if (parent >= 0) t->nodes[parent].children.insert(cur);
+    if (has_right[c]) stack.push_back({right[c], (int32_t)cur});
+    if (has_left[c]) stack.push_back({left[c], (int32_t)cur});
   }
   *out = t;
   return 0;

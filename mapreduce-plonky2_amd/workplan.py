@@ -50,6 +50,21 @@ class UpdateTree:
         return cls(h)
 
     @classmethod
+    def from_map(cls, epoch, root, nodes):
+        """updatetree.rs:296-331. nodes: {key: (left or None, right or None)} (NodeContext)."""
+        keys = np.ascontiguousarray(list(nodes), dtype=np.uint64)
+        lr = [nodes[int(k)] for k in keys]
+        left = np.ascontiguousarray([l if l is not None else 0 for l, _ in lr], dtype=np.uint64)
+        right = np.ascontiguousarray([r if r is not None else 0 for _, r in lr], dtype=np.uint64)
+        hl = np.ascontiguousarray([l is not None for l, _ in lr], dtype=np.uint8)
+        hr = np.ascontiguousarray([r is not None for _, r in lr], dtype=np.uint8)
+        h = ctypes.c_void_p()
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _ck(_lib().mp2g_update_tree_from_map(vp(keys), vp(left), vp(right), vp(hl), vp(hr), len(keys), ctypes.c_uint64(root),
+                                             ctypes.c_int64(epoch), ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
     def from_path(cls, path, epoch=0):
         if len(path) == 0:
             raise Mp2gError("empty path")

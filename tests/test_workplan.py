@@ -153,3 +153,26 @@ def test_assign_subtrees_balances_and_is_deterministic():
     assert owners == wp.assign_subtrees(wave, 4)
     loads = [sum(len(it.subtree) for it, o in zip(wave, owners) if o == r) for r in range(4)]
     assert max(loads) - min(loads) <= 4
+
+
+def test_from_map():
+    """updatetree.rs:296-331: pre-order arena, missing children skipped, is_path_end = the context is a leaf"""
+    nodes = {8: (4, 12), 4: (2, 6), 12: (10, None), 2: (None, None), 6: (5, 7), 5: (None, None), 10: (None, 11), 99: (None, None)}
+    t = wp.UpdateTree.from_map(5, 8, nodes)  # 7 and 11 are referenced but not in the map; 99 is unreachable
+    assert t.epoch == 5 and t.nodes() == [8, 4, 2, 6, 5, 12, 10]
+    par = t.parents()
+    assert par == {8: None, 4: 8, 2: 4, 6: 4, 5: 6, 12: 8, 10: 12}
+    assert t.path_ends() == {2, 5}  # 10 has a right key (absent from the map): not a NodeContext leaf
+    plan = t.into_workplan()
+    order = []
+    while True:
+        wave = wp.drain_wave(plan)
+        if not wave:
+            break
+        for it in wave:
+            order.append(it.k)
+            plan.done(it.k)
+    assert plan.completed() and sorted(order) == sorted(par) and order.index(5) < order.index(6) < order.index(4) < order.index(8)
+    assert len(wp.UpdateTree.from_map(0, 1, {})) == 0
+    with pytest.raises(mp2.Mp2gError):
+        wp.UpdateTree.from_map(0, 1, {1: (2, 2), 2: (None, None)})  # duplicated key found
