@@ -59,3 +59,22 @@ def cells_tree_root(ctx, ids, values, variant=0):
         right = np.where((rch < n)[:, None], hashes[np.minimum(rch, n - 1)], empty)
         hashes[idx] = cell_node_hashes(ctx, left, right, [ids[i] for i in idx], [values[i] for i in idx], variant)
     return hashes[0], hashes
+
+
+def index_node_hashes(ctx, left, right, mins, maxs, ids, values, row_tree_hash, variant=0):
+    """`IndexNode::aggregate` (mp2-v1/src/indexing/index.rs:61-101), the block / primary-index tree:
+    H(hL || hR || min || max || id || value || row_tree_hash), the same 37-limb layout as a row node with the
+    row tree's root hash in the place of the cells root. min / max follow the children as in the reference:
+    no child -> (value, value); left only -> (left.min, value); both -> (left.min, right.max)."""
+    return row_node_hashes(ctx, left, right, mins, maxs, ids, values, row_tree_hash, variant)
+
+
+def index_node_min_max(value, left=None, right=None):
+    """min / max bookkeeping of IndexNode::aggregate; left / right are (min, max) tuples or None"""
+    if left is None and right is None:
+        return value, value
+    if right is None:
+        return left[0], value
+    if left is None:
+        raise ValueError("ryhope sbbst is wrong")  # the reference panics: a right child without a left one
+    return left[0], right[1]
