@@ -47,8 +47,10 @@ GLHD void p2_external_half(u64 v[12]) {
     v[i] += sum; v[4 + i] += sum; v[8 + i] += sum;  // < 2^39
   }
 }
-// circ(2 M4, M4, M4) on weak limbs
-GLHD void p2_external(u64 s[12]) {
+// circ(2 M4, M4, M4) on weak limbs; RC: also add the next round's constants rc[0..12) before the one
+// reduction per limb (a carry into the top word instead of a separate weak addition per limb)
+template <bool RC>
+GLHD void p2_external_rc(u64 s[12], const u64* rc) {
   u64 lo[12], hi[12];
 #pragma unroll
   for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = s[i] >> 32; }
@@ -57,10 +59,24 @@ GLHD void p2_external(u64 s[12]) {
 #pragma unroll
   for (int i = 0; i < 12; i++) {
     // value = lo + hi * 2^32, lo, hi < 2^39
-    u64 l;
-    bool c = __builtin_add_overflow(lo[i], hi[i] << 32, &l);
-    s[i] = gl_reduce96w(l, (hi[i] >> 32) + (c ? 1 : 0));
+    u32 c0, c1, top = (u32)(hi[i] >> 32);
+    u32 l0 = (u32)lo[i];
+    u32 l1 = __builtin_addc((u32)(lo[i] >> 32), (u32)hi[i], 0u, &c0);
+    top += c0;
+    if (RC) {
+      const u64 k = rc[i];
+      l0 = __builtin_addc(l0, (u32)k, 0u, &c0);
+      l1 = __builtin_addc(l1, (u32)(k >> 32), c0, &c1);
+      top += c1;
+    }
+    s[i] = gl_reduce96w(gl_mk(l0, l1), top);
   }
+}
+GLHD void p2_external(u64 s[12]) { p2_external_rc<false>(s, nullptr); }
+// x^7 for a limb whose round constant is already in (p2_external_rc)
+GLHD u64 p2_sbox0(u64 t) {
+  u64 t2 = gl_mulw(t, t), t4 = gl_mulw(t2, t2), t3 = gl_mulw(t, t2);
+  return gl_mulw(t3, t4);
 }
 // s_i <- d_i s_i + sum_j s_j, exactly: 128-bit product plus the 68-bit sum, one reduction
 GLHD void p2_internal(u64 s[12]) {
@@ -88,23 +104,25 @@ GLHD void p2_internal(u64 s[12]) {
 #define P2_PRAGMA(x) _Pragma(#x)
 #define P2_UNROLL(n) P2_PRAGMA(unroll n)
 GLHD void poseidon2_perm(u64 s[12]) {
-  p2_external(s);
+  p2_external_rc<true>(s, c_p2_ext);  // the constants of a full round ride on the preceding linear layer
 P2_UNROLL(P2_UNROLL_EXT)
   for (int r = 0; r < 4; r++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = p2_sbox(s[i], c_p2_ext[12 * r + i]);
-    p2_external(s);
+    for (int i = 0; i < 12; i++) s[i] = p2_sbox0(s[i]);
+    if (r < 3) p2_external_rc<true>(s, c_p2_ext + 12 * (r + 1)); else p2_external(s);
   }
 P2_UNROLL(P2_UNROLL_INT)
   for (int r = 0; r < 22; r++) {
     s[0] = p2_sbox(s[0], c_p2_int[r]);
     p2_internal(s);
   }
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_addw(s[i], c_p2_ext[48 + i]);  // round 4 follows an internal layer
 P2_UNROLL(P2_UNROLL_EXT)
   for (int r = 4; r < 8; r++) {
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = p2_sbox(s[i], c_p2_ext[12 * r + i]);
-    p2_external(s);
+    for (int i = 0; i < 12; i++) s[i] = p2_sbox0(s[i]);
+    if (r < 7) p2_external_rc<true>(s, c_p2_ext + 12 * (r + 1)); else p2_external(s);
   }
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
