@@ -132,6 +132,12 @@ def test_gate_parameter_fuzz(ctx, mp2):
         deg = int(rng.integers(2, min(1 << sb, 7) + 1))
         if 1 + 2 * (1 << sb) + 6 + 4 * (((1 << sb) - 2) // (deg - 1)) <= 135:
             kinds.append((C.COSET_INTERPOLATION, sb, deg, 0))
+        kinds += [(C.U32_ARITHMETIC, int(rng.integers(1, 4)), 0, 0), (C.U32_RANGE_CHECK, int(rng.integers(1, 8)), 0, 0),
+                  (C.U32_SUBTRACTION, int(rng.integers(1, 7)), 0, 0)]
+        na = int(rng.integers(1, 9))
+        kinds.append((C.U32_ADD_MANY, na, int(rng.integers(1, min(135 // (na + 21), 80 // (na + 3)) + 1)), 0))
+        nch = int(rng.choice([4, 8, 16]))
+        kinds.append((C.COMPARISON, nch * int(rng.integers(1, 3)), nch, 0))
         pick = [kinds[0]] + [kinds[i] for i in sorted(rng.choice(np.arange(1, len(kinds)), size=int(rng.integers(1, 6)), replace=False))]
         ckt = C.build(4, pick, 100 + it)
         out = C.eval_on_points(ckt, ckt.pre[:ckt.num_constants], ckt.wires)
