@@ -131,7 +131,9 @@ P2_UNROLL(P2_UNROLL_EXT)
 // Poseidon (WrapC), weak-representative form like Poseidon2 above. MDS: circulant
 // [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,...]; all entries < 2^6, so the 32-bit halves of the
 // limbs accumulate in u64 without overflow (< 2^41) and reduce once per row.
-GLHD void poseidon_mds(u64 s[12]) {
+// RC: also add the next round's constants rc[0..12) before the one reduction per limb
+template <bool RC>
+GLHD void poseidon_mds_rc(u64 s[12], const u64* rc) {
   const u32 circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
   u64 lo[12], hi[12];
 #pragma unroll
@@ -146,26 +148,35 @@ GLHD void poseidon_mds(u64 s[12]) {
       ah += hi[(i + r) % 12] * circ[i];
     }
     if (r == 0) { al += lo[0] * 8; ah += hi[0] * 8; }
-    // value = al + ah * 2^32
-    u64 l;
-    bool c = __builtin_add_overflow(al, ah << 32, &l);
-    out[r] = gl_reduce96w(l, (ah >> 32) + (c ? 1 : 0));
+    // value = al + ah * 2^32, al, ah < 2^41
+    u32 c0, c1, top = (u32)(ah >> 32);
+    u32 l0 = (u32)al;
+    u32 l1 = __builtin_addc((u32)(al >> 32), (u32)ah, 0u, &c0);
+    top += c0;
+    if (RC) {
+      const u64 k = rc[r];
+      l0 = __builtin_addc(l0, (u32)k, 0u, &c0);
+      l1 = __builtin_addc(l1, (u32)(k >> 32), c0, &c1);
+      top += c1;
+    }
+    out[r] = gl_reduce96w(gl_mk(l0, l1), top);
   }
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = out[i];
 }
+GLHD void poseidon_mds(u64 s[12]) { poseidon_mds_rc<false>(s, nullptr); }
 GLHD void poseidon_perm(u64 s[12]) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_addw(s[i], c_p_rc[i]);
 #pragma unroll 1
-  for (int r = 0; r < 30; r++) {
+  for (int r = 0; r < 30; r++) {  // the constants of round r + 1 ride on round r's MDS reduction
     if (r < 4 || r >= 26) {
 #pragma unroll
-      for (int i = 0; i < 12; i++) s[i] = p2_sbox(s[i], c_p_rc[12 * r + i]);
+      for (int i = 0; i < 12; i++) s[i] = p2_sbox0(s[i]);
     } else {
-      s[0] = p2_sbox(s[0], c_p_rc[12 * r]);
-#pragma unroll
-      for (int i = 1; i < 12; i++) s[i] = gl_addw(s[i], c_p_rc[12 * r + i]);
+      s[0] = p2_sbox0(s[0]);
     }
-    poseidon_mds(s);
+    if (r < 29) poseidon_mds_rc<true>(s, c_p_rc + 12 * (r + 1)); else poseidon_mds(s);
   }
 #pragma unroll
   for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
