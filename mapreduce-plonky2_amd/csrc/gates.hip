@@ -128,6 +128,19 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
   auto diff0 = [](u64 s, u64 in) { return WEAK ? gl_subw(s, in) : gl_sub(gl_canon(s), in); };
   // product that only feeds further products or emit(): a weak representative is enough there
   auto mulx = [](u64 a, u64 b) { return WEAK ? gl_mulw(a, b) : gl_mul(a, b); };
+  // Up to 16 wires in flight at once. The gate bodies are loops with run-time bounds, and a loop that fetches one
+  // wire per iteration exposes one global-load latency per constraint (measured: the limb-heavy gates ran at half of
+  // their instruction-issue time); fetching a batch first lets the loads overlap.
+  auto load16 = [&](u32 first, u32 count, u64(&buf)[16]) {
+#pragma unroll
+    for (u32 k = 0; k < 16; k++) buf[k] = k < count ? wire(first + k) : 0;
+  };
+  auto range4 = [&](u64 limb) {  // limb (limb - 1)(limb - 2)(limb - 3)
+    u64 pr = limb;
+#pragma unroll
+    for (u32 x = 1; x < 4; x++) pr = mulx(pr, gl_sub(limb, x));
+    return pr;
+  };
   switch (g.kind) {
     case MP2G_GATE_CONSTANT:
       for (u32 i = 0; i < g.p0; i++) emit(gl_sub(cst(i), wire(i)));
@@ -345,15 +358,14 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
     case MP2G_GATE_U32_RANGE_CHECK: {
       const u32 k = g.p0;
       for (u32 i = 0; i < k; i++) {
+        u64 lm[16];
+        load16(k + 16 * i, 16, lm);
         u64 acc = 0;
-        for (u32 j = 16; j-- > 0;) acc = gl_add(gl_mul_small(acc, 4), wire(k + 16 * i + j));
+#pragma unroll
+        for (int j = 15; j >= 0; j--) acc = gl_add(gl_mul_small(acc, 4), lm[j]);
         emit(gl_sub(acc, wire(i)));
-        for (u32 j = 0; j < 16; j++) {
-          const u64 limb = wire(k + 16 * i + j);
-          u64 pr = limb;
-          for (u32 x = 1; x < 4; x++) pr = mulx(pr, gl_sub(limb, x));
-          emit(pr);
-        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) emit(range4(lm[j]));
       }
       break;
     }
