@@ -157,14 +157,27 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
       break;
     }
     case MP2G_GATE_BASE_SUM: {
-      u64 acc = 0;
-      for (u32 i = g.p0; i-- > 0;) acc = gl_add(gl_mul_small(acc, g.p1), wire(1 + i));
+      u64 acc = 0, lm[16];
+      for (u32 hi = g.p0; hi > 0;) {  // limbs p0-1 .. 0 in batches of 16
+        const u32 lo = hi > 16 ? hi - 16 : 0, cnt = hi - lo;
+        load16(1 + lo, cnt, lm);
+#pragma unroll
+        for (int j = 15; j >= 0; j--)
+          if ((u32)j < cnt) acc = gl_add(gl_mul_small(acc, g.p1), lm[j]);
+        hi = lo;
+      }
       emit(gl_sub(acc, wire(0)));
-      for (u32 i = 0; i < g.p0; i++) {
-        const u64 limb = wire(1 + i);
-        u64 pr = limb;  // k = 0 factor
-        for (u32 k = 1; k < g.p1; k++) pr = mulx(pr, gl_sub(limb, k));
-        emit(pr);
+      for (u32 lo = 0; lo < g.p0; lo += 16) {
+        const u32 cnt = g.p0 - lo < 16 ? g.p0 - lo : 16;
+        load16(1 + lo, cnt, lm);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          if ((u32)j < cnt) {
+            u64 pr = lm[j];  // k = 0 factor
+            for (u32 k = 1; k < g.p1; k++) pr = mulx(pr, gl_sub(lm[j], k));
+            emit(pr);
+          }
+        }
       }
       break;
     }
@@ -342,14 +355,13 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         const u64 hi_not_max = gl_sub(gl_mul(inv, gl_sub(0xFFFFFFFFull, hi)), 1);
         emit(gl_mul(hi_not_max, lo));
         emit(gl_sub(gl_add(gl_mul(hi, (u64)1 << 32), lo), computed));
-        u64 clo = 0, chi = 0;
-        for (u32 j = 32; j-- > 0;) {
-          const u64 limb = wire(6 * ops + 32 * i + j);
-          u64 pr = limb;
-          for (u32 x = 1; x < 4; x++) pr = mulx(pr, gl_sub(limb, x));
-          emit(pr);
-          if (j < 16) clo = gl_add(gl_mul_small(clo, 4), limb); else chi = gl_add(gl_mul_small(chi, 4), limb);
-        }
+        u64 clo = 0, chi = 0, lm[16];
+        load16(6 * ops + 32 * i + 16, 16, lm);  // limbs 31..16: the high half
+#pragma unroll
+        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); chi = gl_add(gl_mul_small(chi, 4), lm[j]); }
+        load16(6 * ops + 32 * i, 16, lm);       // limbs 15..0
+#pragma unroll
+        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); clo = gl_add(gl_mul_small(clo, 4), lm[j]); }
         emit(gl_sub(clo, lo));
         emit(gl_sub(chi, hi));
       }
@@ -376,14 +388,10 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         const u64 initial = gl_sub(gl_sub(wire(b), wire(b + 1)), wire(b + 2));
         const u64 res = wire(b + 3), bo = wire(b + 4);
         emit(gl_sub(res, gl_add(initial, gl_mul((u64)1 << 32, bo))));
-        u64 comb = 0;
-        for (u32 j = 16; j-- > 0;) {
-          const u64 limb = wire(5 * ops + 16 * i + j);
-          u64 pr = limb;
-          for (u32 x = 1; x < 4; x++) pr = mulx(pr, gl_sub(limb, x));
-          emit(pr);
-          comb = gl_add(gl_mul_small(comb, 4), limb);
-        }
+        u64 comb = 0, lm[16];
+        load16(5 * ops + 16 * i, 16, lm);
+#pragma unroll
+        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); comb = gl_add(gl_mul_small(comb, 4), lm[j]); }
         emit(gl_sub(comb, res));
         emit(gl_mul(bo, gl_sub(1, bo)));
       }
@@ -397,14 +405,15 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         for (u32 j = 0; j < na; j++) computed = gl_add(computed, wire(b + j));
         const u64 res = wire(b + na + 1), co = wire(b + na + 2);
         emit(gl_sub(gl_add(gl_mul(co, (u64)1 << 32), res), computed));
-        u64 cres = 0, ccar = 0;
-        for (u32 j = 18; j-- > 0;) {
-          const u64 limb = wire(per * ops + 18 * i + j);
-          u64 pr = limb;
-          for (u32 x = 1; x < 4; x++) pr = mulx(pr, gl_sub(limb, x));
-          emit(pr);
-          if (j < 16) cres = gl_add(gl_mul_small(cres, 4), limb); else ccar = gl_add(gl_mul_small(ccar, 4), limb);
+        u64 cres = 0, ccar = 0, lm[16];
+        {
+          const u64 l17 = wire(per * ops + 18 * i + 17), l16 = wire(per * ops + 18 * i + 16);
+          load16(per * ops + 18 * i, 16, lm);
+          emit(range4(l17)); ccar = l17;
+          emit(range4(l16)); ccar = gl_add(gl_mul_small(ccar, 4), l16);
         }
+#pragma unroll
+        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); cres = gl_add(gl_mul_small(cres, 4), lm[j]); }
         emit(gl_sub(cres, res));
         emit(gl_sub(ccar, co));
       }
