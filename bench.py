@@ -13,15 +13,21 @@ wrap_circuit.rs:122-148). One step = one batch of `--batch` such leaf proofs, sh
 queries), on synthetic witness matrices that are resident in HBM before the timed region. What
 runs per proof is everything `prove()` does after witness generation -- wires commitment, Z / partial
 products, quotient polynomials (permutation terms and the gate constraints), their commitments,
-Fiat-Shamir, openings, FRI (HOT LOOPS 1-3 of SURVEY 3.1) -- for satisfied synthetic circuits composed as the reference composes them
-(tests/circuits.py): the wrap circuit has the gate set of plonky2's recursive verifier (Noop, Constant,
-PublicInput, Arithmetic, ArithmeticExtension, MulExtension, BaseSum<2>, Exponentiation, Reducing,
-ReducingExtension, RandomAccess, CosetInterpolation, Poseidon2: 13 gates), the base (leaf) circuit adds
-the user-logic gates (BaseSum<4>, U32Arithmetic, U32RangeCheck, U32Subtraction, U32AddMany, Comparison:
-19 gates); as in plonky2 every gate of a circuit is evaluated at every LDE point, so the cost depends on
-the gate set, not on the row mix. Rows are dealt over the gates with random copy constraints. Witness
-generation stays on the host. The proofs verify (FRI + the PLONK identity at zeta with the gate terms,
-tests/test_gpu_gates.py).
+Fiat-Shamir, openings, FRI (HOT LOOPS 1-3 of SURVEY 3.1) -- for satisfied synthetic circuits composed
+as the reference composes them (mapreduce-plonky2_amd/circuits.py): the wrap circuit has the gate set of
+plonky2's recursive verifier (13 gates), the base (leaf) circuit adds the user-logic gates (u32 arithmetic,
+range checks, comparisons: 19 gates); as in plonky2 every gate of a circuit is evaluated at every LDE point,
+so the cost depends on the gate set, not on the row mix. Every proof of a batch has its own public inputs
+(bound to the PublicInputGate row on the device) and its own free cells; witness generation stays on the host.
+This is a steady-state "prove() after witness generation" rate: no 2^20-row build, no tree reduction
+(`--workload tree` times the aggregation levels too).
+
+Self-check. After the timed loop the first and the last proof of every prover's batch are downloaded and
+compared, bit for bit, with the CPU oracle's proof of the same witness (caps, openings, FRI proof), and
+run through the oracle's verifier (transcript, PLONK identity with the gate terms, FRI). The JSON line
+carries "verified": k; any mismatch makes the run fail. The oracle proofs of that leg are the `cpu_baseline`
+sample at N=1.
+
 Leaf proofs shard across ranks with no data-path collective ("scaling": "weak"); the per-rank
 multiset digests meet in one 160-byte all_gather outside the per-proof path.
 
@@ -40,12 +46,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 LOG_NTT = 22
-ORACLE_W = (None, 135, 20, 16)  # constants (selectors + 2) + 80 sigmas: from the circuit | wires | Z, partial products | quotient chunks
-NUM_ROUTED = 80  # standard_recursion_config: 80 routed wires, quotient_degree_factor 8 => 2 x (1 + 9) Z / partial products
 SEED = 0xC0FFEE03
 
 
@@ -60,51 +63,64 @@ def gpu_clocks(device):
         return {"error": str(e)[:80]}
 
 
-def build_circuit(C, role, k):
-    """the synthetic circuit of a role: base = leaf gate set (verifier gadget + u32 logic), wrap = verifier gate set"""
-    return C.build(k, C.LEAF_KINDS if role == "base" else C.VERIFIER_KINDS, SEED + k + (0 if role == "base" else 100))
-
-
-def cpu_baseline(base_bits, budget_s=15.0, variant=0):
-    """The CPU oracle (our restatement of the same pipeline; kind 'port') on all host cores, on a bounded sample
-    of the same workload. Leaf proofs are independent, so the cores are used the way a CPU deployment would use
-    them: groups of 32 threads (OpenMP inside a proof: polynomials, leaves, quotient points, PoW candidates) prove
-    one leaf proof each, all groups at once; rounds of that until ~budget_s seconds are spent."""
+def check_against_oracle(samples, budget_s, timed):
+    """The checker leg (and, at N=1, the `cpu_baseline` sample): the CPU oracle proves the witnesses of the sampled
+    GPU proofs -- leaf proof = one base + one wrap prove() -- `groups` leaf proofs at a time with cores/groups
+    OpenMP threads each, until every mandatory sample is done and, when `timed`, ~budget_s seconds are spent.
+    samples: list of leaf proofs, each a list of (label, ckt, ofp, circuit_digest, make_wires, pi_hash, gpu_caps,
+    gpu_openings, gpu_proof, mandatory), mandatory ones first. Returns (n_verified, baseline dict or None); raises on any mismatch."""
     import threading
-    import circuits as C
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import circuits as OC  # oracle-side prove / verify of a built circuit (tests/circuits.py)
     import oracle as O
     cores = os.cpu_count() or 1
-    groups = max(1, cores // 32)
+    groups = max(1, min(len(samples), cores // 32))
     per_group = max(1, cores // groups)
-    shapes = []
-    for role, k in (("base", base_bits), ("wrap", 12)):
-        ckt = build_circuit(C, role, k)
-        shapes.append((O.standard_params(k, (ckt.pre.shape[0],) + ORACLE_W[1:], variant=variant), ckt))
-    cd = O.rand_field(4, 1)
     omp = ctypes.CDLL("libgomp.so.1")
+    errors, verified = [], [0]
+    lock = threading.Lock()
 
-    def one_proof():
+    def one_leaf(parts):
         omp.omp_set_num_threads(per_group)  # per-thread ICV: the parallel regions this thread opens
-        for ofp, ckt in shapes:
-            C.prove(ckt, ofp, cd)
+        for label, ckt, ofp, cd, make_wires, ph, g_caps, g_open, g_proof, _ in parts:
+            caps, openings, proof, _ = OC.prove_witness(ckt, ofp, cd, make_wires(), ph)
+            ok = np.array_equal(caps, g_caps) and np.array_equal(openings, g_open) and np.array_equal(proof, g_proof)
+            rc = OC.verify(ckt, ofp, cd, ph, g_caps, g_open, g_proof)
+            with lock:
+                if not ok:
+                    errors.append(f"{label}: GPU proof differs from the oracle's proof of the same witness")
+                elif rc:
+                    errors.append(f"{label}: the oracle's verifier rejects the GPU proof (code {rc})")
+                else:
+                    verified[0] += 1
 
-    t_total, n_proofs = 0.0, 0
-    while n_proofs < 6 * groups and (n_proofs == 0 or t_total * (n_proofs + groups) / n_proofs < budget_s):
-        ts = [threading.Thread(target=one_proof) for _ in range(groups)]
+    t_total, n_leaf, i = 0.0, 0, 0
+    n_mand = sum(1 for s in samples if s[0][-1])
+    while i < len(samples):
+        if i >= n_mand and (not timed or t_total * (n_leaf + groups) / max(n_leaf, 1) > budget_s):
+            break
+        part = samples[i:i + groups]
+        ts = [threading.Thread(target=one_leaf, args=(s,)) for s in part]
         t0 = time.perf_counter()
         for t in ts:
             t.start()
         for t in ts:
             t.join()
         t_total += time.perf_counter() - t0
-        n_proofs += groups
-    return {"value": n_proofs / t_total, "unit": "leaf proofs/s", "cores": cores, "kind": "port",
-            "sample": f"{n_proofs} leaf proof(s) = base 2^{base_bits} + wrap 2^12 prove() of the same gate-level circuits by oracle/, "
-                      f"{groups} proof(s) at a time with {per_group} OpenMP threads each (polynomials, leaves, quotient points, PoW "
-                      "candidates; FRI composition and transcript are single-threaded)"}
+        n_leaf += len(part)
+        i += len(part)
+    if errors:
+        raise SystemExit("bench.py self-check FAILED:\n  " + "\n  ".join(errors))
+    base = None
+    if timed and n_leaf:
+        base = {"value": n_leaf / t_total, "unit": "leaf proofs/s", "cores": cores, "kind": "port",
+                "single_leaf_latency_s": t_total / ((n_leaf + groups - 1) // groups),
+                "sample": f"{n_leaf} leaf proof(s) = base + wrap prove() of the sampled GPU witnesses by oracle/ (our C restatement, not the "
+                          f"Rust prover), {groups} at a time with {per_group} OpenMP threads each; every one compared bit for bit with the GPU's"}
+    return verified[0], base
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -113,7 +129,7 @@ def main():
     ap.add_argument("--base-bits", type=int, default=13)
     ap.add_argument("--streams", type=int, default=4, help="HIP streams: 1 = both shapes on one; 2 = one per shape; 4 = two half-batches per shape")
     ap.add_argument("--host-inputs", action="store_true",
-                    help="PCIe-inclusive variant: every step uploads its wire / quotient matrices from pinned host memory "
+                    help="PCIe-inclusive variant: every step uploads its wire matrices from pinned host memory "
                          "on the prover's stream (never the headline value; see DESIGN.md)")
     ap.add_argument("--hasher", choices=("poseidon2", "poseidon"), default="poseidon2",
                     help="poseidon2 = the reference's default config (Poseidon2GoldilocksConfig); poseidon = its "
@@ -121,8 +137,10 @@ def main():
     ap.add_argument("--witness-check", action="store_true",
                     help="also run the device-side witness check (gate + copy constraints on H) inside every prove, "
                          "as plonky2's prove() does before it panics on a bad witness")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU leg (the self-check still runs)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the sampled proofs")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work for the cpu_baseline sample")
+    args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,9 +163,9 @@ def main():
     VARIANT = 0 if args.hasher == "poseidon2" else 1
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
-    import circuits as C  # synthetic circuit + witness generator (pure Python)
-    import oracle as O  # rand_field (SplitMix64 stream); the oracle library itself is used by the cpu_baseline leg only
-    # two contexts = two HIP streams on the same GPU: the base and the wrap prover run concurrently, so
+    C = importlib.import_module("mapreduce-plonky2_amd.circuits")  # synthetic circuit + witness generator (pure Python)
+    FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+    # several contexts = several HIP streams on the same GPU: the base and the wrap provers run concurrently, so
     # the latency-bound stretches of one (transcript, top Merkle levels) hide under the other's sponges
     ctx = mp2.Context(local_rank)
     n_ctx = max(1, args.streams)
@@ -162,61 +180,36 @@ def main():
         plan = [("base", args.base_bits, ctxs[0], B), ("wrap", 12, ctxs[1], B)]
     else:
         plan = [("base", args.base_bits, ctx, B), ("wrap", 12, ctx, B)]
+    plan = [p for p in plan if p[3] > 0]
 
     # ---- synthetic inputs, resident in HBM before the timed region -----------------------------
     provers = []
     circuits = {}
-    for role, k, cx, nb in plan:
-        n = 1 << k
+    for pi, (role, k, cx, nb) in enumerate(plan):
         # a satisfied gate-level circuit of the role's gate set: rows dealt over the gates, random copy constraints
         if role not in circuits:
-            circuits[role] = build_circuit(C, role, k)
+            circuits[role] = C.build(k, C.LEAF_KINDS if role == "base" else C.VERIFIER_KINDS, SEED + k + (0 if role == "base" else 100))
         ckt = circuits[role]
-        oracle_w = (ckt.pre.shape[0],) + ORACLE_W[1:]
-        fp = mp2.standard_recursion_params(k, oracle_w, variant=VARIANT)
-        pr = mp2.BatchedProver(cx, fp, nb)
-        pr.set_preprocessed(cx.to_device(ckt.pre))
-        pr.enable_permutation(NUM_ROUTED, 8)  # Z / partial products on the device from wires + sigmas
-        pr.enable_quotient()                  # quotient chunks on the device
-        pr.set_gates([mp2.Gate(g.kind, g.p0, g.p1, g.p2, g.selector_index, g.group_start, g.group_end) for g in ckt.gates],
-                     ckt.num_selectors)       # ... including the gate constraint terms
-        if args.witness_check:
-            pr.enable_witness_check()
-        # the witness, tiled over the batch; the unrouted cells of one Noop row are free, so re-drawing
-        # them per proof keeps the commitments, transcripts and proofs of the batch distinct
-        wires_one = ckt.wires
-        noop_row = ckt.instances.index(next(i for i, g in enumerate(ckt.gates) if g.kind == C.NOOP))
-        d_vals = []
-        for i, w in enumerate(oracle_w[1:]):
-            if i >= 1:
-                d_vals.append(None)  # oracles 2 and 3: produced by the prover itself
-                continue
-            one = wires_one.copy()
-            buf = cx.alloc(nb * w * n * 8)
-            for b in range(nb):
-                one[NUM_ROUTED:, noop_row] = O.rand_field(w - NUM_ROUTED, SEED + 1000 * len(provers) + 31 * rank + b)
-                mp2._ck(mp2.load().mp2g_h2d(cx.h, ctypes.c_void_p(buf.ptr.value + b * w * n * 8), mp2._p(one), ctypes.c_size_t(one.nbytes)))
-            d_vals.append(buf)
-        d_cd = cx.to_device(O.rand_field(4, SEED + 7))
-        d_ph = cx.to_device(np.stack([ckt.pi_hash] * nb))  # bound to the wires by the PublicInput gate
+        cp = FW.CircuitProver(cx, ckt, nb, VARIANT, witness_check=args.witness_check, bind_public_inputs=True)
+        wseed = SEED + 1000 * pi + 31 * rank
+        d_w = FW.tile_witness(cx, ckt, nb, wseed)
+        pi_hash = C.rand_field((nb, 4), wseed + 17)  # every proof has its own public inputs
+        d_ph = cx.to_device(pi_hash)
         staging = []
         if args.host_inputs:
-            for buf in d_vals:
-                if buf is None:
-                    continue
-                view, hptr = cx.host_alloc(buf.nbytes)
-                view[:] = np.frombuffer(buf.download((buf.nbytes // 8,)).tobytes(), dtype=np.uint8)
-                staging.append((buf, hptr, buf.nbytes))
-        provers.append((pr, d_vals, d_cd, d_ph, cx, staging))
+            view, hptr = cx.host_alloc(d_w.nbytes)
+            view[:] = np.frombuffer(d_w.download((d_w.nbytes // 8,)).tobytes(), dtype=np.uint8)
+            staging.append((d_w, hptr, d_w.nbytes))
+        provers.append((cp, d_w, d_ph, cx, staging, wseed, pi_hash, role))
     n_ntt = 1 << LOG_NTT
-    d_poly = ctx.to_device(O.rand_field((1, n_ntt), 0xC0FFEE02 + rank))
+    d_poly = ctx.to_device(C.rand_field((1, n_ntt), 0xC0FFEE02 + rank))
     d_out = ctx.alloc(n_ntt * 8)
 
     def step():
-        for pr, d_vals, d_cd, d_ph, cx, staging in provers:
+        for cp, d_w, d_ph, cx, staging, *_ in provers:
             for buf, hptr, nbytes in staging:
                 cx.h2d_async(buf, hptr, nbytes)
-            pr.prove(d_vals, d_cd, d_ph)
+            cp.prove(d_w, d_ph)
 
     def sync_all():
         for c in ctxs:
@@ -275,28 +268,66 @@ def main():
         dt = float(t.item())
 
     if args.witness_check:
-        for pr, *_ in provers:
-            pr.witness_status()  # raises on a violated constraint
+        for cp, *_ in provers:
+            cp.pr.witness_status()  # raises on a violated constraint
+
+    # ---- self-check: sampled proofs of the LAST timed step vs the CPU oracle (also the cpu_baseline sample) ------
+    verified, cpu_base = 0, None
+    if not args.no_verify:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle as O
+        results = [cp.results() for cp, *_ in provers]
+
+        def sample(idx, b, mandatory):
+            cp, _, _, _, _, wseed, pi_hash, role = provers[idx]
+            ofp = O.standard_params(cp.ckt.log_n, (int(cp.ckt.pre.shape[0]), 135, 20, 16), variant=VARIANT)
+            caps, openings, proofs = results[idx]
+            return (f"{role} prover {idx} proof {b}", cp.ckt, ofp, cp.circuit_digest, lambda: FW.witness_of(cp.ckt, wseed, b, pi_hash[b]),
+                    pi_hash[b], caps[b], openings[b], proofs[b], mandatory)
+
+        # a leaf proof = the base and the wrap proof with the same batch index of a (base, wrap) prover pair; the first
+        # and the last index of every pair are mandatory, further ones follow while the CPU budget lasts
+        base_ids = [i for i, pv in enumerate(provers) if pv[7] == "base"]
+        wrap_ids = [i for i, pv in enumerate(provers) if pv[7] == "wrap"]
+        samples, rounds = [], 0
+        while len(samples) < 64:
+            added = False
+            for ib, iw in zip(base_ids, wrap_ids):
+                nb = min(provers[ib][0].batch, provers[iw][0].batch)
+                order = [0, nb - 1] + list(range(1, nb - 1))
+                order = order[:nb] if nb > 1 else [0]
+                if rounds < len(order):
+                    b = order[rounds]
+                    samples.append([sample(ib, b, rounds < 2), sample(iw, b, rounds < 2)])
+                    added = True
+            rounds += 1
+            if not added:
+                break
+        samples.sort(key=lambda leaf: not leaf[0][-1])
+        timed = world == 1 and not args.no_cpu_baseline
+        # every rank checks its own proofs; the timed sample is rank 0 at N=1 only
+        verified, cpu_base = check_against_oracle(samples, args.cpu_budget, timed)
+
     # per-stage split of one batch per shape, each prover alone on the GPU (outside the timed region)
     stages = {}
     if rank == 0:
         seen_shapes = set()
-        for (role, k, cx, nb), (pr, d_vals, d_cd, d_ph, _, _) in zip(plan, provers):
+        for (role, k, cx, nb), (cp, d_w, d_ph, *_rest) in zip(plan, provers):
             if role in seen_shapes:
                 continue
             seen_shapes.add(role)
             sync_all()
-            pr.enable_timing(True)
-            pr.prove(d_vals, d_cd, d_ph)
-            ms = pr.stage_ms()
-            pr.enable_timing(False)
+            cp.pr.enable_timing(True)
+            cp.prove(d_w, d_ph)
+            ms = cp.pr.stage_ms()
+            cp.pr.enable_timing(False)
             stages[f"{role} 2^{k} x {nb}"] = {s: round(v, 3) for s, v in ms.items()}
 
     # the per-rank multiset digest (2^16 rows x 4 value columns, device resident) meets in one
     # all_gather of one encoded point per rank, outside the per-proof path
     rows, n_cols = 1 << 16, 4
     rng = np.random.default_rng(0xC0FFEE04 + rank)
-    d_ids = ctx.to_device(O.rand_field(n_cols, 0xC0FFEE04))
+    d_ids = ctx.to_device(C.rand_field(n_cols, 0xC0FFEE04))
     d_values = ctx.to_device(rng.integers(0, 1 << 32, size=(rows, n_cols, 8), dtype=np.uint32))
     d_unique = ctx.to_device(rng.integers(0, 1 << 32, size=(rows, 1, 8), dtype=np.uint32))
     mp2.compute_table_row_digest_dev(ctx, d_ids, n_cols, d_values, d_unique, 1, rows)
@@ -306,16 +337,22 @@ def main():
     if dist is not None:
         allw = sharding.all_gather_words(dist, w, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None)
         w = mp2.curve_sum(ctx, allw)
+        v = torch.tensor([verified], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.int64)
+        dist.all_reduce(v)
+        verified = int(v.item())
 
+    out = None
     if rank == 0:
         # HBM-side bytes of the same two launches from the TCC counters (collected in separate
-        # --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/r01/ntt_traffic.json)
+        # --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/rNN/ntt_traffic.json)
         traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01", "ntt_traffic.json")) as f:
-                traffic = json.load(f)["ntt_2p22_forward_bitrev"]["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
+        for rnd in ("r02", "r01"):
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, "ntt_traffic.json")) as f:
+                    traffic = json.load(f)["ntt_2p22_forward_bitrev"]["traffic_bytes"]
+                break
+            except (OSError, KeyError, ValueError):
+                pass
         ntt_s = float(np.median(ntt_ms)) / 1e3
         achieved = 16.0 * n_ntt / ntt_s / 1e9
         out = {
@@ -326,34 +363,39 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 (Goldilocks field)", "data": "synthetic",
-            "config": {"workload": f"configs[3]-shaped leaf proofs: base 2^{args.base_bits} + wrap 2^12 prove() from the wire matrix "
-                                   "(commitments, permutation argument, quotient with gate constraints, Fiat-Shamir, openings, FRI) at "
+            "verified": verified,
+            "config": {"workload": f"configs[3]-shaped leaf proofs, steady state after witness generation: base 2^{args.base_bits} + wrap 2^12 prove() from "
+                                   "the wire matrix (commitments, permutation argument, quotient with gate constraints, Fiat-Shamir, openings, FRI) at "
                                    "standard_recursion_config; base circuit = 19 gates (recursive-verifier set + u32 / comparison logic), wrap circuit = the 13 "
-                                   "gates of plonky2's recursive verifier; "
+                                   "gates of plonky2's recursive verifier; every proof has its own public inputs and free cells; "
                                    "roofline leg = configs[1] 2^22-point NTT",
-                       "batch_per_rank": B, "streams": args.streams, "witness_check": bool(args.witness_check), "host_inputs": bool(args.host_inputs), "oracle_polys": {r: [int(c.pre.shape[0])] + list(ORACLE_W[1:]) for r, c in circuits.items()},
+                       "batch_per_rank": B, "streams": args.streams, "witness_check": bool(args.witness_check), "host_inputs": bool(args.host_inputs),
+                       "oracle_polys": {r: [int(c.pre.shape[0]), 135, 20, 16] for r, c in circuits.items()},
                        "gates": {r: len(c.gates) for r, c in circuits.items()}, "hasher": "Poseidon2" if VARIANT == 0 else "Poseidon (original_poseidon feature)",
-                       "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B"},
-            "roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, both launches)",
+                       "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B",
+                       "verified": f"{verified} sampled GPU proofs (first and last of every prover's batch on every rank, then more while the CPU budget "
+                                   "lasts) equal the CPU oracle's proofs of the same witnesses bit for bit and pass its verifier"},
+            "roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, all launches)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "launch_ms": ntt_s * 1e3, "algorithmic_bytes": 16 * n_ntt},
             "ntt_batched_2p12": {"transforms": nb12, "GBps": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9,
                                  "frac_of_hbm_peak": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9 / HBM_PEAK_GBPS},
             "sponge": {"hasher": args.hasher, "permutations_per_s": n_hash * (limbs // 8) / (hash_ms / 1e3), "bound": "VALU issue (integer ALU)",
-                                 "input": f"{n_hash} x {limbs} limbs, hash_no_pad, resident"},
+                       "input": f"{n_hash} x {limbs} limbs, hash_no_pad, resident"},
             "stage_ms": stages,
             "clocks": gpu_clocks(local_rank),
             "digest_rows_per_s": rows / digest_s,
             "digest_check": [int(x) for x in w],
         }
-        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args.base_bits, variant=VARIANT)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
     for c in reversed(ctxs):
         c.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -235,8 +235,8 @@ int mp2g_proof_deserialize(const mp2g_fri_params* params, uint32_t num_constants
                            uint64_t* caps, uint64_t* openings, uint64_t* fri_proof, uint64_t* public_inputs,
                            uint32_t n_public_inputs);
 /* ProofWithVK::serialize (mp2-common/src/proof.rs:42-52): bincode(proof) followed by the verifier
- * key as a length-prefixed byte blob (plonky2 VerifierOnlyCircuitData::to_bytes: cap length as
- * u64, the cap hashes, the circuit digest). */
+ * key as a length-prefixed byte blob (plonky2 VerifierOnlyCircuitData::to_bytes: cap HEIGHT as
+ * u64, the cap hashes, the circuit digest). vk_cap_len must be a power of two. */
 int mp2g_proof_with_vk_serialize(const uint8_t* proof_bytes, size_t proof_len, const uint64_t* vk_cap,
                                  uint32_t vk_cap_len, const uint64_t vk_circuit_digest[4], uint8_t* out, size_t* out_len);
 
@@ -258,6 +258,13 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
  * only constraints are copy constraints). d_values[2] may then be NULL. Needs
  * mp2g_prover_enable_permutation, rate_bits 3 and oracle_w[3] = zs_count * 8. */
 int mp2g_prover_enable_quotient(mp2g_prover* pr);
+
+/* PublicInputGate's witness generator on the device: before the wires are committed, every proof's
+ * d_pi_hash[b][0..4) is written to wires 0..3 of row `row` (the circuit's PublicInputGate row) of its wire
+ * matrix, IN PLACE in d_values[0] of mp2g_prover_prove_dev. A batch of proofs of one circuit that differ only
+ * in their public inputs can then share one witness template (the aggregation levels of
+ * recursion-framework/tests/integration.rs:138-261). row < 0 turns it off. */
+int mp2g_prover_bind_public_inputs(mp2g_prover* pr, int64_t row);
 
 /* plonky2's prove() panics on a witness that violates a constraint (the reference's tests depend on it:
  * recursion-framework/src/framework.rs:694-700). With the check on, every mp2g_prover_prove_dev also

@@ -71,6 +71,12 @@ class DeviceBuffer:
         _ck(load().mp2g_h2d(self.ctx.h, self.ptr, _p(a), ctypes.c_size_t(a.nbytes)))
         return self
 
+    def upload_at(self, a, offset):
+        a = np.ascontiguousarray(a)
+        assert offset + a.nbytes <= self.nbytes
+        _ck(load().mp2g_h2d(self.ctx.h, ctypes.c_void_p(self.ptr.value + offset), _p(a), ctypes.c_size_t(a.nbytes)))
+        return self
+
     def download(self, shape, dtype=np.uint64):
         out = np.empty(shape, dtype=dtype)
         assert out.nbytes <= self.nbytes
@@ -453,6 +459,11 @@ class BatchedProver:
         arr = (Gate * len(gates))(*gates)
         _ck(load().mp2g_prover_set_gates(self.h, arr, len(gates), num_selectors))
 
+    def bind_public_inputs(self, row):
+        """PublicInputGate's generator on the device: wires 0..3 of `row` of every proof's wire matrix are
+        overwritten (in place) with that proof's public-inputs hash before the commitment."""
+        _ck(load().mp2g_prover_bind_public_inputs(self.h, ctypes.c_int64(-1 if row is None else int(row))))
+
     def enable_witness_check(self, on=True):
         """Check gate and copy constraints of every witness on the device (plonky2 panics on a bad one)."""
         _ck(load().mp2g_prover_enable_witness_check(self.h, int(on)))
@@ -656,38 +667,6 @@ def compute_table_row_digest_dev(ctx, d_col_ids, n_cols, d_values, d_unique, n_u
     _ck(load().mp2g_row_digest_batch_dev(ctx.h, variant, d_col_ids.ptr, n_cols, d_values.ptr, d_unique.ptr, n_unique, rows,
                                          None, _p(w), None))
     return w
-
-
-# ---- map-reduce over an aggregation tree (recursion-framework/tests/integration.rs:138-261) -------
-def prove_aggregation_tree(ctx, fp, preprocessed, leaf_values, circuit_digest, arity=2, variant=POSEIDON2):
-    """Bottom-up batched proving of a complete `arity`-ary tree, one batched launch per level
-    (children before parents, as ryhope's work plan orders them). Level 0 proves the leaves from
-    `leaf_values` (list over oracles 1.. of arrays [n_leaves][w][n]); a parent's witness is modelled by
-    re-using its first child's matrices, and its public-input hash is
-    H(wires cap of child 0 || ... || wires cap of child arity-1) -- the data dependency that forces
-    the level order. Returns a list of levels, each (pi_hash [nodes][4], caps, openings, proofs).
-    The circuit logic itself (universal verifier gadget) is out of scope: DESIGN.md section 6."""
-    n_nodes = leaf_values[0].shape[0]
-    pi = np.zeros((n_nodes, 4), dtype=np.uint64)
-    pi[:, 0] = np.arange(n_nodes, dtype=np.uint64)  # leaf index as the leaf's public input hash stand-in
-    vals = [np.ascontiguousarray(v, dtype=np.uint64) for v in leaf_values]
-    d_pre = ctx.to_device(preprocessed)
-    d_cd = ctx.to_device(circuit_digest)
-    levels = []
-    while True:
-        pr = BatchedProver(ctx, fp, n_nodes)
-        pr.set_preprocessed(d_pre)
-        pr.prove([ctx.to_device(v) for v in vals], d_cd, ctx.to_device(pi))
-        caps, openings, proofs = pr.results()
-        pr.free()
-        levels.append((pi, caps, openings, proofs))
-        if n_nodes == 1:
-            return levels
-        assert n_nodes % arity == 0
-        n_nodes //= arity
-        child_caps = caps[:, 1, :].reshape(n_nodes, arity * fp.cap_words)
-        pi = ctx.hash_no_pad_batch(child_caps, 4, variant)
-        vals = [np.ascontiguousarray(v[::arity]) for v in vals]
 
 
 def partial_products_and_zs(ctx, wires, sigmas, betas, gammas, degree=8):

@@ -41,11 +41,19 @@ int mp2g_ctx_create(int device, mp2g_ctx** out) {
   mp2g_ctx* c = new (std::nothrow) mp2g_ctx();
   if (!c) return fail("out of memory");
   c->device = device;
-  CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  c->own_stream = true;
-  c->ntt.stream = c->stream;
-  CK(hipEventCreate(&c->ev0));
-  CK(hipEventCreate(&c->ev1));
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    c->own_stream = true;
+    c->ntt.stream = c->stream;
+    e = hipEventCreate(&c->ev0);
+  }
+  if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+  if (e != hipSuccess) {  // nothing half-built survives a failed create
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return fail("mp2g_ctx_create: %s", hipGetErrorString(e));
+  }
   *out = c;
   return 0;
 }

@@ -6,6 +6,7 @@
 
 namespace mp2g {
 int fail(const char* fmt, ...);  // records mp2g_last_error(), returns 1
+int params_check(const mp2g_fri_params* p);  // prover.hip: every bound the layout arithmetic relies on
 
 // owning device buffer of u64 words
 struct DevBuf {

@@ -50,5 +50,6 @@ hipError_t fri_soa_to_aos(hipStream_t s, u32 B, u32 n, const u64* in, u64 in_bst
 hipError_t fri_pow(hipStream_t s, int variant, const ChState* st, u32 B, u32 bits, u64* witness);
 hipError_t fri_queries(hipStream_t s, const FriShape& sh, const FriLayers& ly, u32 B, u32 num_queries, const u64* chal,
                        u64 chal_bstride, u64* proof, u64 proof_bstride, u64 q_off, u64 q_words);
+hipError_t bind_public_inputs(hipStream_t s, u32 B, u64* wires, u64 wires_bstride, u64 n, u32 row, const u64* pi_hash);
 hipError_t copy_rows(hipStream_t s, u32 B, const u64* src, u64 src_bstride, u64* dst, u64 dst_bstride, u32 words);
 }  // namespace mp2g

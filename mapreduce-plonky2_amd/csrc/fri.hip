@@ -400,6 +400,12 @@ __global__ void copy_rows_kernel(const u64* src, u64 src_bstride, u64* dst, u64 
   if (i < words) dst[b * dst_bstride + i] = src[b * src_bstride + i];
 }
 
+// PublicInputGate's generator: wires[b][c][row] = pi_hash[b][c], c < 4
+__global__ void bind_pi_kernel(u64* wires, u64 wires_bstride, u64 n, u32 row, const u64* pi_hash, u32 B) {
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 4 * B) wires[(t >> 2) * wires_bstride + (u64)(t & 3) * n + row] = pi_hash[t];
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -451,6 +457,10 @@ hipError_t fri_queries(hipStream_t s, const FriShape& sh, const FriLayers& ly, u
                        u64* proof, u64 proof_bstride, u64 q_off, u64 q_words) {
   if (!num_queries) return hipSuccess;
   hipLaunchKernelGGL(query_kernel, dim3(num_queries, B), dim3(256), 0, s, sh, ly, chal, chal_bstride, proof, proof_bstride, q_off, q_words);
+  return hipGetLastError();
+}
+hipError_t bind_public_inputs(hipStream_t s, u32 B, u64* wires, u64 wires_bstride, u64 n, u32 row, const u64* pi_hash) {
+  hipLaunchKernelGGL(bind_pi_kernel, dim3((4 * B + 63) / 64), dim3(64), 0, s, wires, wires_bstride, n, row, pi_hash, B);
   return hipGetLastError();
 }
 hipError_t copy_rows(hipStream_t s, u32 B, const u64* src, u64 src_bstride, u64* dst, u64 dst_bstride, u32 words) {

@@ -26,6 +26,9 @@ struct NttEngine {
   std::map<u64, std::unique_ptr<CosetTables>> cosets;
   u64* scratch = nullptr;
   size_t scratch_words = 0;
+  // bumped whenever a device buffer a launched kernel may reference (scratch, coset tables) is freed or
+  // replaced: a hipGraph captured under an older generation must not be replayed
+  u64 generation = 0;
   ~NttEngine();
 
   hipError_t plan(u32 log_n, bool inverse, NttPlan** out);

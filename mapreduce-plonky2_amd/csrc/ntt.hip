@@ -408,6 +408,7 @@ hipError_t NttEngine::coset(u32 log_n, u32 logK, u64 shift, CosetTables** out) {
     HIPCHK(hipGetLastError());
   }
   *out = c.get();
+  if (cosets.count(key)) generation++;  // a colliding key replaces (frees) tables a captured graph may reference
   cosets[key] = std::move(c);
   return hipSuccess;
 }
@@ -416,6 +417,7 @@ hipError_t NttEngine::ensure_scratch(size_t words) {
   if (words <= scratch_words) return hipSuccess;
   if (scratch) HIPCHK(hipFree(scratch));
   scratch = nullptr; scratch_words = 0;
+  generation++;  // captured graphs that reference the old scratch are stale
   HIPCHK(dev_alloc(&scratch, words));
   scratch_words = words;
   return hipSuccess;
@@ -430,6 +432,14 @@ template <int LT, int LW> static size_t lds_bytes() {
   return (size_t)(e + (e >> 4) + 1 + R8Tw<LT>::LDS_WORDS + 1) * sizeof(u64);
 }
 
+// hipFuncSetAttribute acts on the current device's copy of the kernel: one flag per device, so a process that
+// drives several GPUs raises the LDS limit on each of them
+#define MP2G_MAX_DEVICES 64
+static bool* attr_flag(bool* flags) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return &flags[dev >= 0 && dev < MP2G_MAX_DEVICES ? dev : 0];
+}
 template <int LT>
 static hipError_t launch_rows(const NttArgs& a, bool nat_two_pass, hipStream_t st) {
   constexpr int LW = rows_lw<LT>();
@@ -437,12 +447,14 @@ static hipError_t launch_rows(const NttArgs& a, bool nat_two_pass, hipStream_t s
   size_t lds = lds_bytes<LT, LW>();
   u64 total_rows = (u64)a.batch << a.log_n1;
   if (nat_two_pass) {
-    static bool attr = false;
-    if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_rows_nat_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    static bool flags[MP2G_MAX_DEVICES];
+    bool* attr = attr_flag(flags);
+    if (!*attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_rows_nat_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); *attr = true; }
     hipLaunchKernelGGL((ntt_rows_nat_kernel<LT, LW>), dim3((u32)(total_rows >> LW)), dim3(NT), lds, st, a);
   } else {
-    static bool attr = false;
-    if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_rows_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    static bool flags[MP2G_MAX_DEVICES];
+    bool* attr = attr_flag(flags);
+    if (!*attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_rows_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); *attr = true; }
     hipLaunchKernelGGL((ntt_rows_kernel<LT, LW>), dim3((u32)((total_rows + (1u << LW) - 1) >> LW)), dim3(NT), lds, st, a);
   }
   return hipGetLastError();
@@ -452,8 +464,9 @@ static hipError_t launch_cols(const NttArgs& a, u64* dst_dense, hipStream_t st) 
   constexpr int LW = cols_lw<LT>();
   constexpr int NT = NttGeom<LT, LW>::NT;
   size_t lds = lds_bytes<LT, LW>();
-  static bool attr = false;
-  if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_cols_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+  static bool flags[MP2G_MAX_DEVICES];
+  bool* attr = attr_flag(flags);
+  if (!*attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_cols_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); *attr = true; }
   hipLaunchKernelGGL((ntt_cols_kernel<LT, LW>), dim3(a.batch << (a.log_n2 - LW)), dim3(NT), lds, st, a, dst_dense);
   return hipGetLastError();
 }

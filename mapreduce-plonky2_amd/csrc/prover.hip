@@ -39,6 +39,8 @@ struct mp2g_prover {
   DevBuf pre_values, zs_values, chunk_q, bg, alphas, qvals;
   // gate constraints (mp2g_prover_set_gates)
   GateTable gates{};
+  // PublicInputGate row whose first four wires the prover fills from d_pi_hash (mp2g_prover_bind_public_inputs)
+  int64_t pi_row = -1;
   // witness check (mp2g_prover_enable_witness_check): bit 0 copy constraints, bit 1 gate constraints
   bool wcheck = false;
   DevBuf wflags;
@@ -50,6 +52,7 @@ struct mp2g_prover {
   int plain_calls = 0;  // the first call runs un-captured: it creates the cached twiddle / coset tables
   hipGraphExec_t gexec = nullptr;
   const void* gkey[12] = {};
+  u64 ggen = 0;  // NttEngine::generation at capture time
   void drop_graph() {
     if (gexec) (void)hipGraphExecDestroy(gexec);
     gexec = nullptr;
@@ -70,7 +73,8 @@ struct ProverGuard {
 };
 }  // namespace
 
-static int params_check(const mp2g_fri_params* p) {
+namespace mp2g {
+int params_check(const mp2g_fri_params* p) {
   NEED(p, "params");
   NEED(p->variant <= 1, "variant");
   NEED(p->log_n >= 1 && p->log_n <= 20, "1 <= log_n <= 20");
@@ -92,6 +96,7 @@ static int params_check(const mp2g_fri_params* p) {
   for (uint32_t o = 0; o < p->n_oracles; o++) NEED(p->oracle_w[o] >= 1, "oracle_w >= 1");
   return 0;
 }
+}  // namespace mp2g
 
 extern "C" {
 
@@ -99,7 +104,8 @@ uint32_t mp2g_reduction_arity_bits(uint32_t degree_bits, uint32_t rate_bits, uin
                                    uint32_t final_poly_bits, uint32_t* out) {
   uint32_t n = 0;
   if (arity_bits == 0) return 0;
-  while (degree_bits > final_poly_bits && degree_bits + rate_bits >= cap_height + arity_bits && n < 8) {
+  // plonky2 asserts degree_bits >= arity_bits inside the loop; stop instead of wrapping the u32
+  while (degree_bits > final_poly_bits && degree_bits >= arity_bits && degree_bits + rate_bits >= cap_height + arity_bits && n < 8) {
     out[n++] = arity_bits;
     degree_bits -= arity_bits;
   }
@@ -341,10 +347,11 @@ int mp2g_prover_set_gates(mp2g_prover* pr, const mp2g_gate* gates, uint32_t n_ga
     for (uint32_t i = 0; i < n_gates; i++) t.g[i] = gates[i];
     const char* msg = gate_table_check(t, pr->P.oracle_w[0] - pr->num_routed, pr->P.oracle_w[1]);
     if (msg) return fail("invalid gate table: %s", msg);
-    // Sum of filter degree and gate degree must fit the quotient degree factor (gates/selectors.rs)
+    // filter degree + gate degree <= quotient_degree_factor + 1 (gates/selectors.rs is called with that bound:
+    // a degree-9n vanishing polynomial divided by Z_H fits the 8n-point coset)
     for (uint32_t i = 0; i < n_gates; i++) {
       uint32_t fdeg = t.g[i].group_end - t.g[i].group_start - 1 + (num_selectors > 1 ? 1 : 0);
-      if (fdeg + gate_degree(t.g[i]) > 8) return fail("invalid gate table: filtered degree of gate %u exceeds the quotient degree factor 8", i);
+      if (fdeg + gate_degree(t.g[i]) > 9) return fail("invalid gate table: filtered degree of gate %u exceeds quotient degree factor + 1 = 9", i);
     }
   }
   pr->gates = t;
@@ -427,15 +434,26 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
   const void* key[12] = {d_circuit_digest, d_pi_hash, d_caps, d_openings, d_proof};
   for (uint32_t o = 1; o < pr->P.n_oracles && o < 8; o++) key[4 + o] = d_values[o - 1];
   hipStream_t s = pr->ctx->stream;
-  if (pr->gexec && memcmp(key, pr->gkey, sizeof key) == 0) {
+  if (pr->gexec && memcmp(key, pr->gkey, sizeof key) == 0 && pr->ggen == pr->ctx->ntt.generation) {
     CK(hipGraphLaunch(pr->gexec, s));
     return 0;
   }
   pr->drop_graph();
   hipGraph_t g = nullptr;
+  // nothing may be (re)allocated inside a capture: the shared NTT scratch another prover or mp2g_ntt_dev call may
+  // have left too small is grown here, before the capture begins (the largest two-pass natural-order transform of
+  // prove_impl is the quotient iNTT: zs_count * B transforms of 8n points)
+  if (pr->quotient)
+    CK(pr->ctx->ntt.ensure_scratch((size_t)pr->B * pr->P.zs_count * ((size_t)8 << pr->P.log_n)));
+  for (uint32_t o = 1; o < pr->P.n_oracles; o++) CK(pr->ctx->ntt.ensure_scratch((size_t)pr->B * pr->P.oracle_w[o] << pr->P.log_n));
+  const u64 gen0 = pr->ctx->ntt.generation;
   CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   int rc = prove_impl(pr, d_values, d_circuit_digest, d_pi_hash, d_caps, d_openings, d_proof);
   hipError_t e = hipStreamEndCapture(s, &g);
+  if (!rc && e == hipSuccess && pr->ctx->ntt.generation != gen0) {
+    if (g) (void)hipGraphDestroy(g);
+    return fail("graph capture: an NTT buffer was reallocated inside the capture");
+  }
   if (rc || e != hipSuccess) {
     if (g) (void)hipGraphDestroy(g);
     return rc ? rc : fail("graph capture: %s", hipGetErrorString(e));
@@ -444,6 +462,7 @@ int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, cons
   (void)hipGraphDestroy(g);
   if (e != hipSuccess) { pr->gexec = nullptr; return fail("hipGraphInstantiate: %s", hipGetErrorString(e)); }
   memcpy(pr->gkey, key, sizeof key);
+  pr->ggen = gen0;
   CK(hipGraphLaunch(pr->gexec, s));
   return 0;
 }
@@ -466,6 +485,8 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
   const u64 caps_b = P.n_oracles * capw;
 
   STAGE_MARK(pr, 0);
+  if (pr->pi_row >= 0)
+    CK(bind_public_inputs(s, B, (u64*)d_values[0], (u64)P.oracle_w[1] * n, n, (u32)pr->pi_row, (const u64*)d_pi_hash));
   if (pr->wcheck) {
     CK(hipMemsetAsync(pr->wflags.p, 0, B * sizeof(u32), s));
     if (pr->gates.n_gates)
@@ -479,9 +500,10 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
   for (uint32_t o = 1; o < P.n_oracles; o++) {
     const u64* vals = (const u64*)d_values[o - 1];
     if (o == 2 && pr->num_routed) {
-      // betas = bg[0..2), gammas = bg[2..4) of every transcript (drawn after the wires cap)
+      // betas = bg[0..nc), gammas = bg[nc..2nc) of every transcript (drawn after the wires cap:
+      // get_n_challenges(num_challenges) twice)
       CK(zpp_compute(s, B, (const u64*)d_values[0], (u64)P.oracle_w[1] * n, pr->pre_values.p + (u64)(P.oracle_w[0] - pr->num_routed) * n,
-                     P.log_n, pr->num_routed, pr->degree, pr->bg.p, pr->bg.p + 2, 4, P.zs_count, pr->chunk_q.p, pr->zs_values.p,
+                     P.log_n, pr->num_routed, pr->degree, pr->bg.p, pr->bg.p + P.zs_count, 4, P.zs_count, pr->chunk_q.p, pr->zs_values.p,
                      (u64)P.oracle_w[2] * n));
       vals = pr->zs_values.p;
       if (pr->wcheck)
@@ -507,8 +529,9 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
     }
     u64* cap_dst = (u64*)d_caps + o * capw;
     CK(copy_rows(s, B, pr->levels[o].p + LW - capw, LW, cap_dst, caps_b, (u32)capw));
-    // plonk/prover.rs: wires cap -> betas, gammas (2+2); zs cap -> alphas (2); all other caps -> 0
-    uint32_t n_get = o == 1 ? 4 : (o == 2 ? 2 : 0);
+    // plonk/prover.rs: wires cap -> num_challenges betas, then as many gammas; zs cap -> num_challenges
+    // alphas; all other caps -> 0
+    uint32_t n_get = o == 1 ? 2 * P.zs_count : (o == 2 ? P.zs_count : 0);
     u64* dst = chal;
     u64 dst_stride = 8;
     if (pr->num_routed && o == 1) { dst = pr->bg.p; dst_stride = 4; }
@@ -536,6 +559,14 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
   int rc = fri_tail(pr, sh, st, (u64*)d_proof);
   if (rc) return rc;
   STAGE_MARK(pr, 7);
+  return 0;
+}
+int mp2g_prover_bind_public_inputs(mp2g_prover* pr, int64_t row) {
+  NEED(pr, "prover");
+  NEED(row < (int64_t)1 << pr->P.log_n, "row < 2^log_n");
+  NEED(pr->P.n_oracles >= 2 && pr->P.oracle_w[1] >= 4, "needs a wires oracle of at least 4 columns");
+  pr->pi_row = row < 0 ? -1 : row;
+  pr->drop_graph();
   return 0;
 }
 int mp2g_prover_enable_witness_check(mp2g_prover* pr, int on) {

@@ -119,8 +119,8 @@ void walk(T& io, const mp2g_fri_params* p, uint32_t num_constants, U64P caps, U6
 void wlen(Writer& w, uint64_t n) { w.len(n); }
 void rlen(Reader& r, uint64_t n) { r.expect_len(n); }
 int shape_check(const mp2g_fri_params* p, uint32_t num_constants) {
-  NEED(p, "params");
-  NEED(p->n_oracles >= 1 && p->n_oracles <= 8, "n_oracles");
+  int rc = params_check(p);  // cap_height / arity / layer bounds: the layout below subtracts them unchecked
+  if (rc) return rc;
   NEED(num_constants <= p->oracle_w[0], "num_constants <= oracle_w[0]");
   NEED(p->zs_oracle == 2 || p->zs_count == 0, "wire format expects the Z polynomials in oracle 2");
   NEED(p->n_oracles <= 4, "wire format has four oracles");
@@ -154,11 +154,16 @@ int mp2g_proof_deserialize(const mp2g_fri_params* p, uint32_t num_constants, con
 int mp2g_proof_with_vk_serialize(const uint8_t* proof_bytes, size_t proof_len, const uint64_t* vk_cap, uint32_t vk_cap_len,
                                  const uint64_t vk_circuit_digest[4], uint8_t* out, size_t* out_len) {
   NEED(out_len && (!out || (proof_bytes && vk_cap && vk_circuit_digest)), "pointers");
+  uint32_t height = 0;
+  while (((uint32_t)1 << height) < vk_cap_len && height < 31) height++;
+  NEED(vk_cap_len >= 1 && ((uint32_t)1 << height) == vk_cap_len, "vk_cap_len must be a power of two");
   Writer w{out};
   w.bytes(proof_bytes, proof_len);
+  // [dep] VerifierOnlyCircuitData::to_bytes = write_usize(cap height), the cap's hashes (no length), the digest;
+  // serialize_with = serialize wraps it as a byte string (u64 length first)
   uint64_t blob = 8 + (uint64_t)vk_cap_len * 32 + 32;
   w.len(blob);
-  w.len(vk_cap_len);
+  w.len(height);
   w.u64s(vk_cap, (size_t)vk_cap_len * 4);
   w.u64s(vk_circuit_digest, 4);
   *out_len = w.pos;

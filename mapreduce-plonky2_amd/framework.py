@@ -1,0 +1,197 @@
+"""Host-side mirror of the recursion framework's proving calls over libmp2gpu.
+
+`CircuitProver` is `CircuitData::prove` for a batch of witnesses of one circuit (everything prove()
+does after witness generation runs on the device, see csrc/prover.hip). `FrameworkProver` is
+`CircuitWithUniversalVerifier::generate_proof` (recursion-framework/src/circuit_builder.rs:286-311):
+a base proof followed by the wrap proof down to 2^12 rows (wrap_circuit.rs:122-148), both carrying
+the same public inputs -- the circuit's own NUM_PUBLIC_INPUTS followed by the 4 limbs of the
+circuit-set digest (circuit_builder.rs:169-171). `MapReduce` is the reference's own integration
+workload (recursion-framework/tests/integration.rs:138-261: a map circuit over chunks of a dataset,
+a 2-to-1 reduce circuit above it) with the public-input chain computed as that test computes it.
+
+The circuits proved here are the synthetic gate-level circuits of circuits.py (the gate sets of a
+leaf and of plonky2's recursive verifier, random satisfied rows): the proving work per node is that
+of the reference's node, the circuit logic is not (a parent's witness does not contain its
+children's proofs; recursion.py builds the real verifier circuit for small trees).
+"""
+import numpy as np
+
+from . import (BatchedProver, CircuitSet, Gate, POSEIDON2, PolynomialBatch, circuit_digest, standard_recursion_params)
+from . import circuits as C
+
+NUM_ROUTED = C.NUM_ROUTED
+# recursion-framework/tests/integration.rs:55: the sum of the even elements and the hash of the elements
+NUM_PUBLIC_INPUTS = 1 + 4
+INPUT_CHUNK_SIZE = 4
+
+
+def circuit_fri_params(ckt, variant=POSEIDON2, **kw):
+    """FRI / oracle shape of a built circuit under standard_recursion_config: constants + sigmas, 135 wires,
+    2 x (1 + 9) Z / partial products, 2 x 8 quotient chunks."""
+    return standard_recursion_params(ckt.log_n, (int(ckt.pre.shape[0]), C.NUM_WIRES, 20, 16), variant=variant, **kw)
+
+
+class CircuitProver:
+    """prove() of `batch` witnesses of one circuit per call, device resident (mp2g_prover with the permutation
+    argument, the quotient and the gate table switched on)."""
+
+    def __init__(self, ctx, ckt, batch, variant=POSEIDON2, witness_check=False, bind_public_inputs=False, **fri_kw):
+        self.ctx, self.ckt, self.batch = ctx, ckt, batch
+        self.fp = circuit_fri_params(ckt, variant, **fri_kw)
+        pr = BatchedProver(ctx, self.fp, batch)
+        self.d_pre = ctx.to_device(ckt.pre)
+        pr.set_preprocessed(self.d_pre)
+        pr.enable_permutation(NUM_ROUTED, 8)
+        pr.enable_quotient()
+        pr.set_gates([Gate(g.kind, g.p0, g.p1, g.p2, g.selector_index, g.group_start, g.group_end) for g in ckt.gates],
+                     ckt.num_selectors)
+        if witness_check:
+            pr.enable_witness_check()
+        if bind_public_inputs:
+            assert ckt.pi_row is not None, "the circuit has no PublicInputGate"
+            pr.bind_public_inputs(ckt.pi_row)
+        self.pr = pr
+        # VerifierOnlyCircuitData: the constants_sigmas cap and the circuit digest
+        # H(cap || H_pad([]) || degree_bits) (circuit_set.rs:136-158), the first thing every transcript absorbs
+        pre = PolynomialBatch.from_values(ctx, ckt.pre, self.fp.rate_bits, self.fp.cap_height, variant)
+        self.constants_sigmas_cap = pre.cap
+        pre.free()
+        self.circuit_digest = circuit_digest(ctx, self.constants_sigmas_cap, ckt.log_n, variant)
+        self.d_circuit_digest = ctx.to_device(self.circuit_digest)
+
+    def prove(self, d_wires, d_pi_hash, d_circuit_digest=None):
+        self.pr.prove([d_wires, None, None], d_circuit_digest or self.d_circuit_digest, d_pi_hash)
+
+    def results(self):
+        return self.pr.results()
+
+    def free(self):
+        self.pr.free()
+
+
+def tile_witness(ctx, ckt, batch, seed, rand_row=True):
+    """[batch][135][n] wire matrices on the device from the circuit's one witness. With rand_row the free
+    (unrouted) cells of one Noop row are re-drawn per proof so that the commitments, transcripts and proofs of
+    the batch all differ; witness_of(ckt, seed, b) gives proof b's matrix back."""
+    w, n = ckt.wires.shape
+    buf = ctx.alloc(batch * w * n * 8)
+    one = ckt.wires.copy()
+    row = noop_row(ckt) if rand_row else None
+    for b in range(batch):
+        if row is not None:
+            one[NUM_ROUTED:, row] = C.rand_field(w - NUM_ROUTED, seed + b)
+        buf.upload_at(one, b * w * n * 8)
+    return buf
+
+
+def noop_row(ckt):
+    return ckt.instances.index(next(i for i, g in enumerate(ckt.gates) if g.kind == C.NOOP))
+
+
+def witness_of(ckt, seed, b, pi_hash=None):
+    """the wire matrix of proof b of tile_witness(ctx, ckt, ., seed) (host copy, for the checker)"""
+    one = ckt.wires.copy()
+    one[NUM_ROUTED:, noop_row(ckt)] = C.rand_field(one.shape[0] - NUM_ROUTED, seed + b)
+    if pi_hash is not None:
+        one[0:4, ckt.pi_row] = pi_hash
+    return one
+
+
+class FrameworkProver:
+    """generate_proof for `batch` nodes at a time: base prove() (2^base_bits rows, the leaf gate set) on one
+    context / stream, wrap prove() (2^12 rows, the recursive-verifier gate set) on another, both bound to the
+    node's public-inputs hash."""
+
+    def __init__(self, ctx_base, ctx_wrap, batch, base_bits=13, wrap_bits=12, variant=POSEIDON2, seed=0xC0FFEE03,
+                 base_kinds=None, wrap_kinds=None, witness_check=False):
+        self.batch, self.variant, self.seed = batch, variant, seed
+        self.base_ckt = C.build(base_bits, base_kinds or C.LEAF_KINDS, seed + base_bits)
+        self.wrap_ckt = C.build(wrap_bits, wrap_kinds or C.VERIFIER_KINDS, seed + wrap_bits + 100)
+        self.base = CircuitProver(ctx_base, self.base_ckt, batch, variant, witness_check, bind_public_inputs=True)
+        self.wrap = CircuitProver(ctx_wrap, self.wrap_ckt, batch, variant, witness_check, bind_public_inputs=True)
+        self.d_base_w = tile_witness(ctx_base, self.base_ckt, batch, seed)
+        self.d_wrap_w = tile_witness(ctx_wrap, self.wrap_ckt, batch, seed + 7)
+        self.d_ph = [ctx_base.alloc(batch * 32), ctx_wrap.alloc(batch * 32)]
+        self.digests = [self.base.circuit_digest, self.wrap.circuit_digest]
+
+    def generate_proofs(self, pi_hashes):
+        """pi_hashes [m <= batch][4]: launches the base and the wrap proofs of m nodes (asynchronous)."""
+        m = len(pi_hashes)
+        buf = np.zeros((self.batch, 4), dtype=np.uint64)
+        buf[:m] = pi_hashes
+        for ph in self.d_ph:
+            ph.upload(buf)
+        self.base.prove(self.d_base_w, self.d_ph[0])
+        self.wrap.prove(self.d_wrap_w, self.d_ph[1])
+
+    def results(self):
+        return self.base.results(), self.wrap.results()
+
+    def free(self):
+        self.base.free()
+        self.wrap.free()
+
+
+class MapReduce:
+    """recursion-framework/tests/integration.rs:138-261 over `n_leaves` map proofs: leaf i covers
+    dataset[4i .. 4i+4) and exposes (sum of its even elements, H(chunk)); a reduce node exposes
+    (sum of its children's sums, H(children's hashes)); every proof's public inputs end with the circuit-set
+    digest. Levels are proved bottom-up in chunks of `chunk` nodes (children before parents, as ryhope's work
+    plan orders them)."""
+
+    def __init__(self, ctx_base, ctx_wrap, n_leaves, chunk=128, variant=POSEIDON2, seed=0xC0FFEE03, base_bits=13, wrap_bits=12):
+        assert n_leaves >= 1 and n_leaves & (n_leaves - 1) == 0
+        self.ctx, self.n_leaves, self.variant = ctx_base, n_leaves, variant
+        self.fw = FrameworkProver(ctx_base, ctx_wrap, min(chunk, n_leaves), base_bits=base_bits, wrap_bits=wrap_bits, variant=variant, seed=seed)
+        self.dataset = C.rand_field(n_leaves * INPUT_CHUNK_SIZE, seed)
+        self.levels = []
+
+    def leaf_public_inputs(self):
+        chunks = self.dataset.reshape(self.n_leaves, INPUT_CHUNK_SIZE)
+        even = (chunks % np.uint64(2)) == 0
+        sums = np.array([sum(int(x) for x, e in zip(row, ev) if e) % C.P for row, ev in zip(chunks, even)], dtype=np.uint64)
+        hashes = self.ctx.hash_no_pad_batch(chunks, 4, self.variant)
+        return np.concatenate([sums[:, None], hashes], axis=1)
+
+    @staticmethod
+    def reduce_public_inputs(ctx, child_pis, variant=POSEIDON2):
+        """ReduceCircuitWires::circuit_logic (integration.rs:108-127), ARITY = 2"""
+        m = child_pis.shape[0] // 2
+        pairs = child_pis.reshape(m, 2, NUM_PUBLIC_INPUTS)
+        sums = np.array([(int(a) + int(b)) % C.P for a, b in pairs[:, :, 0]], dtype=np.uint64)
+        hashes = ctx.hash_no_pad_batch(pairs[:, :, 1:].reshape(m, 8), 4, variant)
+        return np.concatenate([sums[:, None], hashes], axis=1)
+
+    def run(self, keep=lambda level, index: False):
+        """prove the whole tree; returns the root's public inputs (NUM_PUBLIC_INPUTS + 4). keep(level, index)
+        selects the nodes whose proofs are retained in self.kept[(level, index)] = (pi, pi_hash, base, wrap) with
+        base / wrap = (caps, openings, proof)."""
+        fw = self.fw
+        # the set of circuits of the framework: the map and the reduce circuit, both wrapped to the same size
+        self.circuit_set = CircuitSet(self.ctx, np.stack([fw.digests[1], fw.digests[1]]), self.variant)
+        set_digest = self.circuit_set.circuit_set_digest()
+        self.kept, self.n_proofs = {}, 0
+        pis = self.leaf_public_inputs()
+        level = 0
+        while True:
+            full = np.concatenate([pis, np.tile(set_digest, (pis.shape[0], 1))], axis=1)
+            hashes = self.ctx.hash_no_pad_batch(full, 4, self.variant)  # public_inputs_hash of prove()
+            for lo in range(0, len(hashes), fw.batch):
+                part = hashes[lo:lo + fw.batch]
+                fw.generate_proofs(part)
+                want = [i for i in range(len(part)) if keep(level, lo + i)]
+                if want:
+                    (bc, bo, bp), (wc, wo, wp) = fw.results()
+                    for i in want:
+                        self.kept[(level, lo + i)] = (full[lo + i], part[i], (bc[i], bo[i], bp[i]), (wc[i], wo[i], wp[i]))
+                self.n_proofs += len(part)
+            self.levels.append(full)
+            if pis.shape[0] == 1:
+                for c in {fw.base.ctx, fw.wrap.ctx}:
+                    c.sync()
+                return full[0]
+            pis = self.reduce_public_inputs(self.ctx, pis, self.variant)
+            level += 1
+
+    def free(self):
+        self.fw.free()

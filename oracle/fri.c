@@ -298,7 +298,7 @@ static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, c
     if (o == 2 && num_routed) {
       zs_vals = malloc(w * n * sizeof(gl_t));
       orc_partial_products_and_zs(values[1], values[0] + (size_t)(P->oracle_w[0] - num_routed) * n, k, num_routed, degree,
-                                  bg, bg + 2, P->zs_count, zs_vals);
+                                  bg, bg + P->zs_count, P->zs_count, zs_vals);
       src = zs_vals;
     }
     coeffs[o] = malloc(w * n * sizeof(gl_t));
@@ -306,7 +306,7 @@ static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, c
       // PolynomialBatch::from_coeffs: the quotient chunks are produced in coefficient form
       orc_gate_ctx G = {gates, n_gates, num_selectors, P->oracle_w[0] - num_routed, P->oracle_w[1], coeffs[0], pi_hash};
       orc_quotient_polys(coeffs[1], coeffs[0] + (size_t)(P->oracle_w[0] - num_routed) * n, coeffs[2], k, num_routed, degree,
-                         bg, bg + 2, al, P->zs_count, n_gates ? &G : NULL, coeffs[o]);
+                         bg, bg + P->zs_count, al, P->zs_count, n_gates ? &G : NULL, coeffs[o]);
     } else {
       memcpy(coeffs[o], src, w * n * sizeof(gl_t));
       for (size_t p = 0; p < w; p++) orc_fft(coeffs[o] + p * n, k, 1);
@@ -318,13 +318,17 @@ static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, c
     memcpy(caps + o * capw, orc_merkle_cap_ptr(levels[o], lg, P->cap_height), capw * sizeof(gl_t));
     if (o == 0) continue;
     orc_ch_observe(&ch, caps + o * capw, capw);
-    // wires cap -> betas[2], gammas[2]; zs cap -> alphas[2]; quotient cap -> zeta
-    if (o == 1) for (int i = 0; i < 4; i++) bg[i] = orc_ch_get(&ch);
-    else if (o == 2) for (int i = 0; i < 2; i++) al[i] = orc_ch_get(&ch);
+    // wires cap -> num_challenges betas, then as many gammas; zs cap -> alphas; quotient cap -> zeta
+    if (o == 1) for (uint32_t i = 0; i < 2 * P->zs_count; i++) bg[i] = orc_ch_get(&ch);
+    else if (o == 2) for (uint32_t i = 0; i < P->zs_count; i++) al[i] = orc_ch_get(&ch);
   }
   free(zs_vals);
   gl2_t zeta = orc_ch_get_ext(&ch);
-  if (bgao) { memcpy(bgao, bg, 32); memcpy(bgao + 4, al, 16); bgao[6] = zeta.c[0]; bgao[7] = zeta.c[1]; }
+  if (bgao) {  // betas at [0..2), gammas at [2..4), alphas at [4..6) whatever num_challenges is
+    memset(bgao, 0, 8 * sizeof(gl_t));
+    for (uint32_t i = 0; i < P->zs_count; i++) { bgao[i] = bg[i]; bgao[2 + i] = bg[P->zs_count + i]; bgao[4 + i] = al[i]; }
+    bgao[6] = zeta.c[0]; bgao[7] = zeta.c[1];
+  }
   gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(k));
   size_t oi = 0;
   for (uint32_t o = 0; o < P->n_oracles; o++)
@@ -370,8 +374,8 @@ int orc_pcs_verify(const orc_fri_params* P, const gl_t circuit_digest[4], const 
   orc_ch_observe(&ch, pi_hash, 4);
   for (uint32_t o = 1; o < P->n_oracles; o++) {
     orc_ch_observe(&ch, caps + o * capw, capw);
-    if (o == 1) for (int i = 0; i < 4; i++) (void)orc_ch_get(&ch);
-    else if (o == 2) for (int i = 0; i < 2; i++) (void)orc_ch_get(&ch);
+    if (o == 1) for (uint32_t i = 0; i < 2 * P->zs_count; i++) (void)orc_ch_get(&ch);
+    else if (o == 2) for (uint32_t i = 0; i < P->zs_count; i++) (void)orc_ch_get(&ch);
   }
   gl2_t zeta = orc_ch_get_ext(&ch);
   gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(k));
@@ -722,4 +726,28 @@ int orc_plonk_identity_check_gates(const orc_fri_params* P, unsigned num_routed,
   }
 #undef OPEN
   return 0;
+}
+
+// plonk/verifier.rs verify_with_challenges for a circuit with gates: the challenges re-derived from the
+// transcript (get_challenges), the PLONK identity at zeta from the opened values (eval_vanishing_poly with
+// the gate terms), then the FRI verifier. 0 = accept; 10 + a = identity fails for challenge a; 1..5 = FRI codes.
+int orc_verify_gates(const orc_fri_params* P, const gl_t circuit_digest[4], const gl_t pi_hash[4], unsigned num_routed,
+                     unsigned degree, const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* caps,
+                     const gl_t* openings, const gl_t* proof) {
+  size_t capw = ((size_t)4) << P->cap_height;
+  orc_challenger ch;
+  orc_ch_init(&ch, P->variant);
+  orc_ch_observe(&ch, circuit_digest, 4);
+  orc_ch_observe(&ch, pi_hash, 4);
+  gl_t bg[4] = {0, 0, 0, 0}, al[2] = {0, 0};
+  for (uint32_t o = 1; o < P->n_oracles; o++) {
+    orc_ch_observe(&ch, caps + o * capw, capw);
+    if (o == 1) for (uint32_t i = 0; i < 2 * P->zs_count; i++) bg[i] = orc_ch_get(&ch);
+    else if (o == 2) for (uint32_t i = 0; i < P->zs_count; i++) al[i] = orc_ch_get(&ch);
+  }
+  gl2_t zeta = orc_ch_get_ext(&ch);
+  int rc = orc_plonk_identity_check_gates(P, num_routed, degree, openings, zeta, bg, bg + P->zs_count, al, gates, n_gates,
+                                          num_selectors, pi_hash);
+  if (rc) return 10 + rc - 1;
+  return orc_pcs_verify(P, circuit_digest, pi_hash, caps, openings, proof);
 }

@@ -1,461 +1,15 @@
-"""Small gate-level circuits with satisfied witnesses for the gate-constraint tests.
-
-Test infrastructure: a stand-in for what plonky2's CircuitBuilder + witness generators would hand to
-prove() -- constants (selectors first), sigma polynomials, the wire matrix and the gate table. Follows
-[dep] plonky2 gates/selectors.rs selector_polynomials for the selector layout and gates/*.rs for the
-wire layouts (see oracle/gates_body.inc). Pure Python over ints mod p; sized for 2^5..2^8 rows.
+"""Oracle-side companions of the synthetic circuits (mapreduce-plonky2_amd/circuits.py): the CPU oracle's
+prove(), PLONK identity check and constraint evaluation for a built circuit. Test infrastructure.
 """
 import ctypes
-import os
-import re
+import importlib
 
 import numpy as np
 
 import oracle as O
 
-P = O.P
-(NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, BASE_SUM, ARITHMETIC_EXT, MUL_EXT, POSEIDON2, EXPONENTIATION, REDUCING, REDUCING_EXT,
- RANDOM_ACCESS, POSEIDON, POSEIDON_MDS, COSET_INTERPOLATION, U32_ARITHMETIC, U32_RANGE_CHECK, U32_SUBTRACTION, U32_ADD_MANY,
- COMPARISON) = range(20)
-UNUSED_SELECTOR = 0xFFFFFFFF
-NUM_WIRES, NUM_ROUTED, MAX_DEGREE = 135, 80, 8
-
-
-class Gate(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_uint32), ("p0", ctypes.c_uint32), ("p1", ctypes.c_uint32), ("p2", ctypes.c_uint32),
-                ("selector_index", ctypes.c_uint32), ("group_start", ctypes.c_uint32), ("group_end", ctypes.c_uint32)]
-
-
-def gate_degree(g):
-    """Gate::degree()"""
-    return {NOOP: 0, CONSTANT: 1, PUBLIC_INPUT: 1, ARITHMETIC: 3, BASE_SUM: g.p1, ARITHMETIC_EXT: 3, MUL_EXT: 3, POSEIDON2: 7,
-            EXPONENTIATION: 4, REDUCING: 2, REDUCING_EXT: 2, RANDOM_ACCESS: g.p0 + 1, POSEIDON: 7, POSEIDON_MDS: 1, COSET_INTERPOLATION: g.p1,
-            U32_ARITHMETIC: 4, U32_RANGE_CHECK: 4, U32_SUBTRACTION: 4, U32_ADD_MANY: 4,
-            COMPARISON: 1 << ((g.p0 + max(g.p1, 1) - 1) // max(g.p1, 1))}[g.kind]
-
-
-def gate_num_constraints(g):
-    """Gate::num_constraints()"""
-    return {NOOP: 0, CONSTANT: g.p0, PUBLIC_INPUT: 4, ARITHMETIC: g.p0, BASE_SUM: 1 + g.p0, ARITHMETIC_EXT: 2 * g.p0, MUL_EXT: 2 * g.p0,
-            POSEIDON2: 123, EXPONENTIATION: g.p0 + 1, REDUCING: 2 * g.p0, REDUCING_EXT: 2 * g.p0,
-            RANDOM_ACCESS: (g.p0 + 2) * g.p1 + g.p2, POSEIDON: 123, POSEIDON_MDS: 24,
-            COSET_INTERPOLATION: 4 + 4 * (((1 << g.p0) - 2) // max(g.p1 - 1, 1)),
-            U32_ARITHMETIC: 36 * g.p0, U32_RANGE_CHECK: 17 * g.p0, U32_SUBTRACTION: 19 * g.p0, U32_ADD_MANY: 21 * g.p1,
-            COMPARISON: 6 + 5 * g.p1 + (g.p0 + max(g.p1, 1) - 1) // max(g.p1, 1)}[g.kind]
-
-
-_consts = None
-
-
-def poseidon2_constants():
-    global _consts
-    if _consts is None:
-        # the generated constant tables (tools/gen_constants.py writes the same numbers for product and oracle)
-        src = open(os.path.join(O.ROOT, "mapreduce-plonky2_amd", "csrc", "perm_constants.h")).read()
-        out = {}
-        for name in ("POSEIDON2_RC_EXT", "POSEIDON2_RC_INT", "POSEIDON2_DIAG_M1", "POSEIDON_RC", "POSEIDON_MDS_CIRC", "POSEIDON_MDS_DIAG"):
-            body = re.search(name + r"\[\d+\] = \{(.*?)\};", src, re.S).group(1)
-            out[name] = [int(x.rstrip("ULu"), 0) for x in re.findall(r"0x[0-9a-fA-F]+U?L*|\d+U?L*", body)]
-        _consts = out
-    return _consts
-
-
-M4 = ((5, 7, 1, 3), (4, 6, 1, 1), (1, 3, 5, 7), (1, 1, 4, 6))
-
-
-def p2_external(s):
-    t = [sum(s[4 * c + j] * M4[i][j] for j in range(4)) % P for c in range(3) for i in range(4)]
-    sums = [(t[i] + t[4 + i] + t[8 + i]) % P for i in range(4)]
-    return [(t[4 * c + i] + sums[i]) % P for c in range(3) for i in range(4)]
-
-
-def p2_internal(s):
-    d = poseidon2_constants()["POSEIDON2_DIAG_M1"]
-    tot = sum(s) % P
-    return [(s[i] * d[i] + tot) % P for i in range(12)]
-
-
-def poseidon_mds(s):
-    C = poseidon2_constants()
-    circ, diag = C["POSEIDON_MDS_CIRC"], C["POSEIDON_MDS_DIAG"]
-    return [(sum(s[(i + r) % 12] * circ[i] for i in range(12)) + s[r] * diag[r]) % P for r in range(12)]
-
-
-def ext_mul(a, b):
-    return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
-
-
-def ext_sub(a, b):
-    return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
-
-
-def coset_interpolation_degree(subgroup_bits, max_degree=MAX_DEGREE):
-    """CosetInterpolationGate::with_max_degree: the smallest degree that needs no more intermediates"""
-    n_points = 1 << subgroup_bits
-    n_intermediates = (n_points - 2) // (max_degree - 1)
-    return (n_points - 2) // (n_intermediates + 1) + 2
-
-
-def ext_add(a, b):
-    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
-
-
-def fill_row(g, w, consts, inp, rng, pi_hash):
-    """Write a satisfying assignment of gate `g` into the wire list `w` (length NUM_WIRES).
-    inp(col) yields the value of a free routed input cell (random, or copied from an earlier cell)."""
-    k = g.kind
-    rnd = lambda: int(rng.integers(0, P, dtype=np.uint64))
-    if k == CONSTANT:
-        for i in range(g.p0):
-            w[i] = consts[i]
-    elif k == PUBLIC_INPUT:
-        for i in range(4):
-            w[i] = int(pi_hash[i])
-    elif k == ARITHMETIC:
-        for i in range(g.p0):
-            m0, m1, ad = inp(4 * i), inp(4 * i + 1), inp(4 * i + 2)
-            w[4 * i], w[4 * i + 1], w[4 * i + 2] = m0, m1, ad
-            w[4 * i + 3] = (m0 * m1 % P * consts[0] + ad * consts[1]) % P
-    elif k == BASE_SUM:
-        limbs = [int(rng.integers(0, g.p1)) for _ in range(g.p0)]
-        w[0] = sum(l * g.p1 ** i for i, l in enumerate(limbs)) % P
-        w[1:1 + g.p0] = limbs
-    elif k in (ARITHMETIC_EXT, MUL_EXT):
-        per = 8 if k == ARITHMETIC_EXT else 6
-        for i in range(g.p0):
-            b = per * i
-            for c in range(per - 2):
-                w[b + c] = inp(b + c)
-            prod = ext_mul((w[b], w[b + 1]), (w[b + 2], w[b + 3]))
-            o = (prod[0] * consts[0] % P, prod[1] * consts[0] % P)
-            if k == ARITHMETIC_EXT:
-                o = ext_add(o, (w[b + 4] * consts[1] % P, w[b + 5] * consts[1] % P))
-            w[b + per - 2], w[b + per - 1] = o
-    elif k == POSEIDON2:
-        C = poseidon2_constants()
-        for i in range(12):
-            w[i] = inp(i)
-        swap = int(rng.integers(0, 2))
-        w[24] = swap
-        s = [0] * 12
-        for i in range(4):
-            delta = swap * (w[i + 4] - w[i]) % P
-            w[25 + i] = delta
-            s[i], s[i + 4] = (w[i] + delta) % P, (w[i + 4] - delta) % P
-        s[8:12] = w[8:12]
-        s = p2_external(s)
-        for r in range(4):
-            s = [(s[i] + C["POSEIDON2_RC_EXT"][12 * r + i]) % P for i in range(12)]
-            if r:
-                w[29 + 12 * (r - 1):29 + 12 * r] = s
-            s = p2_external([pow(x, 7, P) for x in s])
-        for r in range(22):
-            s[0] = (s[0] + C["POSEIDON2_RC_INT"][r]) % P
-            w[65 + r] = s[0]
-            s[0] = pow(s[0], 7, P)
-            s = p2_internal(s)
-        for r in range(4):
-            s = [(s[i] + C["POSEIDON2_RC_EXT"][12 * (4 + r) + i]) % P for i in range(12)]
-            w[87 + 12 * r:87 + 12 * (r + 1)] = s
-            s = p2_external([pow(x, 7, P) for x in s])
-        w[12:24] = s
-    elif k == POSEIDON:
-        C = poseidon2_constants()
-        for i in range(12):
-            w[i] = inp(i)
-        swap = int(rng.integers(0, 2))
-        w[24] = swap
-        s = [0] * 12
-        for i in range(4):
-            delta = swap * (w[i + 4] - w[i]) % P
-            w[25 + i] = delta
-            s[i], s[i + 4] = (w[i] + delta) % P, (w[i + 4] - delta) % P
-        s[8:12] = w[8:12]
-        for r in range(30):
-            s = [(s[i] + C["POSEIDON_RC"][12 * r + i]) % P for i in range(12)]
-            if 4 <= r < 26:
-                w[65 + r - 4] = s[0]
-                s[0] = pow(s[0], 7, P)
-            else:
-                if r:
-                    base = 29 + 12 * (r - 1) if r < 4 else 87 + 12 * (r - 26)
-                    w[base:base + 12] = s
-                s = [pow(x, 7, P) for x in s]
-            s = poseidon_mds(s)
-        w[12:24] = s
-    elif k == POSEIDON_MDS:
-        for i in range(24):
-            w[i] = inp(i)
-        for c in range(2):
-            o = poseidon_mds([w[2 * i + c] for i in range(12)])
-            for i in range(12):
-                w[24 + 2 * i + c] = o[i]
-    elif k == COSET_INTERPOLATION:
-        npts, deg = 1 << g.p0, g.p1
-        nint = (npts - 2) // (deg - 1)
-        w_pt, w_val = 1 + 2 * npts, 3 + 2 * npts
-        w_int = w_val + 2
-        w_sh = w_int + 4 * nint
-        om = pow(7277203076849721926, 1 << (32 - g.p0), P)
-        dom = [pow(om, i, P) for i in range(npts)]
-        bw = []
-        for i in range(npts):
-            pr = 1
-            for j in range(npts):
-                if j != i:
-                    pr = pr * (dom[i] - dom[j]) % P
-            bw.append(pow(pr, P - 2, P))
-        shift = inp(0)
-        w[0] = shift
-        for c in range(1, 1 + 2 * npts):
-            w[c] = inp(c)
-        sh = (inp(w_sh) if w_sh < NUM_ROUTED else rnd(), rnd())  # shifted point: not routed
-        w[w_sh], w[w_sh + 1] = sh
-        w[w_pt], w[w_pt + 1] = sh[0] * shift % P, sh[1] * shift % P
-        ev, pr = (0, 0), (1, 0)
-        start, end = 0, deg
-        for c in range(nint + 1):
-            for i in range(start, end):
-                val = (w[1 + 2 * i] * bw[i] % P, w[2 + 2 * i] * bw[i] % P)
-                term = ((sh[0] - dom[i]) % P, sh[1])
-                ev, pr = ext_add(ext_mul(ev, term), ext_mul(val, pr)), ext_mul(pr, term)
-            if c == nint:
-                break
-            w[w_int + 2 * c], w[w_int + 2 * c + 1] = ev
-            w[w_int + 2 * (nint + c)], w[w_int + 2 * (nint + c) + 1] = pr
-            start = 1 + (deg - 1) * (c + 1)
-            end = min(start + deg - 1, npts)
-        w[w_val], w[w_val + 1] = ev
-    elif k == U32_ARITHMETIC:
-        ops = g.p0
-        for i in range(ops):
-            b = 6 * i
-            # u32 operands (a copied cell may hold a field element: reduce it so the row stays a valid u32 op)
-            m0, m1, ad = [int(rng.integers(0, 1 << 32)) for _ in range(3)]
-            if i == 0 and rng.random() < 0.5:
-                m0 = m1 = ad = (1 << 32) - 1  # largest product: output_high = 2^32 - 1, output_low = 0 ... exercised below
-            out = m0 * m1 + ad
-            lo, hi = out & 0xFFFFFFFF, out >> 32
-            w[b:b + 5] = [m0, m1, ad, lo, hi]
-            diff = (0xFFFFFFFF - hi) % P
-            w[b + 5] = pow(diff, P - 2, P) if diff else rnd()
-            for j in range(32):
-                w[6 * ops + 32 * i + j] = (out >> (2 * j)) & 3
-    elif k == U32_RANGE_CHECK:
-        kk = g.p0
-        for i in range(kk):
-            v = int(rng.integers(0, 1 << 32))
-            w[i] = v
-            for j in range(16):
-                w[kk + 16 * i + j] = (v >> (2 * j)) & 3
-    elif k == U32_SUBTRACTION:
-        ops = g.p0
-        for i in range(ops):
-            x, y, bi = int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32)), int(rng.integers(0, 2))
-            r = x - y - bi
-            bo = 1 if r < 0 else 0
-            r += bo << 32
-            w[5 * i:5 * i + 5] = [x, y, bi, r, bo]
-            for j in range(16):
-                w[5 * ops + 16 * i + j] = (r >> (2 * j)) & 3
-    elif k == U32_ADD_MANY:
-        na, ops = g.p0, g.p1
-        per = na + 3
-        for i in range(ops):
-            adds = [int(rng.integers(0, 1 << 32)) for _ in range(na)]
-            ci = int(rng.integers(0, 1 << 4))
-            tot = sum(adds) + ci
-            res, co = tot & 0xFFFFFFFF, tot >> 32
-            w[per * i:per * i + per] = adds + [ci, res, co]
-            for j in range(16):
-                w[per * ops + 18 * i + j] = (res >> (2 * j)) & 3
-            for j in range(2):
-                w[per * ops + 18 * i + 16 + j] = (co >> (2 * j)) & 3
-    elif k == COMPARISON:
-        nb, nch = g.p0, g.p1
-        cb = (nb + nch - 1) // nch
-        cs = 1 << cb
-        a, b = int(rng.integers(0, 1 << nb, dtype=np.uint64)), int(rng.integers(0, 1 << nb, dtype=np.uint64))
-        if rng.random() < 0.3:
-            b = a
-        w[0], w[1] = a, b
-        fc = [(a >> (cb * i)) & (cs - 1) for i in range(nch)]
-        sc = [(b >> (cb * i)) & (cs - 1) for i in range(nch)]
-        msd = 0
-        for i in range(nch):
-            diff = (sc[i] - fc[i]) % P
-            eq = 1 if diff == 0 else 0
-            w[4 + i], w[4 + nch + i] = fc[i], sc[i]
-            w[4 + 2 * nch + i] = rnd() if eq else pow(diff, P - 2, P)  # equality dummy: inverse of the difference
-            w[4 + 3 * nch + i] = eq
-            iv = eq * msd % P
-            w[4 + 4 * nch + i] = iv
-            msd = (iv + (1 - eq) * diff) % P
-        w[3] = msd
-        val = (cs + msd) % P  # 2^chunk_bits + most significant difference, in [1, 2^(cb+1))
-        for i in range(cb + 1):
-            w[4 + 5 * nch + i] = (val >> i) & 1
-        w[2] = (val >> cb) & 1
-    elif k == EXPONENTIATION:
-        nb = g.p0
-        base = inp(0)
-        bits = [int(rng.integers(0, 2)) for _ in range(nb)]
-        w[0] = base
-        w[1:1 + nb] = bits
-        cur = 1
-        for i in range(nb):
-            prev = 1 if i == 0 else cur * cur % P
-            cur = prev * (base if bits[nb - 1 - i] else 1) % P
-            w[nb + 2 + i] = cur
-        w[nb + 1] = cur
-    elif k in (REDUCING, REDUCING_EXT):
-        nc, ext = g.p0, k == REDUCING_EXT
-        start_accs = 6 + (2 * nc if ext else nc)
-        for c in range(2, 6):
-            w[c] = inp(c)
-        alpha, acc = (w[2], w[3]), (w[4], w[5])
-        for i in range(nc):
-            if ext:
-                w[6 + 2 * i], w[7 + 2 * i] = inp(6 + 2 * i), inp(7 + 2 * i)
-                coeff = (w[6 + 2 * i], w[7 + 2 * i])
-            else:
-                w[6 + i] = inp(6 + i)
-                coeff = (w[6 + i], 0)
-            acc = ext_add(ext_mul(acc, alpha), coeff)
-            if i == nc - 1:
-                w[0], w[1] = acc
-            else:
-                w[start_accs + 2 * i], w[start_accs + 2 * i + 1] = acc
-    elif k == RANDOM_ACCESS:
-        bits, copies, extra = g.p0, g.p1, g.p2
-        vs = 1 << bits
-        routed = (2 + vs) * copies + extra
-        for c in range(copies):
-            b = (2 + vs) * c
-            idx = int(rng.integers(0, vs))
-            for i in range(vs):
-                w[b + 2 + i] = inp(b + 2 + i)
-            w[b], w[b + 1] = idx, w[b + 2 + idx]
-            for i in range(bits):
-                w[routed + c * bits + i] = (idx >> i) & 1
-        for i in range(extra):
-            w[(2 + vs) * copies + i] = consts[i]
-    for i in range(NUM_WIRES):
-        if w[i] is None:
-            w[i] = rnd()  # unused cells are unconstrained
-
-
-def selector_polynomials(gates, instances, max_degree=MAX_DEGREE):
-    """gates/selectors.rs selector_polynomials: `gates` sorted by degree; instances[row] = gate index.
-    Returns (selector columns, selector_indices, groups)."""
-    n, num_gates = len(instances), len(gates)
-    degs = [gate_degree(g) for g in gates]
-    if max(degs) + num_gates - 1 <= max_degree:
-        return [[i for i in instances]], [0] * num_gates, [(0, num_gates)]
-    groups, start = [], 0
-    while start < num_gates:
-        size = 0
-        while start + size < num_gates and size + degs[start + size] < max_degree:
-            size += 1
-        groups.append((start, start + size))
-        start += size
-    sel_idx = [next(j for j, (a, b) in enumerate(groups) if a <= i < b) for i in range(num_gates)]
-    cols = [[(g if a <= g < b else UNUSED_SELECTOR) for g in instances] for (a, b) in groups]
-    return cols, sel_idx, groups
-
-
-class Circuit:
-    """gates: list of Gate with selector fields filled; pre = constants ‖ sigmas [num_constants + 80][n];
-    wires [135][n]; num_selectors; pi_hash."""
-
-
-def build(log_n, kinds, seed, copy_prob=0.35):
-    """A random satisfied circuit using every gate kind in `kinds` (list of (kind, p0, p1, p2)), rows dealt
-    round-robin (row 0 = PublicInput when present), with random copy constraints between routed cells."""
-    n = 1 << log_n
-    rng = np.random.default_rng(seed)
-    gates = [Gate(k, p0, p1, p2, 0, 0, 0) for (k, p0, p1, p2) in kinds]
-    gates.sort(key=lambda g: (gate_degree(g), g.kind, g.p0))  # CircuitBuilder sorts gates by (degree, id)
-    order = list(range(len(gates)))
-    instances = [order[i % len(order)] for i in range(n)]
-    rng.shuffle(instances)
-    pi_rows = [i for i, g in enumerate(gates) if g.kind == PUBLIC_INPUT]
-    if pi_rows:
-        instances[0] = pi_rows[0]
-        instances = [instances[0]] + [g if g != pi_rows[0] else order[(r + 1) % len(order)] if gates[order[(r + 1) % len(order)]].kind != PUBLIC_INPUT else order[0]
-                                      for r, g in enumerate(instances[1:], 1)]
-    cols, sel_idx, groups = selector_polynomials(gates, instances)
-    for i, g in enumerate(gates):
-        g.selector_index, (g.group_start, g.group_end) = sel_idx[i], groups[sel_idx[i]]
-    num_selectors = len(cols)
-    pi_hash = O.rand_field(4, seed + 1)
-    gate_consts = [[int(x) for x in O.rand_field(2, seed * 1000 + r)] for r in range(n)]
-    wires = [[None] * NUM_WIRES for _ in range(n)]
-    parent = {}
-
-    def find(c):
-        while parent.get(c, c) != c:
-            c = parent[c]
-        return c
-
-    filled = []  # routed cells (row, col) with a value
-    for r in range(n):
-        g = gates[instances[r]]
-        w = wires[r]
-
-        def inp(col, r=r, w=w):
-            if col < NUM_ROUTED and filled and rng.random() < copy_prob:
-                rr, cc = filled[int(rng.integers(0, len(filled)))]
-                parent[find((r, col))] = find((rr, cc))
-                return wires[rr][cc]
-            return int(rng.integers(0, P, dtype=np.uint64))
-
-        fill_row(g, w, gate_consts[r], inp, rng, pi_hash)
-        filled += [(r, c) for c in range(0, NUM_ROUTED, 7)]
-    # sigma: identity with each equivalence class of copy-constrained cells rotated by one
-    wN = pow(7277203076849721926, 1 << (32 - log_n), P)
-    xs = [pow(wN, i, P) for i in range(n)]
-    ks = [pow(O.MULT_GEN, j, P) for j in range(NUM_ROUTED)]
-    sig = [[ks[j] * xs[i] % P for i in range(n)] for j in range(NUM_ROUTED)]
-    classes = {}
-    for c in list(parent):
-        classes.setdefault(find(c), set()).add(c)
-    for root, members in classes.items():
-        cells = sorted(members | {root})
-        vals = {wires[r][c] for r, c in cells}
-        assert len(vals) == 1
-        ids = [ks[c] * xs[r] % P for r, c in cells]
-        for (r, c), v in zip(cells, ids[1:] + ids[:1]):
-            sig[c][r] = v
-    consts = np.array(cols + [[gate_consts[r][k] for r in range(n)] for k in range(2)], dtype=np.uint64)
-    ckt = Circuit()
-    ckt.log_n, ckt.gates, ckt.num_selectors, ckt.pi_hash = log_n, gates, num_selectors, pi_hash
-    ckt.pre = np.concatenate([consts, np.array(sig, dtype=np.uint64)])
-    ckt.wires = np.array(wires, dtype=np.uint64).T.copy()
-    ckt.num_constants = consts.shape[0]
-    ckt.instances = instances
-    ckt.gate_array = (Gate * len(gates))(*gates)
-    return ckt
-
-
-ALL_KINDS = [(NOOP, 0, 0, 0), (CONSTANT, 2, 0, 0), (PUBLIC_INPUT, 0, 0, 0), (ARITHMETIC, 20, 0, 0), (BASE_SUM, 63, 2, 0),
-             (BASE_SUM, 20, 4, 0), (ARITHMETIC_EXT, 10, 0, 0), (MUL_EXT, 13, 0, 0), (POSEIDON2, 0, 0, 0),
-             (EXPONENTIATION, 66, 0, 0), (REDUCING, 43, 0, 0), (REDUCING_EXT, 32, 0, 0), (RANDOM_ACCESS, 4, 4, 2),
-             (POSEIDON, 0, 0, 0), (POSEIDON_MDS, 0, 0, 0), (COSET_INTERPOLATION, 4, coset_interpolation_degree(4), 0),
-             (U32_ARITHMETIC, 3, 0, 0), (U32_RANGE_CHECK, 7, 0, 0), (U32_SUBTRACTION, 6, 0, 0), (U32_ADD_MANY, 3, 5, 0),
-             (COMPARISON, 32, 16, 0)]
-
-
-# Gate sets as the reference composes its circuits. A wrap circuit (recursion-framework/src/universal_verifier_gadget/
-# wrap_circuit.rs) is plonky2's recursive verifier and nothing else; a leaf circuit of the table build (cells / rows tree,
-# values extraction) adds the user logic: u32 / u256 arithmetic and comparisons next to the verifier gadget. Poseidon
-# (original) and PoseidonMds only occur under the Poseidon config of the final wrap (verifiable-db/src/api.rs:148).
-VERIFIER_KINDS = [(NOOP, 0, 0, 0), (CONSTANT, 2, 0, 0), (PUBLIC_INPUT, 0, 0, 0), (ARITHMETIC, 20, 0, 0), (BASE_SUM, 63, 2, 0),
-                  (ARITHMETIC_EXT, 10, 0, 0), (MUL_EXT, 13, 0, 0), (POSEIDON2, 0, 0, 0), (EXPONENTIATION, 66, 0, 0),
-                  (REDUCING, 43, 0, 0), (REDUCING_EXT, 32, 0, 0), (RANDOM_ACCESS, 4, 4, 2),
-                  (COSET_INTERPOLATION, 4, coset_interpolation_degree(4), 0)]
-LEAF_KINDS = VERIFIER_KINDS + [(BASE_SUM, 20, 4, 0), (U32_ARITHMETIC, 3, 0, 0), (U32_RANGE_CHECK, 7, 0, 0), (U32_SUBTRACTION, 6, 0, 0),
-                               (U32_ADD_MANY, 3, 5, 0), (COMPARISON, 32, 16, 0)]
+_pc = importlib.import_module("mapreduce-plonky2_amd.circuits")
+globals().update({k: v for k, v in vars(_pc).items() if not k.startswith("__")})
 
 
 def eval_on_points(ckt, consts, wires):
@@ -470,19 +24,32 @@ def eval_on_points(ckt, consts, wires):
     return out
 
 
-def prove(ckt, fp, circuit_digest):
-    """oracle prove() of the circuit; returns (caps, openings, proof, bgao)"""
+def prove_witness(ckt, fp, circuit_digest, wires, pi_hash):
+    """oracle prove() of the circuit for the given witness and public-inputs hash; returns (caps, openings, proof, bgao)"""
     n = 1 << ckt.log_n
-    vals = [O.arr(ckt.pre), O.arr(ckt.wires), np.zeros((fp.oracle_w[2], n), dtype=np.uint64), np.zeros((fp.oracle_w[3], n), dtype=np.uint64)]
+    vals = [O.arr(ckt.pre), O.arr(wires), np.zeros((fp.oracle_w[2], n), dtype=np.uint64), np.zeros((fp.oracle_w[3], n), dtype=np.uint64)]
     ptrs = (ctypes.c_void_p * 4)(*[v.ctypes.data for v in vals])
     capw = 4 << fp.cap_height
     caps = np.zeros((fp.n_oracles, capw), dtype=np.uint64)
     openings = np.zeros((O.lib().orc_n_openings(ctypes.byref(fp)), 2), dtype=np.uint64)
     proof = np.zeros(O.lib().orc_fri_proof_words(ctypes.byref(fp)), dtype=np.uint64)
-    cd, ph, bgao = O.arr(circuit_digest), O.arr(ckt.pi_hash), np.zeros(8, dtype=np.uint64)
+    cd, ph, bgao = O.arr(circuit_digest), O.arr(pi_hash), np.zeros(8, dtype=np.uint64)
     O.lib().orc_pcs_prove_gates(ctypes.byref(fp), ptrs, O.p(cd), O.p(ph), NUM_ROUTED, 8, ckt.gate_array, len(ckt.gates),
                                 ckt.num_selectors, O.p(bgao), O.p(caps), O.p(openings), O.p(proof))
     return caps, openings, proof, bgao
+
+
+def prove(ckt, fp, circuit_digest):
+    """oracle prove() of the circuit with its own witness; returns (caps, openings, proof, bgao)"""
+    return prove_witness(ckt, fp, circuit_digest, ckt.wires, ckt.pi_hash)
+
+
+def verify(ckt, fp, circuit_digest, pi_hash, caps, openings, proof):
+    """oracle verify(): challenges from the transcript, PLONK identity with the gate terms, FRI. 0 = accept."""
+    cd, ph = O.arr(circuit_digest), O.arr(pi_hash)
+    caps, openings, proof = O.arr(caps), O.arr(openings), O.arr(proof)
+    return O.lib().orc_verify_gates(ctypes.byref(fp), O.p(cd), O.p(ph), NUM_ROUTED, 8, ckt.gate_array, len(ckt.gates), ckt.num_selectors,
+                                    O.p(caps), O.p(openings), O.p(proof))
 
 
 def identity_check(ckt, fp, openings, bgao):

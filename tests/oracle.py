@@ -65,17 +65,10 @@ class SplitMix64:
 
 
 def rand_field(shape, seed):
-    """Vectorised SplitMix64 stream reduced by rejection (values >= p are re-drawn)."""
-    n = int(np.prod(shape))
-    idx = np.arange(1, n + 1, dtype=np.uint64)
-    with np.errstate(over="ignore"):
-        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    bad = z >= np.uint64(P)
-    z[bad] = z[bad] - np.uint64(P)  # 2^32-1 values out of 2^64: fold instead of redraw
-    return z.reshape(shape)
+    """SplitMix64 stream with rejection of values >= p: the workload generator's stream
+    (mapreduce-plonky2_amd/circuits.py rand_field), shared so that tests and bench draw the same inputs."""
+    import importlib
+    return importlib.import_module("mapreduce-plonky2_amd.circuits").rand_field(shape, seed)
 
 
 # ---- thin wrappers ---------------------------------------------------------------------------

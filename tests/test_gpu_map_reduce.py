@@ -1,38 +1,96 @@
-"""Map-reduce shape of recursion-framework/tests/integration.rs:138-261: 8 leaf proofs, a 2-to-1
-reduction tree proved level by level in batches; every proof is accepted by the oracle's FRI
-verifier and parents depend on their children's commitments."""
-import ctypes
+"""Map-reduce of recursion-framework/tests/integration.rs:138-261 through framework.MapReduce: leaf (map) proofs
+over chunks of a dataset, a 2-to-1 reduce tree above them proved level by level in batches; every node = base
+prove() + wrap prove() of gate-level circuits bound to the node's public inputs. Checked as the reference's
+test checks it: root public inputs = (sum of the even elements, digest of the dataset, circuit-set digest), and
+every retained proof is accepted by the oracle's verifier under the public inputs the oracle computes itself."""
+import importlib
 
 import numpy as np
 import pytest
 
+import circuits as C
 import oracle as O
 
 pytestmark = pytest.mark.gpu
+FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+
+
+def expected_public_inputs(dataset, n_leaves):
+    """the test's own reference computation (integration.rs:170-196), with the oracle's hash"""
+    chunks = dataset.reshape(n_leaves, FW.INPUT_CHUNK_SIZE)
+    levels = [np.array([[sum(int(x) for x in row if int(x) % 2 == 0) % O.P] + [int(h) for h in O.hash_n_to_m_no_pad(row, 4)] for row in chunks],
+                       dtype=np.uint64)]
+    while levels[-1].shape[0] > 1:
+        prev = levels[-1]
+        nxt = []
+        for i in range(0, prev.shape[0], 2):
+            s = (int(prev[i, 0]) + int(prev[i + 1, 0])) % O.P
+            h = O.hash_n_to_m_no_pad(np.concatenate([prev[i, 1:], prev[i + 1, 1:]]), 4)
+            nxt.append([s] + [int(x) for x in h])
+        levels.append(np.array(nxt, dtype=np.uint64))
+    return levels
+
+
+def check_kept(mr, levels):
+    fw = mr.fw
+    set_digest = mr.circuit_set.circuit_set_digest()
+    for (level, idx), (pis, pi_hash, base, wrap) in mr.kept.items():
+        want = np.concatenate([levels[level][idx], set_digest])
+        assert np.array_equal(pis, want), (level, idx)
+        ph = O.hash_n_to_m_no_pad(want, 4)  # public_inputs_hash as the verifier recomputes it
+        assert np.array_equal(pi_hash, ph)
+        for cp, (caps, openings, proof) in ((fw.base, base), (fw.wrap, wrap)):
+            ofp = O.standard_params(cp.ckt.log_n, (int(cp.ckt.pre.shape[0]), 135, 20, 16))
+            assert C.verify(cp.ckt, ofp, cp.circuit_digest, ph, caps, openings, proof) == 0, (level, idx)
 
 
 def test_eight_leaves_two_to_one(ctx, mp2):
-    log_n, ws, n_leaves = 6, (5, 9, 4, 3), 8
-    ofp = O.standard_params(log_n, ws, pow_bits=6, num_queries=4)
-    fp = mp2.FriParams()
-    ctypes.memmove(ctypes.byref(fp), ctypes.byref(ofp), ctypes.sizeof(fp))
-    n = 1 << log_n
-    pre = O.rand_field((ws[0], n), 1)
-    leaf_vals = [O.rand_field((n_leaves, w, n), 10 + i) for i, w in enumerate(ws[1:])]
-    cd = O.rand_field(4, 3)
-    levels = mp2.prove_aggregation_tree(ctx, fp, pre, leaf_vals, cd)
-    assert [lv[0].shape[0] for lv in levels] == [8, 4, 2, 1]
-    for li, (pi, caps, openings, proofs) in enumerate(levels):
-        for b in range(pi.shape[0]):
-            assert O.pcs_verify(ofp, cd, pi[b], caps[b], openings[b], proofs[b]) == 0
-        if li:
-            prev_caps = levels[li - 1][1]
-            for b in range(pi.shape[0]):
-                want = O.hash_n_to_m_no_pad(np.concatenate([prev_caps[2 * b, 1], prev_caps[2 * b + 1, 1]]), 4)
-                assert np.array_equal(pi[b], want)
-    # a parent proof does not verify under a sibling's public inputs
-    pi1, caps1, op1, pr1 = levels[1]
-    assert O.pcs_verify(ofp, cd, pi1[1], caps1[0], op1[0], pr1[0]) != 0
+    mr = FW.MapReduce(ctx, ctx, 8, chunk=4, base_bits=6, wrap_bits=5)
+    root = mr.run(keep=lambda level, index: True)
+    assert mr.n_proofs == 15 and len(mr.kept) == 15
+    levels = expected_public_inputs(mr.dataset, 8)
+    assert np.array_equal(root[:FW.NUM_PUBLIC_INPUTS], levels[-1][0])
+    evens = sum(int(x) for x in mr.dataset if int(x) % 2 == 0) % O.P
+    assert int(root[0]) == evens
+    # circuit-set digest = last 4 public inputs (framework.rs:507-510), from the oracle's Merkle tree over the vk digests
+    d = mr.fw.digests[1]
+    assert np.array_equal(root[FW.NUM_PUBLIC_INPUTS:], O.merkle_cap(O.merkle_build(np.stack([d, d]), 0), 0)[0])
+    check_kept(mr, levels)
+    # one node bit for bit against the oracle's proof of the same witness
+    pis, ph, base, wrap = mr.kept[(1, 2)]
+    for cp, seed, got in ((mr.fw.base, mr.fw.seed, base), (mr.fw.wrap, mr.fw.seed + 7, wrap)):
+        ofp = O.standard_params(cp.ckt.log_n, (int(cp.ckt.pre.shape[0]), 135, 20, 16))
+        caps, openings, proof, _ = C.prove_witness(cp.ckt, ofp, cp.circuit_digest, FW.witness_of(cp.ckt, seed, 2, ph), ph)
+        assert np.array_equal(caps, got[0]) and np.array_equal(openings, got[1]) and np.array_equal(proof, got[2])
+    # a proof does not verify under a sibling's public inputs
+    _, ph0, base0, _ = mr.kept[(0, 0)]
+    _, ph1, _, _ = mr.kept[(0, 1)]
+    cp = mr.fw.base
+    ofp = O.standard_params(cp.ckt.log_n, (int(cp.ckt.pre.shape[0]), 135, 20, 16))
+    assert C.verify(cp.ckt, ofp, cp.circuit_digest, ph1, *base0) != 0
+    mr.free()
+
+
+def test_1024_leaf_aggregation_baseline_config2(mp2):
+    """BASELINE configs[2]: 2-to-1 aggregation of 1024 synthetic leaf proofs on one GPU at the full shape (base 2^13 +
+    wrap 2^12, standard_recursion_config): 2047 framework proofs. The first and the last node of every level are
+    retained and verified; the root's public inputs equal the dataset's."""
+    c0, c1 = mp2.Context(0), mp2.Context(0)
+    try:
+        n_leaves = 1024
+        mr = FW.MapReduce(c0, c1, n_leaves, chunk=128)
+        widths = [n_leaves >> l for l in range(11)]
+        root = mr.run(keep=lambda level, index: index in (0, widths[level] - 1))
+        assert mr.n_proofs == 2047
+        levels = expected_public_inputs(mr.dataset, n_leaves)
+        assert np.array_equal(root[:FW.NUM_PUBLIC_INPUTS], levels[-1][0])
+        assert int(root[0]) == sum(int(x) for x in mr.dataset if int(x) % 2 == 0) % O.P
+        assert len(mr.kept) == 2 * 10 + 1
+        check_kept(mr, levels)
+        mr.free()
+    finally:
+        c1.close()
+        c0.close()
 
 
 def test_two_ranks_prove_an_update_tree():

@@ -46,7 +46,7 @@ def test_selector_groups():
     assert degs == sorted(degs)
     assert ckt.num_selectors > 1
     for g in ckt.gates:  # gates/selectors.rs: filter degree + gate degree fits the quotient degree factor
-        assert (g.group_end - g.group_start) + C.gate_degree(g) <= C.MAX_DEGREE
+        assert (g.group_end - g.group_start) + C.gate_degree(g) <= C.MAX_DEGREE + 1
     few = C.build(5, [(C.NOOP, 0, 0, 0), (C.CONSTANT, 2, 0, 0), (C.ARITHMETIC, 20, 0, 0)], 3)
     assert few.num_selectors == 1  # max degree 3 + 3 gates - 1 <= 8: the single-selector special case
 

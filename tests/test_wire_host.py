@@ -62,7 +62,44 @@ def test_proof_with_vk_blob(mp2):
     assert out[:40] == proof
     blob_len = struct.unpack_from("<Q", out, 40)[0]
     assert blob_len == len(out) - 48 == 8 + 16 * 32 + 32
-    assert struct.unpack_from("<Q", out, 48)[0] == 16
+    assert struct.unpack_from("<Q", out, 48)[0] == 4  # the cap HEIGHT (write_usize), not its length
+    with pytest.raises(mp2.Mp2gError):
+        mp2.serialize_proof_with_vk(proof, cap[:12], dig)
+
+
+def fnv1a(data):
+    h = 1469598103934665603
+    for b in data:
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return f"{h:016x}"
+
+
+@pytest.mark.parametrize("log_n,ws,nq", [(6, (5, 9, 4, 3), 3), (12, (84, 135, 20, 16), 28)])
+def test_wire_format_second_opinion(mp2, log_n, ws, nq):
+    """mp2g_proof_serialize / mp2g_proof_with_vk_serialize against the independent bincode writer of
+    tests/bincode_ref.py (written from plonky2's type definitions), on a proof of the standard 2^12 shape"""
+    import bincode_ref as BR
+    ofp = O.standard_params(log_n, ws, pow_bits=4, num_queries=nq)
+    fp = mp2.FriParams()
+    ctypes.memmove(ctypes.byref(fp), ctypes.byref(ofp), ctypes.sizeof(fp))
+    n = 1 << log_n
+    vals = [O.rand_field((w, n), 40 + i) for i, w in enumerate(ws)]
+    cd, ph = O.rand_field(4, 1), O.rand_field(4, 2)
+    caps, openings, proof = O.pcs_prove(ofp, vals, cd, ph)
+    pis = O.rand_field(9, 3)
+    num_constants = ws[0] - (80 if ws[0] > 80 else 3)
+    got = mp2.serialize_proof(fp, num_constants, caps, openings, proof, pis)
+    nested = BR.structured(fp, num_constants, caps, openings, proof, pis)
+    want = BR.proof_with_public_inputs(nested)
+    assert got == want
+    assert len(nested["openings"]["lookup_zs"]) == 0 and len(nested["opening_proof"]["query_round_proofs"]) == nq
+    vk_cap = caps[0].reshape(-1, 4)
+    got_vk = mp2.serialize_proof_with_vk(got, vk_cap, cd)
+    assert got_vk == BR.proof_with_vk(nested, [list(map(int, h)) for h in vk_cap], [int(x) for x in cd])
+    if log_n == 12:  # the committed fingerprint of both serializers on the standard-shape proof
+        import json, os
+        k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wire_fnv.json")))
+        assert {"proof_bytes": len(got), "proof_fnv1a": fnv1a(got), "proof_with_vk_fnv1a": fnv1a(got_vk)} == k["standard_2p12"]
 
 
 def test_shard_ranges_cover(mp2):
