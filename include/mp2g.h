@@ -126,6 +126,11 @@ typedef struct mp2g_fri_params {
   uint32_t oracle_w[8];
   uint32_t zs_oracle;
   uint32_t zs_count;
+  /* lookup argument: polynomials per challenge round (0 = none; ceil((num_routed/2) / 7) + 1 = 7 under
+   * standard_recursion_config). The last zs_count * num_lookup_polys polynomials of oracle zs_oracle are the
+   * lookup polynomials (RE, then the partial Sum/LDC polynomials, per round); they are opened at zeta and at
+   * g*zeta and close both FRI batches (plonk/circuit_data.rs fri_all_polys / fri_next_batch_polys). */
+  uint32_t num_lookup_polys;
 } mp2g_fri_params;
 /* fri/reduction_strategies.rs ConstantArityBits(arity_bits, final_poly_bits); returns the count */
 uint32_t mp2g_reduction_arity_bits(uint32_t degree_bits, uint32_t rate_bits, uint32_t cap_height,
@@ -138,7 +143,10 @@ uint32_t mp2g_reduction_arity_bits(uint32_t degree_bits, uint32_t rate_bits, uin
  *   final_poly [final_len][2]
  *   pow_witness */
 size_t mp2g_fri_proof_words(const mp2g_fri_params* p);
-size_t mp2g_fri_n_openings(const mp2g_fri_params* p); /* sum(oracle_w) + zs_count extension values */
+/* sum(oracle_w) + zs_count + zs_count * num_lookup_polys extension values, in FRI batch order
+ * (OpeningSet::to_fri_openings): at zeta every polynomial in oracle order except the lookup polynomials, which
+ * come last (after the quotient chunks); then at g*zeta the Z polynomials and the lookup polynomials. */
+size_t mp2g_fri_n_openings(const mp2g_fri_params* p);
 
 /* Device-resident challengers: `count` independent transcripts stepped in lockstep. */
 typedef struct mp2g_challenger mp2g_challenger;
@@ -225,7 +233,8 @@ int mp2g_row_digest_batch_dev(mp2g_ctx* ctx, int variant, const uint64_t* d_col_
  * preprocessed one, is not part of a proof and is skipped); `openings` as produced by the prover
  * ([sum w][2] at zeta in oracle order, then [zs_count][2] at g*zeta); the first num_constants
  * polynomials of oracle 0 are `constants`, the rest `plonk_sigmas`; the first zs_count of oracle
- * zs_oracle are `plonk_zs`, the rest `partial_products`; lookup vectors are empty.
+ * zs_oracle are `plonk_zs`, then `partial_products`, then (num_lookup_polys > 0) `lookup_zs`, whose values at
+ * g*zeta are `lookup_zs_next`.
  * Call with out = NULL to get the size in *out_len. */
 int mp2g_proof_serialize(const mp2g_fri_params* params, uint32_t num_constants, const uint64_t* caps,
                          const uint64_t* openings, const uint64_t* fri_proof, const uint64_t* public_inputs,
@@ -271,7 +280,7 @@ int mp2g_prover_bind_public_inputs(mp2g_prover* pr, int64_t row);
  * evaluates, per proof, the gate constraints on the subgroup (needs mp2g_prover_set_gates) and the
  * wrap-around of the permutation product; mp2g_prover_witness_status synchronises and returns non-zero with
  * a message naming the first offending proof. flags (may be NULL) receives one word per proof: bit 0 a
- * copy constraint, bit 1 a gate constraint. The proof itself is still produced (it does not verify). */
+ * copy constraint, bit 1 a gate constraint, bit 2 the lookup argument (a looked-up pair that is not in its table). The proof itself is still produced (it does not verify). */
 int mp2g_prover_enable_witness_check(mp2g_prover* pr, int on);
 int mp2g_prover_witness_status(mp2g_prover* pr, uint32_t* flags);
 /* Replay the prover's launch sequence (several hundred small kernels per call) as a hipGraph: the
@@ -291,9 +300,8 @@ int mp2g_prover_stage_ms(mp2g_prover* pr, float out[MP2G_N_STAGES]);
 
 /* ---- gate constraints: the third part of compute_quotient_polys --------------------------------
  * Replaces [dep] plonky2 plonk/vanishing_poly.rs evaluate_gate_constraints_base_batch and the
- * eval_unfiltered_base of the gates below (gates the reference registers:
- * mp2-common/src/serialization/circuit_data_serialization.rs:236-267). Not yet covered:
- * Lookup / LookupTable, U32Interleave / UninterleaveToB32 / UninterleaveToU32. A circuit using one of those cannot be proved here yet. */
+ * eval_unfiltered_base of the gates below: all 26 entries the reference registers
+ * (mp2-common/src/serialization/circuit_data_serialization.rs:236-267). */
 enum {
   MP2G_GATE_NOOP = 0,
   MP2G_GATE_CONSTANT = 1,       /* p0 = num_consts */
@@ -315,9 +323,18 @@ enum {
   MP2G_GATE_U32_RANGE_CHECK = 16, /* p0 = num_input_limbs */
   MP2G_GATE_U32_SUBTRACTION = 17, /* p0 = num_ops */
   MP2G_GATE_U32_ADD_MANY = 18,    /* p0 = num_addends (<= 16), p1 = num_ops */
-  MP2G_GATE_COMPARISON = 19       /* p0 = num_bits, p1 = num_chunks (chunks of at most 4 bits) */
+  MP2G_GATE_COMPARISON = 19,      /* p0 = num_bits, p1 = num_chunks (chunks of at most 4 bits) */
+  /* plonky2 gates/lookup.rs, gates/lookup_table.rs: no constraints of their own, the lookup argument of prove()
+   * (mp2g_prover_set_lookups) carries them. p0 = num_slots (num_routed / 2, num_routed / 3) */
+  MP2G_GATE_LOOKUP = 20,
+  MP2G_GATE_LOOKUP_TABLE = 21,
+  /* plonky2_crypto u32/gates/{interleave_u32, uninterleave_to_b32, uninterleave_to_u32}.rs (Keccak / SHA in the MPT
+   * circuits), restated from memory of the published crate: p0 = num_ops */
+  MP2G_GATE_U32_INTERLEAVE = 22,
+  MP2G_GATE_UNINTERLEAVE_TO_B32 = 23,
+  MP2G_GATE_UNINTERLEAVE_TO_U32 = 24
 };
-#define MP2G_MAX_GATES 24
+#define MP2G_MAX_GATES 32
 #define MP2G_MAX_GATE_CONSTRAINTS 160
 /* One entry per gate of CommonCircuitData::gates, in that order (sorted by degree). The selector
  * fields restate SelectorsInfo (gates/selectors.rs): the gate's filter is
@@ -336,6 +353,26 @@ uint32_t mp2g_gate_degree(const mp2g_gate* g);
  * preprocessed oracle (selectors first, then the gate constants); the public-inputs hash is the
  * d_pi_hash of mp2g_prover_prove_dev. Needs mp2g_prover_enable_quotient. n_gates = 0 removes it. */
 int mp2g_prover_set_gates(mp2g_prover* pr, const mp2g_gate* gates, uint32_t n_gates, uint32_t num_selectors);
+/* One lookup table of the circuit: plonky2's LookupWire (the rows CircuitBuilder::add_all_lookups appended for it:
+ * LookupGate rows [last_lu_row, last_lut_row), LookupTableGate rows [last_lut_row, first_lut_row] with the table
+ * running DOWN from first_lut_row, then a Noop row) and the table itself (CommonCircuitData::luts). */
+typedef struct {
+  uint32_t last_lu_row, last_lut_row, first_lut_row;
+  uint32_t table_len;
+  const uint16_t* table; /* [table_len][2] = (input, output), host pointer */
+} mp2g_lookup;
+#define MP2G_MAX_LUTS 16
+/* The lookup argument of prove() ([dep] plonk/prover.rs compute_lookup_polys, vanishing_poly.rs
+ * check_lookup_constraints): after the wires cap the transcript also yields the lookup challenges (deltas = betas,
+ * gammas and 2 * num_challenges more), the RE / Sum / LDC polynomials are computed on the device into the tail of
+ * oracle 2, and their constraints enter the quotient between the partial-product and the gate terms. The constants
+ * of the preprocessed oracle are then: selectors, the 4 + n_luts lookup selectors (gates/selectors.rs
+ * selectors_lookup, selector_ends_lookups), gate constants. Needs mp2g_prover_set_gates (with the LookupGate /
+ * LookupTableGate entries), params.num_lookup_polys = ceil((num_routed/2) / (degree-1)) + 1 and
+ * oracle_w[2] = zs_count * (num_routed/degree + num_lookup_polys). The multiplicity wires are part of the witness
+ * (prove()'s set_lookup_wires fills them on the host). n_luts = 0 removes the argument. */
+int mp2g_prover_set_lookups(mp2g_prover* pr, const mp2g_lookup* luts, uint32_t n_luts);
+
 /* The filtered constraints C_j = sum_gates filter_g c_{g,j} at npts arbitrary points (host pointers):
  * consts [num_constants][npts], wires [wires_w][npts], out [max_j][npts] with max_j the largest
  * num_constraints of the table. On the subgroup H a satisfied witness gives all zeros -- the check

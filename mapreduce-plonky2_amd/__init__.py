@@ -306,7 +306,8 @@ class FriParams(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_uint32), ("log_n", ctypes.c_uint32), ("rate_bits", ctypes.c_uint32),
                 ("cap_height", ctypes.c_uint32), ("pow_bits", ctypes.c_uint32), ("num_queries", ctypes.c_uint32),
                 ("n_layers", ctypes.c_uint32), ("arity_bits", ctypes.c_uint32 * 8), ("n_oracles", ctypes.c_uint32),
-                ("oracle_w", ctypes.c_uint32 * 8), ("zs_oracle", ctypes.c_uint32), ("zs_count", ctypes.c_uint32)]
+                ("oracle_w", ctypes.c_uint32 * 8), ("zs_oracle", ctypes.c_uint32), ("zs_count", ctypes.c_uint32),
+                ("num_lookup_polys", ctypes.c_uint32)]
 
     @property
     def proof_words(self):
@@ -326,7 +327,8 @@ class FriParams(ctypes.Structure):
 
 
 def standard_recursion_params(log_n, oracle_w=(84, 135, 20, 16), variant=POSEIDON2, rate_bits=3, cap_height=4,
-                              pow_bits=16, num_queries=28, zs_oracle=2, zs_count=2, arity_bits=4, final_poly_bits=5):
+                              pow_bits=16, num_queries=28, zs_oracle=2, zs_count=2, arity_bits=4, final_poly_bits=5,
+                              num_lookup_polys=0):
     """FRI parameters of standard_recursion_config (mp2-common/src/lib.rs:45-47) for 2^log_n rows:
     135 wires, 2 challenges (=> 20 Z/partial-product and 16 quotient-chunk polynomials),
     ConstantArityBits(4, 5). 84 = constants + 80 sigma polynomials of a typical circuit."""
@@ -339,7 +341,7 @@ def standard_recursion_params(log_n, oracle_w=(84, 135, 20, 16), variant=POSEIDO
     fp.n_oracles = len(oracle_w)
     for i, w in enumerate(oracle_w):
         fp.oracle_w[i] = w
-    fp.zs_oracle, fp.zs_count = zs_oracle, zs_count
+    fp.zs_oracle, fp.zs_count, fp.num_lookup_polys = zs_oracle, zs_count, num_lookup_polys
     return fp
 
 
@@ -413,7 +415,23 @@ class Gate(ctypes.Structure):
 (GATE_NOOP, GATE_CONSTANT, GATE_PUBLIC_INPUT, GATE_ARITHMETIC, GATE_BASE_SUM, GATE_ARITHMETIC_EXT, GATE_MUL_EXT, GATE_POSEIDON2,
  GATE_EXPONENTIATION, GATE_REDUCING, GATE_REDUCING_EXT, GATE_RANDOM_ACCESS, GATE_POSEIDON, GATE_POSEIDON_MDS,
  GATE_COSET_INTERPOLATION, GATE_U32_ARITHMETIC, GATE_U32_RANGE_CHECK, GATE_U32_SUBTRACTION, GATE_U32_ADD_MANY,
- GATE_COMPARISON) = range(20)
+ GATE_COMPARISON, GATE_LOOKUP, GATE_LOOKUP_TABLE, GATE_U32_INTERLEAVE, GATE_UNINTERLEAVE_TO_B32, GATE_UNINTERLEAVE_TO_U32) = range(25)
+
+
+class Lookup(ctypes.Structure):
+    """mp2g_lookup: one lookup table and its rows (plonky2's LookupWire + the table of CommonCircuitData::luts)."""
+    _fields_ = [("last_lu_row", ctypes.c_uint32), ("last_lut_row", ctypes.c_uint32), ("first_lut_row", ctypes.c_uint32),
+                ("table_len", ctypes.c_uint32), ("table", ctypes.c_void_p)]
+
+
+def lookup_array(luts):
+    """(Lookup * n) from the builder's lookup descriptions (dicts with the row fields and a uint16 [len][2] table);
+    the second value keeps the table arrays alive"""
+    tabs = [np.ascontiguousarray(t["table"], dtype=np.uint16) for t in luts]
+    arr = (Lookup * max(1, len(luts)))()
+    for i, (t, tab) in enumerate(zip(luts, tabs)):
+        arr[i] = Lookup(t["last_lu_row"], t["last_lut_row"], t["first_lut_row"], tab.shape[0], tab.ctypes.data)
+    return arr, tabs
 
 
 def eval_gate_constraints(ctx, gates, num_selectors, consts, wires, pi_hash):
@@ -458,6 +476,13 @@ class BatchedProver:
         includes the gate constraint terms -- prove() of a circuit built from the supported gates."""
         arr = (Gate * len(gates))(*gates)
         _ck(load().mp2g_prover_set_gates(self.h, arr, len(gates), num_selectors))
+
+    def set_lookups(self, luts):
+        """Lookup tables of the circuit (CommonCircuitData::luts + ProverOnlyCircuitData::lookup_rows): prove() then
+        draws the lookup challenges, computes the RE / Sum / LDC polynomials into the Z oracle and adds the lookup
+        terms to the quotient. Needs set_gates() with the lookup gates in the table."""
+        arr, keep = lookup_array(luts)
+        _ck(load().mp2g_prover_set_lookups(self.h, arr, len(luts)))
 
     def bind_public_inputs(self, row):
         """PublicInputGate's generator on the device: wires 0..3 of `row` of every proof's wire matrix are

@@ -43,7 +43,11 @@ def rand_field(shape, seed):
 
 (NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, BASE_SUM, ARITHMETIC_EXT, MUL_EXT, POSEIDON2, EXPONENTIATION, REDUCING, REDUCING_EXT,
  RANDOM_ACCESS, POSEIDON, POSEIDON_MDS, COSET_INTERPOLATION, U32_ARITHMETIC, U32_RANGE_CHECK, U32_SUBTRACTION, U32_ADD_MANY,
- COMPARISON) = range(20)
+ COMPARISON, LOOKUP, LOOKUP_TABLE, U32_INTERLEAVE, UNINTERLEAVE_TO_B32, UNINTERLEAVE_TO_U32) = range(25)
+# the lookup argument under standard_recursion_config: LookupGate::num_slots = 80 / 2, LookupTableGate::num_slots = 80 / 3,
+# ceil(40 / (8 - 1)) = 6 partial Sum/LDC polynomials + RE = 7 lookup polynomials per challenge round
+NUM_LU_SLOTS, NUM_LUT_SLOTS, NUM_LOOKUP_POLYS = 40, 26, 7
+LOOKUP_SELECTORS = 4  # TransSre, TransLdc, InitSre, LastLdc; then one "ends" selector per table
 UNUSED_SELECTOR = 0xFFFFFFFF
 NUM_WIRES, NUM_ROUTED, MAX_DEGREE = 135, 80, 8
 
@@ -53,7 +57,8 @@ def gate_degree(g):
     return {NOOP: 0, CONSTANT: 1, PUBLIC_INPUT: 1, ARITHMETIC: 3, BASE_SUM: g.p1, ARITHMETIC_EXT: 3, MUL_EXT: 3, POSEIDON2: 7,
             EXPONENTIATION: 4, REDUCING: 2, REDUCING_EXT: 2, RANDOM_ACCESS: g.p0 + 1, POSEIDON: 7, POSEIDON_MDS: 1, COSET_INTERPOLATION: g.p1,
             U32_ARITHMETIC: 4, U32_RANGE_CHECK: 4, U32_SUBTRACTION: 4, U32_ADD_MANY: 4,
-            COMPARISON: 1 << ((g.p0 + max(g.p1, 1) - 1) // max(g.p1, 1))}[g.kind]
+            COMPARISON: 1 << ((g.p0 + max(g.p1, 1) - 1) // max(g.p1, 1)), LOOKUP: 0, LOOKUP_TABLE: 0, U32_INTERLEAVE: 2,
+            UNINTERLEAVE_TO_B32: 2, UNINTERLEAVE_TO_U32: 2}[g.kind]
 
 
 def gate_num_constraints(g):
@@ -63,7 +68,8 @@ def gate_num_constraints(g):
             RANDOM_ACCESS: (g.p0 + 2) * g.p1 + g.p2, POSEIDON: 123, POSEIDON_MDS: 24,
             COSET_INTERPOLATION: 4 + 4 * (((1 << g.p0) - 2) // max(g.p1 - 1, 1)),
             U32_ARITHMETIC: 36 * g.p0, U32_RANGE_CHECK: 17 * g.p0, U32_SUBTRACTION: 19 * g.p0, U32_ADD_MANY: 21 * g.p1,
-            COMPARISON: 6 + 5 * g.p1 + (g.p0 + max(g.p1, 1) - 1) // max(g.p1, 1)}[g.kind]
+            COMPARISON: 6 + 5 * g.p1 + (g.p0 + max(g.p1, 1) - 1) // max(g.p1, 1), LOOKUP: 0, LOOKUP_TABLE: 0,
+            U32_INTERLEAVE: 34 * g.p0, UNINTERLEAVE_TO_B32: 67 * g.p0, UNINTERLEAVE_TO_U32: 67 * g.p0}[g.kind]
 
 
 _consts = None
@@ -318,6 +324,27 @@ def fill_row(g, w, consts, inp, rng, pi_hash):
         for i in range(cb + 1):
             w[4 + 5 * nch + i] = (val >> i) & 1
         w[2] = (val >> cb) & 1
+    elif k == U32_INTERLEAVE:
+        ops = g.p0
+        for i in range(ops):
+            x = int(rng.integers(0, 1 << 32))
+            w[2 * i] = x
+            w[2 * i + 1] = sum(((x >> b) & 1) << (2 * b) for b in range(32))
+            for j in range(32):  # bit wires most significant first
+                w[2 * ops + 32 * i + j] = (x >> (31 - j)) & 1
+    elif k in (UNINTERLEAVE_TO_B32, UNINTERLEAVE_TO_U32):
+        ops = g.p0
+        for i in range(ops):
+            x = int(rng.integers(0, 1 << 63)) * 2 + int(rng.integers(0, 2))
+            x %= P  # a 64-bit pattern that is also a field element
+            ev = [(x >> (2 * b)) & 1 for b in range(32)]
+            od = [(x >> (2 * b + 1)) & 1 for b in range(32)]
+            sh = 2 if k == UNINTERLEAVE_TO_B32 else 1
+            w[3 * i] = x
+            w[3 * i + 1] = sum(b << (sh * j) for j, b in enumerate(ev))
+            w[3 * i + 2] = sum(b << (sh * j) for j, b in enumerate(od))
+            for j in range(64):
+                w[3 * ops + 64 * i + j] = (x >> (63 - j)) & 1
     elif k == EXPONENTIATION:
         nb = g.p0
         base = inp(0)
@@ -367,6 +394,29 @@ def fill_row(g, w, consts, inp, rng, pi_hash):
             w[i] = rnd()  # unused cells are unconstrained
 
 
+def fill_lookup_row(g, w, r, lut_info, rng):
+    """LookupGate rows (gates/lookup.rs: looking_inp 2i, looking_out 2i+1) and LookupTableGate rows
+    (gates/lookup_table.rs: looked_inp 3i, looked_out 3i+1, multiplicity 3i+2; entry (first_lut_row - row) * slots + i)
+    of the table the row belongs to. Multiplicities are counted while the LookupGate rows (which come first) are filled."""
+    info = next(t for t in lut_info if t["last_lu_row"] <= r <= t["first_lut_row"])
+    table = info["table"]
+    if g.kind == LOOKUP:
+        mult = info.setdefault("mult", [0] * len(table))
+        done = (r - info["last_lu_row"]) * NUM_LU_SLOTS
+        for i in range(NUM_LU_SLOTS):
+            idx = int(rng.integers(0, len(table))) if done + i < info["n_lookups"] else 0  # padding = the first entry
+            w[2 * i], w[2 * i + 1] = int(table[idx][0]), int(table[idx][1])
+            mult[idx] += 1
+    else:
+        mult = info["mult"]
+        for i in range(NUM_LUT_SLOTS):
+            e = (info["first_lut_row"] - r) * NUM_LUT_SLOTS + i
+            w[3 * i], w[3 * i + 1], w[3 * i + 2] = (int(table[e][0]), int(table[e][1]), mult[e]) if e < len(table) else (0, 0, 0)
+    for i in range(NUM_WIRES):
+        if w[i] is None:
+            w[i] = int(rng.integers(0, P, dtype=np.uint64))
+
+
 def selector_polynomials(gates, instances, max_degree=MAX_DEGREE + 1):
     """gates/selectors.rs selector_polynomials: `gates` sorted by degree; instances[row] = gate index.
     CircuitBuilder::build calls it with max_degree = quotient_degree_factor + 1 (a filtered constraint may reach
@@ -393,14 +443,27 @@ class Circuit:
     wires [135][n]; num_selectors; pi_hash."""
 
 
-def build(log_n, kinds, seed, copy_prob=0.35):
+def build(log_n, kinds, seed, copy_prob=0.35, luts=None):
     """A random satisfied circuit using every gate kind in `kinds` (list of (kind, p0, p1, p2)), rows dealt
-    round-robin (row 0 = PublicInput when present), with random copy constraints between routed cells."""
+    round-robin (row 0 = PublicInput when present), with random copy constraints between routed cells.
+    luts: list of (table, n_lookups) with table = [(input, output)] of u16 pairs: the circuit then ends with the
+    rows CircuitBuilder::add_all_lookups appends per table -- LookupGate rows holding n_lookups random lookups (the
+    last row padded with the table's first entry), the LookupTableGate rows (the table runs downwards from the last
+    of them, multiplicities filled as prove()'s set_lookup_wires does) and one Noop row -- and the constants gain the
+    4 + len(luts) lookup selectors (gates/selectors.rs selectors_lookup / selector_ends_lookups)."""
     n = 1 << log_n
     rng = np.random.default_rng(seed)
     gates = [Gate(k, p0, p1, p2, 0, 0, 0) for (k, p0, p1, p2) in kinds]
     gates.sort(key=lambda g: (gate_degree(g), g.kind, g.p0))  # CircuitBuilder sorts gates by (degree, id)
-    order = list(range(len(gates)))
+    order = [i for i, g in enumerate(gates) if g.kind not in (LOOKUP, LOOKUP_TABLE)]
+    # rows of the lookup argument, at the end of the circuit
+    lookup_rows, n_tail = [], 0
+    for table, n_lookups in (luts or []):
+        n_lu = max(1, -(-n_lookups // NUM_LU_SLOTS))
+        n_lut = -(-len(table) // NUM_LUT_SLOTS)
+        lookup_rows.append([n_lu, n_lut])
+        n_tail += n_lu + n_lut + 1
+    assert n_tail < n - 1, "the lookup rows do not fit"
     instances = [order[i % len(order)] for i in range(n)]
     rng.shuffle(instances)
     pi_rows = [i for i, g in enumerate(gates) if g.kind == PUBLIC_INPUT]
@@ -408,6 +471,20 @@ def build(log_n, kinds, seed, copy_prob=0.35):
         instances[0] = pi_rows[0]
         instances = [instances[0]] + [g if g != pi_rows[0] else order[(r + 1) % len(order)] if gates[order[(r + 1) % len(order)]].kind != PUBLIC_INPUT else order[0]
                                       for r, g in enumerate(instances[1:], 1)]
+    lut_info = []
+    if luts:
+        gi = {g.kind: i for i, g in enumerate(gates)}
+        row = n - n_tail
+        for (table, n_lookups), (n_lu, n_lut) in zip(luts, lookup_rows):
+            info = {"table": np.array(table, dtype=np.uint16).reshape(-1, 2), "n_lookups": n_lookups, "last_lu_row": row,
+                    "last_lut_row": row + n_lu, "first_lut_row": row + n_lu + n_lut - 1}
+            for r in range(row, row + n_lu):
+                instances[r] = gi[LOOKUP]
+            for r in range(row + n_lu, row + n_lu + n_lut):
+                instances[r] = gi[LOOKUP_TABLE]
+            instances[row + n_lu + n_lut] = gi[NOOP]
+            row += n_lu + n_lut + 1
+            lut_info.append(info)
     cols, sel_idx, groups = selector_polynomials(gates, instances)
     for i, g in enumerate(gates):
         g.selector_index, (g.group_start, g.group_end) = sel_idx[i], groups[sel_idx[i]]
@@ -434,7 +511,10 @@ def build(log_n, kinds, seed, copy_prob=0.35):
                 return wires[rr][cc]
             return int(rng.integers(0, P, dtype=np.uint64))
 
-        fill_row(g, w, gate_consts[r], inp, rng, pi_hash)
+        if g.kind in (LOOKUP, LOOKUP_TABLE):
+            fill_lookup_row(g, w, r, lut_info, rng)
+        else:
+            fill_row(g, w, gate_consts[r], inp, rng, pi_hash)
         if g.kind != PUBLIC_INPUT:  # nothing is copied from the public-input row: proofs of one circuit may differ there
             filled += [(r, c) for c in range(0, NUM_ROUTED, 7)]
     # sigma: identity with each equivalence class of copy-constrained cells rotated by one
@@ -452,8 +532,21 @@ def build(log_n, kinds, seed, copy_prob=0.35):
         ids = [ks[c] * xs[r] % P for r, c in cells]
         for (r, c), v in zip(cells, ids[1:] + ids[:1]):
             sig[c][r] = v
-    consts = np.array(cols + [[gate_consts[r][k] for r in range(n)] for k in range(2)], dtype=np.uint64)
+    lookup_sel = []
+    if lut_info:
+        lookup_sel = [[0] * n for _ in range(LOOKUP_SELECTORS + len(lut_info))]
+        for t, info in enumerate(lut_info):
+            for r in range(info["last_lut_row"], info["first_lut_row"] + 1):
+                lookup_sel[0][r] = 1  # TransSre
+            for r in range(info["last_lu_row"], info["last_lut_row"]):
+                lookup_sel[1][r] = 1  # TransLdc
+            lookup_sel[2][info["first_lut_row"] + 1] = 1  # InitSre
+            lookup_sel[3][info["last_lu_row"]] = 1        # LastLdc
+            lookup_sel[LOOKUP_SELECTORS + t][info["last_lut_row"]] = 1  # end of table t: RE must equal the table's polynomial
+    consts = np.array(cols + lookup_sel + [[gate_consts[r][k] for r in range(n)] for k in range(2)], dtype=np.uint64)
     ckt = Circuit()
+    ckt.luts, ckt.num_lookup_selectors = lut_info, len(lookup_sel)
+    ckt.num_lookup_polys = NUM_LOOKUP_POLYS if lut_info else 0
     ckt.log_n, ckt.gates, ckt.num_selectors, ckt.pi_hash = log_n, gates, num_selectors, pi_hash
     ckt.pre = np.concatenate([consts, np.array(sig, dtype=np.uint64)])
     ckt.wires = np.array(wires, dtype=np.uint64).T.copy()
@@ -469,7 +562,20 @@ ALL_KINDS = [(NOOP, 0, 0, 0), (CONSTANT, 2, 0, 0), (PUBLIC_INPUT, 0, 0, 0), (ARI
              (EXPONENTIATION, 66, 0, 0), (REDUCING, 43, 0, 0), (REDUCING_EXT, 32, 0, 0), (RANDOM_ACCESS, 4, 4, 2),
              (POSEIDON, 0, 0, 0), (POSEIDON_MDS, 0, 0, 0), (COSET_INTERPOLATION, 4, coset_interpolation_degree(4), 0),
              (U32_ARITHMETIC, 3, 0, 0), (U32_RANGE_CHECK, 7, 0, 0), (U32_SUBTRACTION, 6, 0, 0), (U32_ADD_MANY, 3, 5, 0),
-             (COMPARISON, 32, 16, 0)]
+             (COMPARISON, 32, 16, 0), (U32_INTERLEAVE, 3, 0, 0), (UNINTERLEAVE_TO_B32, 2, 0, 0), (UNINTERLEAVE_TO_U32, 2, 0, 0)]
+# the lookup gates (mp2-common/src/serialization/circuit_data_serialization.rs:246-247): no constraints of their own, they
+# come with lookup tables and the lookup argument of prove() (build(..., luts=...)); with ALL_KINDS: all 26 registered gates
+LOOKUP_KINDS = [(LOOKUP, NUM_LU_SLOTS, 0, 0), (LOOKUP_TABLE, NUM_LUT_SLOTS, 0, 0)]
+# an extraction-leaf-like gate set (BASELINE configs[0]): the leaf set + Keccak's interleave gates + the lookup gates
+EXTRACTION_KINDS = [(U32_INTERLEAVE, 3, 0, 0), (UNINTERLEAVE_TO_B32, 2, 0, 0), (UNINTERLEAVE_TO_U32, 2, 0, 0)] + LOOKUP_KINDS
+
+
+def bits_lookup_tables():
+    """two of the tables mp2-v1/src/values_extraction/gadgets/column_gadget.rs:53-68 registers: the first 5 bits of a
+    byte-sized value (inputs 0..=263) and the last 3 bits (inputs 0..=256), as big-endian integers"""
+    first5 = [(v, (v & 0xFF) >> 3) for v in range(256 + 8)]
+    last3 = [(v, v & 7) for v in range(256 + 1)]
+    return [first5, last3]
 
 
 # Gate sets as the reference composes its circuits. A wrap circuit (recursion-framework/src/universal_verifier_gadget/

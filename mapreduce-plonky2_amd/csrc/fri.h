@@ -24,8 +24,23 @@ struct FriShape {
   u32 log_n, rate_bits, cap_h, n_oracles;
   u32 n_polys;  // sum of w
   u32 zs_oracle, zs_count;
+  u32 lookup_count;  // the last lookup_count polynomials of oracle zs_oracle: opened at zeta AND g*zeta, last in both batches
   OracleRef o[8];
 };
+// FRI batch order (plonk/circuit_data.rs fri_all_polys / fri_next_batch_polys; also the order of the flat openings
+// and of the transcript, OpeningSet::to_fri_openings): batch 0 (zeta) = every polynomial in oracle order except the
+// lookup polynomials, which come last; batch 1 (g zeta) = the Z polynomials, then the lookup polynomials.
+GLHD u32 fri_batch_len(const FriShape& sh, u32 batch) { return batch ? sh.zs_count + sh.lookup_count : sh.n_polys; }
+GLHD void fri_batch_poly(const FriShape& sh, u32 batch, u32 j, u32& o, u32& p) {
+  const u32 zo = sh.zs_oracle, wz = sh.o[zo].w - sh.lookup_count;
+  if (batch) { o = zo; p = j < sh.zs_count ? j : wz + (j - sh.zs_count); return; }
+  for (u32 oi = 0; oi < sh.n_oracles; oi++) {
+    const u32 w = oi == zo ? wz : sh.o[oi].w;
+    if (j < w) { o = oi; p = j; return; }
+    j -= w;
+  }
+  o = zo; p = wz + j;
+}
 struct FriLayers {
   u32 n_layers;
   u32 arity_bits[8];

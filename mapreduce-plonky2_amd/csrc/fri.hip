@@ -120,13 +120,13 @@ hipError_t challenger_step(hipStream_t s, int variant, ChState* st, u32 B, const
 __global__ void __launch_bounds__(256) openings_kernel(FriShape sh, const u64* zeta /*[B][2]*/, u64 zeta_bstride, u64* out /*[B][n_open][2]*/) {
   const u32 j = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
   const u32 n = 1u << sh.log_n;
-  u32 o = 0, p = j;
+  u32 o, p;
   gl2 x = gl2_make(zeta[b * zeta_bstride], zeta[b * zeta_bstride + 1]);
   if (j >= sh.n_polys) {
-    o = sh.zs_oracle; p = j - sh.n_polys;
+    fri_batch_poly(sh, 1, j - sh.n_polys, o, p);
     x = gl2_scale(x, gl_root_of_unity(sh.log_n));
   } else {
-    while (p >= sh.o[o].w) { p -= sh.o[o].w; o++; }
+    fri_batch_poly(sh, 0, j, o, p);
   }
   const u64* c = sh.o[o].coeffs + b * sh.o[o].coeff_bstride + ((u64)p << sh.log_n);
   // lane t owns i = t + 256k: Horner in x^256, then weight by x^t
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) openings_kernel(FriShape sh, const u64* z
     __syncthreads();
   }
   if (t == 0) {
-    u64* d = out + ((u64)b * (sh.n_polys + sh.zs_count) + j) * 2;
+    u64* d = out + ((u64)b * (sh.n_polys + sh.zs_count + sh.lookup_count) + j) * 2;
     d[0] = ra[0]; d[1] = rb[0];
   }
 }
@@ -159,20 +159,20 @@ __global__ void __launch_bounds__(256) compose_kernel(FriShape sh, const u64* al
   if (i >= n) return;
   gl2 al = gl2_make(alpha[b * alpha_bstride], alpha[b * alpha_bstride + 1]);
   gl2 acc = gl2_make(0, 0);
-  if (batch == 0) {
-    for (int o = (int)sh.n_oracles - 1; o >= 0; o--) {
-      const u64* base = sh.o[o].coeffs + b * sh.o[o].coeff_bstride + i;
-      for (int p = (int)sh.o[o].w - 1; p >= 0; p--) {
-        acc = gl2_mul(acc, al);
-        acc.a = gl_add(acc.a, base[(u64)p << sh.log_n]);
-      }
-    }
-  } else {
-    const u64* base = sh.o[sh.zs_oracle].coeffs + b * sh.o[sh.zs_oracle].coeff_bstride + i;
-    for (int p = (int)sh.zs_count - 1; p >= 0; p--) {
+  // Horner from the back of the batch: runs of consecutive polynomials of one oracle (fri_batch_poly order)
+  const u32 zo = sh.zs_oracle, wz = sh.o[zo].w - sh.lookup_count;
+  auto run = [&](u32 o, u32 first, u32 count) {
+    const u64* base = sh.o[o].coeffs + b * sh.o[o].coeff_bstride + i;
+    for (int p = (int)(first + count) - 1; p >= (int)first; p--) {
       acc = gl2_mul(acc, al);
       acc.a = gl_add(acc.a, base[(u64)p << sh.log_n]);
     }
+  };
+  if (sh.lookup_count) run(zo, wz, sh.lookup_count);
+  if (batch == 0) {
+    for (int o = (int)sh.n_oracles - 1; o >= 0; o--) run((u32)o, 0, (u32)o == zo ? wz : sh.o[o].w);
+  } else {
+    run(zo, 0, sh.zs_count);
   }
   u64* d = comp + (((u64)b * 2 + batch) * 2) * n;
   d[i] = acc.a;
@@ -410,7 +410,7 @@ __global__ void bind_pi_kernel(u64* wires, u64 wires_bstride, u64 n, u32 row, co
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
 
 hipError_t fri_openings(hipStream_t s, const FriShape& sh, u32 B, const u64* zeta, u64 zeta_bstride, u64* out) {
-  hipLaunchKernelGGL(openings_kernel, dim3(sh.n_polys + sh.zs_count, B), dim3(256), 0, s, sh, zeta, zeta_bstride, out);
+  hipLaunchKernelGGL(openings_kernel, dim3(sh.n_polys + sh.zs_count + sh.lookup_count, B), dim3(256), 0, s, sh, zeta, zeta_bstride, out);
   return hipGetLastError();
 }
 hipError_t fri_final_poly(hipStream_t s, const FriShape& sh, u32 B, const u64* alpha, u64 alpha_bstride, const u64* zeta, u64 zeta_bstride,
@@ -418,7 +418,8 @@ hipError_t fri_final_poly(hipStream_t s, const FriShape& sh, u32 B, const u64* a
   const u32 n = 1u << sh.log_n;
   hipLaunchKernelGGL(compose_kernel, dim3((n + 255) / 256, B, 2), dim3(256), 0, s, sh, alpha, alpha_bstride, comp);
   hipLaunchKernelGGL(divide_kernel, dim3(2, B), dim3(1024), 0, s, sh.log_n, zeta, zeta_bstride, comp, quot);
-  hipLaunchKernelGGL(combine_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, sh.log_n, sh.zs_count, alpha, alpha_bstride, quot, final_poly);
+  hipLaunchKernelGGL(combine_kernel, dim3((n + 255) / 256, B), dim3(256), 0, s, sh.log_n, sh.zs_count + sh.lookup_count, alpha, alpha_bstride, quot,
+                     final_poly);
   return hipGetLastError();
 }
 hipError_t fri_fold_values(hipStream_t s, u32 B, u32 log_m, u32 ab, const u64* in, u64 in_bstride, u64* out, u64 out_bstride,

@@ -5,6 +5,7 @@
 namespace mp2g {
 struct GateTable {
   u32 n_gates, num_selectors;
+  u32 num_lookup_selectors;  // 0, or 4 + n_luts constants between the selectors and the gate constants
   mp2g_gate g[MP2G_MAX_GATES];
 };
 // validates kinds / parameters against the wire and constant counts; returns nullptr or a message

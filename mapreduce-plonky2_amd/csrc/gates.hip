@@ -32,7 +32,9 @@ u32 gate_num_constraints(const mp2g_gate& g) {
     case MP2G_GATE_EXPONENTIATION: return g.p0 + 1;
     case MP2G_GATE_REDUCING: case MP2G_GATE_REDUCING_EXT: return 2 * g.p0;
     case MP2G_GATE_RANDOM_ACCESS: return (g.p0 + 2) * g.p1 + g.p2;
-    default: return 0;
+    case MP2G_GATE_U32_INTERLEAVE: return 34 * g.p0;
+    case MP2G_GATE_UNINTERLEAVE_TO_B32: case MP2G_GATE_UNINTERLEAVE_TO_U32: return 67 * g.p0;
+    default: return 0;  // Noop, Lookup, LookupTable
   }
 }
 u32 gate_degree(const mp2g_gate& g) {
@@ -48,6 +50,7 @@ u32 gate_degree(const mp2g_gate& g) {
     case MP2G_GATE_EXPONENTIATION: return 4;
     case MP2G_GATE_REDUCING: case MP2G_GATE_REDUCING_EXT: return 2;
     case MP2G_GATE_RANDOM_ACCESS: return g.p0 + 1;
+    case MP2G_GATE_U32_INTERLEAVE: case MP2G_GATE_UNINTERLEAVE_TO_B32: case MP2G_GATE_UNINTERLEAVE_TO_U32: return 2;
     default: return 0;
   }
 }
@@ -73,6 +76,10 @@ static void gate_footprint(const mp2g_gate& g, u32& wires, u32& consts) {
     case MP2G_GATE_REDUCING: wires = 6 + g.p0 + 2 * (g.p0 - 1); break;
     case MP2G_GATE_REDUCING_EXT: wires = 6 + 2 * g.p0 + 2 * (g.p0 - 1); break;
     case MP2G_GATE_RANDOM_ACCESS: wires = (2 + (1u << g.p0)) * g.p1 + g.p2 + g.p0 * g.p1; consts = g.p2; break;
+    case MP2G_GATE_LOOKUP: wires = 2 * g.p0; break;
+    case MP2G_GATE_LOOKUP_TABLE: wires = 3 * g.p0; break;
+    case MP2G_GATE_U32_INTERLEAVE: wires = 34 * g.p0; break;
+    case MP2G_GATE_UNINTERLEAVE_TO_B32: case MP2G_GATE_UNINTERLEAVE_TO_U32: wires = 67 * g.p0; break;
     default: break;
   }
 }
@@ -81,7 +88,8 @@ const char* gate_table_check(const GateTable& t, u32 num_constants, u32 wires_w)
   if (t.num_selectors == 0 || t.num_selectors > num_constants) return "num_selectors must be in 1..num_constants";
   for (u32 i = 0; i < t.n_gates; i++) {
     const mp2g_gate& g = t.g[i];
-    if (g.kind > MP2G_GATE_COMPARISON) return "unknown gate kind";
+    if (g.kind > MP2G_GATE_UNINTERLEAVE_TO_U32) return "unknown gate kind";
+    if (g.kind >= MP2G_GATE_LOOKUP && g.p0 < 1) return "gate needs at least one slot / operation";
     if ((g.kind == MP2G_GATE_U32_ARITHMETIC || g.kind == MP2G_GATE_U32_RANGE_CHECK || g.kind == MP2G_GATE_U32_SUBTRACTION) && g.p0 < 1)
       return "u32 gate needs at least one operation";
     if (g.kind == MP2G_GATE_U32_ADD_MANY && (g.p0 < 1 || g.p0 > 16 || g.p1 < 1)) return "U32AddManyGate needs 1..16 addends and an operation";
@@ -96,7 +104,7 @@ const char* gate_table_check(const GateTable& t, u32 num_constants, u32 wires_w)
     u32 w, c;
     gate_footprint(g, w, c);
     if (w > wires_w) return "gate needs more wires than the wires oracle has";
-    if (t.num_selectors + c > num_constants) return "gate needs more constants than the preprocessed oracle has";
+    if (t.num_selectors + t.num_lookup_selectors + c > num_constants) return "gate needs more constants than the preprocessed oracle has";
     if (g.selector_index >= t.num_selectors) return "selector_index out of range";
     if (!(g.group_start <= i && i < g.group_end && g.group_end <= t.n_gates)) return "gate is not inside its selector group";
     if (gate_num_constraints(g) > MP2G_MAX_GATE_CONSTRAINTS) return "gate has too many constraints";
@@ -508,7 +516,49 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
       for (u32 i = 0; i < extra; i++) emit(gl_sub(cst(i), wire((2 + vs) * copies + i)));
       break;
     }
-    default: break;
+    case MP2G_GATE_U32_INTERLEAVE: {  // x, x_interleaved per op; 32 bit wires after the routed ones, most significant first
+      const u32 ops = g.p0;
+      u64 bt[16];
+      for (u32 i = 0; i < ops; i++) {
+        u64 x = 0, xi = 0;
+        for (u32 h = 0; h < 2; h++) {
+          load16(2 * ops + 32 * i + 16 * h, 16, bt);
+#pragma unroll
+          for (int j = 0; j < 16; j++) {
+            emit(mulx(bt[j], gl_sub(1, bt[j])));
+            x = gl_add(gl_add(x, x), bt[j]);
+            xi = gl_add(gl_mul_small(xi, 4), bt[j]);
+          }
+        }
+        emit(gl_sub(x, wire(2 * i)));
+        emit(gl_sub(xi, wire(2 * i + 1)));
+      }
+      break;
+    }
+    case MP2G_GATE_UNINTERLEAVE_TO_B32:
+    case MP2G_GATE_UNINTERLEAVE_TO_U32: {  // x_interleaved, x_evens, x_odds per op; 64 bit wires, most significant first
+      const u32 ops = g.p0;
+      const bool spread = g.kind == MP2G_GATE_UNINTERLEAVE_TO_B32;
+      u64 bt[16];
+      for (u32 i = 0; i < ops; i++) {
+        u64 x = 0, ev = 0, od = 0;
+        for (u32 h = 0; h < 4; h++) {
+          load16(3 * ops + 64 * i + 16 * h, 16, bt);
+#pragma unroll
+          for (int j = 0; j < 16; j++) {
+            emit(mulx(bt[j], gl_sub(1, bt[j])));
+            x = gl_add(gl_add(x, x), bt[j]);
+            u64& d = (j & 1) ? ev : od;  // wire 16h + j has weight 2^(63 - 16h - j): odd j = even weight
+            d = gl_add(spread ? gl_mul_small(d, 4) : gl_add(d, d), bt[j]);
+          }
+        }
+        emit(gl_sub(x, wire(3 * i)));
+        emit(gl_sub(ev, wire(3 * i + 1)));
+        emit(gl_sub(od, wire(3 * i + 2)));
+      }
+      break;
+    }
+    default: break;  // Noop; LookupGate / LookupTableGate: no constraints of their own
   }
 }
 
@@ -530,7 +580,7 @@ GLD u64 gate_filter(const GateTable& t, u32 gi, ConstAll call) {
 // integer (lo, hi, top), reduced once: per constraint and challenge one 64x64 multiply and a carry chain
 // instead of two modular multiplications. q[b][a][i] is written by the first launch and added to by the rest.
 template <u32 KIND>
-__global__ void __launch_bounds__(256) gate_constraints_lde_kernel(mp2g_gate g, u32 gi, u32 num_selectors, u32 n_cons,
+__global__ void __launch_bounds__(256) gate_constraints_lde_kernel(mp2g_gate g, u32 gi, u32 num_selectors, u32 cst_off, u32 n_cons,
                                                                    const u64* __restrict__ C, const u64* __restrict__ W,
                                                                    u64 w_bstride, u32 lg, const u64* __restrict__ alphas,
                                                                    u64 al_bstride, u32 nc, const u64* __restrict__ pi_hash,
@@ -549,7 +599,7 @@ __global__ void __launch_bounds__(256) gate_constraints_lde_kernel(mp2g_gate g, 
   const u64* c = C + p;
   const u64* pih = pi_hash + 4 * b;
   auto wire = [&](u32 j) { return w[(u64)j << lg]; };
-  auto cst = [&](u32 j) { return c[(u64)(num_selectors + j) << lg]; };
+  auto cst = [&](u32 j) { return c[(u64)(cst_off + j) << lg]; };  // after the selectors and the lookup selectors
   // gates/gate.rs compute_filter
   u64 f = 1;
   {
@@ -590,7 +640,7 @@ __global__ void __launch_bounds__(256) gate_constraints_points_kernel(GateTable 
   if (p >= npts) return;
   auto wire = [&](u32 j) { return wires[(u64)j * npts + p]; };
   auto call = [&](u32 j) { return consts[(u64)j * npts + p]; };
-  const u32 ns = t.num_selectors;
+  const u32 ns = t.num_selectors + t.num_lookup_selectors;
   auto cst = [&](u32 j) { return consts[(u64)(ns + j) * npts + p]; };
   for (u32 j = 0; j < max_j; j++) out[(u64)j * npts + p] = 0;
   for (u32 gi = 0; gi < t.n_gates; gi++) {
@@ -616,7 +666,7 @@ __global__ void __launch_bounds__(256) gate_check_kernel(GateTable t, const u64*
   const u64* w = wires + b * w_bstride;
   auto wire = [&](u32 j) { return w[(u64)j * npts + p]; };
   auto call = [&](u32 j) { return consts[(u64)j * npts + p]; };
-  const u32 ns = t.num_selectors;
+  const u32 ns = t.num_selectors + t.num_lookup_selectors;
   auto cst = [&](u32 j) { return consts[(u64)(ns + j) * npts + p]; };
   bool bad = false;
   for (u32 gi = 0; gi < t.n_gates; gi++) {
@@ -646,8 +696,9 @@ hipError_t gate_constraints_lde(hipStream_t s, u32 B, const GateTable& t, const 
     if (!n_cons) continue;
 #define GATE_CASE(K)                                                                                                        \
   case K:                                                                                                                   \
-    hipLaunchKernelGGL(gate_constraints_lde_kernel<K>, grid, block, 0, s, g, gi, t.num_selectors, n_cons, C, W, w_bstride, lg, \
-                       alphas, al_bstride, nc, pi_hash, q, first);                                                          \
+    hipLaunchKernelGGL(gate_constraints_lde_kernel<K>, grid, block, 0, s, g, gi, t.num_selectors,                          \
+                       t.num_selectors + t.num_lookup_selectors, n_cons, C, W, w_bstride, lg, alphas, al_bstride, nc, pi_hash, q, \
+                       first);                                                                                              \
     break;
     switch (g.kind) {
       GATE_CASE(MP2G_GATE_CONSTANT)
@@ -669,6 +720,9 @@ hipError_t gate_constraints_lde(hipStream_t s, u32 B, const GateTable& t, const 
       GATE_CASE(MP2G_GATE_U32_SUBTRACTION)
       GATE_CASE(MP2G_GATE_U32_ADD_MANY)
       GATE_CASE(MP2G_GATE_COMPARISON)
+      GATE_CASE(MP2G_GATE_U32_INTERLEAVE)
+      GATE_CASE(MP2G_GATE_UNINTERLEAVE_TO_B32)
+      GATE_CASE(MP2G_GATE_UNINTERLEAVE_TO_U32)
       default: return hipErrorInvalidValue;
     }
 #undef GATE_CASE

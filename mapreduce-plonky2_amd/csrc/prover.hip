@@ -8,6 +8,7 @@
 #include "fri.h"
 #include "zperm.h"
 #include "gates.h"
+#include "lookup.h"
 #include <cstring>
 #include <new>
 #include <vector>
@@ -39,6 +40,9 @@ struct mp2g_prover {
   DevBuf pre_values, zs_values, chunk_q, bg, alphas, qvals;
   // gate constraints (mp2g_prover_set_gates)
   GateTable gates{};
+  // lookup argument (mp2g_prover_set_lookups): tables on the device, per-proof table polynomials
+  LookupDev lookups{};
+  DevBuf lut_tables, lut_eval;
   // PublicInputGate row whose first four wires the prover fills from d_pi_hash (mp2g_prover_bind_public_inputs)
   int64_t pi_row = -1;
   // witness check (mp2g_prover_enable_witness_check): bit 0 copy constraints, bit 1 gate constraints
@@ -94,6 +98,8 @@ int params_check(const mp2g_fri_params* p) {
     NEED(lg >= p->cap_height, "layer smaller than cap");
   }
   for (uint32_t o = 0; o < p->n_oracles; o++) NEED(p->oracle_w[o] >= 1, "oracle_w >= 1");
+  NEED(p->num_lookup_polys <= 16, "num_lookup_polys <= 16");
+  NEED((uint64_t)p->zs_count * (1 + p->num_lookup_polys) <= p->oracle_w[p->zs_oracle], "Z + lookup polynomials exceed the zs oracle");
   return 0;
 }
 }  // namespace mp2g
@@ -112,7 +118,7 @@ uint32_t mp2g_reduction_arity_bits(uint32_t degree_bits, uint32_t rate_bits, uin
   return n;
 }
 size_t mp2g_fri_n_openings(const mp2g_fri_params* p) {
-  size_t t = p->zs_count;
+  size_t t = p->zs_count + (size_t)p->zs_count * p->num_lookup_polys;
   for (uint32_t o = 0; o < p->n_oracles; o++) t += p->oracle_w[o];
   return t;
 }
@@ -316,11 +322,11 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
   NEED(degree >= 1 && num_routed >= degree && num_routed % degree == 0 && num_routed / degree <= 16, "num_routed/degree");
   NEED(num_routed <= P.oracle_w[0] && num_routed <= P.oracle_w[1], "num_routed exceeds the sigma / wire counts");
   NEED(P.zs_count >= 1 && P.zs_count <= 2, "1 or 2 challenges");
-  NEED(P.oracle_w[2] == P.zs_count * (num_routed / degree), "oracle_w[2] must be zs_count * num_routed/degree");
+  NEED(P.oracle_w[2] == P.zs_count * (num_routed / degree + P.num_lookup_polys), "oracle_w[2] must be zs_count * (num_routed/degree + num_lookup_polys)");
   const size_t n = (size_t)1 << P.log_n;
   CK(pr->zs_values.alloc((size_t)pr->B * P.oracle_w[2] * n * sizeof(u64)));
   CK(pr->chunk_q.alloc((size_t)pr->B * P.zs_count * (num_routed / degree) * n * sizeof(u64)));
-  CK(pr->bg.alloc((size_t)pr->B * 4 * sizeof(u64)));
+  CK(pr->bg.alloc((size_t)pr->B * 8 * sizeof(u64)));  // betas, gammas (+ the 2 * num_challenges extra lookup challenges)
   CK(pr->alphas.alloc((size_t)pr->B * 2 * sizeof(u64)));
   pr->num_routed = num_routed; pr->degree = degree;
   pr->drop_graph();
@@ -342,6 +348,7 @@ int mp2g_prover_set_gates(mp2g_prover* pr, const mp2g_gate* gates, uint32_t n_ga
   NEED(n_gates <= MP2G_MAX_GATES, "at most MP2G_MAX_GATES gates");
   GateTable t{};
   t.n_gates = n_gates; t.num_selectors = num_selectors;
+  t.num_lookup_selectors = pr->gates.num_lookup_selectors;
   if (n_gates) {
     NEED(gates, "gates");
     for (uint32_t i = 0; i < n_gates; i++) t.g[i] = gates[i];
@@ -503,8 +510,15 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
       // betas = bg[0..nc), gammas = bg[nc..2nc) of every transcript (drawn after the wires cap:
       // get_n_challenges(num_challenges) twice)
       CK(zpp_compute(s, B, (const u64*)d_values[0], (u64)P.oracle_w[1] * n, pr->pre_values.p + (u64)(P.oracle_w[0] - pr->num_routed) * n,
-                     P.log_n, pr->num_routed, pr->degree, pr->bg.p, pr->bg.p + P.zs_count, 4, P.zs_count, pr->chunk_q.p, pr->zs_values.p,
+                     P.log_n, pr->num_routed, pr->degree, pr->bg.p, pr->bg.p + P.zs_count, 8, P.zs_count, pr->chunk_q.p, pr->zs_values.p,
                      (u64)P.oracle_w[2] * n));
+      if (pr->lookups.n_luts) {
+        // compute_all_lookup_polys: deltas of round c = bg[4c .. 4c+4) (betas ++ gammas ++ the extra challenges)
+        CK(lookup_table_polys(s, B, pr->lookups, pr->bg.p, 8, P.zs_count, pr->lut_eval.p));
+        CK(lookup_polys(s, B, pr->lookups, (const u64*)d_values[0], (u64)P.oracle_w[1] * n, P.log_n, pr->bg.p, 8, P.zs_count,
+                        pr->zs_values.p + (u64)P.zs_count * (pr->num_routed / pr->degree) * n, (u64)P.oracle_w[2] * n, pr->lut_eval.p,
+                        pr->wcheck ? (u32*)pr->wflags.p : nullptr));
+      }
       vals = pr->zs_values.p;
       if (pr->wcheck)
         CK(zpp_wrap_check(s, B, pr->chunk_q.p, pr->zs_values.p, (u64)P.oracle_w[2] * n, P.log_n, pr->num_routed / pr->degree, P.zs_count,
@@ -517,8 +531,13 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
       if (pr->gates.n_gates)
         CK(gate_constraints_lde(s, B, pr->gates, pr->values[0].p, pr->values[1].p, (u64)P.oracle_w[1] * N, P.log_n + 3, pr->alphas.p, 2,
                                 nc, (const u64*)d_pi_hash, pr->qvals.p));
+      // vanishing_all_lookup_terms sit between the partial-product and the gate terms of the alpha-reduction
+      if (pr->lookups.n_luts)
+        CK(quotient_lookup_values(s, B, pr->lookups, pr->values[0].p, pr->gates.num_selectors, pr->values[1].p, (u64)P.oracle_w[1] * N,
+                                  pr->values[2].p, (u64)P.oracle_w[2] * N, nc * (pr->num_routed / pr->degree), P.log_n, pr->bg.p, 8,
+                                  pr->lut_eval.p, pr->alphas.p, 2, nc, pr->qvals.p));
       CK(quotient_perm_values(s, B, pr->values[1].p, (u64)P.oracle_w[1] * N, pr->values[0].p + (u64)(P.oracle_w[0] - pr->num_routed) * N,
-                              pr->values[2].p, (u64)P.oracle_w[2] * N, P.log_n, pr->num_routed, pr->degree, pr->bg.p, 4,
+                              pr->values[2].p, (u64)P.oracle_w[2] * N, P.log_n, pr->num_routed, pr->degree, pr->bg.p, 8,
                               pr->alphas.p, 2, nc, pr->gates.n_gates != 0, pr->qvals.p));
       CK(c->ntt.run(pr->qvals.p, pr->coeffs[3].p, P.log_n + 3, B * nc, 0, N, N, true, nullptr, false));
       CK(c->ntt.scale_powers(pr->coeffs[3].p, P.log_n + 3, B * nc, gl_inv(GL_MULT_GEN), 1));
@@ -531,10 +550,12 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
     CK(copy_rows(s, B, pr->levels[o].p + LW - capw, LW, cap_dst, caps_b, (u32)capw));
     // plonk/prover.rs: wires cap -> num_challenges betas, then as many gammas; zs cap -> num_challenges
     // alphas; all other caps -> 0
-    uint32_t n_get = o == 1 ? 2 * P.zs_count : (o == 2 ? P.zs_count : 0);
+    // (the PCS-only skeleton, which accepts any zs_count, draws as for two rounds)
+    const uint32_t nch = P.zs_count >= 1 && P.zs_count <= 2 ? P.zs_count : 2;
+    uint32_t n_get = o == 1 ? (pr->lookups.n_luts ? 4 : 2) * nch : (o == 2 ? nch : 0);
     u64* dst = chal;
     u64 dst_stride = 8;
-    if (pr->num_routed && o == 1) { dst = pr->bg.p; dst_stride = 4; }
+    if (pr->num_routed && o == 1) { dst = pr->bg.p; dst_stride = 8; }
     if (pr->num_routed && o == 2) { dst = pr->alphas.p; dst_stride = 2; }
     CK(challenger_step(s, V, st, B, cap_dst, caps_b, (u32)capw, dst, dst_stride, n_get));
     if (o <= 3) STAGE_MARK(pr, o);  // 1: wires committed, 2: Z / partial products, 3: quotient
@@ -544,7 +565,7 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
 
   FriShape sh{};
   sh.log_n = P.log_n; sh.rate_bits = P.rate_bits; sh.cap_h = P.cap_height; sh.n_oracles = P.n_oracles;
-  sh.zs_oracle = P.zs_oracle; sh.zs_count = P.zs_count;
+  sh.zs_oracle = P.zs_oracle; sh.zs_count = P.zs_count; sh.lookup_count = P.zs_count * P.num_lookup_polys;
   for (uint32_t o = 0; o < P.n_oracles; o++) {
     OracleRef& r = sh.o[o];
     r.coeffs = pr->coeffs[o].p; r.values = pr->values[o].p; r.levels = pr->levels[o].p; r.w = P.oracle_w[o];
@@ -559,6 +580,57 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
   int rc = fri_tail(pr, sh, st, (u64*)d_proof);
   if (rc) return rc;
   STAGE_MARK(pr, 7);
+  return 0;
+}
+int mp2g_prover_set_lookups(mp2g_prover* pr, const mp2g_lookup* luts, uint32_t n_luts) {
+  NEED(pr && pr->quotient, "call mp2g_prover_enable_quotient first");
+  NEED(n_luts <= MP2G_MAX_LUTS, "at most MP2G_MAX_LUTS lookup tables");
+  const mp2g_fri_params& P = pr->P;
+  LookupDev L{};
+  if (!n_luts) {
+    NEED(P.num_lookup_polys == 0, "params.num_lookup_polys != 0 needs lookup tables");
+    pr->lookups = L;
+    pr->gates.num_lookup_selectors = 0;
+    pr->drop_graph();
+    return 0;
+  }
+  NEED(luts && pr->gates.n_gates, "luts; call mp2g_prover_set_gates first");
+  L.n_luts = n_luts;
+  L.num_lu_slots = pr->num_routed / 2; L.num_lut_slots = pr->num_routed / 3;
+  L.lu_degree = pr->degree - 1;
+  NEED(L.lu_degree >= 1 && L.num_lu_slots <= 40 && L.num_lut_slots >= 1, "slot geometry (num_routed <= 80, degree >= 2)");
+  L.num_sldc = (L.num_lu_slots + L.lu_degree - 1) / L.lu_degree;
+  L.lut_degree = (L.num_lut_slots + L.num_sldc - 1) / L.num_sldc;
+  NEED(P.num_lookup_polys == L.num_sldc + 1, "params.num_lookup_polys must be ceil((num_routed/2) / (degree-1)) + 1");
+  NEED(P.oracle_w[1] >= 3 * L.num_lut_slots && P.oracle_w[1] >= 2 * L.num_lu_slots, "wires");
+  const uint32_t n_sel = 4 + n_luts, num_constants = P.oracle_w[0] - pr->num_routed;
+  NEED(pr->gates.num_selectors + n_sel <= num_constants, "the constants must hold 4 + n_luts lookup selectors after the selectors");
+  const uint64_t n = (uint64_t)1 << P.log_n;
+  size_t total = 0;
+  for (uint32_t r = 0; r < n_luts; r++) {
+    const mp2g_lookup& u = luts[r];
+    NEED(u.table && u.table_len >= 1 && u.table_len <= 65536, "table");
+    NEED(u.last_lu_row < u.last_lut_row && u.last_lut_row <= u.first_lut_row && (uint64_t)u.first_lut_row + 1 < n, "lookup rows");
+    NEED((uint64_t)(u.first_lut_row - u.last_lut_row + 1) * L.num_lut_slots >= u.table_len, "the table does not fit its LookupTableGate rows");
+    total += (size_t)u.table_len * 2;
+  }
+  CK(pr->lut_tables.alloc(total * sizeof(uint16_t)));
+  CK(pr->lut_eval.alloc((size_t)pr->B * P.zs_count * MP2G_MAX_LUTS * sizeof(u64)));
+  size_t off = 0;
+  for (uint32_t r = 0; r < n_luts; r++) {
+    const mp2g_lookup& u = luts[r];
+    L.last_lu_row[r] = u.last_lu_row; L.last_lut_row[r] = u.last_lut_row; L.first_lut_row[r] = u.first_lut_row; L.table_len[r] = u.table_len;
+    L.table[r] = (const uint16_t*)pr->lut_tables.p + off;
+    CK(hipMemcpyAsync((uint16_t*)pr->lut_tables.p + off, u.table, (size_t)u.table_len * 2 * sizeof(uint16_t), hipMemcpyHostToDevice, pr->ctx->stream));
+    off += (size_t)u.table_len * 2;
+  }
+  CK(hipStreamSynchronize(pr->ctx->stream));  // the caller's table memory may go away
+  pr->lookups = L;
+  pr->gates.num_lookup_selectors = n_sel;
+  // the gate constants move behind the lookup selectors: re-validate the table against the constant count
+  const char* msg = gate_table_check(pr->gates, num_constants, P.oracle_w[1]);
+  if (msg) { pr->lookups = LookupDev{}; pr->gates.num_lookup_selectors = 0; return fail("invalid gate table with lookups: %s", msg); }
+  pr->drop_graph();
   return 0;
 }
 int mp2g_prover_bind_public_inputs(mp2g_prover* pr, int64_t row) {
@@ -584,8 +656,8 @@ int mp2g_prover_witness_status(mp2g_prover* pr, uint32_t* flags) {
   if (flags) memcpy(flags, h.data(), pr->B * sizeof(u32));
   for (uint32_t b = 0; b < pr->B; b++)
     if (h[b])
-      return fail("invalid witness: proof %u of the batch violates %s%s%s", b, (h[b] & 1) ? "a copy constraint" : "",
-                  h[b] == 3 ? " and " : "", (h[b] & 2) ? "a gate constraint" : "");
+      return fail("invalid witness: proof %u of the batch violates%s%s%s", b, (h[b] & 1) ? " a copy constraint" : "",
+                  (h[b] & 2) ? " a gate constraint" : "", (h[b] & 4) ? " the lookup argument" : "");
   return 0;
 }
 int mp2g_prover_enable_timing(mp2g_prover* pr, int on) {
@@ -691,7 +763,7 @@ int mp2g_fri_prove(mp2g_ctx* c, const mp2g_fri_params* params, mp2g_batch* const
   const mp2g_fri_params& P = pr->P;
   FriShape sh{};
   sh.log_n = P.log_n; sh.rate_bits = P.rate_bits; sh.cap_h = P.cap_height; sh.n_oracles = P.n_oracles;
-  sh.zs_oracle = P.zs_oracle; sh.zs_count = P.zs_count;
+  sh.zs_oracle = P.zs_oracle; sh.zs_count = P.zs_count; sh.lookup_count = P.zs_count * P.num_lookup_polys;
   for (uint32_t o = 0; o < P.n_oracles; o++) {
     const mp2g_batch* b = oracles[o];
     if (!b || b->ctx != c || b->log_n != P.log_n || b->w != P.oracle_w[o] || b->rate_bits != P.rate_bits ||

@@ -75,20 +75,22 @@ void walk(T& io, const mp2g_fri_params* p, uint32_t num_constants, U64P caps, U6
   auto ext_vec = [&](size_t count) { vec_len(io, count); io.u64s(openings + 2 * off, 2 * count); off += count; };
   size_t n_zeta = 0;
   for (uint32_t o = 0; o < p->n_oracles; o++) n_zeta += p->oracle_w[o];
-  // oracle order in `openings`: consts+sigmas | wires | zs + partial products | quotient | zs_next
-  // serde order: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys
+  // FRI batch order in `openings`: consts+sigmas | wires | zs + partial products | quotient | lookup | zs_next | lookup_next
+  // serde order: constants, plonk_sigmas, wires, plonk_zs, plonk_zs_next, partial_products, quotient_polys, lookup_zs, lookup_zs_next
+  const size_t L = (size_t)p->zs_count * p->num_lookup_polys;
   size_t o0 = 0, o1 = p->oracle_w[0], o2 = o1 + (p->n_oracles > 1 ? p->oracle_w[1] : 0);
-  size_t o3 = o2 + (p->n_oracles > 2 ? p->oracle_w[2] : 0);
+  size_t o3 = o2 + (p->n_oracles > 2 ? p->oracle_w[2] - L : 0);
+  size_t o_lu = o3 + (p->n_oracles > 3 ? p->oracle_w[3] : 0);
   (void)o0;
   off = 0; ext_vec(num_constants);
   ext_vec(p->oracle_w[0] - num_constants);
   off = o1; ext_vec(p->n_oracles > 1 ? p->oracle_w[1] : 0);
   off = o2; ext_vec(p->zs_count);
   off = n_zeta; ext_vec(p->zs_count);
-  off = o2 + p->zs_count; ext_vec((p->n_oracles > 2 ? p->oracle_w[2] : 0) - p->zs_count);
+  off = o2 + p->zs_count; ext_vec((p->n_oracles > 2 ? p->oracle_w[2] - L : 0) - p->zs_count);
   off = o3; ext_vec(p->n_oracles > 3 ? p->oracle_w[3] : 0);
-  vec_len(io, 0);  // lookup_zs
-  vec_len(io, 0);  // lookup_zs_next
+  off = o_lu; ext_vec(L);                  // lookup_zs
+  off = n_zeta + p->zs_count; ext_vec(L);  // lookup_zs_next
   // FriProof
   vec_len(io, l.n_layers);
   for (uint32_t i = 0; i < l.n_layers; i++) { vec_len(io, l.cap_n); io.u64s(fri + i * l.capw, l.capw); }
@@ -124,7 +126,8 @@ int shape_check(const mp2g_fri_params* p, uint32_t num_constants) {
   NEED(num_constants <= p->oracle_w[0], "num_constants <= oracle_w[0]");
   NEED(p->zs_oracle == 2 || p->zs_count == 0, "wire format expects the Z polynomials in oracle 2");
   NEED(p->n_oracles <= 4, "wire format has four oracles");
-  NEED(p->n_oracles <= 2 || p->zs_count <= p->oracle_w[2], "zs_count");
+  NEED(p->n_oracles <= 2 || (uint64_t)p->zs_count * (1 + p->num_lookup_polys) <= p->oracle_w[2], "zs_count / num_lookup_polys");
+  NEED(p->num_lookup_polys == 0 || p->n_oracles == 4, "lookup polynomials need the four plonky2 oracles");
   return 0;
 }
 }  // namespace

@@ -27,8 +27,11 @@ INPUT_CHUNK_SIZE = 4
 
 def circuit_fri_params(ckt, variant=POSEIDON2, **kw):
     """FRI / oracle shape of a built circuit under standard_recursion_config: constants + sigmas, 135 wires,
-    2 x (1 + 9) Z / partial products, 2 x 8 quotient chunks."""
-    return standard_recursion_params(ckt.log_n, (int(ckt.pre.shape[0]), C.NUM_WIRES, 20, 16), variant=variant, **kw)
+    2 x (1 + 9) Z / partial products (+ 2 x 7 lookup polynomials when the circuit has lookup tables), 2 x 8 quotient
+    chunks."""
+    nlp = getattr(ckt, "num_lookup_polys", 0)
+    return standard_recursion_params(ckt.log_n, (int(ckt.pre.shape[0]), C.NUM_WIRES, 2 * (NUM_ROUTED // 8 + nlp), 16), variant=variant,
+                                     num_lookup_polys=nlp, **kw)
 
 
 class CircuitProver:
@@ -45,6 +48,8 @@ class CircuitProver:
         pr.enable_quotient()
         pr.set_gates([Gate(g.kind, g.p0, g.p1, g.p2, g.selector_index, g.group_start, g.group_end) for g in ckt.gates],
                      ckt.num_selectors)
+        if getattr(ckt, "luts", None):
+            pr.set_lookups(ckt.luts)
         if witness_check:
             pr.enable_witness_check()
         if bind_public_inputs:

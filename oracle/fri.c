@@ -38,7 +38,17 @@ typedef struct {
   unsigned n_gates, num_selectors, num_constants, wires_w;
   const gl_t* const_coeffs;  // [num_constants][n]
   const gl_t* pi_hash;       // [4]
+  const orc_lookup_ctx* lookups;  // NULL: no lookup argument. Otherwise the zs oracle ends with nc * (num_sldc + 1) lookup polynomials
+  const gl_t* deltas;             // [nc][4] lookup challenges (A, B, alpha, delta) per challenge round
 } orc_gate_ctx;
+// A circuit as prove() / verify() need it beyond the FRI shape: permutation geometry, gate table, lookup tables
+typedef struct {
+  uint32_t num_routed, degree;
+  const orc_gate* gates;
+  uint32_t n_gates, num_selectors;
+  const orc_lookup* luts;
+  uint32_t n_luts;
+} orc_circuit;
 void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, const gl_t* zs_coeffs, unsigned log_n,
                         unsigned num_routed, unsigned degree, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
                         unsigned nc, const orc_gate_ctx* G, gl_t* out);
@@ -110,10 +120,39 @@ size_t orc_fri_proof_words(const orc_fri_params* P) {
   }
   return P->n_layers * capw + P->num_queries * q + (2ull << deg) + 1;
 }
+static size_t n_lookup(const orc_fri_params* P) { return (size_t)P->zs_count * P->num_lookup_polys; }
+// config.num_challenges: one Z polynomial per challenge round, so zs_count when the oracles are plonky2's; the
+// PCS-only skeleton (any zs_count, no permutation argument) draws as for two rounds
+static unsigned num_challenges(const orc_fri_params* P) { return P->zs_count >= 1 && P->zs_count <= 2 ? P->zs_count : 2; }
 size_t orc_n_openings(const orc_fri_params* P) {
-  size_t t = P->zs_count;
+  size_t t = P->zs_count + n_lookup(P);
   for (uint32_t o = 0; o < P->n_oracles; o++) t += P->oracle_w[o];
   return t;
+}
+// FRI batch order ([dep] plonk/circuit_data.rs fri_all_polys / fri_next_batch_polys): at zeta every polynomial in
+// oracle order EXCEPT the lookup polynomials, which close the batch (after the quotient chunks); at g*zeta the Z
+// polynomials, then the lookup polynomials. The flat `openings` array and the transcript use the same order
+// (OpeningSet::to_fri_openings).
+static size_t batch_len(const orc_fri_params* P, int batch) {
+  if (batch) return P->zs_count + n_lookup(P);
+  size_t t = 0;
+  for (uint32_t o = 0; o < P->n_oracles; o++) t += P->oracle_w[o];
+  return t;
+}
+static void batch_poly(const orc_fri_params* P, int batch, size_t j, uint32_t* o, uint32_t* p) {
+  const uint32_t zo = P->zs_oracle, L = (uint32_t)n_lookup(P), wz = P->oracle_w[zo] - L;
+  if (batch) {
+    *o = zo;
+    *p = j < P->zs_count ? (uint32_t)j : wz + (uint32_t)(j - P->zs_count);
+    return;
+  }
+  for (uint32_t oi = 0; oi < P->n_oracles; oi++) {
+    uint32_t w = oi == zo ? wz : P->oracle_w[oi];
+    if (j < w) { *o = oi; *p = (uint32_t)j; return; }
+    j -= w;
+  }
+  *o = zo;
+  *p = wz + (uint32_t)j;
 }
 
 // prove_openings + fri_proof. coeffs[o] = [w_o][n] base coefficients; leaves[o] = [8n][w_o];
@@ -134,16 +173,13 @@ void orc_fri_prove(const orc_fri_params* P, gl_t* const* coeffs, gl_t* const* le
     // reduce_polys_base: sum_j alpha^j f_j, j in batch order
     for (size_t i = 0; i < n; i++) comp[i] = gl2_from(0);
     gl2_t apow = gl2_from(1);
-    size_t count = 0;
-    for (uint32_t o = 0; o < P->n_oracles; o++) {
-      if (batch == 1 && o != P->zs_oracle) continue;
-      uint32_t wo = batch == 0 ? P->oracle_w[o] : P->zs_count;
-      for (uint32_t p = 0; p < wo; p++) {
-        const gl_t* f = coeffs[o] + (size_t)p * n;
-        for (size_t i = 0; i < n; i++) comp[i] = gl2_add(comp[i], gl2_scale(apow, f[i]));
-        apow = gl2_mul(apow, alpha);
-        count++;
-      }
+    size_t count = batch_len(P, batch);
+    for (size_t j = 0; j < count; j++) {
+      uint32_t o, p;
+      batch_poly(P, batch, j, &o, &p);
+      const gl_t* f = coeffs[o] + (size_t)p * n;
+      for (size_t i = 0; i < n; i++) comp[i] = gl2_add(comp[i], gl2_scale(apow, f[i]));
+      apow = gl2_mul(apow, alpha);
     }
     // divide_by_linear(point): q_i = sum_{k>i} c_k point^(k-i-1); pad back with a zero
     // alpha.shift_poly(final): final *= alpha^count ; final += quotient
@@ -270,27 +306,33 @@ void orc_fri_prove(const orc_fri_params* P, gl_t* const* coeffs, gl_t* const* le
 // The PCS skeleton of plonky2's prove(): commitments, Fiat-Shamir, openings, FRI.
 // values[o] = [w_o][n] evaluations over the subgroup (natural order). Oracle 0 is the
 // preprocessed constants_sigmas oracle (its cap is inside circuit_digest, never observed);
-// oracle 1 wires, 2 zs_partial_products, 3 quotient chunks.
-// Outputs: caps[n_oracles][2^cap][4], openings[(sum w + zs_count)][2], proof (flat, see above).
+// oracle 1 wires, 2 zs_partial_products (+ lookup polynomials), 3 quotient chunks.
+// Outputs: caps[n_oracles][2^cap][4], openings[n_openings][2] in FRI batch order, proof (flat, see above).
 // num_routed > 0: oracle 2 (Z / partial products) is not taken from values[2] but computed from the
 // wires (values[1]), the sigma values (last num_routed polynomials of values[0]) and the betas /
-// gammas drawn after the wires cap, as prove() does; needs oracle_w[2] = zs_count * num_routed/degree.
+// gammas drawn after the wires cap, as prove() does; needs oracle_w[2] = zs_count * (num_routed/degree + num_lookup_polys).
 // quotient != 0 (needs num_routed > 0): oracle 3 is not taken from values[3] either but computed as
-// compute_quotient_polys does for a circuit without gate constraints (orc_quotient_perm); bgao, if not
-// NULL, receives betas[2], gammas[2], alphas[2], zeta[2] for the PLONK identity check.
+// compute_quotient_polys does. chal, if not NULL, receives betas[2], gammas[2], alphas[2], zeta[2], deltas[8].
+void orc_lookup_polys(const gl_t* wires, unsigned log_n, const gl_t deltas[4], const orc_lookup_ctx* L, gl_t* out);
 static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4],
-                           const gl_t pi_hash[4], unsigned num_routed, unsigned degree, unsigned quotient,
-                           const orc_gate* gates, unsigned n_gates, unsigned num_selectors, gl_t* bgao,
+                           const gl_t pi_hash[4], unsigned quotient, const orc_circuit* CK, gl_t* chal,
                            gl_t* caps, gl_t* openings, gl_t* proof) {
   unsigned k = P->log_n, lg = k + P->rate_bits;
   size_t n = (size_t)1 << k, N = (size_t)1 << lg;
   size_t capw = ((size_t)4) << P->cap_height;
+  const unsigned num_routed = CK ? CK->num_routed : 0, degree = CK ? CK->degree : 8, nc = P->zs_count, nch = num_challenges(P);
+  const unsigned n_gates = CK ? CK->n_gates : 0;
+  orc_lookup_ctx LU = {0};
+  const int has_lookup = CK && CK->n_luts && P->num_lookup_polys;
+  if (has_lookup) { LU.luts = CK->luts; LU.n_luts = CK->n_luts; orc_lookup_shape(&LU, num_routed, degree); }
+  const unsigned num_lookup_selectors = has_lookup ? ORC_LOOKUP_SELECTORS + CK->n_luts : 0;
   gl_t* coeffs[8]; gl_t* leaves[8]; gl_t* levels[8];
   orc_challenger ch;
   orc_ch_init(&ch, P->variant);
   orc_ch_observe(&ch, circuit_digest, 4);
   orc_ch_observe(&ch, pi_hash, 4);
-  gl_t bg[4] = {0, 0, 0, 0}, al[2] = {0, 0};
+  // betas, gammas, then (with lookups) 2 * nc more: deltas = betas ++ gammas ++ extra, 4 per challenge round
+  gl_t bg[8] = {0}, al[2] = {0, 0};
   gl_t* zs_vals = NULL;
   for (uint32_t o = 0; o < P->n_oracles; o++) {
     size_t w = P->oracle_w[o];
@@ -298,15 +340,20 @@ static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, c
     if (o == 2 && num_routed) {
       zs_vals = malloc(w * n * sizeof(gl_t));
       orc_partial_products_and_zs(values[1], values[0] + (size_t)(P->oracle_w[0] - num_routed) * n, k, num_routed, degree,
-                                  bg, bg + P->zs_count, P->zs_count, zs_vals);
+                                  bg, bg + nc, nc, zs_vals);
+      if (has_lookup)  // compute_all_lookup_polys: per challenge round RE + the partial Sum/LDC polynomials
+        for (unsigned c = 0; c < nc; c++)
+          orc_lookup_polys(values[1], k, bg + 4 * c, &LU, zs_vals + ((size_t)nc * (num_routed / degree) + (size_t)c * P->num_lookup_polys) * n);
       src = zs_vals;
     }
     coeffs[o] = malloc(w * n * sizeof(gl_t));
     if (o == 3 && quotient && num_routed) {
       // PolynomialBatch::from_coeffs: the quotient chunks are produced in coefficient form
-      orc_gate_ctx G = {gates, n_gates, num_selectors, P->oracle_w[0] - num_routed, P->oracle_w[1], coeffs[0], pi_hash};
+      orc_gate_ctx G = {CK->gates, n_gates, CK->num_selectors, P->oracle_w[0] - num_routed, P->oracle_w[1], coeffs[0], pi_hash,
+                        has_lookup ? &LU : NULL, bg};
+      (void)num_lookup_selectors;
       orc_quotient_polys(coeffs[1], coeffs[0] + (size_t)(P->oracle_w[0] - num_routed) * n, coeffs[2], k, num_routed, degree,
-                         bg, bg + P->zs_count, al, P->zs_count, n_gates ? &G : NULL, coeffs[o]);
+                         bg, bg + nc, al, nc, (n_gates || has_lookup) ? &G : NULL, coeffs[o]);
     } else {
       memcpy(coeffs[o], src, w * n * sizeof(gl_t));
       for (size_t p = 0; p < w; p++) orc_fft(coeffs[o] + p * n, k, 1);
@@ -318,28 +365,27 @@ static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, c
     memcpy(caps + o * capw, orc_merkle_cap_ptr(levels[o], lg, P->cap_height), capw * sizeof(gl_t));
     if (o == 0) continue;
     orc_ch_observe(&ch, caps + o * capw, capw);
-    // wires cap -> num_challenges betas, then as many gammas; zs cap -> alphas; quotient cap -> zeta
-    if (o == 1) for (uint32_t i = 0; i < 2 * P->zs_count; i++) bg[i] = orc_ch_get(&ch);
-    else if (o == 2) for (uint32_t i = 0; i < P->zs_count; i++) al[i] = orc_ch_get(&ch);
+    // wires cap -> num_challenges betas, then as many gammas (+ 2 per challenge more with lookups); zs cap -> alphas
+    if (o == 1) for (uint32_t i = 0; i < (has_lookup ? 4 : 2) * nch; i++) bg[i] = orc_ch_get(&ch);
+    else if (o == 2) for (uint32_t i = 0; i < nch; i++) al[i] = orc_ch_get(&ch);
   }
   free(zs_vals);
   gl2_t zeta = orc_ch_get_ext(&ch);
-  if (bgao) {  // betas at [0..2), gammas at [2..4), alphas at [4..6) whatever num_challenges is
-    memset(bgao, 0, 8 * sizeof(gl_t));
-    for (uint32_t i = 0; i < P->zs_count; i++) { bgao[i] = bg[i]; bgao[2 + i] = bg[P->zs_count + i]; bgao[4 + i] = al[i]; }
-    bgao[6] = zeta.c[0]; bgao[7] = zeta.c[1];
+  if (chal) {  // betas at [0..2), gammas at [2..4), alphas at [4..6), zeta, deltas[8] whatever num_challenges is
+    memset(chal, 0, (has_lookup ? 16 : 8) * sizeof(gl_t));
+    for (uint32_t i = 0; i < nch; i++) { chal[i] = bg[i]; chal[2 + i] = bg[nch + i]; chal[4 + i] = al[i]; }
+    chal[6] = zeta.c[0]; chal[7] = zeta.c[1];
+    if (has_lookup) memcpy(chal + 8, bg, 8 * sizeof(gl_t));
   }
   gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(k));
   size_t oi = 0;
-  for (uint32_t o = 0; o < P->n_oracles; o++)
-    for (uint32_t p = 0; p < P->oracle_w[o]; p++, oi++) {
-      gl2_t v = eval_base_poly_ext(coeffs[o] + (size_t)p * n, n, zeta);
+  for (int batch = 0; batch < 2; batch++)
+    for (size_t j = 0; j < batch_len(P, batch); j++, oi++) {
+      uint32_t o, p;
+      batch_poly(P, batch, j, &o, &p);
+      gl2_t v = eval_base_poly_ext(coeffs[o] + (size_t)p * n, n, batch ? g_zeta : zeta);
       openings[2 * oi] = v.c[0]; openings[2 * oi + 1] = v.c[1];
     }
-  for (uint32_t p = 0; p < P->zs_count; p++, oi++) {
-    gl2_t v = eval_base_poly_ext(coeffs[P->zs_oracle] + (size_t)p * n, n, g_zeta);
-    openings[2 * oi] = v.c[0]; openings[2 * oi + 1] = v.c[1];
-  }
   orc_ch_observe(&ch, openings, 2 * oi);
   orc_fri_prove(P, coeffs, leaves, levels, zeta, &ch, proof);
   for (uint32_t o = 0; o < P->n_oracles; o++) { free(coeffs[o]); free(leaves[o]); free(levels[o]); }
@@ -348,7 +394,8 @@ static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, c
 void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4],
                    const gl_t pi_hash[4], unsigned num_routed, unsigned degree, unsigned quotient, gl_t* bgao,
                    gl_t* caps, gl_t* openings, gl_t* proof) {
-  pcs_prove_impl(P, values, circuit_digest, pi_hash, num_routed, degree, quotient, NULL, 0, 0, bgao, caps, openings, proof);
+  orc_circuit CK = {num_routed, degree, NULL, 0, 0, NULL, 0};
+  pcs_prove_impl(P, values, circuit_digest, pi_hash, quotient, &CK, bgao, caps, openings, proof);
 }
 // prove() of a circuit with gates: as orc_pcs_prove(quotient = 1) with the gate constraints as further
 // terms of the vanishing polynomial. The constants are the first oracle_w[0] - num_routed polynomials of
@@ -356,8 +403,54 @@ void orc_pcs_prove(const orc_fri_params* P, const gl_t* const* values, const gl_
 void orc_pcs_prove_gates(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4],
                          const gl_t pi_hash[4], unsigned num_routed, unsigned degree, const orc_gate* gates,
                          unsigned n_gates, unsigned num_selectors, gl_t* bgao, gl_t* caps, gl_t* openings, gl_t* proof) {
-  pcs_prove_impl(P, values, circuit_digest, pi_hash, num_routed, degree, 1, gates, n_gates, num_selectors, bgao, caps, openings,
-                 proof);
+  orc_circuit CK = {num_routed, degree, gates, n_gates, num_selectors, NULL, 0};
+  pcs_prove_impl(P, values, circuit_digest, pi_hash, 1, &CK, bgao, caps, openings, proof);
+}
+// ... and with lookup tables: constants = selectors, 4 + n_luts lookup selectors, gate constants; the zs oracle
+// ends with the lookup polynomials; chal receives 16 words (see pcs_prove_impl)
+void orc_prove_circuit(const orc_fri_params* P, const gl_t* const* values, const gl_t circuit_digest[4], const gl_t pi_hash[4],
+                       const orc_circuit* CK, gl_t* chal, gl_t* caps, gl_t* openings, gl_t* proof) {
+  pcs_prove_impl(P, values, circuit_digest, pi_hash, 1, CK, chal, caps, openings, proof);
+}
+
+// ---- lookup argument: the RE / Sum / LDC polynomials ---------------------------------------------
+// [dep] plonky2 plonk/prover.rs compute_lookup_polys (one challenge round): out[0] = RE, out[1 + s] = partial
+// Sum/LDC polynomial s; all zero outside the lookup rows. The table rows run downwards from first_lut_row, the
+// LookupGate rows below them; every recurrence steps from row + 1 to row (the gate rows are "upside down" so
+// that no constraint needs the next row's wires). wires = [>= routed][n] subgroup values.
+void orc_lookup_polys(const gl_t* wires, unsigned log_n, const gl_t deltas[4], const orc_lookup_ctx* L, gl_t* out) {
+  size_t n = (size_t)1 << log_n;
+  unsigned ns = L->num_sldc;
+  memset(out, 0, (size_t)(ns + 1) * n * sizeof(gl_t));
+  for (unsigned r = 0; r < L->n_luts; r++) {
+    const orc_lookup* lu = &L->luts[r];
+    for (size_t row = lu->first_lut_row + 1; row-- > lu->last_lut_row;) {
+      gl_t re = out[row + 1];  // RE of the row above (0 at the Noop row that follows the table)
+      for (unsigned s = 0; s < L->num_lut_slots; s++) {
+        gl_t inp = wires[(size_t)(3 * s) * n + row], outp = wires[(size_t)(3 * s + 1) * n + row];
+        re = gl_add(gl_mul(re, deltas[3]), gl_add(inp, gl_mul(deltas[1], outp)));
+      }
+      out[row] = re;
+      for (unsigned p = 0; p < ns; p++) {
+        gl_t acc = p == 0 ? out[(size_t)ns * n + row + 1] : out[(size_t)p * n + row];
+        for (unsigned s = p * L->lut_degree; s < (p + 1) * L->lut_degree && s < L->num_lut_slots; s++) {
+          gl_t inp = wires[(size_t)(3 * s) * n + row], outp = wires[(size_t)(3 * s + 1) * n + row], mul = wires[(size_t)(3 * s + 2) * n + row];
+          acc = gl_add(acc, gl_mul(mul, gl_inv(gl_sub(deltas[2], gl_add(inp, gl_mul(deltas[0], outp))))));
+        }
+        out[(size_t)(p + 1) * n + row] = acc;
+      }
+    }
+    for (size_t row = lu->last_lut_row; row-- > lu->last_lu_row;) {
+      for (unsigned p = 0; p < ns; p++) {
+        gl_t acc = p == 0 ? out[(size_t)ns * n + row + 1] : out[(size_t)p * n + row];
+        for (unsigned s = p * L->lu_degree; s < (p + 1) * L->lu_degree && s < L->num_lu_slots; s++) {
+          gl_t inp = wires[(size_t)(2 * s) * n + row], outp = wires[(size_t)(2 * s + 1) * n + row];
+          acc = gl_sub(acc, gl_inv(gl_sub(deltas[2], gl_add(inp, gl_mul(deltas[0], outp)))));
+        }
+        out[(size_t)(p + 1) * n + row] = acc;
+      }
+    }
+  }
 }
 
 // ---- verifier -----------------------------------------------------------------------------
@@ -367,15 +460,15 @@ int orc_pcs_verify(const orc_fri_params* P, const gl_t circuit_digest[4], const 
   unsigned k = P->log_n, lg = k + P->rate_bits;
   size_t N = (size_t)1 << lg;
   size_t capw = ((size_t)4) << P->cap_height;
-  size_t n_open = orc_n_openings(P), n_zeta = n_open - P->zs_count;
+  size_t n_open = orc_n_openings(P), n_zeta = batch_len(P, 0);
   orc_challenger ch;
   orc_ch_init(&ch, P->variant);
   orc_ch_observe(&ch, circuit_digest, 4);
   orc_ch_observe(&ch, pi_hash, 4);
   for (uint32_t o = 1; o < P->n_oracles; o++) {
     orc_ch_observe(&ch, caps + o * capw, capw);
-    if (o == 1) for (uint32_t i = 0; i < 2 * P->zs_count; i++) (void)orc_ch_get(&ch);
-    else if (o == 2) for (uint32_t i = 0; i < P->zs_count; i++) (void)orc_ch_get(&ch);
+    if (o == 1) for (uint32_t i = 0; i < (P->num_lookup_polys ? 4 : 2) * num_challenges(P); i++) (void)orc_ch_get(&ch);
+    else if (o == 2) for (uint32_t i = 0; i < num_challenges(P); i++) (void)orc_ch_get(&ch);
   }
   gl2_t zeta = orc_ch_get_ext(&ch);
   gl2_t g_zeta = gl2_scale(zeta, gl_root_of_unity(k));
@@ -429,13 +522,12 @@ int orc_pcs_verify(const orc_fri_params* P, const gl_t circuit_digest[4], const 
     gl2_t sum = gl2_from(0);
     for (int batch = 0; batch < 2; batch++) {
       gl2_t acc = gl2_from(0);
-      size_t count = 0;
-      // alpha.reduce(evals): sum_j alpha^j e_j  (Horner from the back)
-      if (batch == 0) {
-        for (uint32_t oi = P->n_oracles; oi-- > 0;)
-          for (uint32_t p = P->oracle_w[oi]; p-- > 0;) { acc = gl2_add(gl2_mul(acc, alpha), gl2_from(leaf[oi][p])); count++; }
-      } else {
-        for (uint32_t p = P->zs_count; p-- > 0;) { acc = gl2_add(gl2_mul(acc, alpha), gl2_from(leaf[P->zs_oracle][p])); count++; }
+      size_t count = batch_len(P, batch);
+      // alpha.reduce(evals): sum_j alpha^j e_j  (Horner from the back), j in FRI batch order
+      for (size_t j = count; j-- > 0;) {
+        uint32_t oi, p;
+        batch_poly(P, batch, j, &oi, &p);
+        acc = gl2_add(gl2_mul(acc, alpha), gl2_from(leaf[oi][p]));
       }
       gl2_t num = gl2_sub(acc, red[batch]);
       gl2_t den = gl2_sub(gl2_from(sx), batch == 0 ? zeta : g_zeta);
@@ -597,7 +689,10 @@ void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, cons
   const unsigned rate_bits = 3;
   size_t n = (size_t)1 << log_n, N = n << rate_bits;
   unsigned lg = log_n + rate_bits, chunks = num_routed / degree, num_prods = chunks - 1;
-  unsigned n_zs = nc * chunks;
+  const orc_lookup_ctx* LU = G ? G->lookups : NULL;
+  const unsigned nlp = LU ? LU->num_sldc + 1 : 0;  // lookup polynomials per challenge, after the Z / partial products
+  unsigned n_zs = nc * (chunks + nlp);
+  const unsigned n_lookup_sel = LU ? ORC_LOOKUP_SELECTORS + LU->n_luts : 0;
   // natural-order LDE values on g<w_N>
   unsigned wires_w = G ? G->wires_w : num_routed;
   gl_t* W = malloc((size_t)wires_w * N * sizeof(gl_t));
@@ -621,7 +716,8 @@ void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, cons
   // plonky2 evaluates the coset points in parallel batches (rayon); OpenMP over the points here
 #pragma omp parallel
   {
-  gl_t* terms = malloc((nc + (size_t)nc * chunks + ORC_MAX_GATE_CONSTRAINTS) * sizeof(gl_t));
+  gl_t* terms = malloc((nc + (size_t)nc * chunks + (size_t)nc * 64 + ORC_MAX_GATE_CONSTRAINTS) * sizeof(gl_t));
+  gl_t lz[16], lzn[16];
   gl_t* lc = G ? malloc((G->num_constants + 1) * sizeof(gl_t)) : NULL;
   gl_t* lw = G ? malloc(wires_w * sizeof(gl_t)) : NULL;
 #pragma omp for schedule(static)
@@ -649,7 +745,13 @@ void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, cons
     if (G) {
       for (unsigned j = 0; j < G->num_constants; j++) lc[j] = C[(size_t)j * N + i];
       for (unsigned j = 0; j < wires_w; j++) lw[j] = W[(size_t)j * N + i];
-      t += orc_gates_eval_base(G->gates, G->n_gates, G->num_selectors, lc, lw, G->pi_hash, terms + t);
+      if (LU)  // vanishing_all_lookup_terms: between the partial-product terms and the gate constraints
+        for (unsigned c = 0; c < nc; c++) {
+          const gl_t* lp = Z + ((size_t)nc * chunks + (size_t)c * nlp) * N;
+          for (unsigned q = 0; q < nlp; q++) { lz[q] = lp[(size_t)q * N + i]; lzn[q] = lp[(size_t)q * N + inext]; }
+          t += orc_lookup_terms_base(LU, lc + G->num_selectors, lw, lz, lzn, G->deltas + 4 * c, terms + t);
+        }
+      if (G->n_gates) t += orc_gates_eval_base(G->gates, G->n_gates, G->num_selectors, n_lookup_sel, lc, lw, G->pi_hash, terms + t);
     }
     gl_t zh_inv = gl_inv(zh);
     for (unsigned a = 0; a < nc; a++) {
@@ -670,28 +772,36 @@ void orc_quotient_polys(const gl_t* wires_coeffs, const gl_t* sigma_coeffs, cons
 // plonk/verifier.rs: vanishing(zeta) == Z_H(zeta) * sum_i zeta^(n i) t_i(zeta) for every challenge, from
 // the opened values only (openings layout of orc_pcs_prove; num_constants = oracle_w[0] - num_routed).
 // Returns 0 when the identity holds.
+int orc_identity_check_circuit(const orc_fri_params* P, const orc_circuit* CK, const gl_t* openings, gl2_t zeta, const gl_t* betas,
+                               const gl_t* gammas, const gl_t* alphas, const gl_t* deltas, const gl_t* pi_hash);
 int orc_plonk_identity_check_gates(const orc_fri_params* P, unsigned num_routed, unsigned degree, const gl_t* openings,
                                    gl2_t zeta, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
-                                   const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* pi_hash);
+                                   const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* pi_hash) {
+  orc_circuit CK = {num_routed, degree, gates, n_gates, num_selectors, NULL, 0};
+  return orc_identity_check_circuit(P, &CK, openings, zeta, betas, gammas, alphas, NULL, pi_hash);
+}
 int orc_plonk_identity_check(const orc_fri_params* P, unsigned num_routed, unsigned degree, const gl_t* openings,
                              gl2_t zeta, const gl_t* betas, const gl_t* gammas, const gl_t* alphas) {
   return orc_plonk_identity_check_gates(P, num_routed, degree, openings, zeta, betas, gammas, alphas, NULL, 0, 0, NULL);
 }
 // with gates: the gate constraints evaluated over the extension field on the opened constants / wires
-// (plonk/vanishing_poly.rs eval_vanishing_poly) follow the permutation terms
-int orc_plonk_identity_check_gates(const orc_fri_params* P, unsigned num_routed, unsigned degree, const gl_t* openings,
-                                   gl2_t zeta, const gl_t* betas, const gl_t* gammas, const gl_t* alphas,
-                                   const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* pi_hash) {
+// (plonk/vanishing_poly.rs eval_vanishing_poly) follow the permutation terms and, when the circuit has lookup
+// tables, the lookup terms. deltas = [nc][4] (NULL without lookups). Openings in FRI batch order.
+int orc_identity_check_circuit(const orc_fri_params* P, const orc_circuit* CK, const gl_t* openings, gl2_t zeta, const gl_t* betas,
+                               const gl_t* gammas, const gl_t* alphas, const gl_t* deltas, const gl_t* pi_hash) {
+  const unsigned num_routed = CK->num_routed, degree = CK->degree, n_gates = CK->n_gates;
   unsigned k = P->log_n, nc = P->zs_count, chunks = num_routed / degree, num_prods = chunks - 1;
   size_t n = (size_t)1 << k;
+  const size_t L = n_lookup(P);
+  const int has_lookup = CK->n_luts && L;
   size_t o_sig = P->oracle_w[0] - num_routed, o_w = P->oracle_w[0], o_z = o_w + P->oracle_w[1];
-  size_t o_q = o_z + P->oracle_w[2], o_next = o_q + P->oracle_w[3];
+  size_t o_q = o_z + P->oracle_w[2] - L, o_lu = o_q + P->oracle_w[3], o_next = o_lu + L, o_lu_next = o_next + nc;
 #define OPEN(i) ((gl2_t){{openings[2 * (i)], openings[2 * (i) + 1]}})
   gl2_t zn = zeta;
   for (unsigned i = 0; i < k; i++) zn = gl2_mul(zn, zn);
   gl2_t zh = gl2_sub(zn, gl2_from(1));
   gl2_t l0 = gl2_mul(zh, gl2_inv(gl2_scale(gl2_sub(zeta, gl2_from(1)), (gl_t)n % GL_P)));
-  gl2_t terms[64 + ORC_MAX_GATE_CONSTRAINTS];
+  gl2_t terms[64 + 2 * 64 + ORC_MAX_GATE_CONSTRAINTS];
   size_t t = 0;
   for (unsigned c = 0; c < nc; c++) terms[t++] = gl2_mul(l0, gl2_sub(OPEN(o_z + c), gl2_from(1)));
   gl_t kj = 1;
@@ -710,12 +820,22 @@ int orc_plonk_identity_check_gates(const orc_fri_params* P, unsigned num_routed,
       terms[t++] = gl2_sub(gl2_mul(prev, num), gl2_mul(next, den));
     }
   }
+  gl2_t lc[64], lw[256], ph[4];
+  for (size_t j = 0; j < o_sig; j++) lc[j] = OPEN(j);
+  for (size_t j = 0; j < P->oracle_w[1]; j++) lw[j] = OPEN(o_w + j);
+  if (has_lookup) {
+    orc_lookup_ctx LU = {CK->luts, CK->n_luts, 0, 0, 0, 0, 0};
+    orc_lookup_shape(&LU, num_routed, degree);
+    const unsigned nlp = LU.num_sldc + 1;
+    gl2_t lz[16], lzn[16];
+    for (unsigned c = 0; c < nc; c++) {
+      for (unsigned q = 0; q < nlp; q++) { lz[q] = OPEN(o_lu + (size_t)c * nlp + q); lzn[q] = OPEN(o_lu_next + (size_t)c * nlp + q); }
+      t += orc_lookup_terms_ext(&LU, lc + CK->num_selectors, lw, lz, lzn, deltas + 4 * c, terms + t);
+    }
+  }
   if (n_gates) {
-    gl2_t lc[64], lw[256], ph[4];
-    for (size_t j = 0; j < o_sig; j++) lc[j] = OPEN(j);
-    for (size_t j = 0; j < P->oracle_w[1]; j++) lw[j] = OPEN(o_w + j);
     for (int j = 0; j < 4; j++) ph[j] = gl2_from(pi_hash[j]);
-    t += orc_gates_eval_ext(gates, n_gates, num_selectors, lc, lw, ph, terms + t);
+    t += orc_gates_eval_ext(CK->gates, n_gates, CK->num_selectors, has_lookup ? ORC_LOOKUP_SELECTORS + CK->n_luts : 0, lc, lw, ph, terms + t);
   }
   for (unsigned a = 0; a < nc; a++) {
     gl2_t van = gl2_from(0);
@@ -728,26 +848,32 @@ int orc_plonk_identity_check_gates(const orc_fri_params* P, unsigned num_routed,
   return 0;
 }
 
-// plonk/verifier.rs verify_with_challenges for a circuit with gates: the challenges re-derived from the
-// transcript (get_challenges), the PLONK identity at zeta from the opened values (eval_vanishing_poly with
-// the gate terms), then the FRI verifier. 0 = accept; 10 + a = identity fails for challenge a; 1..5 = FRI codes.
-int orc_verify_gates(const orc_fri_params* P, const gl_t circuit_digest[4], const gl_t pi_hash[4], unsigned num_routed,
-                     unsigned degree, const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* caps,
-                     const gl_t* openings, const gl_t* proof) {
+// plonk/verifier.rs verify_with_challenges: the challenges re-derived from the transcript (get_challenges), the
+// PLONK identity at zeta from the opened values (eval_vanishing_poly with the lookup and gate terms), then the
+// FRI verifier. 0 = accept; 10 + a = identity fails for challenge a; 1..5 = FRI codes.
+int orc_verify_circuit(const orc_fri_params* P, const gl_t circuit_digest[4], const gl_t pi_hash[4], const orc_circuit* CK,
+                       const gl_t* caps, const gl_t* openings, const gl_t* proof) {
   size_t capw = ((size_t)4) << P->cap_height;
+  const unsigned nc = num_challenges(P);
+  const int has_lookup = CK->n_luts && P->num_lookup_polys;
   orc_challenger ch;
   orc_ch_init(&ch, P->variant);
   orc_ch_observe(&ch, circuit_digest, 4);
   orc_ch_observe(&ch, pi_hash, 4);
-  gl_t bg[4] = {0, 0, 0, 0}, al[2] = {0, 0};
+  gl_t bg[8] = {0}, al[2] = {0, 0};
   for (uint32_t o = 1; o < P->n_oracles; o++) {
     orc_ch_observe(&ch, caps + o * capw, capw);
-    if (o == 1) for (uint32_t i = 0; i < 2 * P->zs_count; i++) bg[i] = orc_ch_get(&ch);
-    else if (o == 2) for (uint32_t i = 0; i < P->zs_count; i++) al[i] = orc_ch_get(&ch);
+    if (o == 1) for (uint32_t i = 0; i < (has_lookup ? 4 : 2) * nc; i++) bg[i] = orc_ch_get(&ch);
+    else if (o == 2) for (uint32_t i = 0; i < nc; i++) al[i] = orc_ch_get(&ch);
   }
   gl2_t zeta = orc_ch_get_ext(&ch);
-  int rc = orc_plonk_identity_check_gates(P, num_routed, degree, openings, zeta, bg, bg + P->zs_count, al, gates, n_gates,
-                                          num_selectors, pi_hash);
+  int rc = orc_identity_check_circuit(P, CK, openings, zeta, bg, bg + nc, al, bg, pi_hash);
   if (rc) return 10 + rc - 1;
   return orc_pcs_verify(P, circuit_digest, pi_hash, caps, openings, proof);
+}
+int orc_verify_gates(const orc_fri_params* P, const gl_t circuit_digest[4], const gl_t pi_hash[4], unsigned num_routed,
+                     unsigned degree, const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* caps,
+                     const gl_t* openings, const gl_t* proof) {
+  orc_circuit CK = {num_routed, degree, gates, n_gates, num_selectors, NULL, 0};
+  return orc_verify_circuit(P, circuit_digest, pi_hash, &CK, caps, openings, proof);
 }

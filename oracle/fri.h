@@ -18,6 +18,8 @@ typedef struct {
   uint32_t oracle_w[8];  // polynomials per oracle
   uint32_t zs_oracle;    // oracle whose first zs_count polys are also opened at g*zeta
   uint32_t zs_count;
+  uint32_t num_lookup_polys;  // per challenge (0 = no lookup argument): the last zs_count * num_lookup_polys polynomials
+                              // of oracle zs_oracle, opened at zeta and g*zeta, batched after the quotient polynomials
 } orc_fri_params;
 
 typedef struct {

@@ -41,13 +41,41 @@ void orc_barycentric_weights(unsigned bits, gl_t* domain, gl_t* weights) {
 #define FN(n) e_##n
 #include "gates_body.inc"
 
-unsigned orc_gates_eval_base(const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl_t* consts,
-                             const gl_t* wires, const gl_t* pih, gl_t* acc) {
-  return b_eval_gate_constraints(gates, n_gates, num_selectors, consts, wires, pih, acc);
+unsigned orc_gates_eval_base(const orc_gate* gates, unsigned n_gates, unsigned num_selectors, unsigned num_lookup_selectors,
+                             const gl_t* consts, const gl_t* wires, const gl_t* pih, gl_t* acc) {
+  return b_eval_gate_constraints(gates, n_gates, num_selectors, num_lookup_selectors, consts, wires, pih, acc);
 }
-unsigned orc_gates_eval_ext(const orc_gate* gates, unsigned n_gates, unsigned num_selectors, const gl2_t* consts,
-                            const gl2_t* wires, const gl2_t* pih, gl2_t* acc) {
-  return e_eval_gate_constraints(gates, n_gates, num_selectors, consts, wires, pih, acc);
+unsigned orc_gates_eval_ext(const orc_gate* gates, unsigned n_gates, unsigned num_selectors, unsigned num_lookup_selectors,
+                            const gl2_t* consts, const gl2_t* wires, const gl2_t* pih, gl2_t* acc) {
+  return e_eval_gate_constraints(gates, n_gates, num_selectors, num_lookup_selectors, consts, wires, pih, acc);
+}
+void orc_lookup_shape(orc_lookup_ctx* L, unsigned num_routed, unsigned degree) {
+  L->num_lu_slots = num_routed / 2;
+  L->num_lut_slots = num_routed / 3;
+  L->lu_degree = degree - 1;
+  L->num_sldc = (L->num_lu_slots + L->lu_degree - 1) / L->lu_degree;
+  L->lut_degree = (L->num_lut_slots + L->num_sldc - 1) / L->num_sldc;
+}
+gl_t orc_lut_poly(const orc_lookup* lut, unsigned num_lut_slots, const gl_t deltas[4]) {
+  size_t rows = (lut->table_len + num_lut_slots - 1) / num_lut_slots, padded = rows * num_lut_slots;
+  gl_t acc = 0;  // Horner over the zero-padded, reversed coefficient list = entries in table order
+  for (size_t i = 0; i < padded; i++) {
+    gl_t c = i < lut->table_len ? gl_add(lut->table[2 * i], gl_mul(deltas[1], lut->table[2 * i + 1])) : 0;
+    acc = gl_add(gl_mul(acc, deltas[3]), c);
+  }
+  return acc;
+}
+unsigned orc_lookup_terms_base(const orc_lookup_ctx* L, const gl_t* lookup_sel, const gl_t* wires, const gl_t* zs, const gl_t* zs_next,
+                               const gl_t deltas[4], gl_t* out) {
+  gl_t ev[ORC_MAX_LUTS];
+  for (unsigned r = 0; r < L->n_luts; r++) ev[r] = orc_lut_poly(&L->luts[r], L->num_lut_slots, deltas);
+  return b_eval_lookup_constraints(L, lookup_sel, wires, zs, zs_next, deltas, ev, out);
+}
+unsigned orc_lookup_terms_ext(const orc_lookup_ctx* L, const gl2_t* lookup_sel, const gl2_t* wires, const gl2_t* zs, const gl2_t* zs_next,
+                              const gl_t deltas[4], gl2_t* out) {
+  gl_t ev[ORC_MAX_LUTS];
+  for (unsigned r = 0; r < L->n_luts; r++) ev[r] = orc_lut_poly(&L->luts[r], L->num_lut_slots, deltas);
+  return e_eval_lookup_constraints(L, lookup_sel, wires, zs, zs_next, deltas, ev, out);
 }
 unsigned orc_gate_num_constraints(const orc_gate* g) {
   switch (g->kind) {
@@ -67,7 +95,9 @@ unsigned orc_gate_num_constraints(const orc_gate* g) {
     case ORC_GATE_EXPONENTIATION: return g->p0 + 1;
     case ORC_GATE_REDUCING: case ORC_GATE_REDUCING_EXT: return 2 * g->p0;
     case ORC_GATE_RANDOM_ACCESS: return (g->p0 + 2) * g->p1 + g->p2;
-    default: return 0;
+    case ORC_GATE_U32_INTERLEAVE: return 34 * g->p0;
+    case ORC_GATE_UNINTERLEAVE_TO_B32: case ORC_GATE_UNINTERLEAVE_TO_U32: return 67 * g->p0;
+    default: return 0;  // Noop, Lookup, LookupTable
   }
 }
 // Gate::degree()
@@ -84,6 +114,7 @@ unsigned orc_gate_degree(const orc_gate* g) {
     case ORC_GATE_EXPONENTIATION: return 4;
     case ORC_GATE_REDUCING: case ORC_GATE_REDUCING_EXT: return 2;
     case ORC_GATE_RANDOM_ACCESS: return g->p0 + 1;
+    case ORC_GATE_U32_INTERLEAVE: case ORC_GATE_UNINTERLEAVE_TO_B32: case ORC_GATE_UNINTERLEAVE_TO_U32: return 2;
     default: return 0;
   }
 }
@@ -102,7 +133,7 @@ unsigned orc_gates_eval_points(const orc_gate* gates, unsigned n_gates, unsigned
   for (size_t i = 0; i < npts; i++) {
     for (unsigned j = 0; j < num_constants; j++) lc[j] = consts[(size_t)j * npts + i];
     for (unsigned j = 0; j < wires_w; j++) lw[j] = wires[(size_t)j * npts + i];
-    orc_gates_eval_base(gates, n_gates, num_selectors, lc, lw, pih, acc);
+    orc_gates_eval_base(gates, n_gates, num_selectors, 0, lc, lw, pih, acc);
     for (unsigned j = 0; j < maxc; j++) out[(size_t)j * npts + i] = acc[j];
   }
   free(lc);

@@ -24,8 +24,39 @@ def eval_on_points(ckt, consts, wires):
     return out
 
 
+class OrcLookup(ctypes.Structure):
+    _fields_ = [("last_lu_row", ctypes.c_uint32), ("last_lut_row", ctypes.c_uint32), ("first_lut_row", ctypes.c_uint32),
+                ("table_len", ctypes.c_uint32), ("table", ctypes.c_void_p)]
+
+
+class OrcCircuit(ctypes.Structure):
+    """orc_circuit (oracle/fri.c): permutation geometry, gate table, lookup tables"""
+    _fields_ = [("num_routed", ctypes.c_uint32), ("degree", ctypes.c_uint32), ("gates", ctypes.c_void_p), ("n_gates", ctypes.c_uint32),
+                ("num_selectors", ctypes.c_uint32), ("luts", ctypes.c_void_p), ("n_luts", ctypes.c_uint32)]
+
+
+def orc_circuit(ckt):
+    """(OrcCircuit, keep-alive list) of a built circuit"""
+    luts = getattr(ckt, "luts", None) or []
+    tabs = [np.ascontiguousarray(t["table"], dtype=np.uint16) for t in luts]
+    arr = (OrcLookup * max(1, len(luts)))()
+    for i, (t, tab) in enumerate(zip(luts, tabs)):
+        arr[i] = OrcLookup(t["last_lu_row"], t["last_lut_row"], t["first_lut_row"], tab.shape[0], tab.ctypes.data)
+    ck = OrcCircuit(NUM_ROUTED, 8, ctypes.cast(ckt.gate_array, ctypes.c_void_p), len(ckt.gates), ckt.num_selectors,
+                    ctypes.cast(arr, ctypes.c_void_p) if luts else None, len(luts))
+    return ck, (arr, tabs)
+
+
+def oracle_params(ckt, variant=0, **kw):
+    """standard_recursion_config FRI / oracle shape of a built circuit (with the lookup polynomials, if any)"""
+    nlp = getattr(ckt, "num_lookup_polys", 0)
+    return O.standard_params(ckt.log_n, (int(ckt.pre.shape[0]), NUM_WIRES, 2 * (NUM_ROUTED // 8 + nlp), 16), variant=variant,
+                             num_lookup_polys=nlp, **kw)
+
+
 def prove_witness(ckt, fp, circuit_digest, wires, pi_hash):
-    """oracle prove() of the circuit for the given witness and public-inputs hash; returns (caps, openings, proof, bgao)"""
+    """oracle prove() of the circuit for the given witness and public-inputs hash; returns (caps, openings, proof, chal)
+    with chal = betas[2], gammas[2], alphas[2], zeta[2] (+ the 8 lookup challenges)"""
     n = 1 << ckt.log_n
     vals = [O.arr(ckt.pre), O.arr(wires), np.zeros((fp.oracle_w[2], n), dtype=np.uint64), np.zeros((fp.oracle_w[3], n), dtype=np.uint64)]
     ptrs = (ctypes.c_void_p * 4)(*[v.ctypes.data for v in vals])
@@ -33,30 +64,31 @@ def prove_witness(ckt, fp, circuit_digest, wires, pi_hash):
     caps = np.zeros((fp.n_oracles, capw), dtype=np.uint64)
     openings = np.zeros((O.lib().orc_n_openings(ctypes.byref(fp)), 2), dtype=np.uint64)
     proof = np.zeros(O.lib().orc_fri_proof_words(ctypes.byref(fp)), dtype=np.uint64)
-    cd, ph, bgao = O.arr(circuit_digest), O.arr(pi_hash), np.zeros(8, dtype=np.uint64)
-    O.lib().orc_pcs_prove_gates(ctypes.byref(fp), ptrs, O.p(cd), O.p(ph), NUM_ROUTED, 8, ckt.gate_array, len(ckt.gates),
-                                ckt.num_selectors, O.p(bgao), O.p(caps), O.p(openings), O.p(proof))
-    return caps, openings, proof, bgao
+    cd, ph, chal = O.arr(circuit_digest), O.arr(pi_hash), np.zeros(16, dtype=np.uint64)
+    ck, keep = orc_circuit(ckt)
+    O.lib().orc_prove_circuit(ctypes.byref(fp), ptrs, O.p(cd), O.p(ph), ctypes.byref(ck), O.p(chal), O.p(caps), O.p(openings), O.p(proof))
+    return caps, openings, proof, chal
 
 
 def prove(ckt, fp, circuit_digest):
-    """oracle prove() of the circuit with its own witness; returns (caps, openings, proof, bgao)"""
+    """oracle prove() of the circuit with its own witness; returns (caps, openings, proof, chal)"""
     return prove_witness(ckt, fp, circuit_digest, ckt.wires, ckt.pi_hash)
 
 
 def verify(ckt, fp, circuit_digest, pi_hash, caps, openings, proof):
-    """oracle verify(): challenges from the transcript, PLONK identity with the gate terms, FRI. 0 = accept."""
+    """oracle verify(): challenges from the transcript, PLONK identity with the lookup and gate terms, FRI. 0 = accept."""
     cd, ph = O.arr(circuit_digest), O.arr(pi_hash)
     caps, openings, proof = O.arr(caps), O.arr(openings), O.arr(proof)
-    return O.lib().orc_verify_gates(ctypes.byref(fp), O.p(cd), O.p(ph), NUM_ROUTED, 8, ckt.gate_array, len(ckt.gates), ckt.num_selectors,
-                                    O.p(caps), O.p(openings), O.p(proof))
+    ck, keep = orc_circuit(ckt)
+    return O.lib().orc_verify_circuit(ctypes.byref(fp), O.p(cd), O.p(ph), ctypes.byref(ck), O.p(caps), O.p(openings), O.p(proof))
 
 
-def identity_check(ckt, fp, openings, bgao):
+def identity_check(ckt, fp, openings, chal):
     class G2(ctypes.Structure):
         _fields_ = [("c", ctypes.c_uint64 * 2)]
     z = G2()
-    z.c[0], z.c[1] = int(bgao[6]), int(bgao[7])
-    o, b, g, a, ph = O.arr(openings), O.arr(bgao[0:2]), O.arr(bgao[2:4]), O.arr(bgao[4:6]), O.arr(ckt.pi_hash)
-    return O.lib().orc_plonk_identity_check_gates(ctypes.byref(fp), NUM_ROUTED, 8, O.p(o), z, O.p(b), O.p(g), O.p(a), ckt.gate_array,
-                                                  len(ckt.gates), ckt.num_selectors, O.p(ph))
+    z.c[0], z.c[1] = int(chal[6]), int(chal[7])
+    o, b, g, a, ph = O.arr(openings), O.arr(chal[0:2]), O.arr(chal[2:4]), O.arr(chal[4:6]), O.arr(ckt.pi_hash)
+    d = O.arr(chal[8:16]) if len(chal) >= 16 else np.zeros(8, dtype=np.uint64)
+    ck, keep = orc_circuit(ckt)
+    return O.lib().orc_identity_check_circuit(ctypes.byref(fp), ctypes.byref(ck), O.p(o), z, O.p(b), O.p(g), O.p(a), O.p(d), O.p(ph))

@@ -147,11 +147,12 @@ class FriParams(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_uint32), ("log_n", ctypes.c_uint32), ("rate_bits", ctypes.c_uint32),
                 ("cap_height", ctypes.c_uint32), ("pow_bits", ctypes.c_uint32), ("num_queries", ctypes.c_uint32),
                 ("n_layers", ctypes.c_uint32), ("arity_bits", ctypes.c_uint32 * 8), ("n_oracles", ctypes.c_uint32),
-                ("oracle_w", ctypes.c_uint32 * 8), ("zs_oracle", ctypes.c_uint32), ("zs_count", ctypes.c_uint32)]
+                ("oracle_w", ctypes.c_uint32 * 8), ("zs_oracle", ctypes.c_uint32), ("zs_count", ctypes.c_uint32),
+                ("num_lookup_polys", ctypes.c_uint32)]
 
 
 def standard_params(log_n, oracle_w=(84, 135, 20, 16), variant=0, rate_bits=3, cap_height=4, pow_bits=16,
-                    num_queries=28, zs_oracle=2, zs_count=2, arity=4, final_poly_bits=5):
+                    num_queries=28, zs_oracle=2, zs_count=2, arity=4, final_poly_bits=5, num_lookup_polys=0):
     """standard_recursion_config (mp2-common/src/lib.rs:45-47) FRI parameters for degree 2^log_n."""
     fp = FriParams()
     fp.variant, fp.log_n, fp.rate_bits, fp.cap_height = variant, log_n, rate_bits, cap_height
@@ -162,7 +163,7 @@ def standard_params(log_n, oracle_w=(84, 135, 20, 16), variant=0, rate_bits=3, c
     fp.n_oracles = len(oracle_w)
     for i, w in enumerate(oracle_w):
         fp.oracle_w[i] = w
-    fp.zs_oracle, fp.zs_count = zs_oracle, zs_count
+    fp.zs_oracle, fp.zs_count, fp.num_lookup_polys = zs_oracle, zs_count, num_lookup_polys
     return fp
 
 

@@ -71,3 +71,26 @@ def test_proof_with_gates_verifies(kinds, log_n):
     assert O.pcs_verify(fp, cd, ckt.pi_hash, caps, openings, proof) == 0
     assert C.identity_check(ckt, fp, openings, bgao) != 0
     ckt.wires = good
+
+
+def test_lookup_argument_oracle_self_consistency():
+    """all 26 registered gate kinds + two lookup tables: the oracle's proof passes the oracle's verifier (lookup
+    challenges, RE / Sum / LDC constraints, lookup polynomials in both FRI batches); a looked-up pair that is not in
+    its table, a wrong multiplicity and a corrupted table row all break the PLONK identity"""
+    ckt = C.build(7, C.ALL_KINDS + C.LOOKUP_KINDS, 3, luts=[(t, 100) for t in C.bits_lookup_tables()])
+    assert len(ckt.gates) == 26
+    fp = C.oracle_params(ckt, pow_bits=4, num_queries=3)
+    assert fp.num_lookup_polys == 7 and fp.oracle_w[2] == 34
+    cd = O.rand_field(4, 1)
+    caps, op, pr, chal = C.prove(ckt, fp, cd)
+    assert C.identity_check(ckt, fp, op, chal) == 0
+    assert C.verify(ckt, fp, cd, ckt.pi_hash, caps, op, pr) == 0
+    for (col, row) in ((2, ckt.luts[0]["first_lut_row"]), (1, ckt.luts[1]["last_lu_row"]), (1, ckt.luts[1]["first_lut_row"])):
+        w = ckt.wires.copy()
+        w[col, row] = (int(w[col, row]) + 1) % O.P
+        c2, o2, p2, _ = C.prove_witness(ckt, fp, cd, w, ckt.pi_hash)
+        assert C.verify(ckt, fp, cd, ckt.pi_hash, c2, o2, p2) >= 10
+    # the lookup openings are part of the transcript: moving one breaks the proof
+    bad = op.copy()
+    bad[-1, 0] ^= np.uint64(1)
+    assert C.verify(ckt, fp, cd, ckt.pi_hash, caps, bad, pr) != 0
