@@ -46,6 +46,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the CPU oracle runs several OpenMP teams side by side (one per sampled leaf proof): idle team members must sleep,
+# not spin, or the teams starve each other on a fully subscribed host. Read by libgomp when it is first loaded.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 LOG_NTT = 22

@@ -16,6 +16,7 @@
 #include "gates.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <omp.h>
 
 void orc_perm(int variant, gl_t s[12]);
 void orc_merkle_build(int variant, const gl_t* leaves, size_t leaf_len, unsigned log_leaves, unsigned cap_h, gl_t* levels);
@@ -327,6 +328,9 @@ static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, c
   if (has_lookup) { LU.luts = CK->luts; LU.n_luts = CK->n_luts; orc_lookup_shape(&LU, num_routed, degree); }
   const unsigned num_lookup_selectors = has_lookup ? ORC_LOOKUP_SELECTORS + CK->n_luts : 0;
   gl_t* coeffs[8]; gl_t* leaves[8]; gl_t* levels[8];
+  const int timing = getenv("ORC_TIMING") != NULL;  // stage split on stderr (measurement aid for the cpu_baseline leg)
+  double t_mark = omp_get_wtime(), t_stage[8] = {0};
+#define T_ADD(i) do { double t_now = omp_get_wtime(); t_stage[i] += t_now - t_mark; t_mark = t_now; } while (0)
   orc_challenger ch;
   orc_ch_init(&ch, P->variant);
   orc_ch_observe(&ch, circuit_digest, 4);
@@ -345,6 +349,7 @@ static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, c
         for (unsigned c = 0; c < nc; c++)
           orc_lookup_polys(values[1], k, bg + 4 * c, &LU, zs_vals + ((size_t)nc * (num_routed / degree) + (size_t)c * P->num_lookup_polys) * n);
       src = zs_vals;
+      T_ADD(0);  // Z / partial products / lookup polynomials
     }
     coeffs[o] = malloc(w * n * sizeof(gl_t));
     if (o == 3 && quotient && num_routed) {
@@ -354,14 +359,19 @@ static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, c
       (void)num_lookup_selectors;
       orc_quotient_polys(coeffs[1], coeffs[0] + (size_t)(P->oracle_w[0] - num_routed) * n, coeffs[2], k, num_routed, degree,
                          bg, bg + nc, al, nc, (n_gates || has_lookup) ? &G : NULL, coeffs[o]);
+      T_ADD(1);  // quotient polynomials
     } else {
       memcpy(coeffs[o], src, w * n * sizeof(gl_t));
+#pragma omp parallel for schedule(dynamic)
       for (size_t p = 0; p < w; p++) orc_fft(coeffs[o] + p * n, k, 1);
+      T_ADD(2);  // iFFTs
     }
     leaves[o] = malloc(w * N * sizeof(gl_t));
     orc_lde_leaves(coeffs[o], k, w, P->rate_bits, leaves[o]);
+    T_ADD(3);  // LDE
     levels[o] = malloc(orc_merkle_levels_len(lg, P->cap_height) * sizeof(gl_t));
     orc_merkle_build(P->variant, leaves[o], w, lg, P->cap_height, levels[o]);
+    T_ADD(4);  // Merkle trees
     memcpy(caps + o * capw, orc_merkle_cap_ptr(levels[o], lg, P->cap_height), capw * sizeof(gl_t));
     if (o == 0) continue;
     orc_ch_observe(&ch, caps + o * capw, capw);
@@ -387,7 +397,13 @@ static void pcs_prove_impl(const orc_fri_params* P, const gl_t* const* values, c
       openings[2 * oi] = v.c[0]; openings[2 * oi + 1] = v.c[1];
     }
   orc_ch_observe(&ch, openings, 2 * oi);
+  T_ADD(5);  // openings
   orc_fri_prove(P, coeffs, leaves, levels, zeta, &ch, proof);
+  T_ADD(6);  // FRI
+  if (timing)
+    fprintf(stderr, "oracle prove 2^%u: zs %.3f quotient %.3f ifft %.3f lde %.3f merkle %.3f openings %.3f fri %.3f s (%d threads)\n", k, t_stage[0],
+            t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_stage[5], t_stage[6], omp_get_max_threads());
+#undef T_ADD
   for (uint32_t o = 0; o < P->n_oracles; o++) { free(coeffs[o]); free(leaves[o]); free(levels[o]); }
 }
 

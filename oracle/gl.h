@@ -25,23 +25,29 @@ typedef uint64_t gl_t;
 #define GL_TWO_GEN 7277203076849721926ULL
 #define GL_TWO_ADICITY 32
 
+// branch-free throughout: the conditions are data dependent and unpredictable, a mispredicted branch costs more
+// than the whole multiplication
 static inline gl_t gl_add(gl_t a, gl_t b) {
-  gl_t s = a + b;
-  if (s < a || s >= GL_P) s -= GL_P;
-  return s;
+  gl_t s;
+  uint64_t c = __builtin_add_overflow(a, b, &s);
+  return s - ((0 - (c | (uint64_t)(s >= GL_P))) & GL_P);
 }
-static inline gl_t gl_sub(gl_t a, gl_t b) { return a >= b ? a - b : a - b + GL_P; }
+static inline gl_t gl_sub(gl_t a, gl_t b) {
+  gl_t d;
+  uint64_t br = __builtin_sub_overflow(a, b, &d);
+  return d + ((0 - br) & GL_P);
+}
 static inline gl_t gl_neg(gl_t a) { return a ? GL_P - a : 0; }
 static inline gl_t gl_reduce128(unsigned __int128 x) {
   uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
   uint64_t hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
-  uint64_t t0 = lo - hi_hi;
-  if (lo < hi_hi) t0 -= GL_EPS;
+  uint64_t t0, r;
+  uint64_t br = __builtin_sub_overflow(lo, hi_hi, &t0);
+  t0 -= (0 - br) & GL_EPS;
   uint64_t t1 = hi_lo * GL_EPS;
-  uint64_t r = t0 + t1;
-  if (r < t1) r += GL_EPS;
-  if (r >= GL_P) r -= GL_P;
-  return r;
+  uint64_t c = __builtin_add_overflow(t0, t1, &r);
+  r += (0 - c) & GL_EPS;
+  return r - ((0 - (uint64_t)(r >= GL_P)) & GL_P);
 }
 static inline gl_t gl_mul(gl_t a, gl_t b) { return gl_reduce128((unsigned __int128)a * b); }
 static inline gl_t gl_sqr(gl_t a) { return gl_mul(a, a); }

@@ -86,13 +86,15 @@ def structured(fp, num_constants, caps, openings, fri, public_inputs, n_lookup=0
     cap = lambda words: [list(map(int, words[4 * i:4 * i + 4])) for i in range(len(words) // 4)]
     ws = [fp.oracle_w[o] for o in range(fp.n_oracles)]
     op = [tuple(map(int, e)) for e in openings]
-    o1, o2, o3 = ws[0], ws[0] + ws[1], ws[0] + ws[1] + ws[2]
+    # flat openings = FRI batch order: oracle 0, wires, Z + partial products, quotient, lookup | Z next, lookup next
+    o1, o2 = ws[0], ws[0] + ws[1]
+    o3 = o2 + ws[2] - n_lookup
     n_zeta = sum(ws)
     zs = fp.zs_count
     n_pp = ws[2] - zs - n_lookup
     opening = {"constants": op[:num_constants], "plonk_sigmas": op[num_constants:o1], "wires": op[o1:o2], "plonk_zs": op[o2:o2 + zs],
                "plonk_zs_next": op[n_zeta:n_zeta + zs], "partial_products": op[o2 + zs:o2 + zs + n_pp], "quotient_polys": op[o3:o3 + ws[3]],
-               "lookup_zs": op[o2 + zs + n_pp:o3], "lookup_zs_next": op[n_zeta + zs:n_zeta + zs + n_lookup]}
+               "lookup_zs": op[o3 + ws[3]:o3 + ws[3] + n_lookup], "lookup_zs_next": op[n_zeta + zs:n_zeta + zs + n_lookup]}
     lg = fp.log_n + fp.rate_bits
     depth = lg - fp.cap_height
     pos = 0

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+LIB = os.environ.get("ORC_LIB", os.path.join(ORACLE_DIR, "liboracle.so"))  # ORC_LIB: bench.py's natively built copy
 P = 0xFFFFFFFF00000001
 MULT_GEN = 14293326489335486720
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -24,13 +24,9 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            build()
-        try:
-            _lib = ctypes.CDLL(LIB)
-        except OSError:
-            build()
-            _lib = ctypes.CDLL(LIB)
+        if "ORC_LIB" not in os.environ:
+            build()  # incremental: a no-op when liboracle.so is newer than its sources (a stale .so has bitten before)
+        _lib = ctypes.CDLL(LIB)
         _lib.orc_merkle_levels_len.restype = ctypes.c_size_t
         _lib.orc_fri_proof_words.restype = ctypes.c_size_t
         _lib.orc_n_openings.restype = ctypes.c_size_t
