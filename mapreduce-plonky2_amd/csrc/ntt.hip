@@ -22,6 +22,7 @@
 //     same coefficients scaled by (g w_{N}^j)^i; outputs land bit-reversed, i.e. already in
 //     Merkle-leaf order, so there is no separate transpose / bit-reverse pass.
 #include "ntt.h"
+#include <cstdlib>
 
 namespace mp2g {
 
@@ -338,14 +339,24 @@ NttPlan::~NttPlan() {
 }
 CosetTables::~CosetTables() { (void)hipFree(lo); (void)hipFree(hi); (void)hipFree(full); }
 
+// Cooley-Tukey split n = n1 * n2 of the sizes that do not fit one block (n1 = the strided pass)
+static u32 split_log_n1(u32 log_n) {
+  if (log_n <= 12) return 0;
+  u32 l1 = (log_n + 1) / 2;
+  if (const char* e = getenv("MP2G_NTT_N1")) {  // tuning aid: the strided dimension's size
+    int v = atoi(e);
+    if (v >= 7 && v <= 12 && (int)log_n - v >= 1 && (int)log_n - v <= 12) l1 = (u32)v;
+  }
+  return l1;
+}
 hipError_t NttEngine::plan(u32 log_n, bool inverse, NttPlan** out) {
   u32 key = log_n * 2 + (inverse ? 1 : 0);
   auto it = plans.find(key);
   if (it != plans.end()) { *out = it->second.get(); return hipSuccess; }
   std::unique_ptr<NttPlan> p(new NttPlan());
   p->log_n = log_n;
-  if (log_n <= 12) { p->log_n1 = 0; p->log_n2 = log_n; }
-  else { p->log_n1 = (log_n + 1) / 2; p->log_n2 = log_n - p->log_n1; }
+  p->log_n1 = split_log_n1(log_n);
+  p->log_n2 = log_n - p->log_n1;
   u64 wn = gl_root_of_unity(log_n);
   if (inverse) wn = gl_inv(wn);
   auto powers = [&](u64** dst, u64 base, u32 count) -> hipError_t {
@@ -392,7 +403,7 @@ hipError_t NttEngine::coset(u32 log_n, u32 logK, u64 shift, CosetTables** out) {
   }
   std::unique_ptr<CosetTables> c(new CosetTables());
   c->log_n = log_n; c->logK = logK; c->shift = shift;
-  u32 log_n1 = log_n <= 12 ? 0 : (log_n + 1) / 2, log_n2 = log_n - log_n1;
+  u32 log_n1 = split_log_n1(log_n), log_n2 = log_n - log_n1;
   u32 K = 1u << logK, n1 = 1u << log_n1, n2 = 1u << log_n2;
   HIPCHK(dev_alloc(&c->lo, (size_t)K * n2));
   HIPCHK(dev_alloc(&c->hi, (size_t)K * n1));
@@ -440,9 +451,14 @@ static bool* attr_flag(bool* flags) {
   (void)hipGetDevice(&dev);
   return &flags[dev >= 0 && dev < MP2G_MAX_DEVICES ? dev : 0];
 }
-template <int LT>
-static hipError_t launch_rows(const NttArgs& a, bool nat_two_pass, hipStream_t st) {
-  constexpr int LW = rows_lw<LT>();
+// tuning aid: MP2G_NTT_LW11=1|2|3 overrides the tile width (log2 of rows / columns per block) of the T = 2^11 passes
+static int lw11_override() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MP2G_NTT_LW11"); v = e ? atoi(e) : 0; }
+  return v;
+}
+template <int LT, int LW>
+static hipError_t launch_rows_lw(const NttArgs& a, bool nat_two_pass, hipStream_t st) {
   constexpr int NT = NttGeom<LT, LW>::NT;
   size_t lds = lds_bytes<LT, LW>();
   u64 total_rows = (u64)a.batch << a.log_n1;
@@ -460,8 +476,15 @@ static hipError_t launch_rows(const NttArgs& a, bool nat_two_pass, hipStream_t s
   return hipGetLastError();
 }
 template <int LT>
-static hipError_t launch_cols(const NttArgs& a, u64* dst_dense, hipStream_t st) {
-  constexpr int LW = cols_lw<LT>();
+static hipError_t launch_rows(const NttArgs& a, bool nat_two_pass, hipStream_t st) {
+  if constexpr (LT == 11) {
+    if (lw11_override() == 1) return launch_rows_lw<LT, 1>(a, nat_two_pass, st);
+    if (lw11_override() == 3) return launch_rows_lw<LT, 3>(a, nat_two_pass, st);
+  }
+  return launch_rows_lw<LT, rows_lw<LT>()>(a, nat_two_pass, st);
+}
+template <int LT, int LW>
+static hipError_t launch_cols_lw(const NttArgs& a, u64* dst_dense, hipStream_t st) {
   constexpr int NT = NttGeom<LT, LW>::NT;
   size_t lds = lds_bytes<LT, LW>();
   static bool flags[MP2G_MAX_DEVICES];
@@ -471,6 +494,14 @@ static hipError_t launch_cols(const NttArgs& a, u64* dst_dense, hipStream_t st) 
   return hipGetLastError();
 }
 
+template <int LT>
+static hipError_t launch_cols(const NttArgs& a, u64* dst_dense, hipStream_t st) {
+  if constexpr (LT == 11) {
+    if (lw11_override() == 1) return launch_cols_lw<LT, 1>(a, dst_dense, st);
+    if (lw11_override() == 3) return launch_cols_lw<LT, 3>(a, dst_dense, st);
+  }
+  return launch_cols_lw<LT, cols_lw<LT>()>(a, dst_dense, st);
+}
 #define ROWS_CASE(N) case N: return launch_rows<N>(a, nat, st);
 static hipError_t dispatch_rows(u32 lt, const NttArgs& a, bool nat, hipStream_t st) {
   switch (lt) {
