@@ -343,6 +343,7 @@ CosetTables::~CosetTables() { (void)hipFree(lo); (void)hipFree(hi); (void)hipFre
 static u32 split_log_n1(u32 log_n) {
   if (log_n <= 12) return 0;
   u32 l1 = (log_n + 1) / 2;
+  if (log_n >= 22) l1 = log_n - 12;  // measured (tools/dbg/ntt22.py): 2^10 x 2^12 runs 5-9 % faster than 2^11 x 2^11 at 2^22
   if (const char* e = getenv("MP2G_NTT_N1")) {  // tuning aid: the strided dimension's size
     int v = atoi(e);
     if (v >= 7 && v <= 12 && (int)log_n - v >= 1 && (int)log_n - v <= 12) l1 = (u32)v;
