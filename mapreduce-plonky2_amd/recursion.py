@@ -97,7 +97,10 @@ class Builder:
     REDUCING_COEFFS = 43
     REDUCING_EXT_COEFFS = 32
 
-    def __init__(self):
+    def __init__(self, strict=True):
+        # strict: connect() asserts equal values (a wrong witness fails where it is produced). Off, the builder records
+        # the copy constraint anyway and the witness simply violates it -- what a dishonest prover would hand to prove()
+        self.strict = strict
         self.rows = []
         self.parent = {}
         self.open = {}      # slot key -> [row index, used slots]
@@ -136,7 +139,7 @@ class Builder:
         return T(v, (row, col))
 
     def connect(self, a, b):
-        assert a.v == b.v, f"connect: {a.v} != {b.v}"
+        assert not self.strict or a.v == b.v, f"connect: {a.v} != {b.v}"
         if a.cell is None and b.cell is None:
             # two free targets: give them a home in a constant-free arithmetic slot (0 * 0 * 1 + 0 * x): cheap and rare
             self.arithmetic(0, a, a, 0, a)
@@ -286,15 +289,29 @@ class Builder:
     def mul_sub_ext(self, a, b, c):
         return self.arithmetic_ext(1, a, b, P - 1, c)
 
+    # A row of ArithmeticExtensionGate shares its two gate constants: an operation with a constant nobody else uses
+    # would own a whole row. Small constants that recur everywhere (matrix entries, -1, 7) stay gate constants; any
+    # other constant comes from a ConstantGate wire (two per row) and the operation joins the shared (1, 0) / (1, 1) rows.
+    _HOT = frozenset(list(range(0, 9)) + [P - 1, P - 2])
+
     def mul_const_ext(self, k, a):
-        return self.arithmetic_ext(k, a, self.one_ext(), 0, a)
+        k %= P
+        if k in self._HOT:
+            return self.arithmetic_ext(k, a, self.one_ext(), 0, a)
+        return self.mul_ext(self.constant_ext((k, 0)), a)
 
     def mul_const_add_ext(self, k, a, b):
-        return self.arithmetic_ext(k, a, self.one_ext(), 1, b)
+        k %= P
+        if k in self._HOT:
+            return self.arithmetic_ext(k, a, self.one_ext(), 1, b)
+        return self.mul_add_ext(self.constant_ext((k, 0)), a, b)
 
     def add_const_ext(self, a, k):
         """a + k for a base-field constant k"""
-        return self.arithmetic_ext(1, a, self.one_ext(), k, self.one_ext())
+        k %= P
+        if k in self._HOT:
+            return self.arithmetic_ext(1, a, self.one_ext(), k, self.one_ext())
+        return self.add_ext(a, self.constant_ext((k, 0)))
 
     def scalar_mul_ext(self, s, a):
         """base target s times extension a"""
@@ -380,7 +397,7 @@ class Builder:
     def split_le_base2(self, x, num_bits):
         """one BaseSumGate<2> row: x = sum limbs_i 2^i with num_bits <= 63 boolean limbs (the gate has 63; the unused
         high limbs are zero)"""
-        assert num_bits <= self.BASE_SUM_LIMBS and x.v < (1 << num_bits)
+        assert num_bits <= self.BASE_SUM_LIMBS and (not self.strict or x.v < (1 << num_bits))
         row = self._new_row(C.BASE_SUM, self.BASE_SUM_LIMBS, 2)
         self._put(row, 0, x)
         bits = []
@@ -419,38 +436,55 @@ class Builder:
         w = self.rows[row].wires
         for i in range(self.RA_BITS):
             w[routed + c * self.RA_BITS + i] = (index.v >> i) & 1
-        assert index.v < vs
-        return self._out(row, base + 1, values[index.v].v)
+        assert index.v < vs or not self.strict
+        return self._out(row, base + 1, values[index.v % vs].v)
 
     def random_access_ext(self, index, values):
         return E(self.random_access(index, [v.a for v in values]), self.random_access(index, [v.b for v in values]))
 
     # ---- ReducingGate: acc <- acc alpha + coeff over base-field coefficients ---------------------------------------------------
-    def reduce_base(self, alpha, coeffs, acc=None):
-        """sum_i coeffs[i] alpha^(len - 1 - i) + acc alpha^len (ReducingFactorTarget::reduce_base order is handled by
-        the caller: this is the gate's Horner step)"""
-        acc = acc or self.zero_ext()
+    def reduce_base(self, alpha, terms):
+        """ReducingFactorTarget::reduce_base: sum_i terms[i] alpha^i for base-field targets. The terms are padded with
+        zeros to a multiple of the gate's 43 coefficients and fed highest power first (the padding leads and is inert)."""
         n = self.REDUCING_COEFFS
-        for lo in range(0, len(coeffs), n):
-            chunk = coeffs[lo:lo + n]
+        rev = list(reversed(terms))
+        rev = [self.zero()] * ((-len(rev)) % n) + rev
+        acc = self.zero_ext()
+        start_accs = 6 + n
+        for lo in range(0, len(rev), n):
             row = self._new_row(C.REDUCING, n)
             for k, t in enumerate((alpha.a, alpha.b, acc.a, acc.b)):
                 self._put(row, 2 + k, t)
             w = self.rows[row].wires
             cur = acc.v
-            start_accs = 6 + n
             for i in range(n):
-                if i < len(chunk):
-                    self._put(row, 6 + i, chunk[i])
-                    cv = chunk[i].v
-                else:
-                    # unused tail of the row: plonky2 pads the coefficient list with zeros and keeps multiplying by alpha;
-                    # here the tail is cut by placing the short chunk at the END of the row (leading zero coefficients)
-                    raise AssertionError
-                cur = xadd(xmul(cur, alpha.v), (cv, 0))
-                if i == n - 1:
-                    pass
-                else:
+                self._put(row, 6 + i, rev[lo + i])
+                cur = xadd(xmul(cur, alpha.v), (rev[lo + i].v, 0))
+                if i < n - 1:
+                    w[start_accs + 2 * i], w[start_accs + 2 * i + 1] = cur
+            acc = E(self._out(row, 0, cur[0]), self._out(row, 1, cur[1]))
+        return acc
+
+    def reduce_ext(self, alpha, terms):
+        """ReducingFactorTarget::reduce: sum_i terms[i] alpha^i for extension targets through ReducingExtensionGates
+        (32 coefficients per row)"""
+        n = self.REDUCING_EXT_COEFFS
+        rev = list(reversed(terms))
+        rev = [self.zero_ext()] * ((-len(rev)) % n) + rev
+        acc = self.zero_ext()
+        start_accs = 6 + 2 * n
+        for lo in range(0, len(rev), n):
+            row = self._new_row(C.REDUCING_EXT, n)
+            for k, t in enumerate((alpha.a, alpha.b, acc.a, acc.b)):
+                self._put(row, 2 + k, t)
+            w = self.rows[row].wires
+            cur = acc.v
+            for i in range(n):
+                e = rev[lo + i]
+                self._put(row, 6 + 2 * i, e.a)
+                self._put(row, 7 + 2 * i, e.b)
+                cur = xadd(xmul(cur, alpha.v), e.v)
+                if i < n - 1:
                     w[start_accs + 2 * i], w[start_accs + 2 * i + 1] = cur
             acc = E(self._out(row, 0, cur[0]), self._out(row, 1, cur[1]))
         return acc
@@ -556,3 +590,460 @@ class Builder:
         ckt.luts, ckt.num_lookup_selectors, ckt.num_lookup_polys = [], 0, 0
         ckt.n_used_rows = n_rows - 1
         return ckt
+
+
+# ---- Fiat-Shamir in the circuit ([dep] iop/challenger.rs RecursiveChallenger) -------------------------------------------------------
+class RecursiveChallenger:
+    def __init__(self, b):
+        self.b = b
+        self.state = [b.zero()] * 12
+        self.inp, self.out = [], []
+
+    def observe(self, targets):
+        for t in targets:
+            self.out = []
+            self.inp.append(t)
+            if len(self.inp) == 8:
+                self._duplex()
+
+    def observe_ext(self, exts):
+        for e in exts:
+            self.observe([e.a, e.b])
+
+    def _duplex(self):
+        st = list(self.inp) + self.state[len(self.inp):]
+        self.inp = []
+        self.state = self.b.permute(st)
+        self.out = self.state[:8]
+
+    def get(self):
+        if self.inp or not self.out:
+            self._duplex()
+        return self.out.pop()
+
+    def get_n(self, n):
+        return [self.get() for _ in range(n)]
+
+    def get_ext(self):
+        a = self.get()
+        return E(a, self.get())
+
+
+# ---- Merkle proofs in the circuit ([dep] hash/merkle_proofs.rs verify_merkle_proof_to_cap_with_cap_index) ---------------------------------
+def verify_merkle_proof_to_cap(b, leaf, index_bits, cap_index, cap, siblings):
+    """leaf: base targets; index_bits: little-endian bits of the leaf index below the cap; cap: 2^cap_height hashes
+    (4 targets each); siblings bottom-up. The node hash is two_to_one = permute([l || r || 0000])[0..4] with the
+    Poseidon2 gate's swap wire choosing the order."""
+    state = b.hash_or_noop(leaf)
+    z = b.zero()
+    for bit, sib in zip(index_bits, siblings):
+        out = b.permute_swapped(list(state) + list(sib) + [z] * 4, bit)
+        state = out[:4]
+    for i in range(4):
+        got = b.random_access(cap_index, [h[i] for h in cap]) if len(cap) > 1 else cap[0][i]
+        b.connect(got, state[i])
+
+
+# ---- gate constraints over extension targets ([dep] gates/*.rs eval_unfiltered_circuit) -----------------------------------------------------
+def eval_gate_circuit(b, g, consts, wires, pih):
+    """constraints of gate descriptor g at the opened point: consts = local constants after the selector prefix
+    (extension targets), wires = local wires, pih = public-inputs hash (base targets). Order as eval_unfiltered."""
+    k = g.kind
+    out = []
+    if k == C.NOOP:
+        return out
+    if k == C.CONSTANT:
+        return [b.sub_ext(consts[i], wires[i]) for i in range(g.p0)]
+    if k == C.PUBLIC_INPUT:
+        return [b.sub_ext(wires[i], b.to_ext(pih[i])) for i in range(4)]
+    if k == C.ARITHMETIC:
+        for i in range(g.p0):
+            m0, m1, ad, o = wires[4 * i:4 * i + 4]
+            t = b.mul_ext(b.mul_ext(m0, m1), consts[0])
+            t = b.mul_add_ext(ad, consts[1], t)
+            out.append(b.sub_ext(o, t))
+        return out
+    if k == C.BASE_SUM:
+        acc = b.zero_ext()
+        for i in reversed(range(g.p0)):
+            acc = b.mul_const_add_ext(g.p1, acc, wires[1 + i])
+        out.append(b.sub_ext(acc, wires[0]))
+        for i in range(g.p0):
+            pr = wires[1 + i]
+            for kk in range(1, g.p1):
+                pr = b.mul_ext(pr, b.add_const_ext(wires[1 + i], P - kk))
+            out.append(pr)
+        return out
+    if k == C.ARITHMETIC_EXT:
+        for i in range(g.p0):
+            m0, m1, ad, o = [(wires[8 * i + 2 * j], wires[8 * i + 2 * j + 1]) for j in range(4)]
+            pr = alg_mul(b, m0, m1)
+            c = [b.mul_add_ext(ad[j], consts[1], b.mul_ext(pr[j], consts[0])) for j in range(2)]
+            out += [b.sub_ext(o[0], c[0]), b.sub_ext(o[1], c[1])]
+        return out
+    if k == C.POSEIDON2:
+        Kc = K2()
+        swap = wires[24]
+        out.append(b.mul_sub_ext(swap, swap, swap))  # swap (swap - 1)
+        s = [None] * 12
+        for i in range(4):
+            lhs, rhs, delta = wires[i], wires[i + 4], wires[25 + i]
+            out.append(b.sub_ext(b.mul_ext(swap, b.sub_ext(rhs, lhs)), delta))
+            s[i], s[i + 4] = b.add_ext(lhs, delta), b.sub_ext(rhs, delta)
+        for i in range(8, 12):
+            s[i] = wires[i]
+        s = p2_external_circuit(b, s)
+        for r in range(4):
+            s = [b.add_const_ext(s[i], Kc["POSEIDON2_RC_EXT"][12 * r + i]) for i in range(12)]
+            if r:
+                for i in range(12):
+                    w = wires[29 + 12 * (r - 1) + i]
+                    out.append(b.sub_ext(s[i], w))
+                    s[i] = w
+            s = p2_external_circuit(b, [pow7_circuit(b, x) for x in s])
+        for r in range(22):
+            s[0] = b.add_const_ext(s[0], Kc["POSEIDON2_RC_INT"][r])
+            w = wires[65 + r]
+            out.append(b.sub_ext(s[0], w))
+            s[0] = pow7_circuit(b, w)
+            s = p2_internal_circuit(b, s)
+        for r in range(4):
+            for i in range(12):
+                s[i] = b.add_const_ext(s[i], Kc["POSEIDON2_RC_EXT"][12 * (4 + r) + i])
+                w = wires[87 + 12 * r + i]
+                out.append(b.sub_ext(s[i], w))
+                s[i] = pow7_circuit(b, w)
+            s = p2_external_circuit(b, s)
+        for i in range(12):
+            out.append(b.sub_ext(s[i], wires[12 + i]))
+        return out
+    if k in (C.REDUCING, C.REDUCING_EXT):
+        nc, ext = g.p0, k == C.REDUCING_EXT
+        start_accs = 6 + (2 * nc if ext else nc)
+        alpha, acc = (wires[2], wires[3]), (wires[4], wires[5])
+        for i in range(nc):
+            nxt = (wires[0], wires[1]) if i == nc - 1 else (wires[start_accs + 2 * i], wires[start_accs + 2 * i + 1])
+            t = alg_mul(b, acc, alpha)
+            if ext:
+                out += [b.sub_ext(b.add_ext(t[0], wires[6 + 2 * i]), nxt[0]), b.sub_ext(b.add_ext(t[1], wires[7 + 2 * i]), nxt[1])]
+            else:
+                out += [b.sub_ext(b.add_ext(t[0], wires[6 + i]), nxt[0]), b.sub_ext(t[1], nxt[1])]
+            acc = nxt
+        return out
+    if k == C.RANDOM_ACCESS:
+        bits, copies, extra = g.p0, g.p1, g.p2
+        vs = 1 << bits
+        routed = (2 + vs) * copies + extra
+        for c in range(copies):
+            w0, b0 = (2 + vs) * c, routed + c * bits
+            bt = [wires[b0 + i] for i in range(bits)]
+            for x in bt:
+                out.append(b.mul_sub_ext(x, x, x))
+            idx = b.zero_ext()
+            for x in reversed(bt):
+                idx = b.mul_const_add_ext(2, idx, x)
+            out.append(b.sub_ext(idx, wires[w0]))
+            items = [wires[w0 + 2 + i] for i in range(vs)]
+            for x in bt:
+                items = [b.mul_add_ext(x, b.sub_ext(items[2 * j + 1], items[2 * j]), items[2 * j]) for j in range(len(items) // 2)]
+            out.append(b.sub_ext(items[0], wires[w0 + 1]))
+        for i in range(extra):
+            out.append(b.sub_ext(consts[i], wires[(2 + vs) * copies + i]))
+        return out
+    if k == C.COSET_INTERPOLATION:
+        npts, deg = 1 << g.p0, g.p1
+        nint = (npts - 2) // (deg - 1)
+        w_pt, w_val = 1 + 2 * npts, 3 + 2 * npts
+        w_int = w_val + 2
+        w_sh = w_int + 4 * nint
+        at = lambda i: (wires[i], wires[i + 1])
+        pt, sh = at(w_pt), at(w_sh)
+        out += [b.sub_ext(pt[0], b.mul_ext(sh[0], wires[0])), b.sub_ext(pt[1], b.mul_ext(sh[1], wires[0]))]
+        om = root_of_unity(g.p0)
+        dom = [pow(om, i, P) for i in range(npts)]
+        bw = []
+        for i in range(npts):
+            pr = 1
+            for j in range(npts):
+                if j != i:
+                    pr = pr * (dom[i] - dom[j]) % P
+            bw.append(inv(pr))
+        ev, pr = (b.zero_ext(), b.zero_ext()), (b.one_ext(), b.zero_ext())
+        start, end = 0, deg
+        for c in range(nint + 1):
+            for i in range(start, end):
+                val = tuple(b.mul_const_ext(bw[i], x) for x in at(1 + 2 * i))
+                term = (b.add_const_ext(sh[0], P - dom[i]), sh[1])
+                ev, pr = alg_add(b, alg_mul(b, ev, term), alg_mul(b, val, pr)), alg_mul(b, pr, term)
+            if c == nint:
+                break
+            iev, ipr = at(w_int + 2 * c), at(w_int + 2 * (nint + c))
+            out += [b.sub_ext(iev[0], ev[0]), b.sub_ext(iev[1], ev[1]), b.sub_ext(ipr[0], pr[0]), b.sub_ext(ipr[1], pr[1])]
+            ev, pr = iev, ipr
+            start = 1 + (deg - 1) * (c + 1)
+            end = min(start + deg - 1, npts)
+        val = at(w_val)
+        out += [b.sub_ext(val[0], ev[0]), b.sub_ext(val[1], ev[1])]
+        return out
+    raise NotImplementedError(f"no in-circuit evaluator for gate kind {k}")
+
+
+def alg_mul(b, x, y):
+    """ExtensionAlgebra product (a0 + a1 X)(b0 + b1 X), X^2 = 7, over extension targets"""
+    a = b.mul_add_ext(x[0], y[0], b.mul_const_ext(W7, b.mul_ext(x[1], y[1])))
+    return (a, b.mul_add_ext(x[0], y[1], b.mul_ext(x[1], y[0])))
+
+
+def alg_add(b, x, y):
+    return (b.add_ext(x[0], y[0]), b.add_ext(x[1], y[1]))
+
+
+def pow7_circuit(b, x):
+    x2 = b.mul_ext(x, x)
+    x4 = b.mul_ext(x2, x2)
+    return b.mul_ext(b.mul_ext(x, x2), x4)
+
+
+def p2_external_circuit(b, s):
+    t = []
+    for c in range(3):
+        for i in range(4):
+            acc = None
+            for j in range(4):
+                m = C.M4[i][j]
+                term = s[4 * c + j]
+                acc = b.mul_const_ext(m, term) if acc is None else b.mul_const_add_ext(m, term, acc)
+            t.append(acc)
+    sums = [b.add_ext(b.add_ext(t[i], t[4 + i]), t[8 + i]) for i in range(4)]
+    return [b.add_ext(t[4 * c + i], sums[i]) for c in range(3) for i in range(4)]
+
+
+def p2_internal_circuit(b, s):
+    d = K2()["POSEIDON2_DIAG_M1"]
+    tot = s[0]
+    for x in s[1:]:
+        tot = b.add_ext(tot, x)
+    return [b.mul_const_add_ext(d[i], s[i], tot) for i in range(12)]
+
+
+# ---- the verifier ([dep] plonk/recursive_verifier.rs verify_proof, fri/recursive_verifier.rs) -------------------------------------------------
+class InnerCircuit:
+    """what the verifier circuit needs to know about the circuit whose proofs it checks: CommonCircuitData (FRI
+    parameters, gate table with selector groups, constant / wire / routed counts) and, as constants of the wrap
+    circuit, VerifierOnlyCircuitData (constants_sigmas cap, circuit digest)."""
+
+    def __init__(self, ckt, fp, constants_sigmas_cap, circuit_digest, n_public_inputs):
+        self.ckt, self.fp = ckt, fp
+        self.cap = [[int(x) for x in h] for h in np.asarray(constants_sigmas_cap).reshape(-1, 4)]
+        self.circuit_digest = [int(x) for x in circuit_digest]
+        self.n_public_inputs = n_public_inputs
+
+
+def verify_proof_circuit(b, inner, caps, openings, fri, public_inputs):
+    """Adds the constraints `proof is a valid proof of `inner` with these public inputs` to builder b and returns
+    the public-input targets. caps [n_oracles][16][4] (oracle 0 ignored: the verifier data are constants), openings
+    [n_open][2] (FRI batch order), fri = the flat FriProof words (include/mp2g.h layout), as numpy / int arrays."""
+    fp, ckt = inner.fp, inner.ckt
+    assert fp.num_lookup_polys == 0, "lookup tables: not in the recursive verifier yet"
+    k, lg = fp.log_n, fp.log_n + fp.rate_bits
+    n = 1 << k
+    nc = fp.zs_count
+    capn = 1 << fp.cap_height
+    ws = [fp.oracle_w[o] for o in range(4)]
+    num_routed, degree = NUM_ROUTED, 8
+    chunks = num_routed // degree
+    num_consts = ws[0] - num_routed
+    V, VE = b.add_virtual, b.add_virtual_ext
+    # ---- proof targets (add_virtual_proof_with_pis) and the constant verifier data
+    pis = [V(int(x)) for x in public_inputs]
+    cap_t = [None] + [[[V(int(x)) for x in np.asarray(caps[o]).reshape(capn, 4)[h]] for h in range(capn)] for o in range(1, 4)]
+    cap_t[0] = [[b.constant(x) for x in h] for h in inner.cap]
+    digest = [b.constant(x) for x in inner.circuit_digest]
+    op = [VE((int(e[0]), int(e[1]))) for e in openings]
+    o_w, o_z, o_q, o_next = ws[0], ws[0] + ws[1], ws[0] + ws[1] + ws[2], sum(ws)
+    fri = [int(x) for x in fri]
+    pos = 0
+
+    def take(cnt):
+        nonlocal pos
+        out = [V(x) for x in fri[pos:pos + cnt]]
+        pos += cnt
+        return out
+    hashes = lambda ts: [ts[4 * i:4 * i + 4] for i in range(len(ts) // 4)]
+    exts = lambda ts: [E(ts[2 * i], ts[2 * i + 1]) for i in range(len(ts) // 2)]
+    commit_caps = [hashes(take(4 * capn)) for _ in range(fp.n_layers)]
+    rounds = []
+    for _ in range(fp.num_queries):
+        init = []
+        for o in range(4):
+            leaf = take(ws[o])
+            init.append((leaf, hashes(take(4 * (lg - fp.cap_height)))))
+        steps, clg = [], lg
+        for i in range(fp.n_layers):
+            ab = fp.arity_bits[i]
+            clg -= ab
+            ev = exts(take(2 << ab))
+            steps.append((ev, hashes(take(4 * (clg - fp.cap_height)))))
+        rounds.append((init, steps))
+    deg_bits = k - sum(fp.arity_bits[i] for i in range(fp.n_layers))
+    final_poly = exts(take(2 << deg_bits))
+    pow_witness = take(1)[0]
+    assert pos == len(fri)
+
+    # ---- challenges (plonk/get_challenges.rs)
+    pi_hash = b.hash_n_to_m_no_pad(pis, 4)
+    ch = RecursiveChallenger(b)
+    ch.observe(digest)
+    ch.observe(pi_hash)
+    flat = lambda cap: [t for h in cap for t in h]
+    ch.observe(flat(cap_t[1]))
+    betas, gammas = ch.get_n(nc), ch.get_n(nc)
+    ch.observe(flat(cap_t[2]))
+    alphas = ch.get_n(nc)
+    ch.observe(flat(cap_t[3]))
+    zeta = ch.get_ext()
+    ch.observe_ext(op)
+    fri_alpha = ch.get_ext()
+    fri_betas = []
+    for cap in commit_caps:
+        ch.observe(flat(cap))
+        fri_betas.append(ch.get_ext())
+    ch.observe_ext(final_poly)
+    ch.observe([pow_witness])
+    pow_response = ch.get()
+    query_indices = ch.get_n(fp.num_queries)
+
+    # ---- the PLONK identity at zeta (plonk/vanishing_poly.rs eval_vanishing_poly_circuit)
+    zeta_n = b.exp_power_of_2_ext(zeta, k)
+    z_h = b.add_const_ext(zeta_n, P - 1)
+    l0 = b.div_ext(z_h, b.mul_const_ext(n % P, b.add_const_ext(zeta, P - 1)))
+    consts_o, sigmas_o = op[:num_consts], op[num_consts:o_w]
+    wires_o = op[o_w:o_z]
+    zs_o, pps_o = op[o_z:o_z + nc], op[o_z + nc:o_q]
+    quot_o = op[o_q:o_next]
+    zs_next = op[o_next:o_next + nc]
+    terms = [b.mul_ext(l0, b.add_const_ext(zs_o[c], P - 1)) for c in range(nc)]
+    k_is = [pow(MULT_GEN, j, P) for j in range(num_routed)]
+    num_prods = chunks - 1
+    for c in range(nc):
+        beta_e, gamma_e = b.to_ext(betas[c]), b.to_ext(gammas[c])
+        beta_zeta = b.mul_ext(beta_e, zeta)
+        for chn in range(chunks):
+            num, den = None, None
+            for j in range(chn * degree, (chn + 1) * degree):
+                wg = b.add_ext(wires_o[j], gamma_e)
+                f_num = b.mul_const_add_ext(k_is[j], beta_zeta, wg)
+                f_den = b.mul_add_ext(beta_e, sigmas_o[j], wg)
+                num = f_num if num is None else b.mul_ext(num, f_num)
+                den = f_den if den is None else b.mul_ext(den, f_den)
+            prev = zs_o[c] if chn == 0 else pps_o[c * num_prods + chn - 1]
+            nxt = zs_next[c] if chn == chunks - 1 else pps_o[c * num_prods + chn]
+            terms.append(b.mul_sub_ext(prev, num, b.mul_ext(nxt, den)))
+    # gate constraints. plonky2 sums filter_g c_{g,j} into slot j and alpha-reduces the slots; the same field element is
+    # sum_g filter_g (sum_j alpha^j c_{g,j}) alpha^(#permutation terms): each gate's constraints are alpha-reduced first
+    # (ReducingExtensionGate rows, 32 coefficients each), the filter multiplies the reduced value once.
+    gates = ckt.gates
+    nsel = ckt.num_selectors
+    per_gate = []
+    for gi, g in enumerate(gates):
+        cons = eval_gate_circuit(b, g, consts_o[nsel:], wires_o, pi_hash)
+        if not cons:
+            continue
+        s_sel = consts_o[g.selector_index]
+        filt = None
+        for r in range(g.group_start, g.group_end):
+            if r != gi:
+                f = b.arithmetic_ext(P - 1, s_sel, b.one_ext(), r, b.one_ext())  # r - s
+                filt = f if filt is None else b.mul_ext(filt, f)
+        if nsel > 1:
+            f = b.add_const_ext(b.mul_const_ext(P - 1, s_sel), 0xFFFFFFFF)  # UNUSED_SELECTOR - s
+            filt = f if filt is None else b.mul_ext(filt, f)
+        per_gate.append((filt, cons))
+    for a in range(nc):
+        alpha_e = b.to_ext(alphas[a])
+        gsum = None
+        for filt, cons in per_gate:
+            r = b.reduce_ext(alpha_e, cons) if len(cons) > 8 else b.reduce_with_powers_ext(cons, alpha_e)
+            v = r if filt is None else b.mul_ext(filt, r)
+            gsum = v if gsum is None else b.add_ext(gsum, v)
+        van = b.reduce_with_powers_ext(terms + ([gsum] if gsum is not None else []), alpha_e)
+        tz = b.reduce_with_powers_ext(quot_o[8 * a:8 * a + 8], zeta_n)
+        b.connect_ext(van, b.mul_ext(z_h, tz))
+
+    # ---- FRI (fri/recursive_verifier.rs verify_fri_proof)
+    # proof of work: the response has pow_bits leading zeros
+    b.range_check(pow_response, 64 - fp.pow_bits)
+    # precomputed reduced openings: sum_j alpha^j v_j per batch
+    n_zeta = o_next
+    red = [b.reduce_ext(fri_alpha, op[:n_zeta]), b.reduce_with_powers_ext(op[n_zeta:], fri_alpha)]
+    g_k = root_of_unity(k)
+    zeta_next = b.mul_const_ext(g_k, zeta)
+    alpha_pow_next = fri_alpha
+    for _ in range(len(op) - n_zeta - 1):
+        alpha_pow_next = b.mul_ext(alpha_pow_next, fri_alpha)  # alpha^(number of polynomials in the g*zeta batch)
+    w_lg = root_of_unity(lg)
+    for q in range(fp.num_queries):
+        init, steps = rounds[q]
+        bits = b.split_le(query_indices[q], 64)[:lg]
+        cap_index = b.le_sum(bits[lg - fp.cap_height:lg])
+        for o in range(4):
+            leaf, sib = init[o]
+            verify_merkle_proof_to_cap(b, leaf, bits[:lg - fp.cap_height], cap_index, cap_t[o], sib)
+        # subgroup_x = g * w^(bit-reversed index)
+        sx = b.mul_const(MULT_GEN, b.exp_from_bits_const_base(w_lg, list(reversed(bits))))
+        # fri_combine_initial: (reduce(all leaf evals) - red0) / (x - zeta), shifted, + the g*zeta batch
+        leaf_all = [t for o in range(4) for t in init[o][0]]
+        sx_e = b.to_ext(sx)
+        num0 = b.sub_ext(b.reduce_base(fri_alpha, leaf_all), red[0])
+        q0 = b.div_ext(num0, b.sub_ext(sx_e, zeta))
+        num1 = b.sub_ext(b.reduce_base(fri_alpha, init[2][0][:nc]) if nc > 21 else
+                         b.reduce_with_powers_ext([b.to_ext(t) for t in init[2][0][:nc]], fri_alpha), red[1])
+        q1 = b.div_ext(num1, b.sub_ext(sx_e, zeta_next))
+        old_eval = b.mul_add_ext(q0, alpha_pow_next, q1)
+        xbits = bits
+        clg = lg
+        for i in range(fp.n_layers):
+            ab = fp.arity_bits[i]
+            evals, sib = steps[i]
+            within_bits, coset_bits = xbits[:ab], xbits[ab:]
+            within = b.le_sum(within_bits)
+            b.connect_ext(b.random_access_ext(within, evals), old_eval)
+            # compute_evaluation: interpolate the coset at beta
+            g_ab = root_of_unity(ab)
+            rev = list(evals)
+            rev = [rev[int(format(j, f"0{ab}b")[::-1], 2)] for j in range(1 << ab)]
+            start = b.exp_from_bits_const_base(inv(g_ab), list(reversed(within_bits)))
+            coset_start = b.mul(start, sx)
+            old_eval = b.interpolate_coset(ab, coset_start, rev, fri_betas[i])
+            clg -= ab
+            leaf = [t for e in evals for t in (e.a, e.b)]
+            verify_merkle_proof_to_cap(b, leaf, coset_bits[:clg - fp.cap_height], cap_index, commit_caps[i], sib)
+            sx = b.exp_power_of_2(sx, ab)
+            xbits = coset_bits
+        # final polynomial at the folded point
+        fe = b.reduce_ext(b.to_ext(sx), final_poly) if len(final_poly) > 12 else b.reduce_with_powers_ext(final_poly, b.to_ext(sx))
+        b.connect_ext(fe, old_eval)
+    return pis
+
+
+# ---- the circuits of recursion-framework/tests/integration.rs -------------------------------------------------------------------
+def map_circuit(inputs, builder=None):
+    """MapCircuitWires::circuit_logic (integration.rs:75-93): public inputs = (sum of the even inputs, H(inputs))"""
+    b = builder or Builder()
+    ins = [b.add_virtual(int(x)) for x in inputs]
+    one = b.one()
+    acc = b.zero()
+    for t in ins:
+        is_odd = b.split_le(t, 64)[0]
+        acc = b.mul_add(b.sub(one, is_odd), t, acc)
+    b.register_public_inputs([acc] + b.hash_n_to_m_no_pad(ins, 4))
+    return b.build()
+
+
+def wrap_circuit(inner, caps, openings, fri, public_inputs, strict=True):
+    """WrapCircuit::build_wrap_circuit, first step (wrap_circuit.rs:58-99): verify the inner proof with the inner
+    circuit's verifier data as constants and expose the inner proof's public inputs"""
+    b = Builder(strict)
+    pis = verify_proof_circuit(b, inner, caps, openings, fri, public_inputs)
+    b.register_public_inputs(pis)
+    return b.build()

@@ -1,0 +1,72 @@
+"""Real recursion through the HIP prover: the base proof (map circuit, integration.rs:65-93) and the wrap proof that
+verifies it in-circuit (recursion.py: plonky2's verify_proof gadget, wrap_circuit.rs:58-99) are both produced by
+libmp2gpu at standard_recursion_config, equal the oracle's proofs of the same witnesses bit for bit, and pass the
+oracle's verifier; the wrap proof carries the base proof's public inputs."""
+import importlib
+
+import numpy as np
+import pytest
+
+import circuits as C
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+
+
+def gpu_prove(ctx, ckt, witness_check=True):
+    cp = FW.CircuitProver(ctx, ckt, 1, witness_check=witness_check)
+    cp.prove(ctx.to_device(ckt.wires[None]), ctx.to_device(ckt.pi_hash[None]))
+    flags = cp.pr.witness_status() if witness_check else None
+    caps, openings, proofs = cp.results()
+    out = (cp, caps[0], openings[0], proofs[0], flags)
+    return out
+
+
+def test_base_wrap_verify_on_gpu(ctx, mp2):
+    data = O.rand_field(4, 77)
+    base = R.map_circuit(data)
+    cp, caps, openings, proof, flags = gpu_prove(ctx, base)
+    assert flags.tolist() == [0]
+    fp = C.oracle_params(base)
+    assert bytes(fp) == bytes(cp.fp)
+    assert C.verify(base, fp, cp.circuit_digest, base.pi_hash, caps, openings, proof) == 0
+    inner = R.InnerCircuit(base, fp, cp.constants_sigmas_cap, cp.circuit_digest, len(base.public_inputs))
+    wrap = R.wrap_circuit(inner, caps, openings, proof, base.public_inputs)
+    assert wrap.log_n == 12
+    wcp, wc, wo, wp, wflags = gpu_prove(ctx, wrap)
+    assert wflags.tolist() == [0]
+    wfp = C.oracle_params(wrap)
+    oc, oo, op_, _ = C.prove(wrap, wfp, wcp.circuit_digest)
+    assert np.array_equal(wc, oc) and np.array_equal(wo, oo) and np.array_equal(wp, op_)
+    assert C.verify(wrap, wfp, wcp.circuit_digest, wrap.pi_hash, wc, wo, wp) == 0
+    assert np.array_equal(wrap.public_inputs, base.public_inputs)
+    assert int(wrap.public_inputs[0]) == sum(int(x) for x in data if int(x) % 2 == 0) % O.P
+    # a second wrap step (wrap_circuit.rs: the loop keeps wrapping until the size stops shrinking): the wrap proof itself
+    # is verified by a circuit whose gate evaluators now cover the recursive verifier's own gate set
+    inner2 = R.InnerCircuit(wrap, wfp, wcp.constants_sigmas_cap, wcp.circuit_digest, len(wrap.public_inputs))
+    wrap2 = R.wrap_circuit(inner2, wc, wo, wp, wrap.public_inputs)
+    w2cp, w2c, w2o, w2p, w2flags = gpu_prove(ctx, wrap2)
+    assert w2flags.tolist() == [0]
+    w2fp = C.oracle_params(wrap2)
+    assert C.verify(wrap2, w2fp, w2cp.circuit_digest, wrap2.pi_hash, w2c, w2o, w2p) == 0
+    assert np.array_equal(wrap2.public_inputs, base.public_inputs)
+    for p in (cp, wcp, w2cp):
+        p.free()
+
+
+def test_dishonest_wrap_witness_is_flagged(ctx, mp2):
+    data = O.rand_field(4, 3)
+    base = R.map_circuit(data)
+    cp, caps, openings, proof, _ = gpu_prove(ctx, base)
+    inner = R.InnerCircuit(base, C.oracle_params(base), cp.constants_sigmas_cap, cp.circuit_digest, len(base.public_inputs))
+    bad = proof.copy()
+    bad[-1] = (int(bad[-1]) + 1) % O.P  # another proof-of-work witness: the response loses its leading zeros
+    wrap = R.wrap_circuit(inner, caps, openings, bad, base.public_inputs, strict=False)
+    wcp = FW.CircuitProver(ctx, wrap, 1, witness_check=True)
+    wcp.prove(ctx.to_device(wrap.wires[None]), ctx.to_device(wrap.pi_hash[None]))
+    with pytest.raises(mp2.Mp2gError):
+        wcp.pr.witness_status()
+    cp.free()
+    wcp.free()

@@ -1,0 +1,84 @@
+"""Real recursion on the CPU (no GPU needed): recursion.py's eager builder + recursive verifier, proved and
+verified by the oracle. base (the map circuit of recursion-framework/tests/integration.rs:65-93) -> wrap (plonky2's
+verify_proof gadget with the base circuit's verifier data as constants, wrap_circuit.rs:58-99) -> verify; the wrap
+proof's public inputs are the base proof's. The GPU counterpart is tests/test_gpu_recursion.py."""
+import importlib
+
+import numpy as np
+import pytest
+
+import circuits as C
+import oracle as O
+
+R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+
+
+def verifier_data(ckt):
+    """VerifierOnlyCircuitData by the oracle: constants_sigmas cap and H(cap || H_pad([]) || degree_bits)"""
+    cap = O.merkle_cap(O.merkle_build(O.lde_leaves(O.fft(ckt.pre, inverse=True), 3), 4), 4)
+    dom = O.hash_n_to_m_no_pad([1, 0, 0, 0, 0, 0, 0, 1], 4)
+    return cap, O.hash_n_to_m_no_pad(list(cap.reshape(-1)) + list(dom) + [ckt.log_n], 4)
+
+
+@pytest.fixture(scope="module")
+def base_and_proof():
+    data = O.rand_field(4, 77)
+    base = R.map_circuit(data)
+    fp = C.oracle_params(base)  # standard_recursion_config: 28 queries, 16-bit proof of work
+    cap, cd = verifier_data(base)
+    caps, openings, proof, _ = C.prove(base, fp, cd)
+    assert C.verify(base, fp, cd, base.pi_hash, caps, openings, proof) == 0
+    return data, base, fp, cap, cd, caps, openings, proof
+
+
+def test_builder_map_circuit(base_and_proof):
+    data, base, fp, cap, cd, caps, openings, proof = base_and_proof
+    assert int(base.public_inputs[0]) == sum(int(x) for x in data if int(x) % 2 == 0) % O.P
+    assert np.array_equal(base.public_inputs[1:], O.hash_n_to_m_no_pad(data, 4))
+    assert np.array_equal(base.pi_hash, O.hash_n_to_m_no_pad(base.public_inputs, 4))
+    assert not C.eval_on_points(base, base.pre[:base.num_constants], base.wires).any()  # every gate constraint vanishes on H
+    # the structure does not depend on the witness: another dataset gives the same preprocessed polynomials
+    other = R.map_circuit(O.rand_field(4, 78))
+    assert np.array_equal(other.pre, base.pre) and not np.array_equal(other.wires, base.wires)
+
+
+def test_base_wrap_verify(base_and_proof):
+    data, base, fp, cap, cd, caps, openings, proof = base_and_proof
+    inner = R.InnerCircuit(base, fp, cap, cd, len(base.public_inputs))
+    wrap = R.wrap_circuit(inner, caps, openings, proof, base.public_inputs)
+    assert wrap.log_n == 12  # RECURSION_THRESHOLD (universal_verifier_gadget/mod.rs:34)
+    kinds = {g.kind for g in wrap.gates}
+    assert {C.POSEIDON2, C.ARITHMETIC_EXT, C.BASE_SUM, C.RANDOM_ACCESS, C.REDUCING, C.COSET_INTERPOLATION, C.PUBLIC_INPUT} <= kinds
+    assert not C.eval_on_points(wrap, wrap.pre[:wrap.num_constants], wrap.wires).any()
+    assert np.array_equal(wrap.public_inputs, base.public_inputs)
+    wfp = C.oracle_params(wrap)
+    wcap, wcd = verifier_data(wrap)
+    wc, wo, wp, _ = C.prove(wrap, wfp, wcd)
+    assert C.verify(wrap, wfp, wcd, wrap.pi_hash, wc, wo, wp) == 0
+    # the same wrap circuit around another base proof: same circuit (digest), other witness
+    data2 = O.rand_field(4, 5)
+    base2 = R.map_circuit(data2)
+    c2, o2, p2, _ = C.prove(base2, fp, cd)
+    wrap2 = R.wrap_circuit(inner, c2, o2, p2, base2.public_inputs)
+    assert np.array_equal(wrap2.pre, wrap.pre)
+    assert not C.eval_on_points(wrap2, wrap2.pre[:wrap2.num_constants], wrap2.wires).any()
+
+
+def test_wrap_rejects_a_bad_inner_proof(base_and_proof):
+    data, base, fp, cap, cd, caps, openings, proof = base_and_proof
+    inner = R.InnerCircuit(base, fp, cap, cd, len(base.public_inputs))
+    bad = openings.copy()
+    bad[100, 0] = (int(bad[100, 0]) + 1) % O.P
+    with pytest.raises(AssertionError):
+        R.wrap_circuit(inner, caps, bad, proof, base.public_inputs)  # the eager builder stops at the failing connect()
+    # built anyway, the witness violates the wrap circuit (copy constraints carry the failed equalities)
+    wrap = R.wrap_circuit(inner, caps, bad, proof, base.public_inputs, strict=False)
+    wfp = C.oracle_params(wrap, pow_bits=4, num_queries=2)
+    wcap, wcd = verifier_data(wrap)
+    wc, wo, wp, _ = C.prove(wrap, wfp, wcd)
+    assert C.verify(wrap, wfp, wcd, wrap.pi_hash, wc, wo, wp) != 0
+    # wrong public inputs for a good proof fail too (the transcript starts from their hash)
+    pis = base.public_inputs.copy()
+    pis[0] = (int(pis[0]) + 1) % O.P
+    with pytest.raises(AssertionError):
+        R.wrap_circuit(inner, caps, openings, proof, pis)
