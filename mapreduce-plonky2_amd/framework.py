@@ -200,3 +200,41 @@ class MapReduce:
 
     def free(self):
         self.fw.free()
+
+
+class GpuProver:
+    """The proving back end recursion.RecursiveCircuits drives: prove() of one circuit built by recursion.Builder on
+    the device, the circuit's verifier data from the preprocessed commitment, and the Merkle node hash of the circuit
+    set. One CircuitProver (preprocessed oracle, gate table) per distinct circuit, kept for reuse."""
+
+    def __init__(self, ctx, variant=POSEIDON2, witness_check=True):
+        self.ctx, self.variant, self.witness_check = ctx, variant, witness_check
+        self.provers = {}
+
+    def _prover(self, ckt):
+        key = (ckt.log_n, hash(ckt.pre.tobytes()))
+        cp = self.provers.get(key)
+        if cp is None:
+            cp = self.provers[key] = CircuitProver(self.ctx, ckt, 1, self.variant, witness_check=self.witness_check)
+        return cp
+
+    def verifier_data(self, ckt):
+        cp = self._prover(ckt)
+        return cp.constants_sigmas_cap, cp.circuit_digest
+
+    def prove(self, ckt):
+        cp = self._prover(ckt)
+        cp.prove(self.ctx.to_device(ckt.wires[None]), self.ctx.to_device(ckt.pi_hash[None]))
+        if self.witness_check:
+            cp.pr.witness_status()  # raises like plonky2's prove() on an unsatisfied witness
+        caps, openings, proofs = cp.results()
+        return caps[0], openings[0], proofs[0]
+
+    def two_to_one(self, left, right):
+        """Hasher::two_to_one = permute([l || r || 0000])[0..4] = hash_no_pad of the 8 limbs (one absorb)"""
+        return [int(x) for x in self.ctx.hash_no_pad(list(left) + list(right), self.variant)]
+
+    def free(self):
+        for cp in self.provers.values():
+            cp.free()
+        self.provers = {}

@@ -839,10 +839,12 @@ class InnerCircuit:
         self.n_public_inputs = n_public_inputs
 
 
-def verify_proof_circuit(b, inner, caps, openings, fri, public_inputs):
+def verify_proof_circuit(b, inner, caps, openings, fri, public_inputs, verifier_data=None):
     """Adds the constraints `proof is a valid proof of `inner` with these public inputs` to builder b and returns
-    the public-input targets. caps [n_oracles][16][4] (oracle 0 ignored: the verifier data are constants), openings
-    [n_open][2] (FRI batch order), fri = the flat FriProof words (include/mp2g.h layout), as numpy / int arrays."""
+    the public-input targets. caps [n_oracles][16][4] (oracle 0 ignored: it belongs to the verifier data), openings
+    [n_open][2] (FRI batch order), fri = the flat FriProof words (include/mp2g.h layout), as numpy / int arrays.
+    verifier_data = (cap targets [16][4], circuit digest targets [4]) for a universal verifier whose verifier data are
+    witnesses; None = the constants of inner (verify_proof_fixed_circuit, the first wrap step)."""
     fp, ckt = inner.fp, inner.ckt
     assert fp.num_lookup_polys == 0, "lookup tables: not in the recursive verifier yet"
     k, lg = fp.log_n, fp.log_n + fp.rate_bits
@@ -857,8 +859,11 @@ def verify_proof_circuit(b, inner, caps, openings, fri, public_inputs):
     # ---- proof targets (add_virtual_proof_with_pis) and the constant verifier data
     pis = [V(int(x)) for x in public_inputs]
     cap_t = [None] + [[[V(int(x)) for x in np.asarray(caps[o]).reshape(capn, 4)[h]] for h in range(capn)] for o in range(1, 4)]
-    cap_t[0] = [[b.constant(x) for x in h] for h in inner.cap]
-    digest = [b.constant(x) for x in inner.circuit_digest]
+    if verifier_data is None:
+        cap_t[0] = [[b.constant(x) for x in h] for h in inner.cap]
+        digest = [b.constant(x) for x in inner.circuit_digest]
+    else:
+        cap_t[0], digest = verifier_data
     op = [VE((int(e[0]), int(e[1]))) for e in openings]
     o_w, o_z, o_q, o_next = ws[0], ws[0] + ws[1], ws[0] + ws[1] + ws[2], sum(ws)
     fri = [int(x) for x in fri]
@@ -1047,3 +1052,208 @@ def wrap_circuit(inner, caps, openings, fri, public_inputs, strict=True):
     pis = verify_proof_circuit(b, inner, caps, openings, fri, public_inputs)
     b.register_public_inputs(pis)
     return b.build()
+
+
+# ---- the recursion framework (recursion-framework/src: circuit_builder.rs, universal_verifier_gadget/*, framework.rs) --------------------
+# Every circuit of the framework is wrapped until its proof has the shape all the others have, so that one "universal"
+# verifier (verifier data as witnesses + membership of their digest in the circuit set) can check any of them. The
+# reference's fixed point is RECURSION_THRESHOLD = 12 rows bits (universal_verifier_gadget/mod.rs:34): plonky2's verifier
+# of a 2^13-row proof fits 2^12 rows. The verifier built here needs 4063 rows for a 2^12-row proof and 4238 for a 2^13-row
+# one (its gate evaluators and constants are packed less tightly than plonky2's), so its fixed point is 13: final proofs
+# are 2^13-row proofs. Everything else follows the reference.
+RECURSION_THRESHOLD = 13
+CIRCUIT_SET_CAP_HEIGHT = 0
+DOMAIN_SEPARATOR_PAD = [1, 0, 0, 0, 0, 0, 0, 1]  # hash_pad(&[]) input
+
+
+def common_data(ckt):
+    """what must be equal for two circuits to share a universal verifier: CommonCircuitData (here: degree, gate table
+    with its selector groups, number of constants)"""
+    return (ckt.log_n, ckt.num_selectors, ckt.num_constants,
+            tuple((g.kind, g.p0, g.p1, g.p2, g.selector_index, g.group_start, g.group_end) for g in ckt.gates))
+
+
+def check_circuit_digest(b, cap_t, digest_t, degree_bits):
+    """circuit_set.rs:136-158 check_circuit_digest_target: digest == H(cap || H_pad([]) || degree_bits)"""
+    dom = b.hash_n_to_m_no_pad([b.constant(x) for x in DOMAIN_SEPARATOR_PAD], 4)
+    h = b.hash_n_to_m_no_pad([t for hh in cap_t for t in hh] + dom + [b.constant(degree_bits)], 4)
+    for x, y in zip(h, digest_t):
+        b.connect(x, y)
+
+
+def universal_verifier_circuit(b, rec, circuit_set_t, set_size, proof, vd, membership):
+    """verifier_gadget.rs:129-166: verify `proof` (caps, openings, fri, public_inputs) of a circuit with common data
+    `rec` under verifier data given as witnesses vd = (cap [16][4], digest [4]); check the digest against the cap,
+    its membership in the circuit set (index bits little-endian, siblings bottom-up) and that the proof exposes the
+    same circuit set. Returns the proof's public-input targets."""
+    caps, openings, fri, public_inputs = proof
+    cap_t = [[b.add_virtual(int(x)) for x in h] for h in np.asarray(vd[0]).reshape(-1, 4)]
+    digest_t = [b.add_virtual(int(x)) for x in vd[1]]
+    pis = verify_proof_circuit(b, rec, caps, openings, fri, public_inputs, verifier_data=(cap_t, digest_t))
+    check_circuit_digest(b, cap_t, digest_t, RECURSION_THRESHOLD)
+    bits, siblings = membership
+    height = max(0, (set_size - 1).bit_length()) - CIRCUIT_SET_CAP_HEIGHT
+    assert len(bits) == height and len(siblings) == height
+    bit_t = []
+    for x in bits:
+        t = b.add_virtual(int(x))
+        b.assert_bool(t)  # add_virtual_bool_target_safe
+        bit_t.append(t)
+    sib_t = [[b.add_virtual(int(x)) for x in sb] for sb in siblings]
+    verify_merkle_proof_to_cap(b, digest_t, bit_t, None, [circuit_set_t], sib_t)
+    n_own = len(pis) - 4
+    for x, y in zip(circuit_set_t, pis[n_own:]):
+        b.connect(x, y)
+    return pis
+
+
+class FrameworkCircuit:
+    """CircuitWithUniversalVerifier (circuit_builder.rs:264-311): NUM_VERIFIERS universal verifiers, the circuit's
+    own logic, the circuit-set digest as the last public inputs; then the wrap chain down to the threshold shape.
+    `logic(b, child_public_inputs, inputs)` returns the circuit's own public-input targets (CircuitLogicWires)."""
+
+    def __init__(self, name, num_verifiers, logic, num_public_inputs):
+        self.name, self.num_verifiers, self.logic, self.num_public_inputs = name, num_verifiers, logic, num_public_inputs
+
+    def build_base(self, fw, child_proofs, child_vds, memberships, inputs, set_digest, strict=True):
+        b = Builder(strict)
+        set_t = [b.add_virtual(int(x)) for x in set_digest]  # CircuitSetTarget::build_target: a virtual cap of height 0
+        child_pis = []
+        for proof, vd, mem in zip(child_proofs, child_vds, memberships):
+            pis = universal_verifier_circuit(b, fw.rec, set_t, fw.set_size, proof, vd, mem)
+            child_pis.append(pis[:len(pis) - 4])
+        own = self.logic(b, child_pis, inputs)
+        assert len(own) == self.num_public_inputs
+        b.register_public_inputs(list(own) + set_t)
+        return b.build(min_log_n=6)
+
+
+class RecursiveCircuits:
+    """framework.rs RecursiveCircuits + the per-circuit wrap chains: build every circuit's structure once (dummy
+    witnesses), collect the digests of the final wrap circuits into the circuit set, then generate_proof().
+    prover(ckt) -> (caps, openings, proof, constants_sigmas_cap, circuit_digest) is the proving back end (the HIP
+    prover in production, the oracle in the CPU tests)."""
+
+    def __init__(self, circuits, prover, fri_params):
+        self.prover, self.fri_params = prover, fri_params
+        self.circuits = {c.name: c for c in circuits}
+        self.set_size = len(circuits)
+        # common data of every final wrap circuit: wrap a dummy proof of a dummy circuit, as
+        # build_data_for_universal_verifier does (universal_verifier_gadget/mod.rs:66-87)
+        n_pi = circuits[0].num_public_inputs + 4
+        assert all(c.num_public_inputs + 4 == n_pi for c in circuits)
+        dummy = self._dummy_circuit(n_pi)
+        chain = self._wrap_structure(dummy)
+        self.rec = InnerCircuit(chain[-1][0], fri_params(chain[-1][0]), chain[-1][1], chain[-1][2], n_pi)
+        self.rec_common = common_data(chain[-1][0])
+        # structure of every circuit and of its wrap chain; verifier data of the final wrap circuit
+        self.chains, self.vds = {}, {}
+        zero_set = [0, 0, 0, 0]
+        for c in circuits:
+            proofs = [self._dummy_proof(self.rec) for _ in range(c.num_verifiers)]
+            vds = [(np.zeros((16, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64))] * c.num_verifiers
+            height = max(0, (self.set_size - 1).bit_length())
+            mems = [([0] * height, [[0, 0, 0, 0]] * height)] * c.num_verifiers
+            base = c.build_base(self, proofs, vds, mems, None, zero_set, strict=False)
+            chain = self._wrap_structure(base)
+            assert common_data(chain[-1][0]) == self.rec_common, f"{c.name}: the final wrap circuit does not have the shared shape"
+            self.chains[c.name] = [self._verifier_data(base)] + chain
+            self.vds[c.name] = (chain[-1][1], chain[-1][2])
+        # the circuit set: Merkle tree (cap height 0) over the final wrap circuits' digests, padded with [0] leaves
+        self.digests = [self.vds[c.name][1] for c in circuits]
+        self.set_levels = self._set_tree(self.digests)
+        self.set_digest = self.set_levels[-1][0]
+
+    # -- structure helpers (dummy witnesses, strict off)
+    def _dummy_circuit(self, n_pi):
+        b = Builder()
+        b.register_public_inputs([b.add_virtual(0) for _ in range(n_pi)])
+        return b.build(min_log_n=6)
+
+    def _verifier_data(self, ckt):
+        """(circuit, constants_sigmas cap, circuit digest): the preprocessed commitment by the proving back end"""
+        cap, digest = self.prover.verifier_data(ckt)
+        return (ckt, cap, digest)
+
+    def _dummy_proof(self, inner):
+        fp = inner.fp
+        n_open = sum(fp.oracle_w[o] for o in range(4)) + fp.zs_count
+        return (np.zeros((4, 4 << fp.cap_height), dtype=np.uint64), np.zeros((n_open, 2), dtype=np.uint64),
+                np.zeros(fp.proof_words, dtype=np.uint64), np.zeros(inner.n_public_inputs, dtype=np.uint64))
+
+    def _wrap_structure(self, base):
+        """the wrap chain of a circuit (WrapCircuit::build_wrap_circuit): wrap until the threshold shape is reached"""
+        chain = []
+        cur = self._verifier_data(base)
+        for _ in range(4):
+            inner = InnerCircuit(cur[0], self.fri_params(cur[0]), cur[1], cur[2], len(cur[0].public_inputs))
+            b = Builder(strict=False)
+            pis = verify_proof_circuit(b, inner, *self._dummy_proof(inner))
+            b.register_public_inputs(pis)
+            w = b.build(min_log_n=RECURSION_THRESHOLD)
+            cur = self._verifier_data(w)
+            chain.append(cur)
+            if w.log_n == RECURSION_THRESHOLD:
+                return chain
+        raise AssertionError("the wrap chain does not reach the threshold size")
+
+    def _set_tree(self, digests):
+        size = 1 << max(0, (len(digests) - 1).bit_length())
+        leaves = [[int(x) for x in d] for d in digests] + [[0, 0, 0, 0]] * (size - len(digests))  # hash_or_noop of the 1-limb pad leaf [0]
+        levels = [leaves]
+        while len(levels[-1]) > 1:
+            prev = levels[-1]
+            levels.append([self.prover.two_to_one(prev[2 * i], prev[2 * i + 1]) for i in range(len(prev) // 2)])
+        return levels
+
+    def membership(self, digest):
+        """CircuitSet::set_circuit_membership_target (circuit_set.rs:205-237): little-endian index bits + siblings"""
+        idx = next(i for i, d in enumerate(self.digests) if [int(x) for x in d] == [int(x) for x in digest])
+        bits, sib = [], []
+        for lv in self.set_levels[:-1]:
+            bits.append(idx & 1)
+            sib.append(lv[idx ^ 1])
+            idx >>= 1
+        return bits, sib
+
+    # -- proving
+    def generate_proof(self, name, child_proofs, child_names, inputs):
+        """RecursiveCircuits::generate_proof (framework.rs): base proof of circuit `name` over the children's final
+        proofs, then its wrap chain. Returns the final proof (caps, openings, fri, public_inputs)."""
+        c = self.circuits[name]
+        vds = [self.vds[n] for n in child_names]
+        mems = [self.membership(vd[1]) for vd in vds]
+        base = c.build_base(self, child_proofs, vds, mems, inputs, self.set_digest)
+        assert np.array_equal(base.pre, self.chains[name][0][0].pre), "the circuit structure depends on the witness"
+        caps, openings, proof = self.prover.prove(base)
+        cur_ckt, cur_proof = base, (caps, openings, proof, base.public_inputs)
+        for step, (wckt, wcap, wdig) in enumerate(self.chains[name][1:]):
+            prev = self.chains[name][step]
+            inner = InnerCircuit(cur_ckt, self.fri_params(cur_ckt), prev[1], prev[2], len(cur_ckt.public_inputs))
+            b = Builder()
+            pis = verify_proof_circuit(b, inner, *cur_proof)
+            b.register_public_inputs(pis)
+            w = b.build(min_log_n=RECURSION_THRESHOLD)
+            assert np.array_equal(w.pre, wckt.pre)
+            caps, openings, proof = self.prover.prove(w)
+            cur_ckt, cur_proof = w, (caps, openings, proof, w.public_inputs)
+        return cur_proof
+
+
+def map_logic(b, child_pis, inputs):
+    """MapCircuitWires::circuit_logic (integration.rs:75-93)"""
+    ins = [b.add_virtual(int(x)) for x in (inputs if inputs is not None else [0, 0, 0, 0])]
+    one = b.one()
+    acc = b.zero()
+    for t in ins:
+        is_odd = b.split_le(t, 64)[0]
+        acc = b.mul_add(b.sub(one, is_odd), t, acc)
+    return [acc] + b.hash_n_to_m_no_pad(ins, 4)
+
+
+def reduce_logic(b, child_pis, inputs):
+    """ReduceCircuitWires::circuit_logic (integration.rs:108-127)"""
+    acc = b.zero()
+    for pis in child_pis:
+        acc = b.add(acc, pis[0])
+    return [acc] + b.hash_n_to_m_no_pad([t for pis in child_pis for t in pis[1:5]], 4)

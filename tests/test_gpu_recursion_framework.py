@@ -1,0 +1,37 @@
+"""The recursion framework with real circuits on the HIP prover: four map proofs, two reduce levels above them, every
+proof = base prove() + wrap prove() by libmp2gpu with the device-side witness check on (prove()'s panic on a bad
+witness), universal verifiers inside the reduce circuit; the root's public inputs are the dataset's (integration.rs:224-228)
+and the root proof passes the oracle's verifier."""
+import importlib
+
+import numpy as np
+import pytest
+
+import circuits as C
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+
+
+def test_map_reduce_tree_of_real_proofs(ctx, mp2):
+    prover = FW.GpuProver(ctx)
+    circs = [R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)]
+    fw = R.RecursiveCircuits(circs, prover, FW.circuit_fri_params)
+    data = O.rand_field(16, 0xC0FFEE03)
+    level = [fw.generate_proof("map", [], [], data[4 * i:4 * i + 4]) for i in range(4)]
+    names = ["map"] * 4
+    while len(level) > 1:
+        level = [fw.generate_proof("reduce", [level[2 * i], level[2 * i + 1]], [names[2 * i], names[2 * i + 1]], None) for i in range(len(level) // 2)]
+        names = ["reduce"] * len(level)
+    pis = level[0][3]
+    assert int(pis[0]) == sum(int(x) for x in data if int(x) % 2 == 0) % O.P
+    hs = [O.hash_n_to_m_no_pad(data[4 * i:4 * i + 4], 4) for i in range(4)]
+    while len(hs) > 1:
+        hs = [O.hash_n_to_m_no_pad(np.concatenate([hs[2 * i], hs[2 * i + 1]]), 4) for i in range(len(hs) // 2)]
+    assert np.array_equal(pis[1:5], hs[0])
+    assert np.array_equal(pis[5:], np.asarray(fw.set_digest, dtype=np.uint64))
+    wckt, wcap, wdig = fw.chains["reduce"][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *level[0][:3]) == 0
+    prover.free()

@@ -82,3 +82,52 @@ def test_wrap_rejects_a_bad_inner_proof(base_and_proof):
     pis[0] = (int(pis[0]) + 1) % O.P
     with pytest.raises(AssertionError):
         R.wrap_circuit(inner, caps, openings, proof, pis)
+
+
+class OracleProver:
+    """proving back end for recursion.RecursiveCircuits on the CPU: the oracle proves, and verifies what it proved"""
+
+    def verifier_data(self, ckt):
+        return verifier_data(ckt)
+
+    def prove(self, ckt):
+        cap, cd = verifier_data(ckt)
+        fp = C.oracle_params(ckt)
+        caps, openings, proof, _ = C.prove(ckt, fp, cd)
+        assert C.verify(ckt, fp, cd, ckt.pi_hash, caps, openings, proof) == 0
+        return caps, openings, proof
+
+    def two_to_one(self, left, right):
+        return [int(x) for x in O.perm(np.array(list(left) + list(right) + [0] * 4, dtype=np.uint64))[:4]]
+
+
+def test_map_reduce_with_the_universal_verifier():
+    """recursion-framework/tests/integration.rs:138-228 with real circuits: two map proofs and the reduce proof over
+    them, every one wrapped to the shared shape; the reduce circuit holds two universal verifiers (verifier data as
+    witnesses, their digest recomputed and shown to be in the circuit set, circuit_set.rs:136-237) and exposes (sum of
+    the even elements, digest of the dataset, circuit-set digest)."""
+    FWm = importlib.import_module("mapreduce-plonky2_amd.framework")
+    circs = [R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)]
+    fw = R.RecursiveCircuits(circs, OracleProver(), FWm.circuit_fri_params)
+    assert {k: [c[0].log_n for c in v] for k, v in fw.chains.items()} == {"map": [6, 13], "reduce": [14, 13]}
+    data = O.rand_field(8, 5)
+    p0 = fw.generate_proof("map", [], [], data[:4])
+    p1 = fw.generate_proof("map", [], [], data[4:])
+    root = fw.generate_proof("reduce", [p0, p1], ["map", "map"], None)
+    pis = root[3]
+    assert int(pis[0]) == sum(int(x) for x in data if int(x) % 2 == 0) % O.P
+    want = O.hash_n_to_m_no_pad(np.concatenate([O.hash_n_to_m_no_pad(data[:4], 4), O.hash_n_to_m_no_pad(data[4:], 4)]), 4)
+    assert np.array_equal(pis[1:5], want)
+    # the circuit-set digest: the oracle's Merkle root (cap height 0) over the two final wrap circuits' digests
+    want_set = O.merkle_cap(O.merkle_build(np.stack([np.asarray(d, dtype=np.uint64) for d in fw.digests]), 0), 0)[0]
+    assert np.array_equal(pis[5:], want_set) and np.array_equal(p0[3][5:], want_set)
+    # the final proof verifies under the reduce circuit's final verifier data
+    wckt, wcap, wdig = fw.chains["reduce"][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *root[:3]) == 0
+    # a proof of a circuit outside the set cannot be used: the membership proof does not exist
+    with pytest.raises(StopIteration):
+        fw.membership([1, 2, 3, 4])
+    # a child proof with foreign verifier data fails inside the universal verifier (the digest check / the transcript)
+    with pytest.raises(AssertionError):
+        bad = (p1[0], p1[1], p1[2], p0[3])  # p1's proof under p0's public inputs
+        fw.generate_proof("reduce", [p0, bad], ["map", "map"], None)
