@@ -124,6 +124,107 @@ def check_against_oracle(samples, budget_s, timed):
     return verified[0], base
 
 
+def run_tree(args, rank, local_rank, world, dist, torch, VARIANT):
+    """--workload tree: BASELINE configs[2]/[3] shaped map-reduce. Per step every rank proves the subtree over its
+    `--batch` leaves bottom-up (framework.MapReduce: base 2^13 + wrap 2^12 per node, public-input chain of
+    recursion-framework/tests/integration.rs:108-127), then the log2(world) levels above the shard boundary: the rank
+    that owns a parent (sharding.tree_handoff_plan: the owner of its first leaf) receives the other child's final proof
+    -- caps, openings, FRI proof and public inputs as device tensors over RCCL, no host copy -- and proves the parent
+    from the two children's public inputs. value = leaf proofs per second with all aggregation proving inside the timed
+    region. (The circuits are the synthetic gate-level ones of the headline workload: a parent's witness depends on its
+    children through the public-input chain only; recursion.py holds the real verifier circuits.)"""
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
+    FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+    assert world & (world - 1) == 0 and args.batch & (args.batch - 1) == 0, "powers of two"
+    ctx0, ctx1 = mp2.Context(local_rank), mp2.Context(local_rank)
+    B = args.batch
+    mr = FW.MapReduce(ctx0, ctx1, B, chunk=min(128, B), variant=VARIANT, seed=SEED, base_bits=args.base_bits, data_seed=SEED + 977 * rank)
+    top = FW.FrameworkProver(ctx0, ctx1, 1, variant=VARIANT, seed=SEED, circuits=(mr.fw.base_ckt, mr.fw.wrap_ckt))
+    nccl = dist is not None and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", local_rank) if nccl else None
+    wp = top.wrap
+    fp = wp.fp
+    sizes = [fp.n_oracles * fp.cap_words, fp.n_openings * 2, fp.proof_words, FW.NUM_PUBLIC_INPUTS + 4]
+    n_levels = world.bit_length() - 1
+    moved = [0]
+
+    def step():
+        root = mr.run(keep=lambda level, index: False)  # the subtree of this rank; its root node was proved by a 2-wide or wider prover
+        pv = mr.prover_for(1)
+        pis = root
+        holder = pv.wrap  # the CircuitProver whose device outputs hold this rank's current root proof (slot 0)
+        for lvl in range(n_levels):
+            bit = 1 << lvl
+            if rank & (bit - 1):
+                break  # handed its subtree over at a lower level
+            if rank & bit:
+                dst = rank - bit
+                d_pis = ctx1.to_device(pis)
+                bufs = (holder.pr.d_caps, holder.pr.d_openings, holder.pr.d_proof, d_pis)
+                if nccl:
+                    ctx1.sync()
+                    parts = [sharding.device_words(b, 0, n, dev) for b, n in zip(bufs, sizes)]
+                else:
+                    parts = [torch.from_numpy(b.download((n,)).view(np.int64)) for b, n in zip(bufs, sizes)]
+                sharding.send_proof_words(dist, parts, dst, dev)
+                moved[0] += sum(sizes) * 8
+                break
+            got = sharding.recv_proof_words(dist, sizes, rank + bit, dev)
+            child = got[3].cpu().numpy().view(np.uint64)
+            # the parent's public inputs (ReduceCircuitWires): sum of the sums, hash of the hashes; same circuit set
+            assert np.array_equal(child[FW.NUM_PUBLIC_INPUTS:], pis[FW.NUM_PUBLIC_INPUTS:]), "children of different circuit sets"
+            own = FW.MapReduce.reduce_public_inputs(ctx0, np.stack([pis[:FW.NUM_PUBLIC_INPUTS], child[:FW.NUM_PUBLIC_INPUTS]]), VARIANT)[0]
+            pis = np.concatenate([own, pis[FW.NUM_PUBLIC_INPUTS:]])
+            top.generate_proofs(ctx0.hash_no_pad_batch(pis[None], 4, VARIANT))
+            holder = top.wrap
+        ctx0.sync(); ctx1.sync()
+        return pis
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx0.sync(); ctx1.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        root_pis = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda" if nccl else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    out = None
+    if rank == 0:
+        # the root's public inputs are the whole dataset's: sum of the even elements of every rank's data, hash chain of the hashes
+        total_even, hs = 0, []
+        for r in range(world):
+            data = importlib.import_module("mapreduce-plonky2_amd.circuits").rand_field(B * FW.INPUT_CHUNK_SIZE, SEED + 977 * r)
+            total_even = (total_even + sum(int(x) for x in data if int(x) % 2 == 0)) % ((1 << 64) - (1 << 32) + 1)
+        assert int(root_pis[0]) == total_even, "root sum != sum of the even elements of the dataset"
+        n_nodes = world * (2 * B - 1) + (world - 1)
+        out = {"metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build, 1/2/4/8 GPU",
+               "value": world * B * args.steps / dt, "unit": "leaf proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u64 (Goldilocks field)", "data": "synthetic",
+               "framework_proofs_per_s": n_nodes * args.steps / dt,
+               "config": {"workload": f"tree: {world} x {B} leaf proofs and the {n_nodes - world * B} aggregation nodes above them per step (each node = base "
+                                      f"2^{args.base_bits} + wrap 2^12 prove()); {n_levels} level(s) cross ranks by send/recv of the child's final proof "
+                                      f"({sum(sizes) * 8} B, {'device tensors over RCCL' if nccl else 'host tensors over gloo'})",
+                          "batch_per_rank": B, "hasher": "Poseidon2" if VARIANT == 0 else "Poseidon", "root_public_inputs": [int(x) for x in root_pis]}}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+    mr.free(); top.free()
+    ctx1.close(); ctx0.close()
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +245,10 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU leg (the self-check still runs)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the sampled proofs")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work for the cpu_baseline sample")
+    ap.add_argument("--workload", choices=("leaves", "tree"), default="leaves",
+                    help="leaves (default, the headline): independent leaf proofs. tree: every step also proves the 2-to-1 aggregation "
+                         "levels above the leaves -- locally below the shard boundary, then log2(ranks) levels whose child proofs move "
+                         "between ranks with point-to-point send/recv (RCCL on device tensors)")
     args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,6 +270,8 @@ def main(argv=None):
             dist.init_process_group(backend)
 
     VARIANT = 0 if args.hasher == "poseidon2" else 1
+    if args.workload == "tree":
+        return run_tree(args, rank, local_rank, world, dist, torch, VARIANT)
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
     C = importlib.import_module("mapreduce-plonky2_amd.circuits")  # synthetic circuit + witness generator (pure Python)

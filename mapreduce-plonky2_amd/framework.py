@@ -108,10 +108,11 @@ class FrameworkProver:
     node's public-inputs hash."""
 
     def __init__(self, ctx_base, ctx_wrap, batch, base_bits=13, wrap_bits=12, variant=POSEIDON2, seed=0xC0FFEE03,
-                 base_kinds=None, wrap_kinds=None, witness_check=False):
+                 base_kinds=None, wrap_kinds=None, witness_check=False, circuits=None):
         self.batch, self.variant, self.seed = batch, variant, seed
-        self.base_ckt = C.build(base_bits, base_kinds or C.LEAF_KINDS, seed + base_bits)
-        self.wrap_ckt = C.build(wrap_bits, wrap_kinds or C.VERIFIER_KINDS, seed + wrap_bits + 100)
+        # circuits = (base, wrap) built earlier: provers of several batch sizes share one pair of circuits
+        self.base_ckt, self.wrap_ckt = circuits or (C.build(base_bits, base_kinds or C.LEAF_KINDS, seed + base_bits),
+                                                    C.build(wrap_bits, wrap_kinds or C.VERIFIER_KINDS, seed + wrap_bits + 100))
         self.base = CircuitProver(ctx_base, self.base_ckt, batch, variant, witness_check, bind_public_inputs=True)
         self.wrap = CircuitProver(ctx_wrap, self.wrap_ckt, batch, variant, witness_check, bind_public_inputs=True)
         self.d_base_w = tile_witness(ctx_base, self.base_ckt, batch, seed)
@@ -144,12 +145,21 @@ class MapReduce:
     digest. Levels are proved bottom-up in chunks of `chunk` nodes (children before parents, as ryhope's work
     plan orders them)."""
 
-    def __init__(self, ctx_base, ctx_wrap, n_leaves, chunk=128, variant=POSEIDON2, seed=0xC0FFEE03, base_bits=13, wrap_bits=12):
+    def __init__(self, ctx_base, ctx_wrap, n_leaves, chunk=128, variant=POSEIDON2, seed=0xC0FFEE03, base_bits=13, wrap_bits=12, data_seed=None):
         assert n_leaves >= 1 and n_leaves & (n_leaves - 1) == 0
         self.ctx, self.n_leaves, self.variant = ctx_base, n_leaves, variant
-        self.fw = FrameworkProver(ctx_base, ctx_wrap, min(chunk, n_leaves), base_bits=base_bits, wrap_bits=wrap_bits, variant=variant, seed=seed)
-        self.dataset = C.rand_field(n_leaves * INPUT_CHUNK_SIZE, seed)
+        top = min(chunk, n_leaves)
+        self.fw = FrameworkProver(ctx_base, ctx_wrap, top, base_bits=base_bits, wrap_bits=wrap_bits, variant=variant, seed=seed)
+        # the narrow levels near the root go through smaller provers of the same circuits (a level of 4 nodes must not
+        # cost a batch of 128)
+        self.fws = [self.fw] + [FrameworkProver(ctx_base, ctx_wrap, b, variant=variant, seed=seed, circuits=(self.fw.base_ckt, self.fw.wrap_ckt))
+                                for b in (16, 2) if b < top]
+        # `seed` fixes the circuits (every rank of a job builds the same ones), data_seed this instance's share of the dataset
+        self.dataset = C.rand_field(n_leaves * INPUT_CHUNK_SIZE, seed if data_seed is None else data_seed)
         self.levels = []
+
+    def prover_for(self, n_nodes):
+        return min((f for f in self.fws if f.batch >= n_nodes), key=lambda f: f.batch, default=self.fw)
 
     def leaf_public_inputs(self):
         chunks = self.dataset.reshape(self.n_leaves, INPUT_CHUNK_SIZE)
@@ -183,10 +193,11 @@ class MapReduce:
             hashes = self.ctx.hash_no_pad_batch(full, 4, self.variant)  # public_inputs_hash of prove()
             for lo in range(0, len(hashes), fw.batch):
                 part = hashes[lo:lo + fw.batch]
-                fw.generate_proofs(part)
+                pv = self.prover_for(len(part))
+                pv.generate_proofs(part)
                 want = [i for i in range(len(part)) if keep(level, lo + i)]
                 if want:
-                    (bc, bo, bp), (wc, wo, wp) = fw.results()
+                    (bc, bo, bp), (wc, wo, wp) = pv.results()
                     for i in want:
                         self.kept[(level, lo + i)] = (full[lo + i], part[i], (bc[i], bo[i], bp[i]), (wc[i], wo[i], wp[i]))
                 self.n_proofs += len(part)
@@ -199,7 +210,8 @@ class MapReduce:
             level += 1
 
     def free(self):
-        self.fw.free()
+        for f in self.fws:
+            f.free()
 
 
 class GpuProver:

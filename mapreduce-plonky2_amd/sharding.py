@@ -108,6 +108,38 @@ def exchange_bytes(dist, payload, src, dst, device=None):
     return None
 
 
+class _DevView:
+    """a DeviceBuffer range as a __cuda_array_interface__ object (torch.as_tensor wraps it without a copy)"""
+
+    def __init__(self, buf, offset_bytes, n_words):
+        self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i8", "data": (buf.ptr.value + offset_bytes, False), "version": 2}
+        self._keep = buf
+
+
+def device_words(buf, offset_bytes, n_words, device):
+    """int64 torch view of n_words u64 words of a libmp2gpu device buffer (same bits; RCCL has no u64)"""
+    import torch
+    return torch.as_tensor(_DevView(buf, offset_bytes, n_words), device=device)
+
+
+def send_proof_words(dist, parts, dst, device=None):
+    """hand one child proof to the rank that proves its parent: `parts` = the prover's output ranges (caps, openings,
+    FRI proof words, public inputs) as int64 tensors, device tensors over RCCL (the proof never visits the host) or
+    host tensors over gloo. Sizes are fixed by the circuit shape, so there is no length message."""
+    for t in parts:
+        dist.send(t, dst)
+
+
+def recv_proof_words(dist, sizes, src, device=None):
+    import torch
+    out = []
+    for n in sizes:
+        t = torch.empty(n, dtype=torch.int64, device=device)
+        dist.recv(t, src)
+        out.append(t)
+    return out
+
+
 def all_gather_bytes(dist, payload, device=None):
     """all_gather of one variable-length byte string per rank (serialized root proofs of a wave):
     lengths first, then bodies padded to the longest. Returns [bytes per rank]."""
