@@ -153,7 +153,7 @@ class MapReduce:
         # the narrow levels near the root go through smaller provers of the same circuits (a level of 4 nodes must not
         # cost a batch of 128)
         self.fws = [self.fw] + [FrameworkProver(ctx_base, ctx_wrap, b, variant=variant, seed=seed, circuits=(self.fw.base_ckt, self.fw.wrap_ckt))
-                                for b in (16, 2) if b < top]
+                                for b in (64, 32, 16, 8, 4, 2, 1) if b < top]
         # `seed` fixes the circuits (every rank of a job builds the same ones), data_seed this instance's share of the dataset
         self.dataset = C.rand_field(n_leaves * INPUT_CHUNK_SIZE, seed if data_seed is None else data_seed)
         self.levels = []

@@ -60,6 +60,24 @@ def main():
         root = store[(len(plan), 0)]
         want = b"".join(bytes([i]) * (100 + i) for i in range(n_leaves))
         assert root == want, "aggregation order broken"
+    # ---- the proof hand-off of bench.py --workload tree: fixed-size word tensors, pairwise along the levels above the
+    # shard boundary (rank r with bit l set sends its subtree root to r - 2^l); payload = the sender's rank pattern
+    import torch
+    sizes = [7, 11, 5, 9]
+    mine = [torch.full((n,), 1000 * rank + i, dtype=torch.int64) for i, n in enumerate(sizes)]
+    acc = [rank]
+    for lvl in range(world.bit_length() - 1):
+        bit = 1 << lvl
+        if rank & (bit - 1):
+            break
+        if rank & bit:
+            sh.send_proof_words(dist, mine + [torch.tensor(acc + [-1] * (world - len(acc)), dtype=torch.int64)], rank - bit)
+            break
+        got = sh.recv_proof_words(dist, sizes + [world], rank + bit)
+        assert all(int(t[0]) == 1000 * (rank + bit) + i for i, t in enumerate(got[:4]))
+        acc += [int(x) for x in got[4] if int(x) >= 0]
+    if rank == 0:
+        assert sorted(acc) == list(range(world)), "every rank's subtree reaches the root exactly once"
     # ---- work-plan driven proving: same UpdateTree on every rank, subtrees dealt per wave, root results
     # published by one all_gather per wave; the root must equal the sequential bottom-up result
     import hashlib

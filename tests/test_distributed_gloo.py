@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world_size 2 over gloo (no GPU)."""
+"""N>1 path on CPU: world sizes 2 and 4 over gloo (no GPU)."""
 import os
 import subprocess
 import sys
@@ -8,11 +8,11 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4])
 def test_sharded_digest_and_tree_handoff(world):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(HERE, "_dist_worker.py")]
+           "--master-addr", "127.0.0.1", "--master-port", str(29533 + world), os.path.join(HERE, "_dist_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert r.stdout.count(" ok") == world
