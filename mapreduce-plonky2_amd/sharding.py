@@ -163,33 +163,47 @@ def run_workplan(dist, plan, prove_item, device=None):
     """Drive an UpdatePlan (workplan.py) over the ranks of `dist` (None = single process).
 
     Every rank holds the same plan. Per wave: drain the Ready items, deal them to ranks
-    (`workplan.assign_subtrees`, deterministic), each rank proves its items with
-    `prove_item(item, child_results) -> bytes` -- an item is one node or one spun-off subtree proved
-    bottom-up locally, only its root result leaves the rank -- then one all_gather per wave publishes the
-    root results, and every rank marks the wave's items done. `child_results` maps the keys of already
-    finished items to their results (what a parent above the subtree boundary needs). Returns
-    {key: result} of every item; the last one is the tree root's. Children-before-parents is the plan's
-    own guarantee (ryhope/src/storage/updatetree.rs:449-531); the collective is one small all_gather per
-    wave, latency-bound, outside the per-proof path."""
-    import struct
+    (`workplan.assign_subtrees`, deterministic), hand every item's owner the results it needs from other ranks --
+    the roots of the spun-off subtrees (or single nodes) below it, each sent point to point from the rank that
+    proved it (`exchange_bytes`: one send/recv pair per child proof, the survey's binary-tree pattern; nothing is
+    broadcast) -- then each rank proves its items with `prove_item(item, child_results) -> bytes`: an item is one
+    node or one spun-off subtree proved bottom-up locally, only its root result ever leaves the rank. Every rank
+    walks the same list of transfers in the same order, so a rank is in at most one transfer at a time and the
+    blocking pairs cannot deadlock. Children-before-parents is the plan's own guarantee
+    (ryhope/src/storage/updatetree.rs:449-531). Returns {key: result} of the items this rank holds (proved or
+    received); the tree root's result is published to every rank at the end (one small all_gather)."""
     from . import workplan as wp
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
-    results = {}
+    parents = plan.tree().parents()
+    kids = {}
+    for k, p in parents.items():
+        kids.setdefault(p, []).append(k)
+    root_key = next(k for k, p in parents.items() if p is None)
+    results, producer = {}, {}
     while True:
         wave = wp.drain_wave(plan)
         if not wave:
             if not plan.completed():
                 raise RuntimeError("work plan stalled: items not marked done")
-            return results
+            break
         owners = wp.assign_subtrees(wave, world)
-        mine = [(it.k, prove_item(it, results)) for it, o in zip(wave, owners) if o == rank]
-        blob = b"".join(struct.pack("<QQ", k, len(r)) + r for k, r in mine)
-        for part in (all_gather_bytes(dist, blob, device) if dist is not None else [blob]):
-            off = 0
-            while off < len(part):
-                k, ln = struct.unpack_from("<QQ", part, off)
-                results[k] = part[off + 16:off + 16 + ln]
-                off += 16 + ln
+        for it, o in zip(wave, owners):
+            inside = set(it.subtree.nodes()) if it.subtree is not None else {it.k}
+            needed = sorted(c for n in inside for c in kids.get(n, []) if c not in inside)
+            for c in needed:
+                src = producer[c]
+                if src != o and dist is not None:
+                    got = exchange_bytes(dist, results.get(c, b""), src, o, device)
+                    if rank == o:
+                        results[c] = got
+        for it, o in zip(wave, owners):
+            if o == rank:
+                results[it.k] = prove_item(it, results)
+            producer[it.k] = o
         for it in wave:
             plan.done(it.k)
+    if dist is not None:
+        parts = all_gather_bytes(dist, results.get(root_key, b"") if producer.get(root_key) == rank else b"", device)
+        results[root_key] = parts[producer[root_key]]
+    return results

@@ -66,6 +66,12 @@ def test_column_identifiers(ctx, mp2):
         assert ids.identifier_for_outer_mapping_key_column(ctx, 7, addr, chain, b"x", variant) == want(b"\0OUT_KEY" + bytes([7]) + extra, variant)
         assert ids.identifier_for_inner_mapping_key_column(ctx, 7, addr, chain, b"x", variant) == want(b"\0\0IN_KEY" + bytes([7]) + extra, variant)
     assert ids.identifier_block_column(ctx, 0) != ids.identifier_block_column(ctx, 1)
+    # a whole table's columns in one batch (mixed lengths are grouped per launch, order kept)
+    slots = [(s, o, ln, w) for s in range(6) for (o, ln, w) in ((0, 256, 0), (12, 32, 1))]
+    got = ids.table_column_identifiers(ctx, slots, addr, chain)
+    assert got == [ids.identifier_for_value_column(ctx, s, o, ln, w, addr, chain) for (s, o, ln, w) in slots]
+    mixed = [b"BLOCK_NUMBER", b"x" * 40, b"OFFCHAIN_TABLEtcol", b"y" * 40]
+    assert ids.identifiers_batch(ctx, mixed) == [want(m, 0) for m in mixed]
 
 
 def test_index_node_hash(ctx, mp2):
