@@ -384,7 +384,7 @@ hipError_t NttEngine::plan(u32 log_n, bool inverse, NttPlan** out) {
     HIPCHK(stage_tw(&p->tw_a, w1, p->log_n1));
     HIPCHK(powers(&p->tw4_lo, wn, 4096));
     HIPCHK(powers(&p->tw4_hi, gl_pow(wn, 4096), log_n > 12 ? (1u << (log_n - 12)) : 1));
-    if (log_n <= 22) {  // full 4-step table (<= 32 MB): one multiply per point instead of two
+    if (log_n <= 22 && !getenv("MP2G_NTT_NOFULL")) {  // full 4-step table (<= 32 MB): one multiply per point instead of two
       HIPCHK(dev_alloc(&p->tw4_full, (size_t)1 << log_n));
       hipLaunchKernelGGL(tw4_full_kernel, dim3((u32)((((u64)1 << log_n) + 255) / 256)), dim3(256), 0, stream, p->tw4_full, wn, p->log_n1, p->log_n2);
       HIPCHK(hipGetLastError());
@@ -438,7 +438,7 @@ hipError_t NttEngine::ensure_scratch(size_t words) {
 // points per block (measured on MI355X, tools/dbg/ntt_only.py): 4096 (256 lanes) for T <= 2^10 and
 // T = 2^12, 8192 (512 lanes, two blocks per CU) for T = 2^11 where the twiddle table is amortised
 template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : (LT == 11 ? 2 : 12 - LT); }
-template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : 12 - LT; }
+template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : (LT == 10 ? 3 : 12 - LT); }  // 2^10 x 8 columns: +4 % at 2^22 (ntt22.py)
 template <int LT, int LW> static size_t lds_bytes() {
   int e = (1 << LT) << LW;
   return (size_t)(e + (e >> 4) + 1 + R8Tw<LT>::LDS_WORDS + 1) * sizeof(u64);
@@ -497,6 +497,12 @@ static hipError_t launch_cols_lw(const NttArgs& a, u64* dst_dense, hipStream_t s
 
 template <int LT>
 static hipError_t launch_cols(const NttArgs& a, u64* dst_dense, hipStream_t st) {
+  if constexpr (LT == 10) {  // tuning aid: MP2G_NTT_LW10=1|2
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MP2G_NTT_LW10"); v = e ? atoi(e) : 0; }
+    if (v == 1) return launch_cols_lw<LT, 1>(a, dst_dense, st);
+    if (v == 2) return launch_cols_lw<LT, 2>(a, dst_dense, st);
+  }
   if constexpr (LT == 11) {
     if (lw11_override() == 1) return launch_cols_lw<LT, 1>(a, dst_dense, st);
     if (lw11_override() == 3) return launch_cols_lw<LT, 3>(a, dst_dense, st);

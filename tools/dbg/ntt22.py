@@ -18,6 +18,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         print(f"  batch {batch}: {t*1e3/batch:.1f} us per transform, {16*n*batch/t/1e6:.0f} GB/s", flush=True)
     ctx.close()
 else:
-    for env in ({}, {"MP2G_NTT_LW11": "1"}, {"MP2G_NTT_LW11": "3"}, {"MP2G_NTT_N1": "10"}, {"MP2G_NTT_N1": "12"}, {"MP2G_NTT_N1": "10", "MP2G_NTT_LW11": "1"}):
+    import ast
+    envs = ast.literal_eval(sys.argv[1]) if len(sys.argv) > 1 else ({}, {"MP2G_NTT_LW11": "1"}, {"MP2G_NTT_LW11": "3"}, {"MP2G_NTT_N1": "10"}, {"MP2G_NTT_N1": "12"}, {"MP2G_NTT_N1": "10", "MP2G_NTT_LW11": "1"})
+    for env in envs:
         print(env or "default", flush=True)
         subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, **env))
