@@ -209,6 +209,62 @@ def test_graph_replay_is_identical(ctx, mp2):
     pr.free()
 
 
+def test_graph_survives_a_scratch_reallocation(ctx, mp2):
+    """A captured graph references the context's shared NTT scratch (the quotient iNTT at log_n >= 10 runs two natural-order
+    passes through it). A larger transform on the same context reallocates that buffer: the next prove must notice
+    (generation counter) and re-capture instead of replaying into freed memory."""
+    log_n, B = 10, 1
+    kinds = [(C.NOOP, 0, 0, 0), (C.CONSTANT, 2, 0, 0), (C.PUBLIC_INPUT, 0, 0, 0), (C.ARITHMETIC, 20, 0, 0), (C.POSEIDON2, 0, 0, 0)]
+    ckt = C.build(log_n, kinds, 12)
+    ofp, fp = params(mp2, ckt, log_n, pow_bits=4, num_queries=3)
+    pr = mp2.BatchedProver(ctx, fp, B)
+    pr.set_preprocessed(ctx.to_device(ckt.pre))
+    pr.enable_permutation(C.NUM_ROUTED, 8)
+    pr.enable_quotient()
+    pr.set_gates(gpu_gates(mp2, ckt), ckt.num_selectors)
+    d_w, d_ph, d_cd = ctx.to_device(ckt.wires[None]), ctx.to_device(ckt.pi_hash[None]), ctx.to_device(O.rand_field(4, 1))
+    pr.enable_graph(True)
+    for _ in range(3):  # plain, capture, replay
+        pr.prove([d_w, None, None], d_cd, d_ph)
+    ref = pr.results()
+    oc, oo, op, _ = C.prove(ckt, ofp, O.rand_field(4, 1))
+    assert np.array_equal(ref[0][0], oc) and np.array_equal(ref[1][0], oo) and np.array_equal(ref[2][0], op)
+    big = O.rand_field((64, 1 << 14), 3)  # a natural-order two-pass transform 64x larger than anything the prover ran: scratch grows
+    want = O.fft(big)
+    assert np.array_equal(ctx.ntt(big), want)
+    for _ in range(2):
+        pr.prove([d_w, None, None], d_cd, d_ph)
+        got = pr.results()
+        assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+    pr.free()
+
+
+def test_one_challenge_round(ctx, mp2):
+    """num_challenges = 1 (zs_count 1): one beta, one gamma, one alpha are drawn (plonk/prover.rs get_n_challenges(num_challenges)),
+    Z / partial products and the quotient use the same gamma, and the proof verifies"""
+    log_n = 6
+    ckt = C.build(log_n, C.ALL_KINDS, 17)
+    ofp = O.standard_params(log_n, (int(ckt.pre.shape[0]), C.NUM_WIRES, 10, 8), zs_count=1, pow_bits=4, num_queries=3)
+    fp = mp2.FriParams()
+    ctypes.memmove(ctypes.byref(fp), ctypes.byref(ofp), ctypes.sizeof(fp))
+    pr = mp2.BatchedProver(ctx, fp, 2)
+    pr.set_preprocessed(ctx.to_device(ckt.pre))
+    pr.enable_permutation(C.NUM_ROUTED, 8)
+    pr.enable_quotient()
+    pr.set_gates(gpu_gates(mp2, ckt), ckt.num_selectors)
+    pr.enable_witness_check()
+    cd = O.rand_field(4, 2)
+    pr.prove([ctx.to_device(np.stack([ckt.wires] * 2)), None, None], ctx.to_device(cd), ctx.to_device(np.stack([ckt.pi_hash] * 2)))
+    assert pr.witness_status().tolist() == [0, 0]
+    caps, openings, proofs = pr.results()
+    oc, oo, op, chal = C.prove(ckt, ofp, cd)
+    for b in range(2):
+        assert np.array_equal(caps[b], oc) and np.array_equal(openings[b], oo) and np.array_equal(proofs[b], op)
+    assert C.verify(ckt, ofp, cd, ckt.pi_hash, caps[0], openings[0], proofs[0]) == 0
+    assert C.identity_check(ckt, ofp, openings[0], chal) == 0
+    pr.free()
+
+
 def test_noop_only_table_and_distinct_witnesses(ctx, mp2):
     """(i) a gate table holding only NoopGate gives the copy-constraint-only quotient; (ii) the proofs of one
     batch are independent: different witnesses (free cells re-drawn) and public-input hashes per proof."""
