@@ -381,6 +381,31 @@ int mp2g_eval_gate_constraints(mp2g_ctx* ctx, const mp2g_gate* gates, uint32_t n
                                const uint64_t* consts, uint32_t num_constants, const uint64_t* wires, uint32_t wires_w,
                                uint64_t npts, const uint64_t pi_hash[4], uint64_t* out);
 
+/* ---- witness generation for the recursion circuits (host side, no GPU) -----------------------------------
+ * Replaces [dep] plonky2 iop/generator.rs generate_partial_witness for the circuits the recursion framework builds
+ * (the wrap circuit, the universal-verifier circuits and their logic): the first line of prove() at
+ * recursion-framework/src/circuit_builder.rs:308 and wrap_circuit.rs:143. The circuit builder of the host
+ * (mapreduce-plonky2_amd/recursion.py) records its operations once as a straight-line program over value slots --
+ * the structure of these circuits does not depend on the witness -- and this entry replays it per proof:
+ *   tape        opcodes + operands (recursion.py OP_*: ArithmeticGate / ArithmeticExtensionGate operations,
+ *               Poseidon2Gate rows, BaseSumGate splits, RandomAccessGate copies, ReducingGate / ReducingExtensionGate
+ *               rows, CosetInterpolationGate rows, plain wire writes, division / split hints)
+ *   input_sids  the slots the caller provides, in order (the inner proof's public inputs, caps, openings, FRI proof
+ *               words, verifier data, membership proof, the circuit's own inputs)
+ *   const_slots (slot, value) pairs
+ * Validated at create (opcodes, lengths, slot / row / wire bounds). */
+typedef struct mp2g_witness_program mp2g_witness_program;
+int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t n_slots, uint32_t log_n, const uint32_t* input_sids,
+                                uint32_t n_inputs, const uint64_t* const_slots, uint32_t n_consts, mp2g_witness_program** out);
+uint32_t mp2g_witness_program_num_inputs(const mp2g_witness_program* p);
+/* inputs [batch][n_inputs] canonical field elements -> wires [batch][135][2^log_n] (host memory, the layout of
+ * mp2g_prover_prove_dev's d_values[0]); `threads` host threads (0 = all), one proof per thread at a time.
+ * probe_sids (may be NULL): slots whose final values are also returned, probe_out [batch][n_probe] -- the circuit's
+ * public inputs and their hash, which prove() needs next to the wires. */
+int mp2g_witness_program_run(const mp2g_witness_program* p, const uint64_t* inputs, uint32_t batch, uint32_t threads, uint64_t* wires,
+                             const uint32_t* probe_sids, uint32_t n_probe, uint64_t* probe_out);
+void mp2g_witness_program_free(mp2g_witness_program* p);
+
 /* ---- work plan: the reference's only scheduler --------------------------------------
  * Host-side, no GPU involved. Replaces ryhope/src/storage/updatetree.rs: UpdateTree (:19-242, arena
  * of nodes, node 0 = root, children ordered by arena index) and UpdatePlan (:422-541). Keys are u64

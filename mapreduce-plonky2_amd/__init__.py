@@ -536,6 +536,40 @@ class BatchedProver:
         self.h = None
 
 
+class WitnessProgram:
+    """mp2g_witness_program: the witness generator of one circuit built by recursion.Builder (its recorded tape),
+    replayed on the host for batches of input vectors. No GPU involved."""
+
+    def __init__(self, ckt):
+        tape, ins, cs = _arr(ckt.tape), _arr(ckt.input_sids, np.uint32), _arr(ckt.const_slots).reshape(-1, 2)
+        self.log_n, self.n_inputs = ckt.log_n, int(ins.size)
+        self.probe = _arr(np.concatenate([ckt.pi_hash_sids, ckt.public_input_sids]), np.uint32)
+        self.n_public_inputs = int(ckt.public_input_sids.size)
+        self.h = ctypes.c_void_p()
+        _ck(load().mp2g_witness_program_create(_p(tape), ctypes.c_size_t(tape.size), int(ckt.n_slots), int(ckt.log_n), _p(ins), int(ins.size),
+                                               _p(cs), int(cs.shape[0]), ctypes.byref(self.h)))
+
+    def run(self, inputs, threads=0, out=None):
+        """inputs [batch][n_inputs] -> (wires [batch][135][n], pi_hash [batch][4], public_inputs [batch][n_pi])"""
+        a = _arr(inputs).reshape(-1, self.n_inputs)
+        B = a.shape[0]
+        wires = out if out is not None else np.empty((B, 135, 1 << self.log_n), dtype=np.uint64)
+        probe = np.empty((B, self.probe.size), dtype=np.uint64)
+        _ck(load().mp2g_witness_program_run(self.h, _p(a), B, int(threads), _p(wires), _p(self.probe), int(self.probe.size), _p(probe)))
+        return wires, probe[:, :4], probe[:, 4:]
+
+    def free(self):
+        if self.h:
+            load().mp2g_witness_program_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 # ---- Ecgfp5 multiset digest (mp2-common/src/group_hashing) ---------------------------------
 def map_to_curve_batch(ctx, inputs, variant=POSEIDON2, weierstrass=False):
     """map_to_curve_point for each row of `inputs`; returns encodings [count][5] (and the 11-limb

@@ -1,0 +1,318 @@
+// Witness generation for circuits built by recursion.py (host code; no GPU involved).
+//
+// Replaces [dep] plonky2 iop/generator.rs generate_partial_witness for the circuits of the recursion framework
+// (first line of prove(), recursion-framework/src/circuit_builder.rs:308, wrap_circuit.rs:143): the wrap circuit,
+// the universal-verifier circuits and their logic. plonky2 walks a dependency graph of per-gate generators; here the
+// builder's operations are recorded once, in order, as a straight-line program over value slots (recursion.py OP_*),
+// because the structure of these circuits does not depend on the witness. Replaying the program for one input
+// vector (the inner proof, its verifier data, the circuit's own inputs) fills the 135 x n wire matrix; a batch of
+// input vectors is replayed by a pool of host threads, one proof per thread at a time, straight into the layout
+// mp2g_prover_prove_dev takes ([batch][135][n]).
+#define MP2G_DEVCONST static const
+#include "gl.cuh"
+#include "perm_constants.h"
+#include "ctx.h"
+#include <atomic>
+#include <cstring>
+#include <new>
+#include <thread>
+#include <vector>
+
+using namespace mp2g;
+#define NEED(c, msg) do { if (!(c)) return fail("invalid argument: %s", msg); } while (0)
+
+namespace {
+enum { OP_ARITH = 1, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
+       OP_HINT_LO63, OP_HINT_HI, OP_END };
+const u32 BASE_SUM_LIMBS = 63, RA_BITS = 4, RA_COPIES = 4, RED_COEFFS = 43, RED_EXT_COEFFS = 32, NUM_WIRES = 135;
+
+// operand count after the opcode; 0 = variable (OP_COSET: 3 + 2 * 2^bits + 4)
+u32 op_len(u64 op, const u64* t) {
+  switch (op) {
+    case OP_ARITH: return 8;
+    case OP_ARITH_EXT: return 12;
+    case OP_P2: return 1 + 12 + 1 + 12;
+    case OP_BASE_SUM: return 2 + BASE_SUM_LIMBS;
+    case OP_RA: return 3 + 16 + 1;
+    case OP_REDUCING: return 5 + RED_COEFFS + 2;
+    case OP_REDUCING_EXT: return 5 + 2 * RED_EXT_COEFFS + 2;
+    case OP_COSET: return 3 + (2u << t[1]) + 4;
+    case OP_WIRE: return 3;
+    case OP_HINT_DIV_EXT: return 6;
+    case OP_HINT_LO63: case OP_HINT_HI: return 2;
+    default: return ~0u;
+  }
+}
+
+// Poseidon2 linear layers on canonical values (poseidon.cuh keeps weak forms for the device; the witness wants the
+// intermediate states, canonical, as the gate's wires)
+void p2_external(u64 s[12]) {
+  static const u32 M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
+  u64 t[12];
+  for (int c = 0; c < 3; c++)
+    for (int i = 0; i < 4; i++) {
+      u64 acc = 0;
+      for (int j = 0; j < 4; j++) acc = gl_add(acc, gl_mul_small(s[4 * c + j], M4[i][j]));
+      t[4 * c + i] = acc;
+    }
+  for (int i = 0; i < 4; i++) {
+    u64 sum = gl_add(gl_add(t[i], t[4 + i]), t[8 + i]);
+    for (int c = 0; c < 3; c++) s[4 * c + i] = gl_add(t[4 * c + i], sum);
+  }
+}
+void p2_internal(u64 s[12]) {
+  u64 sum = 0;
+  for (int i = 0; i < 12; i++) sum = gl_add(sum, s[i]);
+  for (int i = 0; i < 12; i++) s[i] = gl_add(gl_mul(s[i], POSEIDON2_DIAG_M1[i]), sum);
+}
+}  // namespace
+
+struct mp2g_witness_program {
+  std::vector<u64> tape;
+  std::vector<u32> input_sids;
+  std::vector<u64> consts;  // (sid, value) pairs
+  u32 n_slots = 0, log_n = 0;
+  u64 dom[6][32], bw[6][32];  // two-adic subgroup of 2^bits points and its barycentric weights, bits <= 5
+};
+
+namespace {
+// one proof: vals = scratch of n_slots words, wires = [135][n] (zero-filled here)
+void run_one(const mp2g_witness_program& P, const u64* inputs, u64* vals, u64* wires) {
+  const u64 n = (u64)1 << P.log_n;
+  memset(wires, 0, NUM_WIRES * n * sizeof(u64));
+  for (size_t i = 0; i < P.consts.size(); i += 2) vals[P.consts[i]] = P.consts[i + 1];
+  for (size_t i = 0; i < P.input_sids.size(); i++) vals[P.input_sids[i]] = inputs[i];
+#define W(col, row) wires[(u64)(col) * n + (row)]
+  const u64* t = P.tape.data();
+  const u64* end = t + P.tape.size();
+  while (t < end) {
+    const u64 op = *t++;
+    switch (op) {
+      case OP_WIRE: W(t[1], t[0]) = vals[t[2]]; t += 3; break;
+      case OP_ARITH: {
+        const u64 row = t[0], i = t[1], c0 = t[2], c1 = t[3];
+        const u64 m0 = vals[t[4]], m1 = vals[t[5]], ad = vals[t[6]];
+        const u64 o = gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1));
+        W(4 * i, row) = m0; W(4 * i + 1, row) = m1; W(4 * i + 2, row) = ad; W(4 * i + 3, row) = o;
+        vals[t[7]] = o;
+        t += 8;
+        break;
+      }
+      case OP_ARITH_EXT: {
+        const u64 row = t[0], i = t[1], c0 = t[2], c1 = t[3];
+        const gl2 m0 = gl2_make(vals[t[4]], vals[t[5]]), m1 = gl2_make(vals[t[6]], vals[t[7]]), ad = gl2_make(vals[t[8]], vals[t[9]]);
+        const gl2 o = gl2_add(gl2_scale(gl2_mul(m0, m1), c0), gl2_scale(ad, c1));
+        const u64 b = 8 * i;
+        W(b, row) = m0.a; W(b + 1, row) = m0.b; W(b + 2, row) = m1.a; W(b + 3, row) = m1.b;
+        W(b + 4, row) = ad.a; W(b + 5, row) = ad.b; W(b + 6, row) = o.a; W(b + 7, row) = o.b;
+        vals[t[10]] = o.a; vals[t[11]] = o.b;
+        t += 12;
+        break;
+      }
+      case OP_P2: {  // Poseidon2Gate: inputs 0..11, outputs 12..23, swap 24, deltas 25..28, S-box inputs 29.., 65.., 87..
+        const u64 row = t[0];
+        u64 in[12], s[12];
+        for (int i = 0; i < 12; i++) { in[i] = vals[t[1 + i]]; W(i, row) = in[i]; }
+        const u64 swap = vals[t[13]];
+        W(24, row) = swap;
+        for (int i = 0; i < 4; i++) {
+          const u64 delta = gl_mul(swap, gl_sub(in[i + 4], in[i]));
+          W(25 + i, row) = delta;
+          s[i] = gl_add(in[i], delta);
+          s[i + 4] = gl_sub(in[i + 4], delta);
+        }
+        for (int i = 8; i < 12; i++) s[i] = in[i];
+        p2_external(s);
+        for (int r = 0; r < 4; r++) {
+          for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], POSEIDON2_RC_EXT[12 * r + i]);
+          if (r) for (int i = 0; i < 12; i++) W(29 + 12 * (r - 1) + i, row) = s[i];
+          for (int i = 0; i < 12; i++) s[i] = gl_pow7(s[i]);
+          p2_external(s);
+        }
+        for (int r = 0; r < 22; r++) {
+          s[0] = gl_add(s[0], POSEIDON2_RC_INT[r]);
+          W(65 + r, row) = s[0];
+          s[0] = gl_pow7(s[0]);
+          p2_internal(s);
+        }
+        for (int r = 0; r < 4; r++) {
+          for (int i = 0; i < 12; i++) { s[i] = gl_add(s[i], POSEIDON2_RC_EXT[12 * (4 + r) + i]); W(87 + 12 * r + i, row) = s[i]; }
+          for (int i = 0; i < 12; i++) s[i] = gl_pow7(s[i]);
+          p2_external(s);
+        }
+        for (int i = 0; i < 12; i++) { W(12 + i, row) = s[i]; vals[t[14 + i]] = s[i]; }
+        t += 26;
+        break;
+      }
+      case OP_BASE_SUM: {
+        const u64 row = t[0], x = vals[t[1]];
+        W(0, row) = x;
+        for (u32 i = 0; i < BASE_SUM_LIMBS; i++) { const u64 b = (x >> i) & 1; W(1 + i, row) = b; vals[t[2 + i]] = b; }
+        t += 2 + BASE_SUM_LIMBS;
+        break;
+      }
+      case OP_RA: {
+        const u64 row = t[0], c = t[1], idx = vals[t[2]];
+        const u32 vs = 1u << RA_BITS, base = (2 + vs) * (u32)c, routed = (2 + vs) * RA_COPIES + 2;
+        W(base, row) = idx;
+        for (u32 i = 0; i < vs; i++) W(base + 2 + i, row) = vals[t[3 + i]];
+        for (u32 i = 0; i < RA_BITS; i++) W(routed + c * RA_BITS + i, row) = (idx >> i) & 1;
+        const u64 o = vals[t[3 + (idx & (vs - 1))]];
+        W(base + 1, row) = o;
+        vals[t[19]] = o;
+        t += 20;
+        break;
+      }
+      case OP_REDUCING: case OP_REDUCING_EXT: {
+        const bool ext = op == OP_REDUCING_EXT;
+        const u32 nc = ext ? RED_EXT_COEFFS : RED_COEFFS, start_accs = 6 + (ext ? 2 * nc : nc);
+        const u64 row = t[0];
+        const gl2 alpha = gl2_make(vals[t[1]], vals[t[2]]);
+        gl2 acc = gl2_make(vals[t[3]], vals[t[4]]);
+        W(2, row) = alpha.a; W(3, row) = alpha.b; W(4, row) = acc.a; W(5, row) = acc.b;
+        for (u32 i = 0; i < nc; i++) {
+          gl2 cf;
+          if (ext) { cf = gl2_make(vals[t[5 + 2 * i]], vals[t[6 + 2 * i]]); W(6 + 2 * i, row) = cf.a; W(7 + 2 * i, row) = cf.b; }
+          else { cf = gl2_make(vals[t[5 + i]], 0); W(6 + i, row) = cf.a; }
+          acc = gl2_add(gl2_mul(acc, alpha), cf);
+          if (i < nc - 1) { W(start_accs + 2 * i, row) = acc.a; W(start_accs + 2 * i + 1, row) = acc.b; }
+        }
+        W(0, row) = acc.a; W(1, row) = acc.b;
+        const u32 o = 5 + (ext ? 2 * nc : nc);
+        vals[t[o]] = acc.a; vals[t[o + 1]] = acc.b;
+        t += o + 2;
+        break;
+      }
+      case OP_COSET: {
+        const u64 row = t[0];
+        const u32 bits = (u32)t[1], npts = 1u << bits;
+        // CosetInterpolationGate::with_max_degree(bits, 8)
+        const u32 nint0 = (npts - 2) / 7, deg = (npts - 2) / (nint0 + 1) + 2, nint = (npts - 2) / (deg - 1);
+        const u32 w_pt = 1 + 2 * npts, w_val = w_pt + 2, w_int = w_val + 2, w_sh = w_int + 4 * nint;
+        const u64 shift = vals[t[2]];
+        W(0, row) = shift;
+        const u64* v = t + 3;
+        for (u32 i = 0; i < 2 * npts; i++) W(1 + i, row) = vals[v[i]];
+        const gl2 pt = gl2_make(vals[v[2 * npts]], vals[v[2 * npts + 1]]);
+        W(w_pt, row) = pt.a; W(w_pt + 1, row) = pt.b;
+        const gl2 sh = gl2_scale(pt, gl_inv(shift));
+        W(w_sh, row) = sh.a; W(w_sh + 1, row) = sh.b;
+        gl2 ev = gl2_make(0, 0), pr = gl2_make(1, 0);
+        u32 start = 0, endi = deg;
+        for (u32 c = 0; c <= nint; c++) {
+          for (u32 i = start; i < endi; i++) {
+            const gl2 val = gl2_scale(gl2_make(vals[v[2 * i]], vals[v[2 * i + 1]]), P.bw[bits][i]);
+            const gl2 term = gl2_make(gl_sub(sh.a, P.dom[bits][i]), sh.b);
+            const gl2 nev = gl2_add(gl2_mul(ev, term), gl2_mul(val, pr));
+            pr = gl2_mul(pr, term);
+            ev = nev;
+          }
+          if (c == nint) break;
+          W(w_int + 2 * c, row) = ev.a; W(w_int + 2 * c + 1, row) = ev.b;
+          W(w_int + 2 * (nint + c), row) = pr.a; W(w_int + 2 * (nint + c) + 1, row) = pr.b;
+          start = 1 + (deg - 1) * (c + 1);
+          endi = start + deg - 1 < npts ? start + deg - 1 : npts;
+        }
+        W(w_val, row) = ev.a; W(w_val + 1, row) = ev.b;
+        vals[v[2 * npts + 2]] = ev.a; vals[v[2 * npts + 3]] = ev.b;
+        t += 3 + 2 * npts + 4;
+        break;
+      }
+      case OP_HINT_DIV_EXT: {
+        const gl2 num = gl2_make(vals[t[0]], vals[t[1]]), den = gl2_make(vals[t[2]], vals[t[3]]);
+        const gl2 q = gl2_mul(num, gl2_inv(den));
+        vals[t[4]] = q.a; vals[t[5]] = q.b;
+        t += 6;
+        break;
+      }
+      case OP_HINT_LO63: vals[t[1]] = vals[t[0]] & (((u64)1 << 63) - 1); t += 2; break;
+      case OP_HINT_HI: vals[t[1]] = vals[t[0]] >> 63; t += 2; break;
+      default: return;  // validated at create
+    }
+  }
+#undef W
+}
+}  // namespace
+
+extern "C" {
+int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t n_slots, uint32_t log_n, const uint32_t* input_sids,
+                                uint32_t n_inputs, const uint64_t* const_slots, uint32_t n_consts, mp2g_witness_program** out) {
+  NEED(out && (tape || !tape_len) && (input_sids || !n_inputs) && (const_slots || !n_consts), "pointers");
+  NEED(log_n >= 1 && log_n <= 20 && n_slots >= 1, "log_n / n_slots");
+  mp2g_witness_program* P = new (std::nothrow) mp2g_witness_program();
+  if (!P) return fail("out of memory");
+  P->tape.assign(tape, tape + tape_len);
+  P->input_sids.assign(input_sids, input_sids + n_inputs);
+  P->consts.assign(const_slots, const_slots + 2 * (size_t)n_consts);
+  P->n_slots = n_slots; P->log_n = log_n;
+  const u64 n = (u64)1 << log_n;
+  // validate: opcodes, lengths, slot and row / column bounds -- the tape indexes host memory
+  auto bad = [&](const char* msg) { delete P; return fail("invalid witness program: %s", msg); };
+  for (uint32_t i = 0; i < n_inputs; i++) if (input_sids[i] >= n_slots) return bad("input slot out of range");
+  for (uint32_t i = 0; i < n_consts; i++) if (const_slots[2 * i] >= n_slots || const_slots[2 * i + 1] >= GL_P) return bad("constant slot / value");
+  const u64* t = P->tape.data();
+  const u64* end = t + tape_len;
+  while (t < end) {
+    const u64 op = *t++;
+    if (op < OP_ARITH || op >= OP_END) return bad("unknown opcode");
+    if (op == OP_COSET && (t + 2 > end || t[1] < 2 || t[1] > 5)) return bad("CosetInterpolation bits");
+    const u32 len = op_len(op, t);
+    if (len == ~0u || t + len > end) return bad("truncated instruction");
+    // operand classes: rows < n; everything else that is not a constant or a small index is a slot
+    u32 first_slot = 0;
+    switch (op) {
+      case OP_ARITH: case OP_ARITH_EXT: if (t[0] >= n || t[1] >= (op == OP_ARITH ? 20u : 10u) || t[2] >= GL_P || t[3] >= GL_P) return bad("arithmetic operands"); first_slot = 4; break;
+      case OP_P2: case OP_BASE_SUM: case OP_REDUCING: case OP_REDUCING_EXT: if (t[0] >= n) return bad("row"); first_slot = 1; break;
+      case OP_RA: if (t[0] >= n || t[1] >= RA_COPIES) return bad("random access operands"); first_slot = 2; break;
+      case OP_COSET: if (t[0] >= n) return bad("row"); first_slot = 2; break;
+      case OP_WIRE: if (t[0] >= n || t[1] >= NUM_WIRES) return bad("wire"); first_slot = 2; break;
+      default: first_slot = 0; break;
+    }
+    for (u32 i = first_slot; i < len; i++) if (t[i] >= n_slots) return bad("slot out of range");
+    t += len;
+  }
+  for (u32 bits = 2; bits <= 5; bits++) {
+    const u32 npts = 1u << bits;
+    const u64 w = gl_root_of_unity(bits);
+    u64 x = 1;
+    for (u32 i = 0; i < npts; i++) { P->dom[bits][i] = x; x = gl_mul(x, w); }
+    for (u32 i = 0; i < npts; i++) {
+      u64 pr = 1;
+      for (u32 j = 0; j < npts; j++) if (j != i) pr = gl_mul(pr, gl_sub(P->dom[bits][i], P->dom[bits][j]));
+      P->bw[bits][i] = gl_inv(pr);
+    }
+  }
+  *out = P;
+  return 0;
+}
+uint32_t mp2g_witness_program_num_inputs(const mp2g_witness_program* P) { return P ? (uint32_t)P->input_sids.size() : 0; }
+int mp2g_witness_program_run(const mp2g_witness_program* P, const uint64_t* inputs, uint32_t batch, uint32_t threads, uint64_t* wires,
+                             const uint32_t* probe_sids, uint32_t n_probe, uint64_t* probe_out) {
+  NEED(P && inputs && wires && batch >= 1, "program / inputs / wires");
+  NEED(!n_probe || (probe_sids && probe_out), "probe");
+  for (uint32_t i = 0; i < n_probe; i++) NEED(probe_sids[i] < P->n_slots, "probe slot");
+  const size_t n_in = P->input_sids.size();
+  for (size_t i = 0; i < (size_t)batch * n_in; i++) NEED(inputs[i] < GL_P, "inputs must be canonical field elements");
+  const size_t per = (size_t)NUM_WIRES << P->log_n;
+  if (!threads) threads = std::thread::hardware_concurrency();
+  if (threads > batch) threads = batch;
+  if (!threads) threads = 1;
+  std::atomic<uint32_t> next{0};
+  auto worker = [&]() {
+    std::vector<u64> vals(P->n_slots);
+    for (;;) {
+      const uint32_t b = next.fetch_add(1);
+      if (b >= batch) return;
+      std::fill(vals.begin(), vals.end(), 0);
+      run_one(*P, inputs + (size_t)b * n_in, vals.data(), wires + (size_t)b * per);
+      for (uint32_t i = 0; i < n_probe; i++) probe_out[(size_t)b * n_probe + i] = vals[probe_sids[i]];
+    }
+  };
+  std::vector<std::thread> pool;
+  for (uint32_t i = 1; i < threads; i++) pool.emplace_back(worker);
+  worker();
+  for (auto& th : pool) th.join();
+  return 0;
+}
+void mp2g_witness_program_free(mp2g_witness_program* P) { delete P; }
+}  // extern "C"

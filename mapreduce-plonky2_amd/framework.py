@@ -242,6 +242,22 @@ class GpuProver:
         caps, openings, proofs = cp.results()
         return caps[0], openings[0], proofs[0]
 
+    def prove_batch(self, ckt, wires, pi_hash):
+        """wires [B][135][n] and pi_hash [B][4] (host) of B witnesses of one circuit -> [(caps, openings, proof)]"""
+        B = wires.shape[0]
+        key = (ckt.log_n, hash(ckt.pre.tobytes()), B)
+        cp = self.provers.get(key)
+        if cp is None:
+            cp = self.provers[key] = CircuitProver(self.ctx, ckt, B, self.variant, witness_check=self.witness_check)
+            cp.d_w, cp.d_ph = self.ctx.alloc(wires.nbytes), self.ctx.alloc(B * 32)
+        cp.d_w.upload(wires)
+        cp.d_ph.upload(np.ascontiguousarray(pi_hash, dtype=np.uint64))
+        cp.prove(cp.d_w, cp.d_ph)
+        if self.witness_check:
+            cp.pr.witness_status()
+        caps, openings, proofs = cp.results()
+        return [(caps[b], openings[b], proofs[b]) for b in range(B)]
+
     def two_to_one(self, left, right):
         """Hasher::two_to_one = permute([l || r || 0000])[0..4] = hash_no_pad of the 8 limbs (one absorb)"""
         return [int(x) for x in self.ctx.hash_no_pad(list(left) + list(right), self.variant)]

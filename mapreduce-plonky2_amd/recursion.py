@@ -61,11 +61,20 @@ def xinv(a):
 
 
 class T:
-    """a base-field target: its value and (once it sits in a routed wire) its home cell"""
-    __slots__ = ("v", "cell")
+    """a base-field target: its value, (once it sits in a routed wire) its home cell, and its slot in the witness
+    program's value table"""
+    __slots__ = ("v", "cell", "sid")
 
-    def __init__(self, v, cell=None):
-        self.v, self.cell = v % P, cell
+    def __init__(self, v, cell=None, sid=-1):
+        self.v, self.cell, self.sid = v % P, cell, sid
+
+
+# Witness program ("tape"): the builder's operations in order, over value slots. The circuit structure does not depend
+# on witness values, so the tape recorded while the structure is built IS the circuit's witness generator
+# (plonky2's generate_partial_witness for this circuit): csrc/witness.hip replays it for a batch of input vectors.
+# Every instruction: opcode, then its operands (row / slot indices, u64 constants), fixed length per opcode.
+(OP_ARITH, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
+ OP_HINT_LO63, OP_HINT_HI) = range(1, 13)
 
 
 class E:
@@ -106,7 +115,11 @@ class Builder:
         self.open = {}      # slot key -> [row index, used slots]
         self.consts = {}    # value -> T
         self.public_inputs = []
-        self.ctx_counts = {}
+        self.tape = []          # flat list of ints (u64)
+        self.n_slots = 0
+        self.input_sids = []    # slots the caller fills, in add_virtual order
+        self.input_vals = []
+        self.const_slots = []   # (sid, value)
 
     # ---- cells and copy constraints ------------------------------------------------------------------------------
     def _find(self, c):
@@ -134,9 +147,13 @@ class Builder:
         else:
             self._union((row, col), t.cell)
 
+    def _sid(self):
+        self.n_slots += 1
+        return self.n_slots - 1
+
     def _out(self, row, col, v):
         self.rows[row].wires[col] = v % P
-        return T(v, (row, col))
+        return T(v, (row, col), self._sid())
 
     def connect(self, a, b):
         assert not self.strict or a.v == b.v, f"connect: {a.v} != {b.v}"
@@ -155,11 +172,18 @@ class Builder:
         self.connect(a.b, b.b)
 
     def add_virtual(self, v):
-        """add_virtual_target: a witness value; its home is the first wire it is used in"""
-        return T(v)
+        """add_virtual_target: a witness value (an input of the witness program); its home is the first wire it is used in"""
+        t = T(v, None, self._sid())
+        self.input_sids.append(t.sid)
+        self.input_vals.append(t.v)
+        return t
 
     def add_virtual_ext(self, v):
-        return E(T(v[0]), T(v[1]))
+        return E(self.add_virtual(v[0]), self.add_virtual(v[1]))
+
+    def _hint(self, v):
+        """a value the witness generator computes from other values (not an input)"""
+        return T(v, None, self._sid())
 
     # ---- rows and slots ---------------------------------------------------------------------------------------------
     def _new_row(self, kind, p0=0, p1=0, p2=0, consts=(0, 0)):
@@ -181,6 +205,8 @@ class Builder:
             row, i = self._slot(("const",), 2, lambda: self._new_row(C.CONSTANT, 2))
             self.rows[row].consts[i] = v
             t = self.consts[v] = self._out(row, i, v)
+            self.const_slots.append((t.sid, v))
+            self.tape += [OP_WIRE, row, i, t.sid]
         return t
 
     def zero(self):
@@ -209,7 +235,9 @@ class Builder:
         self._put(row, 4 * i, m0)
         self._put(row, 4 * i + 1, m1)
         self._put(row, 4 * i + 2, ad)
-        return self._out(row, 4 * i + 3, c0 * m0.v * m1.v + c1 * ad.v)
+        out = self._out(row, 4 * i + 3, c0 * m0.v * m1.v + c1 * ad.v)
+        self.tape += [OP_ARITH, row, i, c0, c1, m0.sid, m1.sid, ad.sid, out.sid]
+        return out
 
     def mul(self, a, b):
         return self.arithmetic(1, a, b, 0, a)
@@ -272,7 +300,9 @@ class Builder:
         for k, t in enumerate((m0.a, m0.b, m1.a, m1.b, ad.a, ad.b)):
             self._put(row, 8 * i + k, t)
         r = xadd(xscale(xmul(m0.v, m1.v), c0), xscale(ad.v, c1))
-        return E(self._out(row, 8 * i + 6, r[0]), self._out(row, 8 * i + 7, r[1]))
+        out = E(self._out(row, 8 * i + 6, r[0]), self._out(row, 8 * i + 7, r[1]))
+        self.tape += [OP_ARITH_EXT, row, i, c0, c1, m0.a.sid, m0.b.sid, m1.a.sid, m1.b.sid, ad.a.sid, ad.b.sid, out.a.sid, out.b.sid]
+        return out
 
     def mul_ext(self, a, b):
         return self.arithmetic_ext(1, a, b, 0, a)
@@ -319,7 +349,9 @@ class Builder:
 
     def div_ext(self, num, den):
         """q with q * den = num (the quotient is a witness, the product is constrained)"""
-        q = self.add_virtual_ext(xmul(num.v, xinv(den.v)))
+        qv = xmul(num.v, xinv(den.v))
+        q = E(self._hint(qv[0]), self._hint(qv[1]))
+        self.tape += [OP_HINT_DIV_EXT, num.a.sid, num.b.sid, den.a.sid, den.b.sid, q.a.sid, q.b.sid]
         self.connect_ext(self.mul_ext(q, den), num)
         return q
 
@@ -366,7 +398,9 @@ class Builder:
             s = [(s[i] + Kc["POSEIDON2_RC_EXT"][12 * (4 + r) + i]) % P for i in range(12)]
             w[87 + 12 * r:87 + 12 * (r + 1)] = s
             s = C.p2_external([pow(x, 7, P) for x in s])
-        return [self._out(row, 12 + i, s[i]) for i in range(12)]
+        outs = [self._out(row, 12 + i, s[i]) for i in range(12)]
+        self.tape += [OP_P2, row] + [t.sid for t in inputs] + [swap.sid] + [t.sid for t in outs]
+        return outs
 
     def permute(self, inputs):
         return self.permute_swapped(inputs, self.zero())
@@ -400,22 +434,20 @@ class Builder:
         assert num_bits <= self.BASE_SUM_LIMBS and (not self.strict or x.v < (1 << num_bits))
         row = self._new_row(C.BASE_SUM, self.BASE_SUM_LIMBS, 2)
         self._put(row, 0, x)
-        bits = []
-        for i in range(self.BASE_SUM_LIMBS):
-            t = self._out(row, 1 + i, (x.v >> i) & 1)
-            if i < num_bits:
-                bits.append(t)
-            else:
-                self.assert_zero(t)
-        return bits
+        limbs = [self._out(row, 1 + i, (x.v >> i) & 1) for i in range(self.BASE_SUM_LIMBS)]
+        self.tape += [OP_BASE_SUM, row, x.sid] + [t.sid for t in limbs]
+        for t in limbs[num_bits:]:
+            self.assert_zero(t)
+        return limbs[:num_bits]
 
     def split_le(self, x, num_bits):
         """split_join.rs split_le: little-endian bits through ceil(num_bits / 63) BaseSum gates, recombined with
         weights 2^(63 i)"""
         if num_bits <= self.BASE_SUM_LIMBS:
             return self.split_le_base2(x, num_bits)
-        lo = self.add_virtual(x.v & ((1 << 63) - 1))
-        hi = self.add_virtual(x.v >> 63)
+        lo = self._hint(x.v & ((1 << 63) - 1))
+        hi = self._hint(x.v >> 63)
+        self.tape += [OP_HINT_LO63, x.sid, lo.sid, OP_HINT_HI, x.sid, hi.sid]
         bits = self.split_le_base2(lo, 63) + self.split_le_base2(hi, num_bits - 63)
         self.connect(self.arithmetic(1 << 63, hi, self.one(), 1, lo), x)
         return bits
@@ -437,7 +469,9 @@ class Builder:
         for i in range(self.RA_BITS):
             w[routed + c * self.RA_BITS + i] = (index.v >> i) & 1
         assert index.v < vs or not self.strict
-        return self._out(row, base + 1, values[index.v % vs].v)
+        out = self._out(row, base + 1, values[index.v % vs].v)
+        self.tape += [OP_RA, row, c, index.sid] + [t.sid for t in values] + [out.sid]
+        return out
 
     def random_access_ext(self, index, values):
         return E(self.random_access(index, [v.a for v in values]), self.random_access(index, [v.b for v in values]))
@@ -462,7 +496,9 @@ class Builder:
                 cur = xadd(xmul(cur, alpha.v), (rev[lo + i].v, 0))
                 if i < n - 1:
                     w[start_accs + 2 * i], w[start_accs + 2 * i + 1] = cur
+            old = acc
             acc = E(self._out(row, 0, cur[0]), self._out(row, 1, cur[1]))
+            self.tape += [OP_REDUCING, row, alpha.a.sid, alpha.b.sid, old.a.sid, old.b.sid] + [t.sid for t in rev[lo:lo + n]] + [acc.a.sid, acc.b.sid]
         return acc
 
     def reduce_ext(self, alpha, terms):
@@ -486,7 +522,10 @@ class Builder:
                 cur = xadd(xmul(cur, alpha.v), e.v)
                 if i < n - 1:
                     w[start_accs + 2 * i], w[start_accs + 2 * i + 1] = cur
+            old = acc
             acc = E(self._out(row, 0, cur[0]), self._out(row, 1, cur[1]))
+            self.tape += [OP_REDUCING_EXT, row, alpha.a.sid, alpha.b.sid, old.a.sid, old.b.sid] + [x for e in rev[lo:lo + n] for x in (e.a.sid, e.b.sid)] + \
+                [acc.a.sid, acc.b.sid]
         return acc
 
     # ---- CosetInterpolationGate (subgroup_bits 4) ---------------------------------------------------------------------------------
@@ -530,7 +569,9 @@ class Builder:
             w[w_int + 2 * (nint + c)], w[w_int + 2 * (nint + c) + 1] = pr
             start = 1 + (deg - 1) * (c + 1)
             end = min(start + deg - 1, npts)
-        return E(self._out(row, w_val, ev[0]), self._out(row, w_val + 1, ev[1]))
+        out = E(self._out(row, w_val, ev[0]), self._out(row, w_val + 1, ev[1]))
+        self.tape += [OP_COSET, row, bits, shift.sid] + [x for v in values for x in (v.a.sid, v.b.sid)] + [point.a.sid, point.b.sid, out.a.sid, out.b.sid]
+        return out
 
     # ---- public inputs -------------------------------------------------------------------------------------------------------------
     def register_public_inputs(self, targets):
@@ -544,6 +585,7 @@ class Builder:
         pi_row = self._new_row(C.PUBLIC_INPUT)
         for i, t in enumerate(pi_hash):
             self._put(pi_row, i, t)
+            self.tape += [OP_WIRE, pi_row, i, t.sid]
         n_rows = len(self.rows) + 1  # at least one Noop (as plonky2's blinding-free padding leaves)
         log_n = max(min_log_n, (n_rows - 1).bit_length())
         n = 1 << log_n
@@ -589,6 +631,14 @@ class Builder:
         ckt.gate_array = (Gate * len(gates))(*gates)
         ckt.luts, ckt.num_lookup_selectors, ckt.num_lookup_polys = [], 0, 0
         ckt.n_used_rows = n_rows - 1
+        # the witness program of this circuit (see the OP_* table above) and the inputs this build was run with
+        ckt.tape = np.array(self.tape, dtype=np.uint64)
+        ckt.n_slots = self.n_slots
+        ckt.input_sids = np.array(self.input_sids, dtype=np.uint32)
+        ckt.const_slots = np.array([[sid, v] for sid, v in self.const_slots], dtype=np.uint64).reshape(-1, 2)
+        ckt.pi_hash_sids = np.array([t.sid for t in pi_hash], dtype=np.uint32)
+        ckt.public_input_sids = np.array([t.sid for t in self.public_inputs], dtype=np.uint32)
+        ckt.input_values = np.array(self.input_vals, dtype=np.uint64)  # what this build was run with, in input order
         return ckt
 
 
@@ -1257,3 +1307,53 @@ def reduce_logic(b, child_pis, inputs):
     for pis in child_pis:
         acc = b.add(acc, pis[0])
     return [acc] + b.hash_n_to_m_no_pad([t for pis in child_pis for t in pis[1:5]], 4)
+
+
+# ---- batched generate_proof: the recorded witness programs instead of the Python builder --------------------------------------------
+def proof_inputs(proof):
+    """the input vector of verify_proof_circuit's virtual targets for one proof (caps, openings, fri, public_inputs), in
+    add_virtual order: public inputs, the three proof caps, openings, the FRI proof words"""
+    caps, openings, fri, pis = proof
+    return np.concatenate([np.asarray(pis, dtype=np.uint64).ravel(), np.asarray(caps, dtype=np.uint64)[1:4].ravel(),
+                           np.asarray(openings, dtype=np.uint64).ravel(), np.asarray(fri, dtype=np.uint64).ravel()])
+
+
+def universal_inputs(proof, vd, membership):
+    """... of universal_verifier_circuit: verifier data (cap, digest), the proof, the membership proof (bits, siblings)"""
+    bits, sib = membership
+    return np.concatenate([np.asarray(vd[0], dtype=np.uint64).ravel(), np.asarray(vd[1], dtype=np.uint64).ravel(), proof_inputs(proof),
+                           np.asarray(bits, dtype=np.uint64).ravel(), np.asarray(sib, dtype=np.uint64).ravel()])
+
+
+def _generate_proofs_batch(self, name, jobs, threads=0):
+    """RecursiveCircuits.generate_proof for a batch of nodes of circuit `name`: jobs = [(child_proofs, child_names, inputs)].
+    Witnesses come from the circuits' recorded programs (csrc/witness.hip: host threads, one proof each), proving from
+    prover.prove_batch(circuit, wires [B][135][n], pi_hash [B][4]). Returns the final proofs, one per job."""
+    from . import WitnessProgram
+    if not hasattr(self, "programs"):
+        self.programs = {}
+    progs = self.programs.get(name)
+    if progs is None:
+        progs = self.programs[name] = [WitnessProgram(c[0]) for c in self.chains[name]]
+    rows = []
+    for child_proofs, child_names, inputs in jobs:
+        parts = [np.asarray(self.set_digest, dtype=np.uint64)]
+        for pr, cn in zip(child_proofs, child_names):
+            vd = self.vds[cn]
+            parts.append(universal_inputs(pr, vd, self.membership(vd[1])))
+        if inputs is not None:
+            parts.append(np.asarray(inputs, dtype=np.uint64).ravel())
+        rows.append(np.concatenate(parts))
+    cur = np.stack(rows)
+    proofs = None
+    for step, prog in enumerate(progs):
+        assert cur.shape[1] == prog.n_inputs, f"{name} step {step}: {cur.shape[1]} inputs for a program of {prog.n_inputs}"
+        wires, pi_hash, pis = prog.run(cur, threads)
+        outs = self.prover.prove_batch(self.chains[name][step][0], wires, pi_hash)
+        proofs = [(c, o, p, pis[i]) for i, (c, o, p) in enumerate(outs)]
+        if step + 1 < len(progs):
+            cur = np.stack([proof_inputs(p) for p in proofs])
+    return proofs
+
+
+RecursiveCircuits.generate_proofs_batch = _generate_proofs_batch

@@ -35,3 +35,32 @@ def test_map_reduce_tree_of_real_proofs(ctx, mp2):
     wckt, wcap, wdig = fw.chains["reduce"][-1]
     assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *level[0][:3]) == 0
     prover.free()
+
+
+def test_sixteen_leaf_tree_through_the_witness_programs(ctx, mp2):
+    """the same framework at 16 leaves, level by level in batches: witnesses by the recorded witness programs
+    (mp2g_witness_program_run on host threads), proofs by batched HIP provers with the witness check on. 31 framework
+    proofs = 62 prove() calls' worth of real circuits (map 2^6 + wrap 2^13, reduce 2^14 + wrap 2^13)."""
+    prover = FW.GpuProver(ctx)
+    circs = [R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)]
+    fw = R.RecursiveCircuits(circs, prover, FW.circuit_fri_params)
+    n_leaves = 16
+    data = O.rand_field(4 * n_leaves, 0xC0FFEE03)
+    level = fw.generate_proofs_batch("map", [([], [], data[4 * i:4 * i + 4]) for i in range(n_leaves)])
+    # the batch path and the Python-builder path agree on a leaf
+    one = fw.generate_proof("map", [], [], data[0:4])
+    assert all(np.array_equal(x, y) for x, y in zip(level[0], one))
+    names = ["map"] * n_leaves
+    while len(level) > 1:
+        jobs = [([level[2 * i], level[2 * i + 1]], [names[2 * i], names[2 * i + 1]], None) for i in range(len(level) // 2)]
+        level = fw.generate_proofs_batch("reduce", jobs)
+        names = ["reduce"] * len(level)
+    pis = level[0][3]
+    assert int(pis[0]) == sum(int(x) for x in data if int(x) % 2 == 0) % O.P
+    hs = [O.hash_n_to_m_no_pad(data[4 * i:4 * i + 4], 4) for i in range(n_leaves)]
+    while len(hs) > 1:
+        hs = [O.hash_n_to_m_no_pad(np.concatenate([hs[2 * i], hs[2 * i + 1]]), 4) for i in range(len(hs) // 2)]
+    assert np.array_equal(pis[1:5], hs[0]) and np.array_equal(pis[5:], np.asarray(fw.set_digest, dtype=np.uint64))
+    wckt, wcap, wdig = fw.chains["reduce"][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *level[0][:3]) == 0
+    prover.free()

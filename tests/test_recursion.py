@@ -97,6 +97,16 @@ class OracleProver:
         assert C.verify(ckt, fp, cd, ckt.pi_hash, caps, openings, proof) == 0
         return caps, openings, proof
 
+    def prove_batch(self, ckt, wires, pi_hash):
+        cap, cd = verifier_data(ckt)
+        fp = C.oracle_params(ckt)
+        out = []
+        for w, ph in zip(wires, pi_hash):
+            caps, openings, proof, _ = C.prove_witness(ckt, fp, cd, w, ph)
+            assert C.verify(ckt, fp, cd, ph, caps, openings, proof) == 0
+            out.append((caps, openings, proof))
+        return out
+
     def two_to_one(self, left, right):
         return [int(x) for x in O.perm(np.array(list(left) + list(right) + [0] * 4, dtype=np.uint64))[:4]]
 
@@ -124,6 +134,11 @@ def test_map_reduce_with_the_universal_verifier():
     # the final proof verifies under the reduce circuit's final verifier data
     wckt, wcap, wdig = fw.chains["reduce"][-1]
     assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *root[:3]) == 0
+    # the same nodes through the recorded witness programs (csrc/witness.hip) instead of the Python builder: identical proofs
+    b0, b1 = fw.generate_proofs_batch("map", [([], [], data[:4]), ([], [], data[4:])])
+    assert all(np.array_equal(x, y) for x, y in zip(b0, p0)) and all(np.array_equal(x, y) for x, y in zip(b1, p1))
+    (broot,) = fw.generate_proofs_batch("reduce", [([b0, b1], ["map", "map"], None)])
+    assert all(np.array_equal(x, y) for x, y in zip(broot, root))
     # a proof of a circuit outside the set cannot be used: the membership proof does not exist
     with pytest.raises(StopIteration):
         fw.membership([1, 2, 3, 4])
