@@ -225,6 +225,76 @@ def run_tree(args, rank, local_rank, world, dist, torch, VARIANT):
     return out
 
 
+def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
+    """--workload recursion: a map-reduce tree of REAL framework proofs per step and rank (recursion.py): `--batch` map
+    proofs (MapCircuit of integration.rs:65-93: base 2^6 rows + wrap to the shared 2^13-row shape) and the batch - 1 reduce
+    proofs above them (two universal verifiers + the reduce logic: base 2^14 rows + wrap 2^13), level by level. Everything
+    generate_proof does is inside the timed region: witness generation (mp2g_witness_program_run on the host's threads),
+    upload, prove() with the device-side witness check, download of the proofs the next level verifies. Ranks work on
+    independent trees (no cross-rank levels in this mode)."""
+    assert VARIANT == 0, "the recursive verifier circuit of recursion.py hashes with Poseidon2 gates (the reference's default config)"
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+    FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+    C = importlib.import_module("mapreduce-plonky2_amd.circuits")
+    ctx = mp2.Context(local_rank)
+    prover = FW.GpuProver(ctx, VARIANT, witness_check=True)
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover,
+                             lambda ckt: FW.circuit_fri_params(ckt, VARIANT))
+    n_leaves = args.batch
+    assert n_leaves & (n_leaves - 1) == 0
+    data = C.rand_field(4 * n_leaves, SEED + 31 * rank)
+
+    def step():
+        level = fw.generate_proofs_batch("map", [([], [], data[4 * i:4 * i + 4]) for i in range(n_leaves)])
+        names = ["map"] * n_leaves
+        while len(level) > 1:
+            level = fw.generate_proofs_batch("reduce", [([level[2 * i], level[2 * i + 1]], [names[2 * i], names[2 * i + 1]], None)
+                                                       for i in range(len(level) // 2)])
+            names = ["reduce"] * len(level)
+        return level[0]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(max(1, args.warmup)):  # the first pass creates the provers of every level width
+        root = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        root = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    pis = root[3]
+    assert int(pis[0]) == sum(int(x) for x in data if int(x) % 2 == 0) % C.P, "root sum != sum of the even elements"
+    out = None
+    if rank == 0:
+        n_nodes = 2 * n_leaves - 1
+        out = {"metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build, 1/2/4/8 GPU",
+               "value": world * n_leaves * args.steps / dt, "unit": "leaf proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u64 (Goldilocks field)", "data": "synthetic",
+               "framework_proofs_per_s": world * n_nodes * args.steps / dt,
+               "config": {"workload": f"recursion: per rank a {n_leaves}-leaf map-reduce tree of REAL framework proofs ({n_nodes} = map: base 2^6 + wrap 2^13 "
+                                      "rows; reduce: two universal verifiers, base 2^14 + wrap 2^13 rows), witness generation on the host threads, "
+                                      "witness check on, every level inside the timed region",
+                          "shapes": {k: [c[0].log_n for c in v] for k, v in fw.chains.items()}, "host_threads": os.cpu_count(),
+                          "hasher": "Poseidon2" if VARIANT == 0 else "Poseidon", "root_public_inputs": [int(x) for x in pis]}}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+    prover.free()
+    ctx.close()
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,10 +315,12 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU leg (the self-check still runs)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the sampled proofs")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work for the cpu_baseline sample")
-    ap.add_argument("--workload", choices=("leaves", "tree"), default="leaves",
+    ap.add_argument("--workload", choices=("leaves", "tree", "recursion"), default="leaves",
                     help="leaves (default, the headline): independent leaf proofs. tree: every step also proves the 2-to-1 aggregation "
                          "levels above the leaves -- locally below the shard boundary, then log2(ranks) levels whose child proofs move "
-                         "between ranks with point-to-point send/recv (RCCL on device tensors)")
+                         "between ranks with point-to-point send/recv (RCCL on device tensors). recursion: REAL circuits -- the map / "
+                         "reduce circuits of recursion-framework/tests/integration.rs with universal verifiers, wrapped to the shared "
+                         "shape; witnesses by the recorded witness programs on host threads, inside the timed region")
     args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -272,6 +344,8 @@ def main(argv=None):
     VARIANT = 0 if args.hasher == "poseidon2" else 1
     if args.workload == "tree":
         return run_tree(args, rank, local_rank, world, dist, torch, VARIANT)
+    if args.workload == "recursion":
+        return run_recursion(args, rank, local_rank, world, dist, torch, VARIANT)
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
     C = importlib.import_module("mapreduce-plonky2_amd.circuits")  # synthetic circuit + witness generator (pure Python)
