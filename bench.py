@@ -230,8 +230,11 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
     proofs (MapCircuit of integration.rs:65-93: base 2^6 rows + wrap to the shared 2^13-row shape) and the batch - 1 reduce
     proofs above them (two universal verifiers + the reduce logic: base 2^14 rows + wrap 2^13), level by level. Everything
     generate_proof does is inside the timed region: witness generation (mp2g_witness_program_run on the host's threads),
-    upload, prove() with the device-side witness check, download of the proofs the next level verifies. Ranks work on
-    independent trees (no cross-rank levels in this mode)."""
+    upload, prove() with the device-side witness check, download of the proofs the next level verifies. With several
+    ranks the tree continues above the shard boundary: log2(world) levels in which the owner of a parent receives the
+    other child's final proof as the reference moves proofs between tree levels -- bincode bytes of
+    ProofWithPublicInputs (mp2g_proof_serialize / mp2g_proof_deserialize; mp2-common/src/proof.rs:42-57) over a
+    point-to-point send/recv -- and proves the reduce node whose universal verifiers check both children in-circuit."""
     assert VARIANT == 0, "the recursive verifier circuit of recursion.py hashes with Poseidon2 gates (the reference's default config)"
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     R = importlib.import_module("mapreduce-plonky2_amd.recursion")
@@ -245,6 +248,13 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
     assert n_leaves & (n_leaves - 1) == 0
     data = C.rand_field(4 * n_leaves, SEED + 31 * rank)
 
+    sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
+    nccl = dist is not None and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", local_rank) if nccl else None
+    final_ckt = fw.chains["reduce"][-1][0]          # every final proof has this shape (the shared common data)
+    final_fp = FW.circuit_fri_params(final_ckt, VARIANT)
+    n_pis = 5 + 4
+
     def step():
         level = fw.generate_proofs_batch("map", [([], [], data[4 * i:4 * i + 4]) for i in range(n_leaves)])
         names = ["map"] * n_leaves
@@ -252,7 +262,21 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
             level = fw.generate_proofs_batch("reduce", [([level[2 * i], level[2 * i + 1]], [names[2 * i], names[2 * i + 1]], None)
                                                        for i in range(len(level) // 2)])
             names = ["reduce"] * len(level)
-        return level[0]
+        root, root_name = level[0], names[0]
+        for lvl in range(world.bit_length() - 1):  # above the shard boundary
+            bit = 1 << lvl
+            if rank & (bit - 1):
+                break
+            if rank & bit:
+                blob = mp2.serialize_proof(final_fp, final_ckt.num_constants, root[0], root[1], root[2], root[3])
+                sharding.exchange_bytes(dist, bytes([0 if root_name == "map" else 1]) + blob, rank, rank - bit, dev)
+                break
+            got = sharding.exchange_bytes(dist, None, rank + bit, rank, dev)
+            c_caps, c_open, c_fri, c_pis = mp2.deserialize_proof(final_fp, final_ckt.num_constants, got[1:], n_pis)
+            child = (c_caps, c_open, c_fri, c_pis)
+            (root,) = fw.generate_proofs_batch("reduce", [([root, child], [root_name, "map" if got[0] == 0 else "reduce"], None)])
+            root_name = "reduce"
+        return root
 
     def barrier():
         if dist is not None:
@@ -273,7 +297,11 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     pis = root[3]
-    assert int(pis[0]) == sum(int(x) for x in data if int(x) % 2 == 0) % C.P, "root sum != sum of the even elements"
+    if rank == 0:
+        want = 0
+        for r in range(world):
+            want = (want + sum(int(x) for x in C.rand_field(4 * n_leaves, SEED + 31 * r) if int(x) % 2 == 0)) % C.P
+        assert int(pis[0]) == want, "root sum != sum of the even elements of every rank's data"
     out = None
     if rank == 0:
         n_nodes = 2 * n_leaves - 1
@@ -281,7 +309,7 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
                "value": world * n_leaves * args.steps / dt, "unit": "leaf proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u64 (Goldilocks field)", "data": "synthetic",
-               "framework_proofs_per_s": world * n_nodes * args.steps / dt,
+               "framework_proofs_per_s": (world * n_nodes + world - 1) * args.steps / dt,
                "config": {"workload": f"recursion: per rank a {n_leaves}-leaf map-reduce tree of REAL framework proofs ({n_nodes} = map: base 2^6 + wrap 2^13 "
                                       "rows; reduce: two universal verifiers, base 2^14 + wrap 2^13 rows), witness generation on the host threads, "
                                       "witness check on, every level inside the timed region",
