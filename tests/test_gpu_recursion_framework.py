@@ -64,3 +64,22 @@ def test_sixteen_leaf_tree_through_the_witness_programs(ctx, mp2):
     wckt, wcap, wdig = fw.chains["reduce"][-1]
     assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *level[0][:3]) == 0
     prover.free()
+
+
+def test_two_ranks_real_recursion_with_proof_handoff():
+    """bench.py --workload recursion on two ranks (gloo rendezvous, both on the test box's GPU): each rank proves an 8-leaf
+    tree of real framework proofs, then rank 1's root proof travels as bincode bytes (mp2g_proof_serialize ->
+    send/recv -> mp2g_proof_deserialize) to rank 0, whose reduce node verifies both roots in-circuit; the run itself
+    asserts that the final public input is the sum of the even elements of both ranks' data."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "recursion", "--batch", "8", "--steps", "1", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MP2G_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["shapes"] == {"map": [6, 13], "reduce": [14, 13]}
+    assert line["framework_proofs_per_s"] > 0 and len(line["config"]["root_public_inputs"]) == 9
