@@ -227,8 +227,8 @@ def run_tree(args, rank, local_rank, world, dist, torch, VARIANT):
 
 def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
     """--workload recursion: a map-reduce tree of REAL framework proofs per step and rank (recursion.py): `--batch` map
-    proofs (MapCircuit of integration.rs:65-93: base 2^6 rows + wrap to the shared 2^13-row shape) and the batch - 1 reduce
-    proofs above them (two universal verifiers + the reduce logic: base 2^14 rows + wrap 2^13), level by level. Everything
+    proofs (MapCircuit of integration.rs:65-93: base 2^6 rows + wrap to the shared 2^12-row shape, RECURSION_THRESHOLD) and the
+    batch - 1 reduce proofs above them (two universal verifiers + the reduce logic: base 2^13 rows + wrap 2^12), level by level. Everything
     generate_proof does is inside the timed region: witness generation (mp2g_witness_program_run on the host's threads),
     upload, prove() with the device-side witness check, download of the proofs the next level verifies. With several
     ranks the tree continues above the shard boundary: log2(world) levels in which the owner of a parent receives the
@@ -310,8 +310,8 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u64 (Goldilocks field)", "data": "synthetic",
                "framework_proofs_per_s": (world * n_nodes + world - 1) * args.steps / dt,
-               "config": {"workload": f"recursion: per rank a {n_leaves}-leaf map-reduce tree of REAL framework proofs ({n_nodes} = map: base 2^6 + wrap 2^13 "
-                                      "rows; reduce: two universal verifiers, base 2^14 + wrap 2^13 rows), witness generation on the host threads, "
+               "config": {"workload": f"recursion: per rank a {n_leaves}-leaf map-reduce tree of REAL framework proofs ({n_nodes} = map: base 2^6 + wrap 2^12 "
+                                      "rows; reduce: two universal verifiers, base 2^13 + wrap 2^12 rows), witness generation on the host threads, "
                                       "witness check on, every level inside the timed region",
                           "shapes": {k: [c[0].log_n for c in v] for k, v in fw.chains.items()}, "host_threads": os.cpu_count(),
                           "hasher": "Poseidon2" if VARIANT == 0 else "Poseidon", "root_public_inputs": [int(x) for x in pis]}}

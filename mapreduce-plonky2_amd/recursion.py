@@ -199,15 +199,34 @@ class Builder:
 
     # ---- ConstantGate ------------------------------------------------------------------------------------------------
     def constant(self, v):
+        """CircuitBuilder::constant: one target per distinct value. Its source wire is chosen at build() (plonky2 defers
+        it the same way): first the two extra-constant slots every RandomAccessGate row carries, ConstantGate rows only
+        for what is left -- a verifier circuit has ~200 RandomAccess rows and ~300 constants, so it needs no ConstantGate."""
         v %= P
         t = self.consts.get(v)
         if t is None:
-            row, i = self._slot(("const",), 2, lambda: self._new_row(C.CONSTANT, 2))
-            self.rows[row].consts[i] = v
-            t = self.consts[v] = self._out(row, i, v)
+            t = self.consts[v] = T(v, None, self._sid())
             self.const_slots.append((t.sid, v))
-            self.tape += [OP_WIRE, row, i, t.sid]
         return t
+
+    def _place_constants(self):
+        vs = 1 << self.RA_BITS
+        free = [(r, i) for r, row in enumerate(self.rows) if row.kind == C.RANDOM_ACCESS for i in range(2)]
+        free.reverse()
+        for v, t in self.consts.items():
+            if free:
+                r, i = free.pop()
+                col = (2 + vs) * self.RA_COPIES + i
+            else:
+                r, i = self._slot(("const",), 2, lambda: self._new_row(C.CONSTANT, 2))
+                col = i
+            self.rows[r].consts[i] = v
+            self.rows[r].wires[col] = v
+            if t.cell is None:
+                t.cell = (r, col)
+            else:
+                self._union((r, col), t.cell)
+            self.tape += [OP_WIRE, r, col, t.sid]
 
     def zero(self):
         return self.constant(0)
@@ -586,6 +605,7 @@ class Builder:
         for i, t in enumerate(pi_hash):
             self._put(pi_row, i, t)
             self.tape += [OP_WIRE, pi_row, i, t.sid]
+        self._place_constants()
         n_rows = len(self.rows) + 1  # at least one Noop (as plonky2's blinding-free padding leaves)
         log_n = max(min_log_n, (n_rows - 1).bit_length())
         n = 1 << log_n
@@ -719,6 +739,9 @@ def eval_gate_circuit(b, g, consts, wires, pih):
             acc = b.mul_const_add_ext(g.p1, acc, wires[1 + i])
         out.append(b.sub_ext(acc, wires[0]))
         for i in range(g.p0):
+            if g.p1 == 2:
+                out.append(b.mul_sub_ext(wires[1 + i], wires[1 + i], wires[1 + i]))  # limb (limb - 1)
+                continue
             pr = wires[1 + i]
             for kk in range(1, g.p1):
                 pr = b.mul_ext(pr, b.add_const_ext(wires[1 + i], P - kk))
@@ -773,11 +796,12 @@ def eval_gate_circuit(b, g, consts, wires, pih):
         alpha, acc = (wires[2], wires[3]), (wires[4], wires[5])
         for i in range(nc):
             nxt = (wires[0], wires[1]) if i == nc - 1 else (wires[start_accs + 2 * i], wires[start_accs + 2 * i + 1])
-            t = alg_mul(b, acc, alpha)
+            # acc alpha + coeff - next, the addends riding on the products
             if ext:
-                out += [b.sub_ext(b.add_ext(t[0], wires[6 + 2 * i]), nxt[0]), b.sub_ext(b.add_ext(t[1], wires[7 + 2 * i]), nxt[1])]
+                z = (b.sub_ext(wires[6 + 2 * i], nxt[0]), b.sub_ext(wires[7 + 2 * i], nxt[1]))
             else:
-                out += [b.sub_ext(b.add_ext(t[0], wires[6 + i]), nxt[0]), b.sub_ext(t[1], nxt[1])]
+                z = (b.sub_ext(wires[6 + i], nxt[0]), b.mul_const_ext(P - 1, nxt[1]))
+            out += list(alg_mul_add(b, acc, alpha, z))
             acc = nxt
         return out
     if k == C.RANDOM_ACCESS:
@@ -824,7 +848,7 @@ def eval_gate_circuit(b, g, consts, wires, pih):
             for i in range(start, end):
                 val = tuple(b.mul_const_ext(bw[i], x) for x in at(1 + 2 * i))
                 term = (b.add_const_ext(sh[0], P - dom[i]), sh[1])
-                ev, pr = alg_add(b, alg_mul(b, ev, term), alg_mul(b, val, pr)), alg_mul(b, pr, term)
+                ev, pr = alg_mul_add(b, ev, term, alg_mul(b, val, pr)), alg_mul(b, pr, term)
             if c == nint:
                 break
             iev, ipr = at(w_int + 2 * c), at(w_int + 2 * (nint + c))
@@ -840,8 +864,14 @@ def eval_gate_circuit(b, g, consts, wires, pih):
 
 def alg_mul(b, x, y):
     """ExtensionAlgebra product (a0 + a1 X)(b0 + b1 X), X^2 = 7, over extension targets"""
-    a = b.mul_add_ext(x[0], y[0], b.mul_const_ext(W7, b.mul_ext(x[1], y[1])))
+    a = b.mul_add_ext(x[0], y[0], b.arithmetic_ext(W7, x[1], y[1], 0, x[1]))
     return (a, b.mul_add_ext(x[0], y[1], b.mul_ext(x[1], y[0])))
+
+
+def alg_mul_add(b, x, y, z):
+    """x y + z in the extension algebra, the addend folded into the products' own operations"""
+    a = b.mul_add_ext(x[0], y[0], b.arithmetic_ext(W7, x[1], y[1], 1, z[0]))
+    return (a, b.mul_add_ext(x[0], y[1], b.mul_add_ext(x[1], y[0], z[1])))
 
 
 def alg_add(b, x, y):
@@ -855,15 +885,15 @@ def pow7_circuit(b, x):
 
 
 def p2_external_circuit(b, s):
+    """circ(2 M4, M4, M4) with M4 by the addition chain of HorizenLabs' matmul_m4 (8 operations per block instead of 16
+    multiply-adds): t0 = a + b, t1 = c + d, t2 = 2b + t1, t3 = 2d + t0, t4 = 4 t1 + t3, t5 = 4 t0 + t2 -> (t3 + t5, t5, t2 + t4, t4)"""
     t = []
     for c in range(3):
-        for i in range(4):
-            acc = None
-            for j in range(4):
-                m = C.M4[i][j]
-                term = s[4 * c + j]
-                acc = b.mul_const_ext(m, term) if acc is None else b.mul_const_add_ext(m, term, acc)
-            t.append(acc)
+        x0, x1, x2, x3 = s[4 * c:4 * c + 4]
+        t0, t1 = b.add_ext(x0, x1), b.add_ext(x2, x3)
+        t2, t3 = b.mul_const_add_ext(2, x1, t1), b.mul_const_add_ext(2, x3, t0)
+        t4, t5 = b.mul_const_add_ext(4, t1, t3), b.mul_const_add_ext(4, t0, t2)
+        t += [b.add_ext(t3, t5), t5, b.add_ext(t2, t4), t4]
     sums = [b.add_ext(b.add_ext(t[i], t[4 + i]), t[8 + i]) for i in range(4)]
     return [b.add_ext(t[4 * c + i], sums[i]) for c in range(3) for i in range(4)]
 
@@ -1106,12 +1136,12 @@ def wrap_circuit(inner, caps, openings, fri, public_inputs, strict=True):
 
 # ---- the recursion framework (recursion-framework/src: circuit_builder.rs, universal_verifier_gadget/*, framework.rs) --------------------
 # Every circuit of the framework is wrapped until its proof has the shape all the others have, so that one "universal"
-# verifier (verifier data as witnesses + membership of their digest in the circuit set) can check any of them. The
-# reference's fixed point is RECURSION_THRESHOLD = 12 rows bits (universal_verifier_gadget/mod.rs:34): plonky2's verifier
-# of a 2^13-row proof fits 2^12 rows. The verifier built here needs 4063 rows for a 2^12-row proof and 4238 for a 2^13-row
-# one (its gate evaluators and constants are packed less tightly than plonky2's), so its fixed point is 13: final proofs
-# are 2^13-row proofs. Everything else follows the reference.
-RECURSION_THRESHOLD = 13
+# verifier (verifier data as witnesses + membership of their digest in the circuit set) can check any of them. The fixed
+# point is RECURSION_THRESHOLD = 12 row bits as in the reference (universal_verifier_gadget/mod.rs:34): the verifier built
+# here needs 3847 rows for a 2^12-row standard-config proof and 4022 for a 2^13-row one (its constants ride in the
+# RandomAccessGate rows' spare constant slots, so it has no ConstantGate rows at all), a reduce circuit with two universal
+# verifiers fits 2^13 rows, and its wrap lands on 2^12 again.
+RECURSION_THRESHOLD = 12
 CIRCUIT_SET_CAP_HEIGHT = 0
 DOMAIN_SEPARATOR_PAD = [1, 0, 0, 0, 0, 0, 0, 1]  # hash_pad(&[]) input
 

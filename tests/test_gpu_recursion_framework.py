@@ -40,7 +40,7 @@ def test_map_reduce_tree_of_real_proofs(ctx, mp2):
 def test_sixteen_leaf_tree_through_the_witness_programs(ctx, mp2):
     """the same framework at 16 leaves, level by level in batches: witnesses by the recorded witness programs
     (mp2g_witness_program_run on host threads), proofs by batched HIP provers with the witness check on. 31 framework
-    proofs = 62 prove() calls' worth of real circuits (map 2^6 + wrap 2^13, reduce 2^14 + wrap 2^13)."""
+    proofs = 62 prove() calls' worth of real circuits (map 2^6 + wrap 2^12, reduce 2^13 + wrap 2^12)."""
     prover = FW.GpuProver(ctx)
     circs = [R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)]
     fw = R.RecursiveCircuits(circs, prover, FW.circuit_fri_params)
@@ -81,5 +81,5 @@ def test_two_ranks_real_recursion_with_proof_handoff():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MP2G_BENCH_BACKEND="gloo"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["shapes"] == {"map": [6, 13], "reduce": [14, 13]}
+    assert line["n_gpus"] == 2 and line["config"]["shapes"] == {"map": [6, 12], "reduce": [13, 12]}
     assert line["framework_proofs_per_s"] > 0 and len(line["config"]["root_public_inputs"]) == 9

@@ -47,6 +47,7 @@ def test_base_wrap_verify(base_and_proof):
     inner = R.InnerCircuit(base, fp, cap, cd, len(base.public_inputs))
     wrap = R.wrap_circuit(inner, caps, openings, proof, base.public_inputs)
     assert wrap.log_n == 12  # RECURSION_THRESHOLD (universal_verifier_gadget/mod.rs:34)
+    assert C.CONSTANT not in {g.kind for g in wrap.gates}  # the constants ride in the RandomAccess rows' spare slots
     kinds = {g.kind for g in wrap.gates}
     assert {C.POSEIDON2, C.ARITHMETIC_EXT, C.BASE_SUM, C.RANDOM_ACCESS, C.REDUCING, C.COSET_INTERPOLATION, C.PUBLIC_INPUT} <= kinds
     assert not C.eval_on_points(wrap, wrap.pre[:wrap.num_constants], wrap.wires).any()
@@ -119,7 +120,7 @@ def test_map_reduce_with_the_universal_verifier():
     FWm = importlib.import_module("mapreduce-plonky2_amd.framework")
     circs = [R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)]
     fw = R.RecursiveCircuits(circs, OracleProver(), FWm.circuit_fri_params)
-    assert {k: [c[0].log_n for c in v] for k, v in fw.chains.items()} == {"map": [6, 13], "reduce": [14, 13]}
+    assert {k: [c[0].log_n for c in v] for k, v in fw.chains.items()} == {"map": [6, 12], "reduce": [13, 12]}
     data = O.rand_field(8, 5)
     p0 = fw.generate_proof("map", [], [], data[:4])
     p1 = fw.generate_proof("map", [], [], data[4:])
