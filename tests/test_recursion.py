@@ -147,3 +147,37 @@ def test_map_reduce_with_the_universal_verifier():
     with pytest.raises(AssertionError):
         bad = (p1[0], p1[1], p1[2], p0[3])  # p1's proof under p0's public inputs
         fw.generate_proof("reduce", [p0, bad], ["map", "map"], None)
+
+
+def test_witness_program_replays_the_builder_and_validates_its_tape():
+    """mp2g_witness_program_*: the recorded tape reproduces the builder's wire matrix for other inputs (no GPU involved),
+    and a malformed tape is refused at create (the tape indexes host memory)."""
+    import ctypes
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    a, b = O.rand_field(4, 1), O.rand_field(4, 2)
+    ca, cb = R.map_circuit(a), R.map_circuit(b)
+    assert np.array_equal(ca.tape, cb.tape) and np.array_equal(ca.input_sids, cb.input_sids)  # structure only
+    prog = mp2.WitnessProgram(ca)
+    wires, pi_hash, pis = prog.run(np.stack([a, b]))
+    assert np.array_equal(wires[0], ca.wires) and np.array_equal(wires[1], cb.wires)
+    assert np.array_equal(pi_hash[1], cb.pi_hash) and np.array_equal(pis[1], cb.public_inputs)
+    with pytest.raises(mp2.Mp2gError):  # non-canonical input
+        prog.run(np.array([[O.P, 0, 0, 0]], dtype=np.uint64))
+
+    def create(tape, n_slots=None):
+        h = ctypes.c_void_p()
+        t = np.ascontiguousarray(tape, dtype=np.uint64)
+        ins, cs = np.ascontiguousarray(ca.input_sids, dtype=np.uint32), np.ascontiguousarray(ca.const_slots, dtype=np.uint64)
+        rc = mp2.load().mp2g_witness_program_create(t.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(t.size), int(n_slots or ca.n_slots), int(ca.log_n),
+                                                    ins.ctypes.data_as(ctypes.c_void_p), int(ins.size), cs.ctypes.data_as(ctypes.c_void_p), int(cs.shape[0]),
+                                                    ctypes.byref(h))
+        if rc == 0:
+            mp2.load().mp2g_witness_program_free(h)
+        return rc
+    assert create(ca.tape) == 0
+    assert create(ca.tape[:-1]) != 0                      # truncated instruction
+    bad = ca.tape.copy(); bad[0] = 99
+    assert create(bad) != 0                               # unknown opcode
+    assert create(ca.tape, n_slots=ca.n_slots - 5) != 0   # slot out of range
+    bad = ca.tape.copy(); bad[1] = 1 << 20                # row beyond the circuit (first instruction is an ARITH or a P2 row)
+    assert create(bad) != 0

@@ -178,7 +178,14 @@ int main() {
   double ops = (double)blocks * threads * ITERS * 8;
 #define RUN(N) { float ms = timeit([&] { hipLaunchKernelGGL(k<N>, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull); }); \
     printf("%-14s %8.3f ms  %8.2f Gop/s (lane-ops)\n", names[N], ms, ops / ms / 1e6); }
-  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(20) RUN(21) RUN(22) RUN(23) RUN(24) RUN(25) RUN(26)
+  // issue slots per operation = (rate of the full-rate 32-bit add, measured first) / (rate of the operation). The dropped reduction
+  // variants asm2 / asm3 (rows 20-22 of the round-1 file; the mulw(asm3) row there was a failed launch, not a measurement) are not run.
+  float add32_ms = timeit([&] { hipLaunchKernelGGL(k<7>, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull); });
+#undef RUN
+#define RUN(N) { float ms = timeit([&] { hipLaunchKernelGGL(k<N>, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull); }); \
+    hipError_t e_ = hipGetLastError(); \
+    printf("%-14s %8.3f ms  %8.2f Gop/s (lane-ops)  %5.1f slots%s\n", names[N], ms, ops / ms / 1e6, ms / add32_ms, e_ == hipSuccess ? "" : "  LAUNCH FAILED"); }
+  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(23) RUN(24) RUN(25) RUN(26)
   {
     int reps = 64;
     float ms = timeit([&] { hipLaunchKernelGGL(kperm, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull, reps); });
