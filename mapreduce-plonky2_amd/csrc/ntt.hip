@@ -18,6 +18,9 @@
 //     has no general twiddle at all. (radix-16 halves the LDS round trips but also the waves per tile
 //     and measured 15 % slower.) LDS indices are padded by 1/16 so the strided rounds are bank-conflict
 //     free; the twiddles of all rounds but the first are staged in LDS once per block.
+//   * a tile has ONE block barrier: the first round reads global memory directly, every later round stays inside
+//     the 512 points a wave owns ("one-barrier tiles" below; the barrier-per-round kernels remain for the shapes
+//     that do not fit that scheme and for A/B runs with MP2G_NTT_V1=1).
 //   * LDE: the 2^r cosets of the blown-up domain are 2^r independent size-n transforms of the
 //     same coefficients scaled by (g w_{N}^j)^i; outputs land bit-reversed, i.e. already in
 //     Merkle-leaf order, so there is no separate transpose / bit-reverse pass.
@@ -48,6 +51,10 @@ struct NttArgs {
 };
 
 // lanes per block: one radix-2^NTT_RMAX item per lane and round
+// NTT_DBG (tools/dbg only): 1 = no butterflies (memory phases alone), 2 = no global traffic (butterflies alone)
+#ifndef NTT_DBG
+#define NTT_DBG 0
+#endif
 #ifndef NTT_RMAX
 #define NTT_RMAX 3
 #endif
@@ -84,12 +91,49 @@ template <int K> __device__ __forceinline__ u64 gl_mul_w8(u64 x) {  // x * w_8^K
 template <int K> __device__ __forceinline__ u64 bfly_lo(u64 u, u64 v, bool inverse) {
   return inverse ? gl_mul_w8<4 - K>(gl_sub(v, u)) : gl_mul_w8<K>(gl_sub(u, v));
 }
+// the 2^R-point DIF butterfly of one lane (R = 3: true radix-8 with the w_8 shifts; R < 3: the last, partial round) followed by
+// the round's general twiddles w_T^(E r), r = bitrev3(m), looked up at [r-1][below]
+template <int LT, int HI, int R, bool TWG = false>
+__device__ __forceinline__ void butterfly(u64* x, int below, const u64* tw, const u64* __restrict__ twg, bool inverse) {
+  constexpr int LO = HI - R + 1;
+  constexpr int RHO = (LT - 1 - HI) / 3;
+  static_assert(R == 3 || LO == 0, "a partial round can only be the last one");
+  if constexpr (R == 3) {
+    // stage 0: pairs (m, m + 4), lower output times w_8^m
+    { u64 u = x[0], v = x[4]; x[0] = gl_add(u, v); x[4] = gl_sub(u, v); }
+    { u64 u = x[1], v = x[5]; x[1] = gl_add(u, v); x[5] = bfly_lo<1>(u, v, inverse); }
+    { u64 u = x[2], v = x[6]; x[2] = gl_add(u, v); x[6] = bfly_lo<2>(u, v, inverse); }
+    { u64 u = x[3], v = x[7]; x[3] = gl_add(u, v); x[7] = bfly_lo<3>(u, v, inverse); }
+    // stage 1: pairs (m, m + 2) inside each half, lower output times w_4^(m & 1)
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+      { u64 u = x[h], v = x[h + 2]; x[h] = gl_add(u, v); x[h + 2] = gl_sub(u, v); }
+      { u64 u = x[h + 1], v = x[h + 3]; x[h + 1] = gl_add(u, v); x[h + 3] = bfly_lo<2>(u, v, inverse); }
+    }
+    // stage 2: pairs (m, m + 1)
+#pragma unroll
+    for (int m = 0; m < 8; m += 2) { u64 u = x[m], v = x[m + 1]; x[m] = gl_add(u, v); x[m + 1] = gl_sub(u, v); }
+    if constexpr (LO > 0) {
+      const u64* tab = (TWG || RHO < R8Tw<LT>::GLOBAL_ROUNDS) ? twg + R8Tw<LT>::off(RHO) : tw + (R8Tw<LT>::off(RHO) - R8Tw<LT>::LDS_OFF);
+#pragma unroll
+      for (int m = 1; m < 8; m++) {
+        const int r = ((m & 1) << 2) | (m & 2) | (m >> 2);
+        x[m] = gl_mul(x[m], tab[((r - 1) << LO) + below]);
+      }
+    }
+  } else if constexpr (R == 2) {
+    { u64 u = x[0], v = x[2]; x[0] = gl_add(u, v); x[2] = gl_sub(u, v); }
+    { u64 u = x[1], v = x[3]; x[1] = gl_add(u, v); x[3] = bfly_lo<2>(u, v, inverse); }
+    { u64 u = x[0], v = x[1]; x[0] = gl_add(u, v); x[1] = gl_sub(u, v); }
+    { u64 u = x[2], v = x[3]; x[2] = gl_add(u, v); x[3] = gl_sub(u, v); }
+  } else {
+    u64 u = x[0], v = x[1]; x[0] = gl_add(u, v); x[1] = gl_sub(u, v);
+  }
+}
 template <int LT, int HI, int R, bool COLS, int LW, int NTT_THREADS>
 __device__ __forceinline__ void dif_round(u64* s, const u64* tw, const u64* __restrict__ twg, int tid, bool inverse) {
   constexpr int T = 1 << LT, LO = HI - R + 1, W = 1 << LW;
   constexpr int ITEMS = W << (LT - R);
-  constexpr int RHO = (LT - 1 - HI) / 3;
-  static_assert(R == 3 || LO == 0, "a partial round can only be the last one");
   for (int item = tid; item < ITEMS; item += NTT_THREADS) {
     int c, rest;
     if (COLS) { c = item & (W - 1); rest = item >> LW; }
@@ -102,39 +146,7 @@ __device__ __forceinline__ void dif_round(u64* s, const u64* tw, const u64* __re
       int j = j0 + (m << LO);
       x[m] = s[lds_pad(COLS ? (j << LW) + c : (c << LT) + j)];
     }
-    if constexpr (R == 3) {
-      // stage 0: pairs (m, m + 4), lower output times w_8^m
-      { u64 u = x[0], v = x[4]; x[0] = gl_add(u, v); x[4] = gl_sub(u, v); }
-      { u64 u = x[1], v = x[5]; x[1] = gl_add(u, v); x[5] = bfly_lo<1>(u, v, inverse); }
-      { u64 u = x[2], v = x[6]; x[2] = gl_add(u, v); x[6] = bfly_lo<2>(u, v, inverse); }
-      { u64 u = x[3], v = x[7]; x[3] = gl_add(u, v); x[7] = bfly_lo<3>(u, v, inverse); }
-      // stage 1: pairs (m, m + 2) inside each half, lower output times w_4^(m & 1)
-#pragma unroll
-      for (int h = 0; h < 8; h += 4) {
-        { u64 u = x[h], v = x[h + 2]; x[h] = gl_add(u, v); x[h + 2] = gl_sub(u, v); }
-        { u64 u = x[h + 1], v = x[h + 3]; x[h + 1] = gl_add(u, v); x[h + 3] = bfly_lo<2>(u, v, inverse); }
-      }
-      // stage 2: pairs (m, m + 1)
-#pragma unroll
-      for (int m = 0; m < 8; m += 2) { u64 u = x[m], v = x[m + 1]; x[m] = gl_add(u, v); x[m + 1] = gl_sub(u, v); }
-      // general twiddles w^(E r), r = bitrev3(m)
-      if constexpr (LO > 0) {
-        const u64* tab = RHO < R8Tw<LT>::GLOBAL_ROUNDS ? twg + R8Tw<LT>::off(RHO) : tw + (R8Tw<LT>::off(RHO) - R8Tw<LT>::LDS_OFF);
-#pragma unroll
-        for (int m = 1; m < 8; m++) {
-          constexpr int dummy = 0; (void)dummy;
-          const int r = ((m & 1) << 2) | (m & 2) | (m >> 2);
-          x[m] = gl_mul(x[m], tab[((r - 1) << LO) + below]);
-        }
-      }
-    } else if constexpr (R == 2) {
-      { u64 u = x[0], v = x[2]; x[0] = gl_add(u, v); x[2] = gl_sub(u, v); }
-      { u64 u = x[1], v = x[3]; x[1] = gl_add(u, v); x[3] = bfly_lo<2>(u, v, inverse); }
-      { u64 u = x[0], v = x[1]; x[0] = gl_add(u, v); x[1] = gl_sub(u, v); }
-      { u64 u = x[2], v = x[3]; x[2] = gl_add(u, v); x[3] = gl_sub(u, v); }
-    } else {
-      u64 u = x[0], v = x[1]; x[0] = gl_add(u, v); x[1] = gl_sub(u, v);
-    }
+    butterfly<LT, HI, R>(x, below, tw, twg, inverse);
 #pragma unroll
     for (int m = 0; m < (1 << R); m++) {
       int j = j0 + (m << LO);
@@ -160,9 +172,8 @@ __device__ __forceinline__ u64* out_base(const NttArgs& a, u32 b) {
   return a.out + (u64)(b >> a.logK) * a.out_poly_stride + ((u64)bitrev32(coset, a.logK) << a.log_n);
 }
 
-// (A persistent, register-prefetching variant of these kernels was measured and dropped: the 16
-// staged points per lane cost 32 VGPRs, pushed the kernels into spills at 4 waves/SIMD and ran
-// 15-35 % slower; the limiter is VALU issue, not HBM latency -- see DESIGN.md "NTT".)
+// (A persistent, register-prefetching variant of these kernels was measured in round 1 and dropped: the 16
+// staged points per lane cost 32 VGPRs, pushed the kernels into spills and ran 15-35 % slower.)
 
 // ---- pass B / single pass: contiguous rows of length T = 2^LT, 2^LW rows per block ----------
 template <int LT, int LW>
@@ -184,7 +195,11 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_kernel(NttArgs
     if (g < total_rows) {
       u32 b = (u32)(g >> a.log_n1), jr = (u32)(g & (n1 - 1));
       if (two_pass) {
+#if NTT_DBG == 2
+        v = (u64)e * 0x9E3779B97F4A7C15ull + jr;
+#else
         v = out_base(a, b)[((u64)jr << LT) + j];  // pass A left row jr in place
+#endif
       } else {
         v = in_base(a, b)[j];
         if (a.pre_lo) v = gl_mul(v, a.pre_lo[((u64)(b & ((1u << a.logK) - 1)) << LT) + j]);
@@ -193,7 +208,9 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_kernel(NttArgs
     s[lds_pad(e)] = v;
   }
   __syncthreads();
+#if NTT_DBG != 1
   dif_all<LT, LT - 1, false, LW, NT>(s, tw, a.tw, tid, a.inverse != 0);
+#endif
   for (int e = tid; e < E; e += NT) {
     int r = e >> LT, p = e & (T - 1);
     u64 g = row0 + r;
@@ -201,6 +218,9 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_rows_kernel(NttArgs
     u32 b = (u32)(g >> a.log_n1), jr = (u32)(g & (n1 - 1));
     u64 v = a.bitrev_out ? s[lds_pad(e)] : s[lds_pad((r << LT) + (int)bitrev32((u32)p, LT))];
     if (a.post) v = gl_mul(v, a.post);
+#if NTT_DBG == 2
+    if (v == 0x123456789ull)
+#endif
     out_base(a, b)[((u64)jr << LT) + p] = v;
   }
 }
@@ -255,7 +275,11 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
   const u64* src = in_base(a, b);
   for (int e = tid; e < E; e += NT) {
     int c = e & (W - 1), j = e >> LW;
+#if NTT_DBG == 2
+    u64 v = (u64)e * 0x9E3779B97F4A7C15ull + c0;
+#else
     u64 v = src[((u64)j << a.log_n2) + c0 + c];
+#endif
     if (a.pre_full) {
       v = gl_mul(v, a.pre_full[((u64)coset << a.log_n) + ((u64)j << a.log_n2) + c0 + c]);
     } else if (a.pre_lo) {
@@ -265,7 +289,9 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
     s[lds_pad(e)] = v;
   }
   __syncthreads();
+#if NTT_DBG != 1
   dif_all<LT, LT - 1, true, LW, NT>(s, tw, a.tw, tid, a.inverse != 0);
+#endif
   // row j holds k1 = bitrev(j); multiply by w_n^(i2*k1) and leave it at row j
   u64* dst = dst_dense ? dst_dense + (u64)b * ((u64)1 << a.log_n) : out_base(a, b);
   for (int e = tid; e < E; e += NT) {
@@ -273,13 +299,243 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
     u64 v = s[lds_pad(e)];
     u64 w;
     if (a.tw4_full) {
+#if NTT_DBG == 2
+      w = (u64)e * 0x9E3779B97F4A7C55ull + c0;
+#else
       w = a.tw4_full[((u64)j << a.log_n2) + c0 + c];
+#endif
     } else {
       u32 k1 = bitrev32((u32)j, LT);
       u32 ex = (c0 + c) * k1;  // < n <= 2^24
       w = gl_mul(a.tw4_lo[ex & 4095], a.tw4_hi[ex >> 12]);
     }
+#if NTT_DBG == 1
+    dst[((u64)j << a.log_n2) + c0 + c] = v ^ w;
+#elif NTT_DBG == 2
+    v = gl_mul(v, w);
+    if (v == 0x123456789ull) dst[((u64)j << a.log_n2) + c0 + c] = v;
+#else
     dst[((u64)j << a.log_n2) + c0 + c] = gl_mul(v, w);
+#endif
+  }
+}
+
+// ---- one-barrier tiles ----------------------------------------------------------------------------
+// The kernels above put a block barrier around every round and stage the tile through LDS on the way in; measured on the
+// 2^22 transform (tools/dbg/ntt_phases.sh, tools/dbg/ntt_pmc.sh) their waves sit parked for 56 % of their cycles. Here
+//   * the first radix-8 round takes its inputs straight from global memory (the coalesced load pattern of a tile IS the
+//     item pattern of that round: lane `below` needs elements below + m T/8) and its twiddles from the global table;
+//   * its outputs go to LDS and the one block barrier of the tile follows;
+//   * every later round works on index bits below T/8 <= 2^9, i.e. inside 512 points that one wave owns (rows: 512
+//     consecutive points of the tile; columns: T/8 rows x 512/(T/8) adjacent columns), so the wave runs them alone: its LDS
+//     operations execute in issue order, and between rounds only the compiler has to be told not to move them;
+//   * a row tile is stored by the owning waves (no barrier), a column tile after one more barrier so that the stores keep
+//     whole 64-byte row segments.
+template <int LT, int LW, bool COLS> struct WaveGeom {
+  static constexpr int R0 = 3;
+  static constexpr int LTS = LT - R0;  // index bits left after the first round
+  static constexpr int LWL = 9 - LTS;  // log2 of the sub-transforms (rows) / columns of a wave's 512 points
+  static constexpr bool OK = LT >= 3 && LT <= 12 && ((1 << LT) << LW) == 8 * NttGeom<LT, LW>::NT && (!COLS || LW >= LWL);
+};
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// one round of the sub-transforms of length 2^LTS inside the 512 points at `base`; LWS = log2 of the tile's row stride (COLS)
+template <int LT, int LTS, int HI, int R, bool COLS, int LWL, int LWS>
+__device__ __forceinline__ void wave_round(u64* s, int base, const u64* tw, int lane, bool inverse) {
+  constexpr int LO = HI - R + 1, WL = 1 << LWL;
+  constexpr int ITEMS = 512 >> R;
+#pragma unroll
+  for (int item0 = 0; item0 < ITEMS; item0 += 64) {
+    int item = item0 + lane;
+    int c, rest;
+    if (COLS) { c = item & (WL - 1); rest = item >> LWL; }
+    else { rest = item & ((1 << (LTS - R)) - 1); c = item >> (LTS - R); }
+    int below = rest & ((1 << LO) - 1), above = rest >> LO;
+    int j0 = (above << (HI + 1)) | below;
+    u64 x[1 << R];
+#pragma unroll
+    for (int m = 0; m < (1 << R); m++) {
+      int j = j0 + (m << LO);
+      x[m] = s[lds_pad(base + (COLS ? (j << LWS) + c : (c << LTS) + j))];
+    }
+    butterfly<LT, HI, R>(x, below, tw, nullptr, inverse);
+#pragma unroll
+    for (int m = 0; m < (1 << R); m++) {
+      int j = j0 + (m << LO);
+      s[lds_pad(base + (COLS ? (j << LWS) + c : (c << LTS) + j))] = x[m];
+    }
+  }
+}
+template <int LT, int LTS, int HI, bool COLS, int LWL, int LWS>
+__device__ __forceinline__ void wave_rounds(u64* s, int base, const u64* tw, int lane, bool inverse) {
+  if constexpr (HI >= 0) {
+    constexpr int R = (HI + 1 >= 3) ? 3 : HI + 1;
+    wave_sync();
+    wave_round<LT, LTS, HI, R, COLS, LWL, LWS>(s, base, tw, lane, inverse);
+    wave_rounds<LT, LTS, HI - R, COLS, LWL, LWS>(s, base, tw, lane, inverse);
+  }
+}
+
+template <int LT, int LW>
+__global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) __attribute__((amdgpu_waves_per_eu(8))) ntt_rows_v2_kernel(NttArgs a) {
+  using G = WaveGeom<LT, LW, false>;
+  constexpr int T = 1 << LT, E = T << LW, NT = NttGeom<LT, LW>::NT, LTS = G::LTS;
+  extern __shared__ __align__(16) u64 smem[];
+  u64* s = smem;
+  u64* tw = smem + lds_pad(E) + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < R8Tw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[R8Tw<LT>::LDS_OFF + i];
+  const u32 n1 = 1u << a.log_n1;
+  const u64 total_rows = (u64)a.batch << a.log_n1;
+  const u64 row0 = (u64)blockIdx.x << LW;
+  const bool two_pass = a.log_n1 != 0, inverse = a.inverse != 0;
+  {
+    const int c = tid >> LTS, below = tid & ((1 << LTS) - 1);
+    const u64 g = row0 + c;
+    u64 x[8];
+    if (g < total_rows) {
+      u32 b = (u32)(g >> a.log_n1), jr = (u32)(g & (n1 - 1));
+      if (two_pass) {
+        const u64* src = out_base(a, b) + ((u64)jr << LT);  // pass A left row jr in place
+#pragma unroll
+#if NTT_DBG == 2
+        for (int m = 0; m < 8; m++) x[m] = (u64)(tid + m) * 0x9E3779B97F4A7C15ull + (u64)(size_t)src;
+#else
+        for (int m = 0; m < 8; m++) x[m] = src[below + (m << LTS)];
+#endif
+      } else {
+        const u64* src = in_base(a, b);
+#pragma unroll
+        for (int m = 0; m < 8; m++) x[m] = src[below + (m << LTS)];
+        if (a.pre_lo) {
+          const u64* pre = a.pre_lo + ((u64)(b & ((1u << a.logK) - 1)) << LT);
+#pragma unroll
+          for (int m = 0; m < 8; m++) x[m] = gl_mul(x[m], pre[below + (m << LTS)]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; m++) x[m] = 0;
+    }
+#if NTT_DBG != 1
+    butterfly<LT, LT - 1, 3, true>(x, below, tw, a.tw, inverse);
+#endif
+#pragma unroll
+    for (int m = 0; m < 8; m++) s[lds_pad((c << LT) + below + (m << LTS))] = x[m];
+  }
+  __syncthreads();
+#if NTT_DBG != 1
+  wave_rounds<LT, LTS, LTS - 1, false, G::LWL, 0>(s, wave << 9, tw, lane, inverse);
+#endif
+  if (a.bitrev_out) {
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int e = (wave << 9) + lane + (k << 6);
+      int r = e >> LT, p = e & (T - 1);
+      u64 g = row0 + r;
+      if (g >= total_rows) continue;
+      u32 b = (u32)(g >> a.log_n1), jr = (u32)(g & (n1 - 1));
+      u64 v = s[lds_pad(e)];
+      if (a.post) v = gl_mul(v, a.post);
+#if NTT_DBG == 2
+      if (v == 0x123456789ull)
+#endif
+      out_base(a, b)[((u64)jr << LT) + p] = v;
+    }
+  } else {
+    __syncthreads();
+    for (int e = tid; e < E; e += NT) {
+      int r = e >> LT, p = e & (T - 1);
+      u64 g = row0 + r;
+      if (g >= total_rows) continue;
+      u32 b = (u32)(g >> a.log_n1), jr = (u32)(g & (n1 - 1));
+      u64 v = s[lds_pad((r << LT) + (int)bitrev32((u32)p, LT))];
+      if (a.post) v = gl_mul(v, a.post);
+      out_base(a, b)[((u64)jr << LT) + p] = v;
+    }
+  }
+}
+
+template <int LT, int LW>
+__global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) __attribute__((amdgpu_waves_per_eu(8))) ntt_cols_v2_kernel(NttArgs a, u64* dst_dense) {
+  using G = WaveGeom<LT, LW, true>;
+  constexpr int W = 1 << LW, E = (1 << LT) << LW, NT = NttGeom<LT, LW>::NT, LTS = G::LTS, LWL = G::LWL;
+  extern __shared__ __align__(16) u64 smem[];
+  u64* s = smem;
+  u64* tw = smem + lds_pad(E) + 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < R8Tw<LT>::LDS_WORDS; i += NT) tw[i] = a.tw[R8Tw<LT>::LDS_OFF + i];
+  const u32 tiles_per = 1u << (a.log_n2 - LW);
+  u32 bid = blockIdx.x;  // XCD-aware order, as in ntt_cols_kernel
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const u32 b = bid / tiles_per, c0 = (bid % tiles_per) << LW;
+  const u32 coset = b & ((1u << a.logK) - 1);
+  const u64* src = in_base(a, b);
+  const bool inverse = a.inverse != 0;
+  {
+    const int c = tid & (W - 1), below = tid >> LW;
+    u64 x[8];
+#pragma unroll
+#if NTT_DBG == 2
+    for (int m = 0; m < 8; m++) x[m] = (u64)(tid + m) * 0x9E3779B97F4A7C15ull + (u64)(size_t)src + c0;
+#else
+    for (int m = 0; m < 8; m++) x[m] = src[((u64)(below + (m << LTS)) << a.log_n2) + c0 + c];
+#endif
+    if (a.pre_full) {
+      const u64* pre = a.pre_full + ((u64)coset << a.log_n) + c0 + c;
+#pragma unroll
+      for (int m = 0; m < 8; m++) x[m] = gl_mul(x[m], pre[(u64)(below + (m << LTS)) << a.log_n2]);
+    } else if (a.pre_lo) {
+      u64 pl = a.pre_lo[((u64)coset << a.log_n2) + c0 + c];
+#pragma unroll
+      for (int m = 0; m < 8; m++) x[m] = gl_mul(gl_mul(x[m], pl), a.pre_hi[((u64)coset << LT) + below + (m << LTS)]);
+    }
+#if NTT_DBG != 1
+    butterfly<LT, LT - 1, 3, true>(x, below, tw, a.tw, inverse);
+#endif
+#pragma unroll
+    for (int m = 0; m < 8; m++) s[lds_pad(((below + (m << LTS)) << LW) + c)] = x[m];
+  }
+  __syncthreads();
+#if NTT_DBG != 1
+  {
+    constexpr int GW = W >> LWL;  // column groups of a tile; wave = (top three row bits, column group)
+    const int cg = wave & (GW - 1), jh = wave / GW;
+    wave_rounds<LT, LTS, LTS - 1, true, LWL, LW>(s, ((jh << LTS) << LW) + (cg << LWL), tw, lane, inverse);
+  }
+#endif
+  __syncthreads();
+  // row j holds k1 = bitrev(j); multiply by w_n^(i2*k1) and leave it at row j
+  u64* dst = dst_dense ? dst_dense + (u64)b * ((u64)1 << a.log_n) : out_base(a, b);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    int e = tid + k * NT;
+    int c = e & (W - 1), j = e >> LW;
+    u64 v = s[lds_pad(e)];
+    u64 w;
+    if (a.tw4_full) {
+#if NTT_DBG == 2
+      w = (u64)e * 0x9E3779B97F4A7C55ull + c0;
+#else
+      w = a.tw4_full[((u64)j << a.log_n2) + c0 + c];
+#endif
+    } else {
+      u32 k1 = bitrev32((u32)j, LT);
+      u32 ex = (c0 + c) * k1;  // < n <= 2^24
+      w = gl_mul(a.tw4_lo[ex & 4095], a.tw4_hi[ex >> 12]);
+    }
+#if NTT_DBG == 1
+    dst[((u64)j << a.log_n2) + c0 + c] = v ^ w;
+#elif NTT_DBG == 2
+    v = gl_mul(v, w);
+    if (v == 0x123456789ull) dst[((u64)j << a.log_n2) + c0 + c] = v;
+#else
+    dst[((u64)j << a.log_n2) + c0 + c] = gl_mul(v, w);
+#endif
   }
 }
 
@@ -458,11 +714,26 @@ static int lw11_override() {
   if (v < 0) { const char* e = getenv("MP2G_NTT_LW11"); v = e ? atoi(e) : 0; }
   return v;
 }
+// tuning / A-B aid: MP2G_NTT_V1=1 runs the barrier-per-round kernels everywhere
+static bool use_v1() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MP2G_NTT_V1"); v = e ? atoi(e) : 0; }
+  return v != 0;
+}
 template <int LT, int LW>
 static hipError_t launch_rows_lw(const NttArgs& a, bool nat_two_pass, hipStream_t st) {
   constexpr int NT = NttGeom<LT, LW>::NT;
   size_t lds = lds_bytes<LT, LW>();
   u64 total_rows = (u64)a.batch << a.log_n1;
+  if constexpr (WaveGeom<LT, LW, false>::OK) {
+    if (!nat_two_pass && !use_v1()) {
+      static bool flags[MP2G_MAX_DEVICES];
+      bool* attr = attr_flag(flags);
+      if (!*attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_rows_v2_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); *attr = true; }
+      hipLaunchKernelGGL((ntt_rows_v2_kernel<LT, LW>), dim3((u32)((total_rows + (1u << LW) - 1) >> LW)), dim3(NT), lds, st, a);
+      return hipGetLastError();
+    }
+  }
   if (nat_two_pass) {
     static bool flags[MP2G_MAX_DEVICES];
     bool* attr = attr_flag(flags);
@@ -488,6 +759,15 @@ template <int LT, int LW>
 static hipError_t launch_cols_lw(const NttArgs& a, u64* dst_dense, hipStream_t st) {
   constexpr int NT = NttGeom<LT, LW>::NT;
   size_t lds = lds_bytes<LT, LW>();
+  if constexpr (WaveGeom<LT, LW, true>::OK) {
+    if (!use_v1()) {
+      static bool flags[MP2G_MAX_DEVICES];
+      bool* attr = attr_flag(flags);
+      if (!*attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_cols_v2_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); *attr = true; }
+      hipLaunchKernelGGL((ntt_cols_v2_kernel<LT, LW>), dim3(a.batch << (a.log_n2 - LW)), dim3(NT), lds, st, a, dst_dense);
+      return hipGetLastError();
+    }
+  }
   static bool flags[MP2G_MAX_DEVICES];
   bool* attr = attr_flag(flags);
   if (!*attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_cols_kernel<LT, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); *attr = true; }
