@@ -67,7 +67,7 @@ def gpu_clocks(device):
         return {"error": str(e)[:80]}
 
 
-def check_against_oracle(samples, budget_s, timed):
+def check_against_oracle(samples, budget_s, timed, ranks_on_host=1):
     """The checker leg (and, at N=1, the `cpu_baseline` sample): the CPU oracle proves the witnesses of the sampled
     GPU proofs -- leaf proof = one base + one wrap prove() -- `groups` leaf proofs at a time with cores/groups
     OpenMP threads each, until every mandatory sample is done and, when `timed`, ~budget_s seconds are spent.
@@ -77,7 +77,7 @@ def check_against_oracle(samples, budget_s, timed):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import circuits as OC  # oracle-side prove / verify of a built circuit (tests/circuits.py)
     import oracle as O
-    cores = os.cpu_count() or 1
+    cores = max(1, (os.cpu_count() or 1) // max(1, ranks_on_host))  # every rank of the node checks its own proofs at the same time
     groups = max(1, min(len(samples), cores // 32))
     per_group = max(1, cores // groups)
     omp = ctypes.CDLL("libgomp.so.1")
@@ -519,7 +519,7 @@ def main(argv=None):
         samples.sort(key=lambda leaf: not leaf[0][-1])
         timed = world == 1 and not args.no_cpu_baseline
         # every rank checks its own proofs; the timed sample is rank 0 at N=1 only
-        verified, cpu_base = check_against_oracle(samples, args.cpu_budget, timed)
+        verified, cpu_base = check_against_oracle(samples, args.cpu_budget, timed, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     # per-stage split of one batch per shape, each prover alone on the GPU (outside the timed region)
     stages = {}

@@ -51,6 +51,10 @@ struct NttArgs {
 };
 
 // lanes per block: one radix-2^NTT_RMAX item per lane and round
+// 8 waves per SIMD (64 VGPRs) for the one-barrier kernels unless built with -DNTT_WAVES_ATTR= (tools/dbg A/B)
+#ifndef NTT_WAVES_ATTR
+#define NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(8)))
+#endif
 // NTT_DBG (tools/dbg only): 1 = no butterflies (memory phases alone), 2 = no global traffic (butterflies alone)
 #ifndef NTT_DBG
 #define NTT_DBG 0
@@ -332,10 +336,10 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) ntt_cols_kernel(NttArgs
 //   * a row tile is stored by the owning waves (no barrier), a column tile after one more barrier so that the stores keep
 //     whole 64-byte row segments.
 template <int LT, int LW, bool COLS> struct WaveGeom {
-  static constexpr int R0 = 3;
-  static constexpr int LTS = LT - R0;  // index bits left after the first round
-  static constexpr int LWL = 9 - LTS;  // log2 of the sub-transforms (rows) / columns of a wave's 512 points
-  static constexpr bool OK = LT >= 3 && LT <= 12 && ((1 << LT) << LW) == 8 * NttGeom<LT, LW>::NT && (!COLS || LW >= LWL);
+  static constexpr int NBR = LT > 12 ? 2 : 1;  // rounds that cross waves (T = 2^13: the second one too, with a barrier of its own)
+  static constexpr int LTS = LT - 3 * NBR;     // index bits left after them
+  static constexpr int LWL = 9 - LTS;          // log2 of the sub-transforms (rows) / columns of a wave's 512 points
+  static constexpr bool OK = LT >= 3 && LT <= 13 && (!COLS || LT <= 12) && ((1 << LT) << LW) == 8 * NttGeom<LT, LW>::NT && (!COLS || LW >= LWL);
 };
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -380,9 +384,9 @@ __device__ __forceinline__ void wave_rounds(u64* s, int base, const u64* tw, int
 }
 
 template <int LT, int LW>
-__global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) __attribute__((amdgpu_waves_per_eu(8))) ntt_rows_v2_kernel(NttArgs a) {
+__global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_rows_v2_kernel(NttArgs a) {
   using G = WaveGeom<LT, LW, false>;
-  constexpr int T = 1 << LT, E = T << LW, NT = NttGeom<LT, LW>::NT, LTS = G::LTS;
+  constexpr int T = 1 << LT, E = T << LW, NT = NttGeom<LT, LW>::NT, LTS = G::LTS, L0 = LT - 3;
   extern __shared__ __align__(16) u64 smem[];
   u64* s = smem;
   u64* tw = smem + lds_pad(E) + 1;
@@ -393,7 +397,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) __attribute__((amdgpu_w
   const u64 row0 = (u64)blockIdx.x << LW;
   const bool two_pass = a.log_n1 != 0, inverse = a.inverse != 0;
   {
-    const int c = tid >> LTS, below = tid & ((1 << LTS) - 1);
+    const int c = tid >> L0, below = tid & ((1 << L0) - 1);
     const u64 g = row0 + c;
     u64 x[8];
     if (g < total_rows) {
@@ -404,16 +408,16 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) __attribute__((amdgpu_w
 #if NTT_DBG == 2
         for (int m = 0; m < 8; m++) x[m] = (u64)(tid + m) * 0x9E3779B97F4A7C15ull + (u64)(size_t)src;
 #else
-        for (int m = 0; m < 8; m++) x[m] = src[below + (m << LTS)];
+        for (int m = 0; m < 8; m++) x[m] = src[below + (m << L0)];
 #endif
       } else {
         const u64* src = in_base(a, b);
 #pragma unroll
-        for (int m = 0; m < 8; m++) x[m] = src[below + (m << LTS)];
+        for (int m = 0; m < 8; m++) x[m] = src[below + (m << L0)];
         if (a.pre_lo) {
           const u64* pre = a.pre_lo + ((u64)(b & ((1u << a.logK) - 1)) << LT);
 #pragma unroll
-          for (int m = 0; m < 8; m++) x[m] = gl_mul(x[m], pre[below + (m << LTS)]);
+          for (int m = 0; m < 8; m++) x[m] = gl_mul(x[m], pre[below + (m << L0)]);
         }
       }
     } else {
@@ -424,10 +428,14 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) __attribute__((amdgpu_w
     butterfly<LT, LT - 1, 3, true>(x, below, tw, a.tw, inverse);
 #endif
 #pragma unroll
-    for (int m = 0; m < 8; m++) s[lds_pad((c << LT) + below + (m << LTS))] = x[m];
+    for (int m = 0; m < 8; m++) s[lds_pad((c << LT) + below + (m << L0))] = x[m];
   }
   __syncthreads();
 #if NTT_DBG != 1
+  if constexpr (G::NBR == 2) {
+    dif_round<LT, LT - 4, 3, false, LW, NT>(s, tw, a.tw, tid, inverse);
+    __syncthreads();
+  }
   wave_rounds<LT, LTS, LTS - 1, false, G::LWL, 0>(s, wave << 9, tw, lane, inverse);
 #endif
   if (a.bitrev_out) {
@@ -461,7 +469,7 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) __attribute__((amdgpu_w
 }
 
 template <int LT, int LW>
-__global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) __attribute__((amdgpu_waves_per_eu(8))) ntt_cols_v2_kernel(NttArgs a, u64* dst_dense) {
+__global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_cols_v2_kernel(NttArgs a, u64* dst_dense) {
   using G = WaveGeom<LT, LW, true>;
   constexpr int W = 1 << LW, E = (1 << LT) << LW, NT = NttGeom<LT, LW>::NT, LTS = G::LTS, LWL = G::LWL;
   extern __shared__ __align__(16) u64 smem[];
@@ -597,7 +605,7 @@ CosetTables::~CosetTables() { (void)hipFree(lo); (void)hipFree(hi); (void)hipFre
 
 // Cooley-Tukey split n = n1 * n2 of the sizes that do not fit one block (n1 = the strided pass)
 static u32 split_log_n1(u32 log_n) {
-  if (log_n <= 12) return 0;
+  if (log_n <= 13) return 0;  // 2^13 points = one 64 KB tile of 1024 lanes: a single pass over HBM
   u32 l1 = (log_n + 1) / 2;
   if (log_n >= 22) l1 = log_n - 12;  // measured (tools/dbg/ntt22.py): 2^10 x 2^12 runs 5-9 % faster than 2^11 x 2^11 at 2^22
   if (const char* e = getenv("MP2G_NTT_N1")) {  // tuning aid: the strided dimension's size
@@ -693,7 +701,7 @@ hipError_t NttEngine::ensure_scratch(size_t words) {
 
 // points per block (measured on MI355X, tools/dbg/ntt_only.py): 4096 (256 lanes) for T <= 2^10 and
 // T = 2^12, 8192 (512 lanes, two blocks per CU) for T = 2^11 where the twiddle table is amortised
-template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : (LT == 11 ? 2 : 12 - LT); }
+template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : (LT == 11 ? 2 : 12 - LT); }  // 2^13: one row of 8192 points
 template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : (LT == 10 ? 3 : 12 - LT); }  // 2^10 x 8 columns: +4 % at 2^22 (ntt22.py)
 template <int LT, int LW> static size_t lds_bytes() {
   int e = (1 << LT) << LW;
@@ -793,7 +801,7 @@ static hipError_t launch_cols(const NttArgs& a, u64* dst_dense, hipStream_t st) 
 static hipError_t dispatch_rows(u32 lt, const NttArgs& a, bool nat, hipStream_t st) {
   switch (lt) {
     ROWS_CASE(1) ROWS_CASE(2) ROWS_CASE(3) ROWS_CASE(4) ROWS_CASE(5) ROWS_CASE(6)
-    ROWS_CASE(7) ROWS_CASE(8) ROWS_CASE(9) ROWS_CASE(10) ROWS_CASE(11) ROWS_CASE(12)
+    ROWS_CASE(7) ROWS_CASE(8) ROWS_CASE(9) ROWS_CASE(10) ROWS_CASE(11) ROWS_CASE(12) ROWS_CASE(13)
     default: return hipErrorInvalidValue;
   }
 }

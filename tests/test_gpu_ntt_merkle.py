@@ -68,6 +68,36 @@ def test_ntt_edge_values(ctx):
     assert np.array_equal(ctx.ntt(a), O.fft(a))
 
 
+_V1_CHILD = """
+import hashlib, importlib, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+import oracle as O
+mp2 = importlib.import_module("mapreduce-plonky2_amd")
+ctx = mp2.Context(0)
+h = hashlib.sha256()
+for log_n in (3, 7, 10, 12, 13, 16, 18, 22):
+    a = O.rand_field((3 if log_n < 20 else 1, 1 << log_n), 4100 + log_n)
+    for kw in ({}, {"bitrev_out": True}, {"inverse": True}, {"coset_shift": O.MULT_GEN, "bitrev_out": True}):
+        h.update(ctx.ntt(a, **kw).tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_ntt_barrier_per_round_kernels_agree_with_the_one_barrier_ones():
+    """the two kernel families of ntt.hip (default: one-barrier tiles; MP2G_NTT_V1=1: a barrier per round, also the
+    fallback for the tile shapes the first does not cover) give the same transforms, size by size"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for v1 in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", _V1_CHILD, root], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, MP2G_NTT_V1=v1))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0]) == 64
+
+
 def test_ntt_2p22_config2(ctx):
     """BASELINE config 2(i): one 2^22-point polynomial, seed 0xC0FFEE02; fwd, inv, coset."""
     n = 1 << 22

@@ -37,15 +37,16 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in by.items():
         res.setdefault(k, {})[c] = statistics.median(v)
 cal = 32768.0 / res["mp2g::scale_powers_kernel"]["FETCH_SIZE"]
-cols_name = next(k for k in res if "ntt_cols_kernel<10" in k)
-cols, rows = res[cols_name], res["void mp2g::ntt_rows_kernel<12, 0>"]
+cols_name = next(k for k in res if "ntt_cols" in k and "kernel<10" in k)
+rows_name = next(k for k in res if "ntt_rows" in k and "nat" not in k and "kernel<12, 0>" in k)
+cols, rows = res[cols_name], res[rows_name]
 fetch = (cols["FETCH_SIZE"] + rows["FETCH_SIZE"]) * cal * 1024
 write = (cols["WRITE_SIZE"] + rows["WRITE_SIZE"]) * 1024
 json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, WRITE_SIZE) --kernel-trace --output-format csv -- python3 tools/dbg/traffic_run.py   (tools/dbg/profile_r02.sh)",
            "units": "KB per dispatch as reported (median over the dispatches of each kernel); FETCH_SIZE scaled by the factor calibrated in this same run on scale_powers_kernel, which reads exactly 32768 KB with 8 B/lane loads (MI355X_MICROARCH.md: FETCH_SIZE under-reports 8 B/lane patterns by 2x)",
            "fetch_calibration_factor": cal, "kernels": {k: v for k, v in res.items() if "ntt" in k or "scale_powers" in k or "tw4" in k},
            "ntt_2p22_forward_bitrev": {"fetch_bytes_corrected": fetch, "write_bytes": write, "traffic_bytes": fetch + write, "algorithmic_bytes": 16 << 22,
-                                       "note": f"two launches ({cols_name.split('::')[-1]}, ntt_rows_kernel<12,0>); pass A also streams the 32 MiB 4-step twiddle table (one multiply per point instead of two)"},
+                                       "note": f"two launches ({cols_name.split('::')[-1]}, {rows_name.split('::')[-1]}); pass A also streams the 32 MiB 4-step twiddle table (one multiply per point instead of two)"},
            "note_natural_order_pass": "ntt_rows_nat_kernel<12,0> (natural-order output of a 2^22 transform, used by the calibration call only, never by prove()) writes ~4x its 32 MiB: with one row per tile its stores are 8-byte scatters. The prover's natural-order transforms are 2^15 / 2^16 points (16 rows per tile: 128-byte stores)."},
           open(f"{dst}/ntt_traffic.json", "w"), indent=1)
 summary["ntt_traffic_bytes"] = fetch + write
@@ -54,9 +55,9 @@ for tag in ("prof4", "prof1"):
     rows_ = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     pairs = []
     for i, r in enumerate(rows_):
-        if "ntt_cols_kernel<10" in r["Kernel_Name"]:
+        if "ntt_cols" in r["Kernel_Name"] and "kernel<10" in r["Kernel_Name"]:
             for s in rows_[i + 1:i + 6]:
-                if "ntt_rows_kernel<12, 0>" in s["Kernel_Name"] and s["Stream_Id"] == r["Stream_Id"]:
+                if "ntt_rows" in s["Kernel_Name"] and "nat" not in s["Kernel_Name"] and "kernel<12, 0>" in s["Kernel_Name"] and s["Stream_Id"] == r["Stream_Id"]:
                     pairs.append(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, (int(s["End_Timestamp"]) - int(s["Start_Timestamp"])) / 1e3))
                     break
     summary[f"ntt_pair_{tag}"] = {"n": len(pairs), "cols_us": statistics.mean(p[0] for p in pairs), "rows_us": statistics.mean(p[1] for p in pairs)}
