@@ -240,13 +240,22 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
     R = importlib.import_module("mapreduce-plonky2_amd.recursion")
     FW = importlib.import_module("mapreduce-plonky2_amd.framework")
     C = importlib.import_module("mapreduce-plonky2_amd.circuits")
+    import threading
     ctx = mp2.Context(local_rank)
     prover = FW.GpuProver(ctx, VARIANT, witness_check=True)
     fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover,
                              lambda ckt: FW.circuit_fri_params(ckt, VARIANT))
     n_leaves = args.batch
     assert n_leaves & (n_leaves - 1) == 0
-    data = C.rand_field(4 * n_leaves, SEED + 31 * rank)
+    # --trees independent trees per rank and step (the reference's independent rows / blocks), one host thread, GPU context and
+    # prover each: one tree's witness programs run on the host while another's prove() occupies the GPU
+    n_trees = max(1, args.trees)
+    ctxs = [ctx] + [mp2.Context(local_rank) for _ in range(n_trees - 1)]
+    provers = [prover] + [FW.GpuProver(c, VARIANT, witness_check=True) for c in ctxs[1:]]
+    sessions = [R.ProofSession(p) for p in provers]
+    for name in ("map", "reduce"):
+        fw.witness_programs(name)  # shared and read-only from here on
+    datas = [C.rand_field(4 * n_leaves, SEED + 31 * rank + 7919 * t) for t in range(n_trees)]
 
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
     nccl = dist is not None and dist.get_backend() == "nccl"
@@ -255,14 +264,31 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
     final_fp = FW.circuit_fri_params(final_ckt, VARIANT)
     n_pis = 5 + 4
 
-    def step():
-        level = fw.generate_proofs_batch("map", [([], [], data[4 * i:4 * i + 4]) for i in range(n_leaves)])
+    def local_tree(t, out):
+        sess, data = sessions[t], datas[t]
+        level = fw.generate_proofs_batch("map", [([], [], data[4 * i:4 * i + 4]) for i in range(n_leaves)], session=sess)
         names = ["map"] * n_leaves
         while len(level) > 1:
             level = fw.generate_proofs_batch("reduce", [([level[2 * i], level[2 * i + 1]], [names[2 * i], names[2 * i + 1]], None)
-                                                       for i in range(len(level) // 2)])
+                                                       for i in range(len(level) // 2)], session=sess)
             names = ["reduce"] * len(level)
-        root, root_name = level[0], names[0]
+        out[t] = (level[0], names[0])
+
+    def step():
+        local = [None] * n_trees
+        if n_trees == 1:
+            local_tree(0, local)
+        else:
+            ths = [threading.Thread(target=local_tree, args=(t, local)) for t in range(n_trees)]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            if any(r is None for r in local):
+                raise SystemExit("bench.py: a tree thread failed")
+        return [above_shards(*local[t]) for t in range(n_trees)]
+
+    def above_shards(root, root_name):
         for lvl in range(world.bit_length() - 1):  # above the shard boundary
             bit = 1 << lvl
             if rank & (bit - 1):
@@ -282,35 +308,37 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
 
     for _ in range(max(1, args.warmup)):  # the first pass creates the provers of every level width
-        root = step()
+        roots = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        root = step()
+        roots = step()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    pis = root[3]
+    pis = roots[0][3]
     if rank == 0:
-        want = 0
-        for r in range(world):
-            want = (want + sum(int(x) for x in C.rand_field(4 * n_leaves, SEED + 31 * r) if int(x) % 2 == 0)) % C.P
-        assert int(pis[0]) == want, "root sum != sum of the even elements of every rank's data"
+        for t in range(n_trees):
+            want = 0
+            for r in range(world):
+                want = (want + sum(int(x) for x in C.rand_field(4 * n_leaves, SEED + 31 * r + 7919 * t) if int(x) % 2 == 0)) % C.P
+            assert int(roots[t][3][0]) == want, "root sum != sum of the even elements of every rank's data"
     out = None
     if rank == 0:
         n_nodes = 2 * n_leaves - 1
         out = {"metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build, 1/2/4/8 GPU",
-               "value": world * n_leaves * args.steps / dt, "unit": "leaf proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "value": world * n_trees * n_leaves * args.steps / dt, "unit": "leaf proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u64 (Goldilocks field)", "data": "synthetic",
-               "framework_proofs_per_s": (world * n_nodes + world - 1) * args.steps / dt,
-               "config": {"workload": f"recursion: per rank a {n_leaves}-leaf map-reduce tree of REAL framework proofs ({n_nodes} = map: base 2^6 + wrap 2^12 "
+               "framework_proofs_per_s": n_trees * (world * n_nodes + world - 1) * args.steps / dt,
+               "config": {"workload": f"recursion: per rank {n_trees} independent {n_leaves}-leaf map-reduce tree(s) of REAL framework proofs, one host thread and GPU stream each ({n_nodes} per tree = map: base 2^6 + wrap 2^12 "
                                       "rows; reduce: two universal verifiers, base 2^13 + wrap 2^12 rows), witness generation on the host threads, "
                                       "witness check on, every level inside the timed region",
                           "shapes": {k: [c[0].log_n for c in v] for k, v in fw.chains.items()}, "host_threads": os.cpu_count(),
@@ -318,8 +346,10 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
-    prover.free()
-    ctx.close()
+    for p in provers:
+        p.free()
+    for c in ctxs:
+        c.close()
     return out
 
 
@@ -343,6 +373,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU leg (the self-check still runs)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the sampled proofs")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work for the cpu_baseline sample")
+    ap.add_argument("--trees", type=int, default=4, help="--workload recursion: independent trees per rank and step, one host thread + GPU stream each")
     ap.add_argument("--workload", choices=("leaves", "tree", "recursion"), default="leaves",
                     help="leaves (default, the headline): independent leaf proofs. tree: every step also proves the 2-to-1 aggregation "
                          "levels above the leaves -- locally below the shard boundary, then log2(ranks) levels whose child proofs move "

@@ -242,8 +242,9 @@ class GpuProver:
         caps, openings, proofs = cp.results()
         return caps[0], openings[0], proofs[0]
 
-    def prove_batch(self, ckt, wires, pi_hash):
-        """wires [B][135][n] and pi_hash [B][4] (host) of B witnesses of one circuit -> [(caps, openings, proof)]"""
+    def prove_batch_launch(self, ckt, wires, pi_hash):
+        """upload B witnesses of one circuit (wires [B][135][n], pi_hash [B][4], host) and queue their prove() on the context's
+        stream; returns the handle prove_batch_finish waits on. One batch per (circuit, B) in flight at a time."""
         B = wires.shape[0]
         key = (ckt.log_n, hash(ckt.pre.tobytes()), B)
         cp = self.provers.get(key)
@@ -253,10 +254,18 @@ class GpuProver:
         cp.d_w.upload(wires)
         cp.d_ph.upload(np.ascontiguousarray(pi_hash, dtype=np.uint64))
         cp.prove(cp.d_w, cp.d_ph)
+        return cp, B
+
+    def prove_batch_finish(self, handle):
+        cp, B = handle
         if self.witness_check:
-            cp.pr.witness_status()
+            cp.pr.witness_status()  # raises like plonky2's prove() on an unsatisfied witness
         caps, openings, proofs = cp.results()
         return [(caps[b], openings[b], proofs[b]) for b in range(B)]
+
+    def prove_batch(self, ckt, wires, pi_hash):
+        """wires [B][135][n] and pi_hash [B][4] (host) of B witnesses of one circuit -> [(caps, openings, proof)]"""
+        return self.prove_batch_finish(self.prove_batch_launch(ckt, wires, pi_hash))
 
     def two_to_one(self, left, right):
         """Hasher::two_to_one = permute([l || r || 0000])[0..4] = hash_no_pad of the 8 limbs (one absorb)"""

@@ -1355,16 +1355,15 @@ def universal_inputs(proof, vd, membership):
                            np.asarray(bits, dtype=np.uint64).ravel(), np.asarray(sib, dtype=np.uint64).ravel()])
 
 
-def _generate_proofs_batch(self, name, jobs, threads=0):
+def _generate_proofs_batch(self, name, jobs, threads=0, session=None):
     """RecursiveCircuits.generate_proof for a batch of nodes of circuit `name`: jobs = [(child_proofs, child_names, inputs)].
     Witnesses come from the circuits' recorded programs (csrc/witness.hip: host threads, one proof each), proving from
-    prover.prove_batch(circuit, wires [B][135][n], pi_hash [B][4]). Returns the final proofs, one per job."""
-    from . import WitnessProgram
-    if not hasattr(self, "programs"):
-        self.programs = {}
-    progs = self.programs.get(name)
-    if progs is None:
-        progs = self.programs[name] = [WitnessProgram(c[0]) for c in self.chains[name]]
+    prover.prove_batch(circuit, wires [B][135][n], pi_hash [B][4]). Returns the final proofs, one per job.
+    `session` (ProofSession): the prover and the host wire matrices to use instead of the framework's own -- independent trees
+    (the reference's independent rows / blocks) run in one thread each with a session of their own, so that one tree's witness
+    generation fills the time another's prove() spends on the GPU; circuits, verifier data and witness programs are shared."""
+    sess = session if session is not None else self.default_session()
+    progs = self.witness_programs(name)
     rows = []
     for child_proofs, child_names, inputs in jobs:
         parts = [np.asarray(self.set_digest, dtype=np.uint64)]
@@ -1378,12 +1377,46 @@ def _generate_proofs_batch(self, name, jobs, threads=0):
     proofs = None
     for step, prog in enumerate(progs):
         assert cur.shape[1] == prog.n_inputs, f"{name} step {step}: {cur.shape[1]} inputs for a program of {prog.n_inputs}"
-        wires, pi_hash, pis = prog.run(cur, threads)
-        outs = self.prover.prove_batch(self.chains[name][step][0], wires, pi_hash)
+        wires, pi_hash, pis = prog.run(cur, threads, out=sess.wire_buffer(name, step, cur.shape[0], prog.log_n))
+        outs = sess.prover.prove_batch(self.chains[name][step][0], wires, pi_hash)
         proofs = [(c, o, p, pis[i]) for i, (c, o, p) in enumerate(outs)]
         if step + 1 < len(progs):
             cur = np.stack([proof_inputs(p) for p in proofs])
     return proofs
 
 
+class ProofSession:
+    """what one thread of generate_proofs_batch owns: its prover (a GPU context / stream of its own) and the host wire
+    matrices it fills, one per (circuit, batch size), reused from call to call"""
+
+    def __init__(self, prover):
+        self.prover, self.buffers = prover, {}
+
+    def wire_buffer(self, name, step, batch, log_n):
+        key = (name, step, batch)
+        buf = self.buffers.get(key)
+        if buf is None:
+            buf = self.buffers[key] = np.empty((batch, 135, 1 << log_n), dtype=np.uint64)
+        return buf
+
+
+def _default_session(self):
+    if not hasattr(self, "_session"):
+        self._session = ProofSession(self.prover)
+    return self._session
+
+
+def _witness_programs(self, name):
+    """the recorded witness programs of a circuit's chain (base, wraps); read-only once made, shared by every session"""
+    from . import WitnessProgram
+    if not hasattr(self, "programs"):
+        self.programs = {}
+    progs = self.programs.get(name)
+    if progs is None:
+        progs = self.programs[name] = [WitnessProgram(c[0]) for c in self.chains[name]]
+    return progs
+
+
+RecursiveCircuits.default_session = _default_session
+RecursiveCircuits.witness_programs = _witness_programs
 RecursiveCircuits.generate_proofs_batch = _generate_proofs_batch

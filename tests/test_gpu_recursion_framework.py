@@ -66,6 +66,45 @@ def test_sixteen_leaf_tree_through_the_witness_programs(ctx, mp2):
     prover.free()
 
 
+def test_independent_trees_in_parallel_sessions(ctx, mp2):
+    """two independent 4-leaf trees proved at the same time, one thread + GPU context + ProofSession each (the way
+    bench.py --workload recursion --trees N fills the GPU while another tree's witnesses are generated): same root
+    proofs, word for word, as the two trees proved one after the other on the framework's own session"""
+    import threading
+    prover = FW.GpuProver(ctx)
+    circs = [R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)]
+    fw = R.RecursiveCircuits(circs, prover, FW.circuit_fri_params)
+    datas = [O.rand_field(16, 0xC0FFEE03 + t) for t in range(2)]
+
+    def tree(data, session):
+        level = fw.generate_proofs_batch("map", [([], [], data[4 * i:4 * i + 4]) for i in range(4)], session=session)
+        names = ["map"] * 4
+        while len(level) > 1:
+            jobs = [([level[2 * i], level[2 * i + 1]], [names[2 * i], names[2 * i + 1]], None) for i in range(len(level) // 2)]
+            level = fw.generate_proofs_batch("reduce", jobs, session=session)
+            names = ["reduce"] * len(level)
+        return level[0]
+
+    sequential = [tree(d, None) for d in datas]
+    ctxs = [mp2.Context(0), mp2.Context(0)]
+    provers = [FW.GpuProver(c) for c in ctxs]
+    sessions = [R.ProofSession(p) for p in provers]
+    out = [None, None]
+    ths = [threading.Thread(target=lambda t=t: out.__setitem__(t, tree(datas[t], sessions[t]))) for t in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for t in range(2):
+        assert out[t] is not None
+        assert all(np.array_equal(x, y) for x, y in zip(out[t], sequential[t]))
+        assert int(out[t][3][0]) == sum(int(x) for x in datas[t] if int(x) % 2 == 0) % O.P
+    for p in provers + [prover]:
+        p.free()
+    for c in ctxs:
+        c.close()
+
+
 def test_two_ranks_real_recursion_with_proof_handoff():
     """bench.py --workload recursion on two ranks (gloo rendezvous, both on the test box's GPU): each rank proves an 8-leaf
     tree of real framework proofs, then rank 1's root proof travels as bincode bytes (mp2g_proof_serialize ->
@@ -77,7 +116,7 @@ def test_two_ranks_real_recursion_with_proof_handoff():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29547",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "recursion", "--batch", "8", "--steps", "1", "--warmup", "1"]
+           os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "recursion", "--batch", "8", "--trees", "2", "--steps", "1", "--warmup", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MP2G_BENCH_BACKEND="gloo"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
