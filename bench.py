@@ -373,7 +373,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU leg (the self-check still runs)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the sampled proofs")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work for the cpu_baseline sample")
-    ap.add_argument("--trees", type=int, default=4, help="--workload recursion: independent trees per rank and step, one host thread + GPU stream each")
+    ap.add_argument("--trees", type=int, default=8, help="--workload recursion: independent trees per rank and step, one host thread + GPU stream each")
     ap.add_argument("--workload", choices=("leaves", "tree", "recursion"), default="leaves",
                     help="leaves (default, the headline): independent leaf proofs. tree: every step also proves the 2-to-1 aggregation "
                          "levels above the leaves -- locally below the shard boundary, then log2(ranks) levels whose child proofs move "
