@@ -56,15 +56,49 @@ LOG_NTT = 22
 SEED = 0xC0FFEE03
 
 
-def gpu_clocks(device):
-    """rocm-smi's current clocks of the device (state the measured clocks with every report)"""
-    import subprocess
+_CLOCK_HELPER = r"""
+import subprocess, sys
+for line in sys.stdin:
     try:
-        r = subprocess.run(["rocm-smi", "-d", str(device), "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
-        card = next(iter(json.loads(r.stdout).values()))
-        return {k.strip(): v for k, v in card.items() if "clock" in k.lower() and ("sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower())}
-    except Exception as e:  # no rocm-smi / no permission: say so instead of guessing
-        return {"error": str(e)[:80]}
+        r = subprocess.run(["rocm-smi", "-d", line.strip(), "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        out = " ".join(r.stdout.split())
+    except Exception as e:
+        out = "error: " + str(e)[:80]
+    print(out, flush=True)
+"""
+
+
+class ClockReader:
+    """rocm-smi's current clocks of a device (state the measured clocks with every report). rocm-smi is run by a
+    helper process started before this one touches the GPU: a process that has initialised the GPU must not fork + exec."""
+
+    def __init__(self):
+        import subprocess
+        try:
+            self.p = subprocess.Popen([sys.executable, "-c", _CLOCK_HELPER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        except Exception:
+            self.p = None
+
+    def read(self, device):
+        if self.p is None:
+            return {"error": "no helper process"}
+        try:
+            self.p.stdin.write(f"{device}\n")
+            self.p.stdin.flush()
+            line = self.p.stdout.readline()
+            card = next(iter(json.loads(line).values()))
+            return {k.strip(): v for k, v in card.items() if "clock" in k.lower() and ("sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower())}
+        except Exception as e:  # no rocm-smi / no permission: say so instead of guessing
+            return {"error": str(e)[:80]}
+
+    def close(self):
+        if self.p is not None:
+            try:
+                self.p.stdin.close()
+                self.p.wait(timeout=5)
+            except Exception:
+                self.p.kill()
+            self.p = None
 
 
 def check_against_oracle(samples, budget_s, timed, ranks_on_host=1):
@@ -381,6 +415,7 @@ def main(argv=None):
                          "reduce circuits of recursion-framework/tests/integration.rs with universal verifiers, wrapped to the shared "
                          "shape; witnesses by the recorded witness programs on host threads, inside the timed region")
     args = ap.parse_args(argv)
+    clocks = ClockReader()  # before anything initialises the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -401,10 +436,9 @@ def main(argv=None):
             dist.init_process_group(backend)
 
     VARIANT = 0 if args.hasher == "poseidon2" else 1
-    if args.workload == "tree":
-        return run_tree(args, rank, local_rank, world, dist, torch, VARIANT)
-    if args.workload == "recursion":
-        return run_recursion(args, rank, local_rank, world, dist, torch, VARIANT)
+    if args.workload in ("tree", "recursion"):
+        clocks.close()
+        return (run_tree if args.workload == "tree" else run_recursion)(args, rank, local_rank, world, dist, torch, VARIANT)
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
     C = importlib.import_module("mapreduce-plonky2_amd.circuits")  # synthetic circuit + witness generator (pure Python)
@@ -628,13 +662,14 @@ def main(argv=None):
             "sponge": {"hasher": args.hasher, "permutations_per_s": n_hash * (limbs // 8) / (hash_ms / 1e3), "bound": "VALU issue (integer ALU)",
                        "input": f"{n_hash} x {limbs} limbs, hash_no_pad, resident"},
             "stage_ms": stages,
-            "clocks": gpu_clocks(local_rank),
+            "clocks": clocks.read(local_rank),
             "digest_rows_per_s": rows / digest_s,
             "digest_check": [int(x) for x in w],
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
+    clocks.close()
     if dist is not None:
         dist.destroy_process_group()
     for c in reversed(ctxs):

@@ -129,6 +129,31 @@ GLD u64 gl_subw(u64 a, u64 b) {
 // eval_unfiltered_base of one gate: wire(j) / cst(j) fetch local wire j / gate constant j (after the
 // selector prefix), emit(c) receives the constraints in plonky2's order. WEAK = true lets the Poseidon
 // gates hand over un-canonicalised representatives (the lazy accumulator of the LDE kernel takes any u64).
+// one copy of RandomAccessGate<BITS>: bit constraints, index reconstruction, the fold of the 2^BITS items by the index bits
+// (least significant first), the claimed element; constraint order of gates/random_access.rs eval_unfiltered
+template <int BITS, class WireF, class Emit>
+GLD void ra_copy(WireF& wire, Emit& emit, u32 w0, u32 b0) {
+  constexpr int VS = 1 << BITS;
+  u64 bit[BITS], items[VS];
+#pragma unroll
+  for (int i = 0; i < BITS; i++) bit[i] = wire(b0 + i);
+#pragma unroll
+  for (int k = 0; k < VS; k++) items[k] = wire(w0 + 2 + k);
+  const u64 access = wire(w0), claimed = wire(w0 + 1);
+#pragma unroll
+  for (int i = 0; i < BITS; i++) emit(gl_mul(bit[i], gl_sub(bit[i], 1)));
+  u64 idx = 0;
+#pragma unroll
+  for (int i = BITS; i-- > 0;) idx = gl_add(gl_add(idx, idx), bit[i]);
+  emit(gl_sub(idx, access));
+#pragma unroll
+  for (int i = 0; i < BITS; i++) {
+#pragma unroll
+    for (int k = 0; k < (VS >> (i + 1)); k++) items[k] = gl_add(items[2 * k], gl_mul(bit[i], gl_sub(items[2 * k + 1], items[2 * k])));
+  }
+  emit(gl_sub(items[0], claimed));
+}
+
 template <bool WEAK, class WireF, class ConstF, class Emit>
 __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF cst, const u64* __restrict__ pih, Emit emit) {
   // state limb + round constant - wire
@@ -490,28 +515,39 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
     case MP2G_GATE_RANDOM_ACCESS: {
       const u32 bits = g.p0, copies = g.p1, extra = g.p2, vs = 1u << bits;
       const u32 routed = (2 + vs) * copies + extra;
-      u64 items[32];
       for (u32 c = 0; c < copies; c++) {
         const u32 w0 = (2 + vs) * c, b0 = routed + c * bits;
-        for (u32 i = 0; i < bits; i++) {
-          u64 b = wire(b0 + i);
-          emit(gl_mul(b, gl_sub(b, 1)));
-        }
-        u64 idx = 0;
-        for (u32 i = bits; i-- > 0;) idx = gl_add(gl_add(idx, idx), wire(b0 + i));
-        emit(gl_sub(idx, wire(w0)));
-        {  // first fold straight from the wires
-          const u64 b = wire(b0);
-          for (u32 k = 0; k < vs / 2; k++) {
-            u64 x = wire(w0 + 2 + 2 * k), y = wire(w0 + 3 + 2 * k);
-            items[k] = gl_add(x, gl_mul(b, gl_sub(y, x)));
+        // the fold of one copy with the vector size a compile-time constant: the item list stays in registers and its 2^bits + bits
+        // wire loads are in flight together (with run-time bounds the list lived in scratch memory and the kernel sat parked on it
+        // for 82 % of its cycles, tools/dbg/step_pmc.sh)
+        switch (bits) {
+          case 1: ra_copy<1>(wire, emit, w0, b0); break;
+          case 2: ra_copy<2>(wire, emit, w0, b0); break;
+          case 3: ra_copy<3>(wire, emit, w0, b0); break;
+          case 4: ra_copy<4>(wire, emit, w0, b0); break;
+          default: {  // 32 / 64 items: run-time bounds (a register-resident list this long would halve every circuit's occupancy)
+            u64 items[32];
+            for (u32 i = 0; i < bits; i++) {
+              u64 b = wire(b0 + i);
+              emit(gl_mul(b, gl_sub(b, 1)));
+            }
+            u64 idx = 0;
+            for (u32 i = bits; i-- > 0;) idx = gl_add(gl_add(idx, idx), wire(b0 + i));
+            emit(gl_sub(idx, wire(w0)));
+            {
+              const u64 b = wire(b0);
+              for (u32 k = 0; k < vs / 2; k++) {
+                u64 x = wire(w0 + 2 + 2 * k), y = wire(w0 + 3 + 2 * k);
+                items[k] = gl_add(x, gl_mul(b, gl_sub(y, x)));
+              }
+            }
+            for (u32 i = 1, len = vs / 2; i < bits; i++, len >>= 1) {
+              const u64 b = wire(b0 + i);
+              for (u32 k = 0; k < len / 2; k++) items[k] = gl_add(items[2 * k], gl_mul(b, gl_sub(items[2 * k + 1], items[2 * k])));
+            }
+            emit(gl_sub(items[0], wire(w0 + 1)));
           }
         }
-        for (u32 i = 1, len = vs / 2; i < bits; i++, len >>= 1) {
-          const u64 b = wire(b0 + i);
-          for (u32 k = 0; k < len / 2; k++) items[k] = gl_add(items[2 * k], gl_mul(b, gl_sub(items[2 * k + 1], items[2 * k])));
-        }
-        emit(gl_sub(items[0], wire(w0 + 1)));
       }
       for (u32 i = 0; i < extra; i++) emit(gl_sub(cst(i), wire((2 + vs) * copies + i)));
       break;
