@@ -17,6 +17,7 @@
 //   * the proof-of-work search returns the smallest valid witness (the reference's rayon
 //     find_any returns an arbitrary one).
 #include "fri.h"
+#include <cstdlib>
 #include "poseidon_wave.cuh"
 
 namespace mp2g {
@@ -307,15 +308,19 @@ __global__ void soa_to_aos_kernel(u32 n, const u64* in, u64 in_bstride, u32 n_in
 
 // ---- proof of work ----------------------------------------------------------------------------
 // witness[b * POW_STRIDE] = min { w : perm(state with w at position n_in)[7] has >= bits leading zeros }.
-// POW_BLOCKS blocks of 1024 lanes per proof sweep the candidates in order. Blocks of one proof
+// POW_BLOCKS blocks of 256 lanes per proof sweep the candidates in order (four blocks share a CU, so one block's poll and
+// barrier leave the ALUs to the other three; with one 1024-lane block per CU 37 % of the wave cycles were parked: 3.45 -> 3.08 ms
+// per 64 base proofs. Handing the candidates out in chunks from a per-proof counter so that the blocks of finished proofs help the
+// stragglers was measured too and lost, 4.6-11.9 ms: the helpers gang up on a proof and overshoot its nonce). Blocks of one proof
 // talk through one word: a finder publishes with atomicMin, and once per sweep lane 0 of every
 // block reads it back with a returning (no-op) atomicMin -- the per-XCD L2s are not coherent, a
 // plain or sc1 load of a word that another XCD updates atomically can stay stale for seconds,
 // while an atomic executes at the coherence point. Each proof's word sits in its own 128-B line.
-#define POW_BLOCKS 16
+#define POW_BLOCKS 64
+#define POW_THREADS 256
 #define POW_STRIDE 16
 template <int V>
-__global__ void __launch_bounds__(1024) pow_kernel(const ChState* st, u32 bits, unsigned long long* witness) {
+__global__ void __launch_bounds__(POW_THREADS) pow_kernel(const ChState* st, u32 bits, unsigned long long* witness) {
   const u32 b = blockIdx.y;
   const ChState& c = st[b];
   unsigned long long* wit = witness + (u64)b * POW_STRIDE;
@@ -446,10 +451,10 @@ hipError_t fri_pow(hipStream_t s, int variant, const ChState* st, u32 B, u32 bit
   hipLaunchKernelGGL(fill_u64_kernel, dim3((B * POW_STRIDE + 63) / 64), dim3(64), 0, s, witness, ~(u64)0, B * POW_STRIDE);
   // blocks per proof: 2^14 candidates per sweep when many proofs share the chip, up to 2^18 for a
   // lone proof (its search is otherwise confined to 16 CUs and dominates single-proof latency)
-  u32 blocks = 1024 / (B ? B : 1);
+  u32 blocks = 4096 / (B ? B : 1);
   if (blocks < POW_BLOCKS) blocks = POW_BLOCKS;
-  if (blocks > 256) blocks = 256;
-  dim3 g(blocks, B), bl(1024);
+  if (blocks > 1024) blocks = 1024;
+  dim3 g(blocks, B), bl(POW_THREADS);
   if (variant == MP2G_POSEIDON2) hipLaunchKernelGGL((pow_kernel<MP2G_POSEIDON2>), g, bl, 0, s, st, bits, (unsigned long long*)witness);
   else hipLaunchKernelGGL((pow_kernel<MP2G_POSEIDON>), g, bl, 0, s, st, bits, (unsigned long long*)witness);
   return hipGetLastError();
