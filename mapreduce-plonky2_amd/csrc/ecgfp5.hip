@@ -77,10 +77,15 @@ GLD u128 mulw(u64 a, u64 b) {
   gl_mul_wide(a, b, lo, hi);
   return ((u128)hi << 64) | lo;
 }
-GLN gl5 gl5_mul(const gl5& a, const gl5& b) {
+// The one out-of-line body of a GF(p^5) product takes its ten limbs as scalars: clang's AMDGPU ABI keeps at most 16 dwords of
+// aggregate arguments in registers and sends the rest through the stack, scalars all travel in VGPRs. (With both operands by
+// reference every 600-instruction multiplication began with six flat loads from the stack, and row_digest_kernel sat parked for
+// 43 % of its cycles -- tools/dbg/step_pmc.sh.)
+GLN gl5 gl5_mul_limbs(u64 x0, u64 x1, u64 x2, u64 x3, u64 x4, u64 y0, u64 y1, u64 y2, u64 y3, u64 y4) {
+  const u64 a[5] = {x0, x1, x2, x3, x4}, b[5] = {y0, y1, y2, y3, y4};
   u64 a3[5];
 #pragma unroll
-  for (int j = 1; j < 5; j++) a3[j] = gl_mul_small(a.c[j], 3);
+  for (int j = 1; j < 5; j++) a3[j] = gl_mul_small(a[j], 3);
   a3[0] = 0;
   gl5 r;
 #pragma unroll
@@ -89,13 +94,16 @@ GLN gl5 gl5_mul(const gl5& a, const gl5& b) {
     u32 top = 0;
 #pragma unroll
     for (int j = 0; j < 5; j++) {
-      u128 p = j <= i ? mulw(a.c[j], b.c[i - j]) : mulw(a3[j], b.c[i + 5 - j]);
+      u128 p = j <= i ? mulw(a[j], b[i - j]) : mulw(a3[j], b[i + 5 - j]);
       acc += p;
       top += acc < p ? 1 : 0;
     }
     r.c[i] = gl_reduce160(acc, top);
   }
   return r;
+}
+GLD gl5 gl5_mul(const gl5& a, const gl5& b) {
+  return gl5_mul_limbs(a.c[0], a.c[1], a.c[2], a.c[3], a.c[4], b.c[0], b.c[1], b.c[2], b.c[3], b.c[4]);
 }
 GLD gl5 gl5_sqr(const gl5& a) { return gl5_mul(a, a); }
 // Frobenius powers: coefficient i times (3^((p-1)/5))^(i*e)
@@ -127,7 +135,7 @@ GLD u64 gl_inv_chain(u64 a) {
   gl_ones(a, o31, o32);
   return gl_mul(gl_sqn(gl_sqr(o31), 32), o32);
 }
-GLN gl5 gl5_inv(const gl5& a) {  // inverse_or_zero
+GLN gl5 gl5_inv(gl5 a) {  // inverse_or_zero
   gl5 f1 = gl5_frob1(a), f2 = gl5_frob2(a);
   gl5 f12 = gl5_mul(f1, f2);           // a^(p+p^2)
   gl5 f34 = gl5_frob2(f12);            // a^(p^3+p^4)
@@ -183,7 +191,7 @@ GLN bool gl_sqrt(u64 a, u64& out) {
   out = R;
   return true;
 }
-GLN bool gl5_sqrt(const gl5& x, gl5& out) {
+GLN bool gl5_sqrt(gl5 x, gl5& out) {
   gl5 v = x;
 #pragma unroll 1
   for (int i = 0; i < 31; i++) v = gl5_sqr(v);
@@ -244,7 +252,7 @@ GLN pt pt_dbl(const pt& p) {
 }
 GLD gl5 pt_encode(const pt& p) { return gl5_mul(p.T, gl5_inv(p.U)); }  // neutral -> 0
 // decode(w): x^2 - (w^2 - a) x + b = 0, keep the non-square root; (x, 1, 1, w)
-GLN bool pt_decode(const gl5& w, pt& out) {
+GLN bool pt_decode(gl5 w, pt& out) {
   gl5 e = gl5_sub(gl5_sqr(w), gl5_from(2));
   gl5 b4 = gl5_zero(); b4.c[1] = 4 * EC_B1;
   gl5 delta = gl5_sub(gl5_sqr(e), b4);
@@ -284,7 +292,7 @@ GLD pt pt_mul128(const pt& p, const u32 k[4]) {
 }
 
 // sswu_value.rs:31-77
-GLN pt simple_swu(const gl5& u) {
+GLN pt simple_swu(gl5 u) {
   const gl5 two_thirds = gl5_from(6148914689804861441ULL);
   const gl5 a_sw = gl5_make(6148914689804861439ULL, 263, 0, 0, 0);
   const gl5 b_sw = gl5_make(15713893096167979237ULL, 6148914689804861265ULL, 0, 0, 0);
