@@ -394,7 +394,7 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=128, help="leaf proofs per step and rank")
     ap.add_argument("--base-bits", type=int, default=13)
-    ap.add_argument("--streams", type=int, default=4, help="HIP streams: 1 = both shapes on one; 2 = one per shape; 4 = two half-batches per shape")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams: 1 = both shapes on one; 2 = one per shape; 4, 6, 8 ... = streams / 2 part-batches per shape")
     ap.add_argument("--host-inputs", action="store_true",
                     help="PCIe-inclusive variant: every step uploads its wire matrices from pinned host memory "
                          "on the prover's stream (never the headline value; see DESIGN.md)")
@@ -452,8 +452,9 @@ def main(argv=None):
     # provers: (shape, context, share of the batch). 1 stream: both shapes on it; 2: one each;
     # 4: every shape split into two half-batches
     if n_ctx >= 4:
-        plan = [("base", args.base_bits, ctxs[0], B // 2), ("wrap", 12, ctxs[1], B // 2), ("base", args.base_bits, ctxs[2], B - B // 2),
-                ("wrap", 12, ctxs[3], B - B // 2)]
+        parts = n_ctx // 2  # streams per shape: every shape's batch is cut into that many parts
+        sizes = [B * (k + 1) // parts - B * k // parts for k in range(parts)]
+        plan = [(role, bits, ctxs[2 * k + j], sizes[k]) for k in range(parts) for j, (role, bits) in enumerate((("base", args.base_bits), ("wrap", 12)))]
     elif n_ctx >= 2:
         plan = [("base", args.base_bits, ctxs[0], B), ("wrap", 12, ctxs[1], B)]
     else:
