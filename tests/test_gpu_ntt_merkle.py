@@ -80,6 +80,8 @@ for log_n in (3, 7, 10, 12, 13, 16, 18, 22):
     a = O.rand_field((3 if log_n < 20 else 1, 1 << log_n), 4100 + log_n)
     for kw in ({}, {"bitrev_out": True}, {"inverse": True}, {"coset_shift": O.MULT_GEN, "bitrev_out": True}):
         h.update(ctx.ntt(a, **kw).tobytes())
+for log_n, w in ((5, 7), (9, 5), (12, 3), (13, 5), (14, 2), (16, 1)):  # LDE: 8 cosets per polynomial, leaves in Merkle order
+    h.update(ctx.lde_leaves(O.rand_field((w, 1 << log_n), 4200 + log_n), 3).tobytes())
 print(h.hexdigest())
 """
 
