@@ -10,6 +10,7 @@
 // constraints and the filter multiplies the reduced value -- the same field element with
 // (#constraints - 1) fewer multiplications per gate and challenge.
 #include "gates.h"
+#include <cstdlib>
 #include "poseidon.cuh"
 
 namespace mp2g {
@@ -669,6 +670,93 @@ __global__ void __launch_bounds__(256) gate_constraints_lde_kernel(mp2g_gate g, 
   }
 }
 
+// The light gates of a table in ONE launch: Constant, PublicInput, Arithmetic, BaseSum, ArithmeticExtension and MulExtension
+// rows all live on the first 80 wire columns, evaluate a few dozen constraints each and are bound by streaming those wires and the
+// accumulator (5-6.6 cycles per VALU instruction against ~3.1 for the compute-bound gates, tools/dbg/step_pmc.sh). Fused, the
+// wires and constants of a point are fetched once (the loads of the gates overlap), the alpha powers are shared (same alpha, the
+// longest gate's table) and q is read and written once instead of once per gate. Each case pins the kind at compile time so that
+// eval_gate's switch folds to that gate's body, as in the per-kind kernels.
+#define MP2G_MAX_LIGHT_GATES 12
+struct LightGates {
+  u32 n;
+  mp2g_gate g[MP2G_MAX_LIGHT_GATES];
+  u32 gi[MP2G_MAX_LIGHT_GATES];
+};
+static bool gate_is_light(const mp2g_gate& g) {
+  switch (g.kind) {
+    case MP2G_GATE_CONSTANT: case MP2G_GATE_PUBLIC_INPUT: case MP2G_GATE_ARITHMETIC: case MP2G_GATE_BASE_SUM:
+    case MP2G_GATE_ARITHMETIC_EXT: case MP2G_GATE_MUL_EXT: return true;
+    default: return false;
+  }
+}
+__global__ void __launch_bounds__(256) gate_constraints_lde_light_kernel(LightGates lg_, u32 num_selectors, u32 cst_off, u32 max_cons,
+                                                                         const u64* __restrict__ C, const u64* __restrict__ W,
+                                                                         u64 w_bstride, u32 lg, const u64* __restrict__ alphas,
+                                                                         u64 al_bstride, u32 nc, const u64* __restrict__ pi_hash,
+                                                                         u64* __restrict__ q, int first) {
+  __shared__ u64 apw[2][MP2G_MAX_GATE_CONSTRAINTS];
+  const u64 N = (u64)1 << lg;
+  const u32 p = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  for (u32 j = threadIdx.x; j < 2 * max_cons; j += 256) {
+    const u32 a = j >= max_cons ? 1 : 0, e = j - a * max_cons;
+    apw[a][e] = a < nc ? gl_pow(alphas[b * al_bstride + a], e) : 0;
+  }
+  __syncthreads();
+  if (p >= N) return;
+  const u64* w = W + b * w_bstride + p;
+  const u64* c = C + p;
+  const u64* pih = pi_hash + 4 * b;
+  auto wire = [&](u32 j) { return w[(u64)j << lg]; };
+  auto cst = [&](u32 j) { return c[(u64)(cst_off + j) << lg]; };
+  u64 total[2] = {0, 0};
+  for (u32 k = 0; k < lg_.n; k++) {
+    mp2g_gate g = lg_.g[k];
+    const u32 gi = lg_.gi[k];
+    u64 f = 1;
+    {
+      const u64 s = c[(u64)g.selector_index << lg];
+      for (u32 r = g.group_start; r < g.group_end; r++)
+        if (r != gi) f = gl_mul(f, gl_sub(r, s));
+      if (num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
+    }
+    u64 lo[2] = {0, 0}, hi[2] = {0, 0};
+    u32 top[2] = {0, 0};
+    u32 j = 0;
+    auto emit = [&](u64 v) {
+#pragma unroll
+      for (u32 a = 0; a < 2; a++) {
+        u64 pl, ph;
+        gl_mul_wide(v, apw[a][j], pl, ph);
+        bool c0 = __builtin_add_overflow(lo[a], pl, &lo[a]);
+        bool c1 = __builtin_add_overflow(hi[a], ph, &hi[a]);
+        bool c2 = __builtin_add_overflow(hi[a], (u64)(c0 ? 1 : 0), &hi[a]);
+        top[a] += (c1 ? 1 : 0) + (c2 ? 1 : 0);
+      }
+      j++;
+    };
+    switch (g.kind) {
+#define LIGHT_CASE(K) case K: g.kind = K; eval_gate<true>(g, wire, cst, pih, emit); break;
+      LIGHT_CASE(MP2G_GATE_CONSTANT)
+      LIGHT_CASE(MP2G_GATE_PUBLIC_INPUT)
+      LIGHT_CASE(MP2G_GATE_ARITHMETIC)
+      LIGHT_CASE(MP2G_GATE_BASE_SUM)
+      LIGHT_CASE(MP2G_GATE_ARITHMETIC_EXT)
+      LIGHT_CASE(MP2G_GATE_MUL_EXT)
+#undef LIGHT_CASE
+      default: break;
+    }
+    for (u32 a = 0; a < nc; a++) {
+      u64 r = gl_sub(gl_reduce128(lo[a], hi[a]), (u64)top[a] << 32);
+      total[a] = gl_add(total[a], gl_mul(f, r));
+    }
+  }
+  const u32 i = bitrev32(p, lg);
+  for (u32 a = 0; a < nc; a++) {
+    u64* dst = q + (((u64)b * nc + a) << lg) + i;
+    *dst = first ? total[a] : gl_add(*dst, total[a]);
+  }
+}
+
 __global__ void __launch_bounds__(256) gate_constraints_points_kernel(GateTable t, const u64* __restrict__ consts,
                                                                       const u64* __restrict__ wires, u64 npts, u32 max_j,
                                                                       const u64* __restrict__ pih, u64* __restrict__ out) {
@@ -726,10 +814,32 @@ hipError_t gate_constraints_lde(hipStream_t s, u32 B, const GateTable& t, const 
   const u64 N = (u64)1 << lg;
   const dim3 grid((u32)((N + 255) / 256), B), block(256);
   int first = 1;
+  // the light gates first, in one launch (MP2G_GATES_UNFUSED=1: one launch per gate, for A/B runs)
+  static int unfused = -1;
+  if (unfused < 0) { const char* e = getenv("MP2G_GATES_UNFUSED"); unfused = e ? atoi(e) : 0; }
+  LightGates lgs{};
+  u32 light_cons = 0;
+  if (!unfused)
+    for (u32 gi = 0; gi < t.n_gates; gi++) {
+      const u32 n_cons = gate_num_constraints(t.g[gi]);
+      if (n_cons && gate_is_light(t.g[gi]) && lgs.n < MP2G_MAX_LIGHT_GATES) {
+        lgs.g[lgs.n] = t.g[gi]; lgs.gi[lgs.n] = gi; lgs.n++;
+        if (n_cons > light_cons) light_cons = n_cons;
+      }
+    }
+  if (lgs.n < 2) lgs.n = 0;  // a lone light gate goes the ordinary way
+  if (lgs.n) {
+    hipLaunchKernelGGL(gate_constraints_lde_light_kernel, grid, block, 0, s, lgs, t.num_selectors, t.num_selectors + t.num_lookup_selectors,
+                       light_cons, C, W, w_bstride, lg, alphas, al_bstride, nc, pi_hash, q, first);
+    first = 0;
+  }
   for (u32 gi = 0; gi < t.n_gates; gi++) {
     const mp2g_gate& g = t.g[gi];
     const u32 n_cons = gate_num_constraints(g);
     if (!n_cons) continue;
+    bool fused = false;
+    for (u32 k = 0; k < lgs.n; k++) fused |= lgs.gi[k] == gi;
+    if (fused) continue;
 #define GATE_CASE(K)                                                                                                        \
   case K:                                                                                                                   \
     hipLaunchKernelGGL(gate_constraints_lde_kernel<K>, grid, block, 0, s, g, gi, t.num_selectors,                          \
