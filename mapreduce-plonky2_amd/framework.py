@@ -222,6 +222,16 @@ class GpuProver:
     def __init__(self, ctx, variant=POSEIDON2, witness_check=True):
         self.ctx, self.variant, self.witness_check = ctx, variant, witness_check
         self.provers = {}
+        self.pinned = {}  # data address of a pinned wire matrix -> its host pointer
+
+    def pinned_wires(self, shape):
+        """a [B][135][n] u64 wire matrix in pinned host memory: prove_batch_launch sends it up with an asynchronous copy on
+        the context's stream instead of a blocking pageable one"""
+        nbytes = int(np.prod(shape)) * 8
+        view, hptr = self.ctx.host_alloc(nbytes)
+        a = view.view(np.uint64).reshape(shape)
+        self.pinned[a.ctypes.data] = hptr
+        return a
 
     def _prover(self, ckt):
         key = (ckt.log_n, hash(ckt.pre.tobytes()))
@@ -251,8 +261,12 @@ class GpuProver:
         if cp is None:
             cp = self.provers[key] = CircuitProver(self.ctx, ckt, B, self.variant, witness_check=self.witness_check)
             cp.d_w, cp.d_ph = self.ctx.alloc(wires.nbytes), self.ctx.alloc(B * 32)
-        cp.d_w.upload(wires)
         cp.d_ph.upload(np.ascontiguousarray(pi_hash, dtype=np.uint64))
+        hptr = self.pinned.get(wires.ctypes.data) if wires.flags["C_CONTIGUOUS"] else None
+        if hptr is not None:
+            self.ctx.h2d_async(cp.d_w, hptr, wires.nbytes)  # ordered before the prove() kernels on the same stream
+        else:
+            cp.d_w.upload(wires)
         cp.prove(cp.d_w, cp.d_ph)
         return cp, B
 
@@ -275,3 +289,6 @@ class GpuProver:
         for cp in self.provers.values():
             cp.free()
         self.provers = {}
+        for hptr in self.pinned.values():
+            self.ctx.host_free(hptr)
+        self.pinned = {}

@@ -1387,7 +1387,8 @@ def _generate_proofs_batch(self, name, jobs, threads=0, session=None):
 
 class ProofSession:
     """what one thread of generate_proofs_batch owns: its prover (a GPU context / stream of its own) and the host wire
-    matrices it fills, one per (circuit, batch size), reused from call to call"""
+    matrices it fills, one per (circuit, batch size), reused from call to call. With a GPU prover the matrices live in pinned
+    host memory and go up asynchronously on the prover's stream (prover.pinned_wires)."""
 
     def __init__(self, prover):
         self.prover, self.buffers = prover, {}
@@ -1396,7 +1397,9 @@ class ProofSession:
         key = (name, step, batch)
         buf = self.buffers.get(key)
         if buf is None:
-            buf = self.buffers[key] = np.empty((batch, 135, 1 << log_n), dtype=np.uint64)
+            shape = (batch, 135, 1 << log_n)
+            make = getattr(self.prover, "pinned_wires", None)
+            buf = self.buffers[key] = make(shape) if make is not None else np.empty(shape, dtype=np.uint64)
         return buf
 
 
