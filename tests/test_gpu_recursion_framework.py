@@ -66,6 +66,56 @@ def test_sixteen_leaf_tree_through_the_witness_programs(ctx, mp2):
     prover.free()
 
 
+def _hash_chain_leaf_logic(n_hashes):
+    """LeafCircuitWires::circuit_logic (recursion-framework/src/circuit_builder.rs:398-430, flag false): a chain of n_hashes
+    hashes over (state ++ generated), generated *= generator after every hash; the last state is the public input"""
+    def logic(b, child_pis, inputs):
+        vals = inputs if inputs is not None else [0] * 9
+        state = [b.add_virtual(int(x)) for x in vals[:8]]
+        generator = b.add_virtual(int(vals[8]))
+        generated = generator
+        for _ in range(n_hashes):
+            state = b.hash_n_to_m_no_pad(state + [generated], 4)
+            generated = b.mul(generated, generator)
+        return state
+    return logic
+
+
+def _recursive_logic(b, child_pis, inputs):
+    """RecursiveCircuitWires::circuit_logic (circuit_builder.rs:463-481): hash of the children's public inputs and an 8-limb payload"""
+    payload = [b.add_virtual(int(x)) for x in (inputs if inputs is not None else [0] * 8)]
+    return b.hash_n_to_m_no_pad([t for pis in child_pis for t in pis[:4]] + payload, 4)
+
+
+def test_reference_framework_test_circuits_with_one_to_four_verifiers(ctx, mp2):
+    """recursion-framework/src/framework.rs:482-563 (`TestRecursiveCircuits::run_test`) on the HIP prover: a circuit set of
+    five -- a hash-chain leaf and recursive circuits with 1, 2, 3 and 4 universal verifiers --, seven leaf proofs, four of them
+    under the 4-verifier circuit, three under the 3-verifier one, both results under the 2-verifier one, that under the
+    1-verifier one; every proof ends with the circuit-set digest and the last one passes the oracle's verifier. The 3- and
+    4-verifier circuits have 2^14 rows: their wrap chains take two steps (2^14 -> 2^13 -> 2^12, WrapCircuit::wrap_proof with W = 2).
+    The leaf is the reference's: a chain of 2^12 hashes (2^13 rows before wrapping)."""
+    prover = FW.GpuProver(ctx)
+    circs = [R.FrameworkCircuit("leaf", 0, _hash_chain_leaf_logic(1 << 12), 4)] + \
+            [R.FrameworkCircuit(f"rec{k}", k, _recursive_logic, 4) for k in (1, 2, 3, 4)]
+    fw = R.RecursiveCircuits(circs, prover, FW.circuit_fri_params)
+    shapes = {k: [c[0].log_n for c in v] for k, v in fw.chains.items()}
+    assert all(v[-1] == R.RECURSION_THRESHOLD for v in shapes.values())
+    assert len(shapes["rec4"]) == 3 and shapes["rec4"][0] == 14, shapes  # a two-step wrap chain
+    set_digest = np.asarray(fw.set_digest, dtype=np.uint64)
+    rng = np.random.default_rng(0xC0FFEE03)
+    rand = lambda n: O.rand_field(n, int(rng.integers(1 << 30)))
+    leaves = fw.generate_proofs_batch("leaf", [([], [], rand(9)) for _ in range(7)])
+    (p4,) = fw.generate_proofs_batch("rec4", [(leaves[:4], ["leaf"] * 4, rand(8))])
+    (p3,) = fw.generate_proofs_batch("rec3", [(leaves[4:], ["leaf"] * 3, rand(8))])
+    (p2,) = fw.generate_proofs_batch("rec2", [([p4, p3], ["rec4", "rec3"], rand(8))])
+    (p1,) = fw.generate_proofs_batch("rec1", [([p2], ["rec2"], rand(8))])
+    for pr in leaves + [p4, p3, p2, p1]:
+        assert np.array_equal(pr[3][4:], set_digest)
+    wckt, wcap, wdig = fw.chains["rec1"][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(p1[3], 4), *p1[:3]) == 0
+    prover.free()
+
+
 def test_independent_trees_in_parallel_sessions(ctx, mp2):
     """two independent 4-leaf trees proved at the same time, one thread + GPU context + ProofSession each (the way
     bench.py --workload recursion --trees N fills the GPU while another tree's witnesses are generated): same root
