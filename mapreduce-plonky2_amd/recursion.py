@@ -1320,6 +1320,38 @@ class RecursiveCircuits:
         return cur_proof
 
 
+class RecursiveCircuitsVerifierGadget:
+    """RecursiveCircuitsVerifierGagdet (framework.rs:186-262): what a circuit OUTSIDE a set of recursive circuits uses to verify a
+    proof generated with that set's framework `fw`. The set's digest enters as constants (CircuitSetTarget::from_circuit_set_digest)."""
+
+    def __init__(self, fw):
+        self.fw = fw
+
+    def dummy_inputs(self):
+        """(proof, verifier data, membership) of the right shapes with zero values: what the structure pass of a circuit feeds the gadget"""
+        fw = self.fw
+        height = max(0, (fw.set_size - 1).bit_length()) - CIRCUIT_SET_CAP_HEIGHT
+        vd = (np.zeros((1 << fw.rec.fp.cap_height, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64))
+        return fw._dummy_proof(fw.rec), vd, ([0] * height, [np.zeros(4, dtype=np.uint64)] * height)
+
+    def verify_proof_in_circuit_set(self, b, proof, vd, membership):
+        """any circuit of the set: verifier data as witnesses, digest check, membership in the set, same set in the proof
+        (verify_proof_in_circuit_set, framework.rs:219-234). Returns the verified proof's public-input targets."""
+        set_t = [b.constant(int(x)) for x in self.fw.set_digest]
+        return universal_verifier_circuit(b, self.fw.rec, set_t, self.fw.set_size, proof, vd, membership)
+
+    def verify_proof_fixed_circuit_in_circuit_set(self, b, proof, fixed_vd):
+        """one fixed circuit of the set: its verifier data are constants of the verifying circuit; the proof must expose the set's
+        digest (verify_proof_fixed_circuit_in_circuit_set + check_circuit_set_equality, framework.rs:238-261)"""
+        set_t = [b.constant(int(x)) for x in self.fw.set_digest]
+        cap_t = [[b.constant(int(x)) for x in h] for h in np.asarray(fixed_vd[0]).reshape(-1, 4)]
+        digest_t = [b.constant(int(x)) for x in fixed_vd[1]]
+        pis = verify_proof_circuit(b, self.fw.rec, *proof, verifier_data=(cap_t, digest_t))
+        for x, y in zip(set_t, pis[len(pis) - 4:]):
+            b.connect(x, y)
+        return pis
+
+
 def map_logic(b, child_pis, inputs):
     """MapCircuitWires::circuit_logic (integration.rs:75-93)"""
     ins = [b.add_virtual(int(x)) for x in (inputs if inputs is not None else [0, 0, 0, 0])]

@@ -116,6 +116,74 @@ def test_reference_framework_test_circuits_with_one_to_four_verifiers(ctx, mp2):
     prover.free()
 
 
+@pytest.mark.parametrize("num_verifiers", [1, 2, 3, 4, 5])
+def test_circuit_with_universal_verifiers(ctx, mp2, num_verifiers):
+    """recursion-framework/src/circuit_builder.rs:497-583 (`test_circuit_with_universal_verifier::<NUM_VERIFIERS>`; the reference
+    runs 1..5, the map-reduce tests above cover 2): a circuit set of two -- a leaf chaining 2^7 hashes and a recursive circuit with
+    NUM_VERIFIERS universal verifiers --, 2 N - 1 leaf proofs, a recursive proof over N of them, then a recursive proof over the
+    N - 1 others AND that recursive proof (the circuit verifies a proof of itself through the universal verifier). Both end with
+    the circuit-set digest and pass the oracle's verifier. With five verifiers the base circuit has 2^15 rows."""
+    prover = FW.GpuProver(ctx)
+    N = num_verifiers
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("leaf", 0, _hash_chain_leaf_logic(1 << 7), 4), R.FrameworkCircuit("rec", N, _recursive_logic, 4)],
+                             prover, FW.circuit_fri_params)
+    if N == 5:
+        assert fw.chains["rec"][0][0].log_n == 15
+    set_digest = np.asarray(fw.set_digest, dtype=np.uint64)
+    rng = np.random.default_rng(0xC0FFEE03 + N)
+    rand = lambda n: O.rand_field(n, int(rng.integers(1 << 30)))
+    leaves = fw.generate_proofs_batch("leaf", [([], [], rand(9)) for _ in range(2 * N - 1)])
+    wckt, wcap, wdig = fw.chains["rec"][-1]
+    (first,) = fw.generate_proofs_batch("rec", [(leaves[:N], ["leaf"] * N, rand(8))])
+    assert np.array_equal(first[3][4:], set_digest)
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(first[3], 4), *first[:3]) == 0
+    (second,) = fw.generate_proofs_batch("rec", [(leaves[N:] + [first], ["leaf"] * (N - 1) + ["rec"], rand(8))])
+    assert np.array_equal(second[3][4:], set_digest)
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(second[3], 4), *second[:3]) == 0
+    prover.free()
+
+
+def test_verifier_circuit_of_recursive_circuits_set(ctx, mp2):
+    """recursion-framework/src/framework.rs:598-701: circuits OUTSIDE a set verify proofs of the set with the
+    RecursiveCircuitsVerifierGadget. Set one: the hash-chain leaf and a 1-verifier recursive circuit; a leaf proof and a
+    recursive proof over it. Set two: a circuit that verifies a proof of ANY circuit of set one (verifier data as witnesses,
+    membership in set one) and a circuit that verifies proofs of the recursive circuit only (its verifier data as constants).
+    The first accepts both proofs, the second accepts the recursive proof and -- like the reference's check_panic -- refuses
+    the leaf proof."""
+    prover = FW.GpuProver(ctx)
+    fw1 = R.RecursiveCircuits([R.FrameworkCircuit("leaf", 0, _hash_chain_leaf_logic(1 << 12), 4), R.FrameworkCircuit("rec", 1, _recursive_logic, 4)],
+                              prover, FW.circuit_fri_params)
+    base_proof = fw1.generate_proof("leaf", [], [], O.rand_field(9, 11))
+    rec_proof = fw1.generate_proof("rec", [base_proof], ["leaf"], O.rand_field(8, 12))
+    gadget = R.RecursiveCircuitsVerifierGadget(fw1)
+
+    def any_logic(b, child_pis, inputs):  # VerifierCircuitWires: NUM_PUBLIC_INPUTS = 0
+        proof, vd, mem = inputs if inputs is not None else gadget.dummy_inputs()
+        gadget.verify_proof_in_circuit_set(b, proof, vd, mem)
+        return []
+
+    def fixed_logic(b, child_pis, inputs):  # VerifierCircuitFixedWires, fixed to the recursive circuit
+        proof = inputs if inputs is not None else gadget.dummy_inputs()[0]
+        gadget.verify_proof_fixed_circuit_in_circuit_set(b, proof, fw1.vds["rec"])
+        return []
+
+    fw2 = R.RecursiveCircuits([R.FrameworkCircuit("verifier", 0, any_logic, 0), R.FrameworkCircuit("verifier_fixed", 0, fixed_logic, 0)],
+                              prover, FW.circuit_fri_params)
+    set2 = np.asarray(fw2.set_digest, dtype=np.uint64)
+    for proof, name in ((base_proof, "leaf"), (rec_proof, "rec")):
+        vd = fw1.vds[name]
+        out = fw2.generate_proof("verifier", [], [], (proof, vd, fw1.membership(vd[1])))
+        wckt, wcap, wdig = fw2.chains["verifier"][-1]
+        assert np.array_equal(out[3], set2)
+        assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(out[3], 4), *out[:3]) == 0
+    out = fw2.generate_proof("verifier_fixed", [], [], rec_proof)
+    wckt, wcap, wdig = fw2.chains["verifier_fixed"][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(out[3], 4), *out[:3]) == 0
+    with pytest.raises(Exception):
+        fw2.generate_proof("verifier_fixed", [], [], base_proof)
+    prover.free()
+
+
 def test_independent_trees_in_parallel_sessions(ctx, mp2):
     """two independent 4-leaf trees proved at the same time, one thread + GPU context + ProofSession each (the way
     bench.py --workload recursion --trees N fills the GPU while another tree's witnesses are generated): same root
