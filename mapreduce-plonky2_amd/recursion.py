@@ -1288,7 +1288,9 @@ class RecursiveCircuits:
 
     def membership(self, digest):
         """CircuitSet::set_circuit_membership_target (circuit_set.rs:205-237): little-endian index bits + siblings"""
-        idx = next(i for i, d in enumerate(self.digests) if [int(x) for x in d] == [int(x) for x in digest])
+        idx = next((i for i, d in enumerate(self.digests) if [int(x) for x in d] == [int(x) for x in digest]), None)
+        if idx is None:
+            raise KeyError("circuit digest not found")  # the reference's error (circuit_set.rs set_circuit_membership_target)
         bits, sib = [], []
         for lv in self.set_levels[:-1]:
             bits.append(idx & 1)

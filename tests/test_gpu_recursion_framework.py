@@ -184,6 +184,65 @@ def test_verifier_circuit_of_recursive_circuits_set(ctx, mp2):
     prover.free()
 
 
+def test_universal_verifier_negative_tests(ctx, mp2):
+    """recursion-framework/src/universal_verifier_gadget/verifier_gadget.rs:465-606 (`negative_tests`): what the universal verifier
+    and the wrap circuit must refuse. `variant` is the leaf circuit with its hash inputs reversed (flag true): same shape, another
+    circuit, not in the set."""
+    prover = FW.GpuProver(ctx)
+
+    def variant_logic(b, child_pis, inputs):  # LeafCircuitWires with the flag set: every hash takes its inputs reversed
+        vals = inputs if inputs is not None else [0] * 9
+        state = [b.add_virtual(int(x)) for x in vals[:8]]
+        generator = b.add_virtual(int(vals[8]))
+        generated = generator
+        for _ in range(1 << 7):
+            state = b.hash_n_to_m_no_pad((state + [generated])[::-1], 4)
+            generated = b.mul(generated, generator)
+        return state
+
+    mk = lambda leaf_logic: R.RecursiveCircuits([R.FrameworkCircuit("leaf", 0, leaf_logic, 4), R.FrameworkCircuit("rec", 1, _recursive_logic, 4)],
+                                                prover, FW.circuit_fri_params)
+    fw, fw_var = mk(_hash_chain_leaf_logic(1 << 7)), mk(variant_logic)
+    assert not np.array_equal(fw.vds["leaf"][1], fw_var.vds["leaf"][1])
+    fw_var.set_digest = fw.set_digest  # the variant's proof claims the right circuit set, as in the reference's test
+    inputs = O.rand_field(9, 21)
+    rec = fw.circuits["rec"]
+    # 1. the wrap circuit of the leaf refuses a base proof of the variant
+    var_base = fw_var.circuits["leaf"].build_base(fw_var, [], [], [], inputs, fw.set_digest)
+    caps, openings, proof = prover.prove(var_base)
+    leaf_ckt, leaf_cap, leaf_dig = fw.chains["leaf"][0]
+    inner = R.InnerCircuit(leaf_ckt, FW.circuit_fri_params(leaf_ckt), leaf_cap, leaf_dig, len(leaf_ckt.public_inputs))
+    with pytest.raises(AssertionError):
+        R.wrap_circuit(inner, caps, openings, proof, var_base.public_inputs)
+    # the variant's own wrap chain accepts it: a valid final proof of a circuit outside the set
+    wrapped = fw_var.generate_proof("leaf", [], [], inputs)
+    var_vd, leaf_vd = fw_var.vds["leaf"], fw.vds["leaf"]
+    # 2. its digest is not in the set
+    with pytest.raises(KeyError, match="circuit digest not found"):
+        fw.membership(var_vd[1])
+    build = lambda vd, mem: rec.build_base(fw, [wrapped], [vd], [mem], O.rand_field(8, 22), fw.set_digest)
+    # 3. verifier data of a circuit that IS in the set do not verify the proof
+    with pytest.raises(AssertionError):
+        build(leaf_vd, fw.membership(leaf_vd[1]))
+    # 4. membership proved against another set (one that holds the variant): the set digest differs
+    with pytest.raises(AssertionError):
+        build(var_vd, fw_var.membership(var_vd[1]))
+    # 5. a valid membership proof of the leaf's digest beside the variant's verifier data
+    with pytest.raises(AssertionError):
+        build(var_vd, fw.membership(leaf_vd[1]))
+    # 6. the variant's cap under the leaf's circuit digest
+    with pytest.raises(AssertionError):
+        build((var_vd[0], leaf_vd[1]), fw.membership(leaf_vd[1]))
+    # 3 again through the production path: the witness program fills the wires without judging them, and prove()'s device-side
+    # witness check refuses them (plonky2's prove() panics on an unsatisfied witness)
+    with pytest.raises(Exception, match="witness"):
+        fw.generate_proofs_batch("rec", [([wrapped], ["leaf"], O.rand_field(8, 22))])
+    # and the same builder accepts the honest input
+    good = fw.generate_proof("leaf", [], [], inputs)
+    rec.build_base(fw, [good], [leaf_vd], [fw.membership(leaf_vd[1])], O.rand_field(8, 22), fw.set_digest)
+    prover.free()
+
+
 def test_independent_trees_in_parallel_sessions(ctx, mp2):
     """two independent 4-leaf trees proved at the same time, one thread + GPU context + ProofSession each (the way
     bench.py --workload recursion --trees N fills the GPU while another tree's witnesses are generated): same root
