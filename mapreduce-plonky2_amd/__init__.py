@@ -682,11 +682,12 @@ def hash_pad_input(values):
     return v + [1]
 
 
-def circuit_digest(ctx, constants_sigmas_cap, degree_bits, variant=POSEIDON2):
+def circuit_digest(ctx, constants_sigmas_cap, degree_bits, variant=POSEIDON2, domain_separator=()):
     """recursion-framework/src/universal_verifier_gadget/circuit_set.rs:136-158:
-    H(flatten(constants_sigmas_cap) || H_pad([]) || degree_bits) (no domain separator)."""
+    H(flatten(constants_sigmas_cap) || H_pad(domain separator) || degree_bits); the framework's circuits have no domain
+    separator, a base circuit may (CircuitBuilder::set_domain_separator, wrap_circuit.rs:327-358)."""
     cap = [int(x) for x in _arr(constants_sigmas_cap).reshape(-1)]
-    domain_sep = [int(x) for x in ctx.hash_no_pad(hash_pad_input([]), variant)]
+    domain_sep = [int(x) for x in ctx.hash_no_pad(hash_pad_input(domain_separator), variant)]
     return ctx.hash_no_pad(cap + domain_sep + [degree_bits], variant)
 
 

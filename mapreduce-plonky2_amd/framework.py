@@ -61,7 +61,7 @@ class CircuitProver:
         pre = PolynomialBatch.from_values(ctx, ckt.pre, self.fp.rate_bits, self.fp.cap_height, variant)
         self.constants_sigmas_cap = pre.cap
         pre.free()
-        self.circuit_digest = circuit_digest(ctx, self.constants_sigmas_cap, ckt.log_n, variant)
+        self.circuit_digest = circuit_digest(ctx, self.constants_sigmas_cap, ckt.log_n, variant, getattr(ckt, "domain_separator", ()))
         self.d_circuit_digest = ctx.to_device(self.circuit_digest)
 
     def prove(self, d_wires, d_pi_hash, d_circuit_digest=None):

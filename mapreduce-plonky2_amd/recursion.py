@@ -597,6 +597,11 @@ class Builder:
         self.public_inputs += list(targets)
 
     # ---- build ---------------------------------------------------------------------------------------------------------------------
+    def set_domain_separator(self, values):
+        """CircuitBuilder::set_domain_separator: field elements hashed (hash_pad) into the circuit digest, which every transcript of
+        the circuit's proofs starts from. The framework's wrapped circuits have none (check_circuit_digest_target)."""
+        self.domain_separator = [int(x) for x in values]
+
     def build(self, min_log_n=6):
         """CircuitBuilder::build: the public-inputs hash bound to a PublicInputGate, rows padded with Noops to a
         power of two, selectors, sigma polynomials from the copy classes. Returns a circuits.Circuit."""
@@ -653,6 +658,7 @@ class Builder:
         ckt.n_used_rows = n_rows - 1
         # the witness program of this circuit (see the OP_* table above) and the inputs this build was run with
         ckt.tape = np.array(self.tape, dtype=np.uint64)
+        ckt.domain_separator = list(getattr(self, "domain_separator", []))  # CircuitBuilder::set_domain_separator: part of the circuit digest
         ckt.n_slots = self.n_slots
         ckt.input_sids = np.array(self.input_sids, dtype=np.uint32)
         ckt.const_slots = np.array([[sid, v] for sid, v in self.const_slots], dtype=np.uint64).reshape(-1, 2)

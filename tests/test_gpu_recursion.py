@@ -70,3 +70,33 @@ def test_dishonest_wrap_witness_is_flagged(ctx, mp2):
         wcp.pr.witness_status()
     cp.free()
     wcp.free()
+
+
+def test_wrapping_base_circuit_with_domain_separator(ctx, mp2):
+    """recursion-framework/src/universal_verifier_gadget/wrap_circuit.rs:327-358: a base circuit of more than 2^12 Noop rows
+    (degree 13) with a domain separator and one public input; its circuit digest -- H(cap || H_pad(separator) || 13) -- is
+    what the proof's transcript starts from and what the wrap circuit holds as a constant. The wrapped proof carries the
+    public input and passes the oracle's verifier."""
+    public_input, separator = int(O.rand_field(1, 5)[0]), int(O.rand_field(1, 6)[0])
+    b = R.Builder()
+    b.register_public_inputs([b.add_virtual(public_input)])
+    b.set_domain_separator([separator])
+    base = b.build(min_log_n=13)
+    assert base.log_n == 13 and base.domain_separator == [separator]
+    cp, caps, openings, proof, flags = gpu_prove(ctx, base)
+    assert flags.tolist() == [0]
+    plain = mp2.circuit_digest(ctx, cp.constants_sigmas_cap, 13)
+    assert not np.array_equal(cp.circuit_digest, plain)  # the separator is part of the digest
+    assert np.array_equal(cp.circuit_digest, O.hash_n_to_m_no_pad(
+        np.concatenate([np.asarray(cp.constants_sigmas_cap, dtype=np.uint64).ravel(), O.hash_n_to_m_no_pad(np.array(mp2.hash_pad_input([separator]), dtype=np.uint64), 4),
+                        np.array([13], dtype=np.uint64)]), 4))
+    fp = C.oracle_params(base)
+    assert C.verify(base, fp, cp.circuit_digest, base.pi_hash, caps, openings, proof) == 0
+    assert C.verify(base, fp, plain, base.pi_hash, caps, openings, proof) != 0  # a verifier that ignores the separator rejects
+    inner = R.InnerCircuit(base, fp, cp.constants_sigmas_cap, cp.circuit_digest, len(base.public_inputs))
+    wrap = R.wrap_circuit(inner, caps, openings, proof, base.public_inputs)
+    assert wrap.log_n == R.RECURSION_THRESHOLD
+    wcp, wcaps, wopen, wproof, wflags = gpu_prove(ctx, wrap)
+    assert wflags.tolist() == [0]
+    assert int(wrap.public_inputs[0]) == public_input
+    assert C.verify(wrap, C.oracle_params(wrap), wcp.circuit_digest, wrap.pi_hash, wcaps, wopen, wproof) == 0
