@@ -141,7 +141,7 @@ def test_map_reduce_with_the_universal_verifier():
     (broot,) = fw.generate_proofs_batch("reduce", [([b0, b1], ["map", "map"], None)])
     assert all(np.array_equal(x, y) for x, y in zip(broot, root))
     # a proof of a circuit outside the set cannot be used: the membership proof does not exist
-    with pytest.raises(StopIteration):
+    with pytest.raises(KeyError, match="circuit digest not found"):
         fw.membership([1, 2, 3, 4])
     # a child proof with foreign verifier data fails inside the universal verifier (the digest check / the transcript)
     with pytest.raises(AssertionError):
