@@ -181,3 +181,51 @@ def test_witness_program_replays_the_builder_and_validates_its_tape():
     assert create(ca.tape, n_slots=ca.n_slots - 5) != 0   # slot out of range
     bad = ca.tape.copy(); bad[1] = 1 << 20                # row beyond the circuit (first instruction is an ARITH or a P2 row)
     assert create(bad) != 0
+
+
+def test_circuit_set_gadgets():
+    """recursion-framework/src/universal_verifier_gadget/circuit_set.rs:297-372 (`test_circuit_set_gadgets`): ONE circuit proves
+    that each of 42 digests belongs to a circuit set of 42 (padded to 64 leaves, cap height 0) given as a public input; the
+    same witness against another set is refused. The oracle proves and verifies."""
+    n_elements = 42
+    prover = OracleProver()
+
+    def tree(digests):
+        size = 1 << (len(digests) - 1).bit_length()
+        levels = [[[int(x) for x in d] for d in digests] + [[0, 0, 0, 0]] * (size - len(digests))]
+        while len(levels[-1]) > 1:
+            prev = levels[-1]
+            levels.append([prover.two_to_one(prev[2 * i], prev[2 * i + 1]) for i in range(len(prev) // 2)])
+        return levels
+
+    def circuit(elements, levels, strict=True):
+        b = R.Builder(strict)
+        set_t = [b.add_virtual(int(x)) for x in levels[-1][0]]  # CircuitSetTarget::build_target
+        for idx, el in enumerate(elements):
+            el_t = [b.add_virtual(int(x)) for x in el]
+            bits, sib, i = [], [], idx
+            for lv in levels[:-1]:
+                t = b.add_virtual(i & 1)
+                b.assert_bool(t)
+                bits.append(t)
+                sib.append([b.add_virtual(int(x)) for x in lv[i ^ 1]])
+                i >>= 1
+            R.verify_merkle_proof_to_cap(b, el_t, bits, None, [set_t], sib)  # check_circuit_digest_membership
+        b.register_public_inputs(set_t)
+        return b.build()
+
+    elements = [O.hash_n_to_m_no_pad(O.rand_field(4, 300 + i), 4) for i in range(n_elements)]
+    levels = tree(elements)
+    assert len(levels) == 7
+    ckt = circuit(elements, levels)
+    caps, openings, proof = prover.prove(ckt)  # proves and verifies
+    assert [int(x) for x in ckt.public_inputs] == levels[-1][0]
+    # the membership witnesses of another set do not open to this set's digest
+    other = tree([O.hash_n_to_m_no_pad(O.rand_field(4, 900 + i), 4) for i in range(n_elements)])
+    with pytest.raises(AssertionError):
+        circuit(elements, other)
+    # and the same circuit filled with that wrong witness does not give a proof the verifier accepts
+    bad = circuit(elements, other, strict=False)
+    assert np.array_equal(bad.pre, ckt.pre)
+    with pytest.raises(AssertionError):
+        prover.prove(bad)
