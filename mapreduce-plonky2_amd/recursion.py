@@ -1328,6 +1328,32 @@ class RecursiveCircuits:
         return cur_proof
 
 
+class TestingRecursiveCircuits:
+    """framework_testing.rs:71-245: the framework plus a dummy circuit that exposes NUM_PUBLIC_INPUTS unconstrained public inputs,
+    so that a circuit with universal verifiers can be tested (or timed) on input proofs with chosen public inputs instead of
+    proofs of the real circuits below it."""
+    __test__ = False  # not a pytest class
+    DUMMY = "dummy circuit"
+
+    def __init__(self, circuits, prover, fri_params):
+        n = circuits[0].num_public_inputs
+
+        def dummy_logic(b, child_pis, inputs):  # DummyCircuitWires::circuit_logic: add_virtual_public_input_arr
+            return [b.add_virtual(int(x)) for x in (inputs if inputs is not None else [0] * n)]
+
+        self.fw = RecursiveCircuits(list(circuits) + [FrameworkCircuit(self.DUMMY, 0, dummy_logic, n)], prover, fri_params)
+
+    def generate_input_proofs(self, public_inputs):
+        """one dummy proof per row of public_inputs: verifiable by every circuit of the set"""
+        return self.fw.generate_proofs_batch(self.DUMMY, [([], [], pis) for pis in public_inputs])
+
+    def generate_proof(self, name, input_proofs, custom_inputs):
+        return self.fw.generate_proofs_batch(name, [(list(input_proofs), [self.DUMMY] * len(input_proofs), custom_inputs)])[0]
+
+    def generate_proof_from_public_inputs(self, name, public_inputs, custom_inputs):
+        return self.generate_proof(name, self.generate_input_proofs(public_inputs), custom_inputs)
+
+
 class RecursiveCircuitsVerifierGadget:
     """RecursiveCircuitsVerifierGagdet (framework.rs:186-262): what a circuit OUTSIDE a set of recursive circuits uses to verify a
     proof generated with that set's framework `fw`. The set's digest enters as constants (CircuitSetTarget::from_circuit_set_digest)."""

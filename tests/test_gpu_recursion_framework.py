@@ -243,6 +243,23 @@ def test_universal_verifier_negative_tests(ctx, mp2):
     prover.free()
 
 
+def test_reduce_circuit_with_testing_framework(ctx, mp2):
+    """recursion-framework/tests/integration.rs:262-310: the reduce circuit tested in isolation with TestingRecursiveCircuits --
+    its two input proofs are dummy proofs with chosen public inputs (a sum and a hash each), its own public inputs the sum of the
+    sums and the hash of the hashes"""
+    prover = FW.GpuProver(ctx)
+    tf = R.TestingRecursiveCircuits([R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover, FW.circuit_fri_params)
+    test_pis = [np.concatenate([O.rand_field(1, 40 + i), O.hash_n_to_m_no_pad(O.rand_field(8, 50 + i), 4)]) for i in range(2)]
+    proof = tf.generate_proof_from_public_inputs("reduce", test_pis, None)
+    pis = proof[3]
+    assert int(pis[0]) == (int(test_pis[0][0]) + int(test_pis[1][0])) % O.P
+    assert np.array_equal(pis[1:5], O.hash_n_to_m_no_pad(np.concatenate([test_pis[0][1:], test_pis[1][1:]]), 4))
+    assert np.array_equal(pis[5:], np.asarray(tf.fw.set_digest, dtype=np.uint64))
+    wckt, wcap, wdig = tf.fw.chains["reduce"][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *proof[:3]) == 0
+    prover.free()
+
+
 def test_independent_trees_in_parallel_sessions(ctx, mp2):
     """two independent 4-leaf trees proved at the same time, one thread + GPU context + ProofSession each (the way
     bench.py --workload recursion --trees N fills the GPU while another tree's witnesses are generated): same root
