@@ -100,3 +100,42 @@ def test_wrapping_base_circuit_with_domain_separator(ctx, mp2):
     assert wflags.tolist() == [0]
     assert int(wrap.public_inputs[0]) == public_input
     assert C.verify(wrap, C.oracle_params(wrap), wcp.circuit_digest, wrap.pi_hash, wcaps, wopen, wproof) == 0
+
+
+def test_verify_proof_with_fixed_circuit(ctx, mp2):
+    """mp2-common/src/proof.rs:171-262: two circuits with the same common data and different verifier data (a constant, 42 or
+    24, tied to the first of four public inputs); a verifier circuit built for one of them (verify_proof_fixed_circuit: its
+    verifier data as constants) verifies that circuit's proofs and refuses the other's, both ways."""
+    def test_circuit(value):
+        b = R.Builder()
+        pis = [b.add_virtual(value) for _ in range(4)]
+        b.connect(pis[0], b.constant(value))
+        b.register_public_inputs(pis)
+        return b.build()
+
+    circuits = [test_circuit(42), test_circuit(24)]
+    assert circuits[0].log_n == circuits[1].log_n and [g.kind for g in circuits[0].gates] == [g.kind for g in circuits[1].gates]
+    assert not np.array_equal(circuits[0].pre, circuits[1].pre)
+    proved = []
+    for ckt in circuits:
+        cp, caps, openings, proof, flags = gpu_prove(ctx, ckt)
+        assert flags.tolist() == [0]
+        inner = R.InnerCircuit(ckt, C.oracle_params(ckt), cp.constants_sigmas_cap, cp.circuit_digest, 4)
+        proved.append((ckt, inner, caps, openings, proof))
+    assert not np.array_equal(proved[0][1].circuit_digest, proved[1][1].circuit_digest)
+    for own, other in ((0, 1), (1, 0)):
+        ckt, inner, caps, openings, proof = proved[own]
+        verifier = R.wrap_circuit(inner, caps, openings, proof, ckt.public_inputs)
+        wcp, wcaps, wopen, wproof, wflags = gpu_prove(ctx, verifier)
+        assert wflags.tolist() == [0]
+        assert C.verify(verifier, C.oracle_params(verifier), wcp.circuit_digest, verifier.pi_hash, wcaps, wopen, wproof) == 0
+        o_ckt, _, o_caps, o_open, o_proof = proved[other]
+        with pytest.raises(AssertionError):
+            R.wrap_circuit(inner, o_caps, o_open, o_proof, o_ckt.public_inputs)
+        # the same through prove(): the witness of the foreign proof does not satisfy the verifier circuit
+        bad = R.wrap_circuit(inner, o_caps, o_open, o_proof, o_ckt.public_inputs, strict=False)
+        assert np.array_equal(bad.pre, verifier.pre)
+        bcp = FW.CircuitProver(ctx, bad, 1, witness_check=True)
+        bcp.prove(ctx.to_device(bad.wires[None]), ctx.to_device(bad.pi_hash[None]))
+        with pytest.raises(Exception, match="witness"):
+            bcp.pr.witness_status()
