@@ -387,6 +387,35 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
     return out
 
 
+def run_ntt_leg(args, local_rank, clocks):
+    """--workload ntt: the roofline leg alone -- `--steps` forward 2^22-point NTTs (bit-reversed output), HIP events on the stream
+    around each -- so that a `rocprofv3 --kernel-trace --stats` of this command holds nothing but the kernels `roofline` is about
+    (their average durations there must add up to `launch_ms` minus the gap between the two launches)."""
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    C = importlib.import_module("mapreduce-plonky2_amd.circuits")
+    ctx = mp2.Context(local_rank)
+    n = 1 << LOG_NTT
+    d_poly = ctx.to_device(C.rand_field((1, n), 0xC0FFEE02))
+    d_out = ctx.alloc(n * 8)
+    for _ in range(max(1, args.warmup)):
+        ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
+    ms = []
+    for _ in range(args.steps):
+        ctx.timer_start()
+        ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
+        ms.append(ctx.timer_stop())
+    t = float(np.median(ms)) / 1e3
+    out = {"metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build, 1/2/4/8 GPU", "value": None, "unit": "leaf proofs/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "data": "synthetic", "dtype": "u64 (Goldilocks field)",
+           "config": {"workload": "ntt: the roofline leg alone (2^22-point forward NTT, bit-reversed output); no proofs are made, `value` is null"},
+           "roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, all launches)", "achieved": 16.0 * n / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": 16.0 * n / t / 1e9 / HBM_PEAK_GBPS, "launch_ms": t * 1e3, "algorithmic_bytes": 16 * n},
+           "clocks": clocks.read(local_rank)}
+    print(json.dumps(out))
+    ctx.close()
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -408,7 +437,7 @@ def main(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the sampled proofs")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work for the cpu_baseline sample")
     ap.add_argument("--trees", type=int, default=8, help="--workload recursion: independent trees per rank and step, one host thread + GPU stream each")
-    ap.add_argument("--workload", choices=("leaves", "tree", "recursion"), default="leaves",
+    ap.add_argument("--workload", choices=("leaves", "tree", "recursion", "ntt"), default="leaves",
                     help="leaves (default, the headline): independent leaf proofs. tree: every step also proves the 2-to-1 aggregation "
                          "levels above the leaves -- locally below the shard boundary, then log2(ranks) levels whose child proofs move "
                          "between ranks with point-to-point send/recv (RCCL on device tensors). recursion: REAL circuits -- the map / "
@@ -439,6 +468,10 @@ def main(argv=None):
     if args.workload in ("tree", "recursion"):
         clocks.close()
         return (run_tree if args.workload == "tree" else run_recursion)(args, rank, local_rank, world, dist, torch, VARIANT)
+    if args.workload == "ntt":
+        out = run_ntt_leg(args, local_rank, clocks)
+        clocks.close()
+        return out
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
     C = importlib.import_module("mapreduce-plonky2_amd.circuits")  # synthetic circuit + witness generator (pure Python)

@@ -14,9 +14,11 @@ src, dst = os.path.join(ROOT, "gpurun_out", "r02"), os.path.join(ROOT, "profiles
 os.makedirs(dst, exist_ok=True)
 shutil.copy(newest(f"{src}/prof4/runc/*_kernel_stats.csv"), f"{dst}/bench_r02_kernel_stats.csv")
 shutil.copy(newest(f"{src}/prof1/runc/*_kernel_stats.csv"), f"{dst}/bench_r02_single_stream_kernel_stats.csv")
+if glob.glob(f"{src}/prof_ntt/runc/*_kernel_stats.csv"):
+    shutil.copy(newest(f"{src}/prof_ntt/runc/*_kernel_stats.csv"), f"{dst}/bench_r02_ntt_kernel_stats.csv")
 summary = {}
 for a, b in (("bench.json", "bench_r02.json"), ("tree.json", "bench_r02_tree.json"), ("recursion.json", "bench_r02_recursion.json"),
-             ("bench_poseidon.json", "bench_r02_poseidon.json"), ("prof4.json", "bench_r02_under_rocprof.json")):
+             ("bench_poseidon.json", "bench_r02_poseidon.json"), ("prof4.json", "bench_r02_under_rocprof.json"), ("ntt.json", "bench_r02_ntt_under_rocprof.json")):
     if not os.path.exists(f"{src}/{a}"):
         continue
     line = [l for l in open(f"{src}/{a}").read().splitlines() if l.startswith("{")][-1]

@@ -8,6 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof4 -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-verify > $O/prof4.json 2> $O/prof4.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof1 -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-verify > $O/prof1.json 2> $O/prof1.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ntt -- python3 $R/bench.py --workload ntt --steps 20 --warmup 2 > $O/ntt.json 2> $O/ntt.err
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/traffic_$c -- python3 $R/tools/dbg/traffic_run.py > /dev/null 2> $O/traffic_$c.err
 done
