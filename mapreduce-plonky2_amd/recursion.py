@@ -1328,6 +1328,15 @@ class RecursiveCircuits:
         return cur_proof
 
 
+def hash_maybe_swap(b, inputs, do_swap):
+    """mp2-common/src/poseidon.rs:134-172: H(inputs[0] || inputs[1]) or, when do_swap is set, H(inputs[1] || inputs[0]) -- one
+    Poseidon2 gate whose swap wire does the exchange (the node hash of every Merkle path the reference's tree circuits walk).
+    inputs: two lists of 4 targets; do_swap: a boolean target. Returns 4 targets."""
+    z = b.zero()
+    out = b.permute_swapped(list(inputs[0]) + list(inputs[1]) + [z] * 4, do_swap)
+    return out[:4]
+
+
 class TestingRecursiveCircuits:
     """framework_testing.rs:71-245: the framework plus a dummy circuit that exposes NUM_PUBLIC_INPUTS unconstrained public inputs,
     so that a circuit with universal verifiers can be tested (or timed) on input proofs with chosen public inputs instead of

@@ -229,3 +229,20 @@ def test_circuit_set_gadgets():
     assert np.array_equal(bad.pre, ckt.pre)
     with pytest.raises(AssertionError):
         prover.prove(bad)
+
+
+@pytest.mark.parametrize("do_swap", [False, True])
+def test_hash_maybe_swap_is_equivalent_to_hash_n(do_swap):
+    """mp2-common/src/poseidon.rs:243-277: hash_maybe_swap(a, b, false) = hash_no_pad(a || b) and hash_maybe_swap(b, a, true) is the
+    same hash; the circuit exposes it as its public inputs and the oracle proves and verifies."""
+    a, bb = [0] * 4, [1] * 4
+    want = O.hash_n_to_m_no_pad(np.array(a + bb, dtype=np.uint64), 4)
+    first, second = (bb, a) if do_swap else (a, bb)
+    b = R.Builder()
+    ta, tb = [b.add_virtual(x) for x in first], [b.add_virtual(x) for x in second]
+    swap = b.add_virtual(int(do_swap))
+    b.assert_bool(swap)
+    b.register_public_inputs(R.hash_maybe_swap(b, [ta, tb], swap))
+    ckt = b.build()
+    assert np.array_equal(np.asarray(ckt.public_inputs, dtype=np.uint64), want)
+    OracleProver().prove(ckt)  # proves and verifies
