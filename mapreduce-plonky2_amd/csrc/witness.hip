@@ -23,7 +23,7 @@ using namespace mp2g;
 
 namespace {
 enum { OP_ARITH = 1, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
-       OP_HINT_LO63, OP_HINT_HI, OP_END };
+       OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_END };
 const u32 BASE_SUM_LIMBS = 63, RA_BITS = 4, RA_COPIES = 4, RED_COEFFS = 43, RED_EXT_COEFFS = 32, NUM_WIRES = 135;
 
 // operand count after the opcode; 0 = variable (OP_COSET: 3 + 2 * 2^bits + 4)
@@ -40,6 +40,7 @@ u32 op_len(u64 op, const u64* t) {
     case OP_WIRE: return 3;
     case OP_HINT_DIV_EXT: return 6;
     case OP_HINT_LO63: case OP_HINT_HI: return 2;
+    case OP_HINT_SPLIT: return 4;  // source slot, bit position, low slot, high slot (split_low_high's LowHighGenerator)
     default: return ~0u;
   }
 }
@@ -227,6 +228,7 @@ void run_one(const mp2g_witness_program& P, const u64* inputs, u64* vals, u64* w
       }
       case OP_HINT_LO63: vals[t[1]] = vals[t[0]] & (((u64)1 << 63) - 1); t += 2; break;
       case OP_HINT_HI: vals[t[1]] = vals[t[0]] >> 63; t += 2; break;
+      case OP_HINT_SPLIT: vals[t[2]] = vals[t[0]] & (((u64)1 << t[1]) - 1); vals[t[3]] = vals[t[0]] >> t[1]; t += 4; break;
       default: return;  // validated at create
     }
   }
@@ -266,6 +268,7 @@ int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t 
       case OP_RA: if (t[0] >= n || t[1] >= RA_COPIES) return bad("random access operands"); first_slot = 2; break;
       case OP_COSET: if (t[0] >= n) return bad("row"); first_slot = 2; break;
       case OP_WIRE: if (t[0] >= n || t[1] >= NUM_WIRES) return bad("wire"); first_slot = 2; break;
+      case OP_HINT_SPLIT: if (t[0] >= n_slots || t[1] < 1 || t[1] > 63) return bad("split hint"); first_slot = 2; break;
       default: first_slot = 0; break;
     }
     for (u32 i = first_slot; i < len; i++) if (t[i] >= n_slots) return bad("slot out of range");

@@ -74,7 +74,7 @@ class T:
 # (plonky2's generate_partial_witness for this circuit): csrc/witness.hip replays it for a batch of input vectors.
 # Every instruction: opcode, then its operands (row / slot indices, u64 constants), fixed length per opcode.
 (OP_ARITH, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
- OP_HINT_LO63, OP_HINT_HI) = range(1, 13)
+ OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT) = range(1, 14)
 
 
 class E:
@@ -473,6 +473,36 @@ class Builder:
 
     def range_check(self, x, n_bits):
         self.split_le_base2(x, n_bits)
+
+    def split_low_high(self, x, n_log, num_bits):
+        """gadgets/range_check.rs split_low_high: x = low + 2^n_log high with low < 2^n_log and high < 2^(num_bits - n_log), both
+        range-checked (LowHighGenerator supplies them)"""
+        lo = self._hint(x.v & ((1 << n_log) - 1))
+        hi = self._hint(x.v >> n_log)
+        self.tape += [OP_HINT_SPLIT, x.sid, n_log, lo.sid, hi.sid]
+        self.range_check(lo, n_log)
+        self.range_check(hi, num_bits - n_log)
+        self.connect(self.arithmetic(1 << n_log, hi, self.one(), 1, lo), x)
+        return lo, hi
+
+    def is_equal(self, x, y):
+        """gadgets/arithmetic.rs is_equal: equal = 1 - (x - y) inv with inv = (x - y)^-1 or 0 (EqualityGenerator), and
+        (x - y) equal = 0; the result is a boolean by construction"""
+        diff = self.sub(x, y)
+        inv_v = pow(diff.v, P - 2, P)
+        inv, unused = self._hint(inv_v), self._hint(0)
+        one, zero = self.one(), self.zero()
+        self.tape += [OP_HINT_DIV_EXT, one.sid, zero.sid, diff.sid, zero.sid, inv.sid, unused.sid]  # (1, 0) / (diff, 0); 0 for diff = 0
+        equal = self.sub(one, self.mul(diff, inv))
+        self.connect(self.mul(diff, equal), zero)
+        return equal
+
+    def not_(self, a):
+        return self.sub(self.one(), a)
+
+    def or_(self, a, b):
+        """a + b - a b for booleans"""
+        return self.sub(self.add(a, b), self.mul(a, b))
 
     # ---- RandomAccessGate (bits 4, 4 copies, 2 extra constants) ---------------------------------------------------------------
     def random_access(self, index, values):
@@ -1326,6 +1356,35 @@ class RecursiveCircuits:
             caps, openings, proof = self.prover.prove(w)
             cur_ckt, cur_proof = w, (caps, openings, proof, w.public_inputs)
         return cur_proof
+
+
+def split_hash_element_to_low_high(b, element):
+    """mp2-common/src/poseidon.rs:59-72: the low and the high 32 bits of a hash limb, with the check that makes the split unique for
+    a CANONICAL field element: high = 2^32 - 1 forces low = 0 (p = 2^64 - 2^32 + 1)"""
+    lo, hi = b.split_low_high(element, 32, 64)
+    low_zero = b.is_equal(lo, b.zero())
+    high_high = b.is_equal(hi, b.constant(0xFFFFFFFF))
+    b.connect(b.or_(low_zero, b.not_(high_high)), b.one())
+    return lo, hi
+
+
+def flatten_poseidon_hash_target(b, h):
+    """poseidon.rs:75-89: the 4 limbs as 8 u32 targets, big-endian per limb (high, low)"""
+    out = []
+    for t in h:
+        lo, hi = split_hash_element_to_low_high(b, t)
+        out += [hi, lo]
+    return out
+
+
+def hash_to_int_target(b, h):
+    """poseidon.rs:105-117: the 128-bit scalar of a hash as four u32 limbs, least significant first (low, high of limb 0, then
+    of limb 1) -- what field_hashed_scalar_mul multiplies a curve point by"""
+    out = []
+    for t in h[:2]:
+        lo, hi = split_hash_element_to_low_high(b, t)
+        out += [lo, hi]
+    return out
 
 
 def hash_maybe_swap(b, inputs, do_swap):

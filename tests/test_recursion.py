@@ -246,3 +246,34 @@ def test_hash_maybe_swap_is_equivalent_to_hash_n(do_swap):
     ckt = b.build()
     assert np.array_equal(np.asarray(ckt.public_inputs, dtype=np.uint64), want)
     OracleProver().prove(ckt)  # proves and verifies
+
+
+def test_poseidon_hash_flattening_and_hash_to_int():
+    """mp2-common/src/poseidon.rs:193-241 (`test_poseidon_hash_flattening`, `test_hash_to_int`): the in-circuit split of hash limbs
+    into u32 limbs (big-endian flattening; the little-endian 128-bit scalar of hash_to_int) equals the value-side functions; the
+    circuit connects them to the expected constants and the oracle proves it. Edge limbs included: 0, 2^32 - 1, p - 1 = (2^32 - 1,
+    0) whose split is only unique through the canonicity check, and the witness program replays the same wires."""
+    import importlib
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    for seed, h in ((1, [int(x) for x in O.rand_field(4, 71)]), (2, [0, 0xFFFFFFFF, O.P - 1, (0xFFFFFFFE << 32) | 0xFFFFFFFF])):
+        flat_want = [v for x in h for v in (x >> 32, x & 0xFFFFFFFF)]          # flatten_poseidon_hash_value
+        int_want = [v for x in h[:2] for v in (x & 0xFFFFFFFF, x >> 32)]       # hash_to_int_value's u32 limbs
+        b = R.Builder()
+        ht = [b.add_virtual(x) for x in h]
+        for got, want in zip(R.flatten_poseidon_hash_target(b, ht), flat_want):
+            b.connect(got, b.constant(want))
+        for got, want in zip(R.hash_to_int_target(b, ht), int_want):
+            b.connect(got, b.constant(want))
+        b.register_public_inputs(ht)
+        ckt = b.build()
+        OracleProver().prove(ckt)
+        wires, pi_hash, pis = mp2.WitnessProgram(ckt).run(np.array([h], dtype=np.uint64))
+        assert np.array_equal(wires[0], ckt.wires) and np.array_equal(pis[0], np.array(h, dtype=np.uint64))
+    # a non-canonical split (high = 2^32 - 1 with low != 0 would be p + something) cannot be witnessed: the check refuses it
+    b = R.Builder(strict=False)
+    x = b.add_virtual(5)
+    lo, hi = b.split_low_high(x, 32, 64)
+    bad_lo, bad_hi = b.add_virtual(6), b.add_virtual(0xFFFFFFFF)   # 6 + 2^32 (2^32 - 1) = 5 + p
+    assert (6 + (0xFFFFFFFF << 32)) % O.P == 5
+    low_zero, high_high = b.is_equal(bad_lo, b.zero()), b.is_equal(bad_hi, b.constant(0xFFFFFFFF))
+    assert b.or_(low_zero, b.not_(high_high)).v == 0
