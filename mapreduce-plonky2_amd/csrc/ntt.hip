@@ -440,6 +440,13 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_rows
 #endif
   if (a.bitrev_out) {
     wave_sync();
+    u64 v[8];  // all eight LDS reads in flight before the first store (one read - wait - store per point otherwise)
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = s[lds_pad((wave << 9) + lane + (k << 6))];
+    if (a.post) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = gl_mul(v[k], a.post);
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       int e = (wave << 9) + lane + (k << 6);
@@ -447,12 +454,10 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_rows
       u64 g = row0 + r;
       if (g >= total_rows) continue;
       u32 b = (u32)(g >> a.log_n1), jr = (u32)(g & (n1 - 1));
-      u64 v = s[lds_pad(e)];
-      if (a.post) v = gl_mul(v, a.post);
 #if NTT_DBG == 2
-      if (v == 0x123456789ull)
+      if (v[k] == 0x123456789ull)
 #endif
-      out_base(a, b)[((u64)jr << LT) + p] = v;
+      out_base(a, b)[((u64)jr << LT) + p] = v[k];
     }
   } else {
     __syncthreads();
@@ -519,6 +524,8 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_cols
   __syncthreads();
   // row j holds k1 = bitrev(j); multiply by w_n^(i2*k1) and leave it at row j
   u64* dst = dst_dense ? dst_dense + (u64)b * ((u64)1 << a.log_n) : out_base(a, b);
+  // (one load - wait - multiply - store chain per point: requesting the eight 4-step twiddles of a lane together, here or before
+  // the barrier, costs registers this kernel does not have at 8 waves per SIMD -- 2-14 spills, 31.9 -> 33.5 / 34.7 us)
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     int e = tid + k * NT;
