@@ -524,8 +524,8 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_cols
   __syncthreads();
   // row j holds k1 = bitrev(j); multiply by w_n^(i2*k1) and leave it at row j
   u64* dst = dst_dense ? dst_dense + (u64)b * ((u64)1 << a.log_n) : out_base(a, b);
-  // (one load - wait - multiply - store chain per point: requesting the eight 4-step twiddles of a lane together, here or before
-  // the barrier, costs registers this kernel does not have at 8 waves per SIMD -- 2-14 spills, 31.9 -> 33.5 / 34.7 us)
+  // (one load - wait - multiply - store chain per point: requesting the 4-step twiddles of a lane eight or four at a time, here or
+  // before the barrier, costs registers this kernel does not have at 8 waves per SIMD -- 2-14 spills, 31.9 -> 33.5-34.7 us)
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     int e = tid + k * NT;
