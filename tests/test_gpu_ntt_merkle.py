@@ -192,3 +192,50 @@ def test_api_errors(ctx, mp2):
         t.prove([4])
     with pytest.raises(mp2.Mp2gError):
         ctx.hash_no_pad_batch(np.zeros((1, 3), dtype=np.uint64), 4, variant=2)
+
+
+class _At:
+    """a view into a DeviceBuffer at a byte offset, for the *_dev entry points (they take .ptr)"""
+
+    def __init__(self, buf, offset):
+        import ctypes
+        self.ptr = ctypes.c_void_p(buf.ptr.value + offset)
+
+
+@pytest.mark.parametrize("log_n,batch", [(3, 5), (6, 7), (9, 3), (10, 5), (11, 3), (12, 3), (13, 3), (14, 2), (16, 1)])
+def test_ntt_and_lde_stay_inside_their_buffers(ctx, log_n, batch):
+    """no GPU AddressSanitizer on this pool: the transforms run between guard bands of a sentinel pattern -- ragged batches, so
+    that the last tile of every pass is partly empty -- and the bands must come back untouched (in place and out of place,
+    both output orders, inverse with the coset scaling, and the LDE with its 8 cosets per polynomial)"""
+    n, guard = 1 << log_n, 1 << 12  # words
+    sentinel = np.uint64(0xDEADBEEFCAFEF00D)
+    a = O.rand_field((batch, n), 5200 + log_n)
+
+    def banded(payload_words):
+        host = np.full(payload_words + 2 * guard, sentinel, dtype=np.uint64)
+        return ctx.to_device(host), host
+
+    for kw in ({"bitrev_out": True}, {}, {"inverse": True, "coset_shift": O.MULT_GEN}):
+        d_in, h_in = banded(batch * n)
+        d_out, h_out = banded(batch * n)
+        d_in.upload_at(a.ravel(), guard * 8)
+        ctx.ntt_dev(_At(d_in, guard * 8), _At(d_out, guard * 8), log_n, batch, **kw)
+        got = d_out.download((batch * n + 2 * guard,))
+        assert (got[:guard] == sentinel).all() and (got[-guard:] == sentinel).all()
+        assert np.array_equal(got[guard:-guard].reshape(batch, n), ctx.ntt(a, **kw))
+        back = d_in.download((batch * n + 2 * guard,))
+        assert (back[:guard] == sentinel).all() and (back[-guard:] == sentinel).all() and np.array_equal(back[guard:-guard], a.ravel())
+        ctx.ntt_dev(_At(d_in, guard * 8), _At(d_in, guard * 8), log_n, batch, **kw)  # in place
+        got = d_in.download((batch * n + 2 * guard,))
+        assert (got[:guard] == sentinel).all() and (got[-guard:] == sentinel).all()
+        assert np.array_equal(got[guard:-guard].reshape(batch, n), ctx.ntt(a, **kw))
+        d_in.free(); d_out.free()
+    if log_n <= 14:
+        d_c, _ = banded(batch * n)
+        d_v, _ = banded(batch * n * 8)
+        d_c.upload_at(a.ravel(), guard * 8)
+        ctx.lde_dev(_At(d_c, guard * 8), log_n, batch, 3, _At(d_v, guard * 8))
+        got = d_v.download((batch * n * 8 + 2 * guard,))
+        assert (got[:guard] == sentinel).all() and (got[-guard:] == sentinel).all()
+        assert np.array_equal(got[guard:-guard].reshape(batch, n * 8).T, ctx.lde_leaves(a, 3))
+        d_c.free(); d_v.free()
