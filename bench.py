@@ -290,6 +290,9 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
     for name in ("map", "reduce"):
         fw.witness_programs(name)  # shared and read-only from here on
     datas = [C.rand_field(4 * n_leaves, SEED + 31 * rank + 7919 * t) for t in range(n_trees)]
+    # the host's threads are shared by the trees in flight (and by the ranks of the node): a tree's witness programs run one proof
+    # per thread and, where a level has fewer proofs than that, the parallel regions of each proof on the spare ones
+    host_threads = max(1, (os.cpu_count() or 1) // (n_trees * int(os.environ.get("LOCAL_WORLD_SIZE", world))))
 
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
     nccl = dist is not None and dist.get_backend() == "nccl"
@@ -300,11 +303,11 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
 
     def local_tree(t, out):
         sess, data = sessions[t], datas[t]
-        level = fw.generate_proofs_batch("map", [([], [], data[4 * i:4 * i + 4]) for i in range(n_leaves)], session=sess)
+        level = fw.generate_proofs_batch("map", [([], [], data[4 * i:4 * i + 4]) for i in range(n_leaves)], threads=host_threads, session=sess)
         names = ["map"] * n_leaves
         while len(level) > 1:
             level = fw.generate_proofs_batch("reduce", [([level[2 * i], level[2 * i + 1]], [names[2 * i], names[2 * i + 1]], None)
-                                                       for i in range(len(level) // 2)], session=sess)
+                                                       for i in range(len(level) // 2)], threads=host_threads, session=sess)
             names = ["reduce"] * len(level)
         out[t] = (level[0], names[0])
 

@@ -389,7 +389,9 @@ int mp2g_eval_gate_constraints(mp2g_ctx* ctx, const mp2g_gate* gates, uint32_t n
  * the structure of these circuits does not depend on the witness -- and this entry replays it per proof:
  *   tape        opcodes + operands (recursion.py OP_*: ArithmeticGate / ArithmeticExtensionGate operations,
  *               Poseidon2Gate rows, BaseSumGate splits, RandomAccessGate copies, ReducingGate / ReducingExtensionGate
- *               rows, CosetInterpolationGate rows, plain wire writes, division / split hints)
+ *               rows, CosetInterpolationGate rows, plain wire writes, division / split hints; parallel regions: runs of
+ *               sections that do not read each other's values -- the query rounds of a FRI verifier -- which spare threads replay
+ *               concurrently when the batch is smaller than `threads`)
  *   input_sids  the slots the caller provides, in order (the inner proof's public inputs, caps, openings, FRI proof
  *               words, verifier data, membership proof, the circuit's own inputs)
  *   const_slots (slot, value) pairs

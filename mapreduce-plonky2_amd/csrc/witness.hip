@@ -23,7 +23,7 @@ using namespace mp2g;
 
 namespace {
 enum { OP_ARITH = 1, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
-       OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_END };
+       OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR, OP_END };
 const u32 BASE_SUM_LIMBS = 63, RA_BITS = 4, RA_COPIES = 4, RED_COEFFS = 43, RED_EXT_COEFFS = 32, NUM_WIRES = 135;
 
 // operand count after the opcode; 0 = variable (OP_COSET: 3 + 2 * 2^bits + 4)
@@ -41,6 +41,7 @@ u32 op_len(u64 op, const u64* t) {
     case OP_HINT_DIV_EXT: return 6;
     case OP_HINT_LO63: case OP_HINT_HI: return 2;
     case OP_HINT_SPLIT: return 4;  // source slot, bit position, low slot, high slot (split_low_high's LowHighGenerator)
+    case OP_PAR: return t[0] <= 4096 ? 1 + (u32)t[0] : ~0u;  // section count, then the sections' lengths in words; the sections follow
     default: return ~0u;
   }
 }
@@ -77,18 +78,44 @@ struct mp2g_witness_program {
 };
 
 namespace {
-// one proof: vals = scratch of n_slots words, wires = [135][n] (zero-filled here)
-void run_one(const mp2g_witness_program& P, const u64* inputs, u64* vals, u64* wires) {
+// the instructions of [t, end). A parallel region (OP_PAR) is a run of sections that read what came before the region and each
+// other's nothing: the builder brackets the query rounds of a FRI verifier this way (28 per verified proof). With inner > 1 the
+// sections of a region are dealt to that many threads; every instruction writes value slots and wire cells of its own.
+void exec(const mp2g_witness_program& P, const u64* t, const u64* end, u64* vals, u64* wires, u32 inner) {
   const u64 n = (u64)1 << P.log_n;
-  memset(wires, 0, NUM_WIRES * n * sizeof(u64));
-  for (size_t i = 0; i < P.consts.size(); i += 2) vals[P.consts[i]] = P.consts[i + 1];
-  for (size_t i = 0; i < P.input_sids.size(); i++) vals[P.input_sids[i]] = inputs[i];
 #define W(col, row) wires[(u64)(col) * n + (row)]
-  const u64* t = P.tape.data();
-  const u64* end = t + P.tape.size();
   while (t < end) {
     const u64 op = *t++;
     switch (op) {
+      case OP_PAR: {
+        const u32 ns = (u32)t[0];
+        const u64* len = t + 1;
+        const u64* body = t + 1 + ns;
+        u64 total = 0;
+        for (u32 i = 0; i < ns; i++) total += len[i];
+        if (inner <= 1 || ns <= 1) {
+          exec(P, body, body + total, vals, wires, 1);
+        } else {
+          std::vector<const u64*> start(ns + 1);
+          start[0] = body;
+          for (u32 i = 0; i < ns; i++) start[i + 1] = start[i] + len[i];
+          std::atomic<u32> next{0};
+          auto worker = [&]() {
+            for (;;) {
+              const u32 i = next.fetch_add(1);
+              if (i >= ns) return;
+              exec(P, start[i], start[i + 1], vals, wires, 1);
+            }
+          };
+          const u32 nt = inner < ns ? inner : ns;
+          std::vector<std::thread> pool;
+          for (u32 i = 1; i < nt; i++) pool.emplace_back(worker);
+          worker();
+          for (auto& th : pool) th.join();
+        }
+        t = body + total;
+        break;
+      }
       case OP_WIRE: W(t[1], t[0]) = vals[t[2]]; t += 3; break;
       case OP_ARITH: {
         const u64 row = t[0], i = t[1], c0 = t[2], c1 = t[3];
@@ -234,6 +261,14 @@ void run_one(const mp2g_witness_program& P, const u64* inputs, u64* vals, u64* w
   }
 #undef W
 }
+// one proof: vals = scratch of n_slots words, wires = [135][n] (zero-filled here)
+void run_one(const mp2g_witness_program& P, const u64* inputs, u64* vals, u64* wires, u32 inner) {
+  const u64 n = (u64)1 << P.log_n;
+  memset(wires, 0, NUM_WIRES * n * sizeof(u64));
+  for (size_t i = 0; i < P.consts.size(); i += 2) vals[P.consts[i]] = P.consts[i + 1];
+  for (size_t i = 0; i < P.input_sids.size(); i++) vals[P.input_sids[i]] = inputs[i];
+  exec(P, P.tape.data(), P.tape.data() + P.tape.size(), vals, wires, inner);
+}
 }  // namespace
 
 extern "C" {
@@ -254,12 +289,34 @@ int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t 
   for (uint32_t i = 0; i < n_consts; i++) if (const_slots[2 * i] >= n_slots || const_slots[2 * i + 1] >= GL_P) return bad("constant slot / value");
   const u64* t = P->tape.data();
   const u64* end = t + tape_len;
+  const u64* par_end = nullptr;        // end of the parallel region being scanned (regions do not nest)
+  std::vector<const u64*> boundaries;  // its section boundaries: each must fall on an instruction start
+  size_t next_boundary = 0;
   while (t < end) {
+    if (par_end) {
+      while (next_boundary < boundaries.size() && t == boundaries[next_boundary]) next_boundary++;
+      if (next_boundary < boundaries.size() && t > boundaries[next_boundary]) return bad("a parallel section ends inside an instruction");
+      if (t >= par_end) { par_end = nullptr; boundaries.clear(); next_boundary = 0; }
+    }
     const u64 op = *t++;
     if (op < OP_ARITH || op >= OP_END) return bad("unknown opcode");
     if (op == OP_COSET && (t + 2 > end || t[1] < 2 || t[1] > 5)) return bad("CosetInterpolation bits");
+    if (op == OP_PAR && (t + 1 > end || par_end)) return bad("parallel region header / nesting");
     const u32 len = op_len(op, t);
     if (len == ~0u || t + len > end) return bad("truncated instruction");
+    if (op == OP_PAR) {
+      const u64* body = t + len;
+      const u64* b = body;
+      for (u32 i = 1; i < len; i++) {
+        if (t[i] > (u64)(end - b)) return bad("parallel section length");
+        b += t[i];
+        boundaries.push_back(b);
+      }
+      par_end = b;
+      next_boundary = 0;
+      t += len;
+      continue;
+    }
     // operand classes: rows < n; everything else that is not a constant or a small index is a slot
     u32 first_slot = 0;
     switch (op) {
@@ -274,6 +331,8 @@ int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t 
     for (u32 i = first_slot; i < len; i++) if (t[i] >= n_slots) return bad("slot out of range");
     t += len;
   }
+  for (; par_end && next_boundary < boundaries.size(); next_boundary++)
+    if (boundaries[next_boundary] != end) return bad("a parallel section ends inside an instruction");
   for (u32 bits = 2; bits <= 5; bits++) {
     const u32 npts = 1u << bits;
     const u64 w = gl_root_of_unity(bits);
@@ -298,8 +357,10 @@ int mp2g_witness_program_run(const mp2g_witness_program* P, const uint64_t* inpu
   for (size_t i = 0; i < (size_t)batch * n_in; i++) NEED(inputs[i] < GL_P, "inputs must be canonical field elements");
   const size_t per = (size_t)NUM_WIRES << P->log_n;
   if (!threads) threads = std::thread::hardware_concurrency();
-  if (threads > batch) threads = batch;
   if (!threads) threads = 1;
+  // fewer proofs than threads: the spare ones work inside the proofs, on the sections of their parallel regions
+  const uint32_t inner = threads > batch ? (threads / batch > 16 ? 16 : threads / batch) : 1;  // 16: past that the thread starts cost more than they save
+  if (threads > batch) threads = batch;
   std::atomic<uint32_t> next{0};
   auto worker = [&]() {
     std::vector<u64> vals(P->n_slots);
@@ -307,7 +368,7 @@ int mp2g_witness_program_run(const mp2g_witness_program* P, const uint64_t* inpu
       const uint32_t b = next.fetch_add(1);
       if (b >= batch) return;
       std::fill(vals.begin(), vals.end(), 0);
-      run_one(*P, inputs + (size_t)b * n_in, vals.data(), wires + (size_t)b * per);
+      run_one(*P, inputs + (size_t)b * n_in, vals.data(), wires + (size_t)b * per, inner);
       for (uint32_t i = 0; i < n_probe; i++) probe_out[(size_t)b * n_probe + i] = vals[probe_sids[i]];
     }
   };

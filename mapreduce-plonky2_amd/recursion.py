@@ -74,7 +74,7 @@ class T:
 # (plonky2's generate_partial_witness for this circuit): csrc/witness.hip replays it for a batch of input vectors.
 # Every instruction: opcode, then its operands (row / slot indices, u64 constants), fixed length per opcode.
 (OP_ARITH, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
- OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT) = range(1, 14)
+ OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR) = range(1, 15)
 
 
 class E:
@@ -96,6 +96,59 @@ class Row:
         self.kind, self.p0, self.p1, self.p2 = kind, p0, p1, p2
         self.consts = list(consts)
         self.wires = [None] * NUM_WIRES
+
+
+def tape_instructions(tape):
+    """(position, opcode) of every instruction of a recorded witness program (the lengths csrc/witness.hip's op_len gives)"""
+    fixed = {OP_ARITH: 8, OP_ARITH_EXT: 12, OP_P2: 26, OP_BASE_SUM: 2 + 63, OP_RA: 20, OP_REDUCING: 5 + 43 + 2, OP_REDUCING_EXT: 5 + 64 + 2,
+             OP_WIRE: 3, OP_HINT_DIV_EXT: 6, OP_HINT_LO63: 2, OP_HINT_HI: 2, OP_HINT_SPLIT: 4}
+    t, n = 0, len(tape)
+    while t < n:
+        op = int(tape[t])
+        yield t, op
+        if op == OP_COSET:
+            t += 1 + 3 + (2 << int(tape[t + 2])) + 4
+        elif op == OP_PAR:
+            t += 1 + 1 + int(tape[t + 1])
+        else:
+            t += 1 + fixed[op]
+
+
+class _ParallelRegion:
+    def __init__(self, b):
+        self.b, self.lengths, self.at = b, [], None
+
+    def __enter__(self):
+        assert not getattr(self.b, "_in_region", False), "parallel regions do not nest"
+        self.b._in_region = True
+        self.start = self.at = len(self.b.tape)
+        return self
+
+    def section(self):
+        return _ParallelSection(self)
+
+    def __exit__(self, exc_type, exc, tb):
+        self.b._in_region = False
+        if exc_type is None:
+            assert len(self.b.tape) == self.at, "witness operations recorded between the sections of a parallel region"
+            if len(self.lengths) > 1:
+                self.b.tape[self.start:self.start] = [OP_PAR, len(self.lengths)] + self.lengths
+        return False
+
+
+class _ParallelSection:
+    def __init__(self, region):
+        self.r = region
+
+    def __enter__(self):
+        assert len(self.r.b.tape) == self.r.at, "witness operations recorded between the sections of a parallel region"
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.r.lengths.append(len(self.r.b.tape) - self.r.at)
+            self.r.at = len(self.r.b.tape)
+        return False
 
 
 class Builder:
@@ -184,6 +237,13 @@ class Builder:
     def _hint(self, v):
         """a value the witness generator computes from other values (not an input)"""
         return T(v, None, self._sid())
+
+    def parallel_sections(self):
+        """`with b.parallel_sections() as region:` then `with region.section():` around each of a run of INDEPENDENT pieces of the
+        circuit (they may read what was built before the region, not each other's values): the recorded witness program marks
+        them, and the executor replays them on separate threads when it has fewer proofs than threads. Nothing changes in the
+        circuit or in the values. Regions do not nest."""
+        return _ParallelRegion(self)
 
     # ---- rows and slots ---------------------------------------------------------------------------------------------
     def _new_row(self, kind, p0=0, p1=0, p2=0, consts=(0, 0)):
@@ -1103,47 +1163,49 @@ def verify_proof_circuit(b, inner, caps, openings, fri, public_inputs, verifier_
     for _ in range(len(op) - n_zeta - 1):
         alpha_pow_next = b.mul_ext(alpha_pow_next, fri_alpha)  # alpha^(number of polynomials in the g*zeta batch)
     w_lg = root_of_unity(lg)
-    for q in range(fp.num_queries):
-        init, steps = rounds[q]
-        bits = b.split_le(query_indices[q], 64)[:lg]
-        cap_index = b.le_sum(bits[lg - fp.cap_height:lg])
-        for o in range(4):
-            leaf, sib = init[o]
-            verify_merkle_proof_to_cap(b, leaf, bits[:lg - fp.cap_height], cap_index, cap_t[o], sib)
-        # subgroup_x = g * w^(bit-reversed index)
-        sx = b.mul_const(MULT_GEN, b.exp_from_bits_const_base(w_lg, list(reversed(bits))))
-        # fri_combine_initial: (reduce(all leaf evals) - red0) / (x - zeta), shifted, + the g*zeta batch
-        leaf_all = [t for o in range(4) for t in init[o][0]]
-        sx_e = b.to_ext(sx)
-        num0 = b.sub_ext(b.reduce_base(fri_alpha, leaf_all), red[0])
-        q0 = b.div_ext(num0, b.sub_ext(sx_e, zeta))
-        num1 = b.sub_ext(b.reduce_base(fri_alpha, init[2][0][:nc]) if nc > 21 else
-                         b.reduce_with_powers_ext([b.to_ext(t) for t in init[2][0][:nc]], fri_alpha), red[1])
-        q1 = b.div_ext(num1, b.sub_ext(sx_e, zeta_next))
-        old_eval = b.mul_add_ext(q0, alpha_pow_next, q1)
-        xbits = bits
-        clg = lg
-        for i in range(fp.n_layers):
-            ab = fp.arity_bits[i]
-            evals, sib = steps[i]
-            within_bits, coset_bits = xbits[:ab], xbits[ab:]
-            within = b.le_sum(within_bits)
-            b.connect_ext(b.random_access_ext(within, evals), old_eval)
-            # compute_evaluation: interpolate the coset at beta
-            g_ab = root_of_unity(ab)
-            rev = list(evals)
-            rev = [rev[int(format(j, f"0{ab}b")[::-1], 2)] for j in range(1 << ab)]
-            start = b.exp_from_bits_const_base(inv(g_ab), list(reversed(within_bits)))
-            coset_start = b.mul(start, sx)
-            old_eval = b.interpolate_coset(ab, coset_start, rev, fri_betas[i])
-            clg -= ab
-            leaf = [t for e in evals for t in (e.a, e.b)]
-            verify_merkle_proof_to_cap(b, leaf, coset_bits[:clg - fp.cap_height], cap_index, commit_caps[i], sib)
-            sx = b.exp_power_of_2(sx, ab)
-            xbits = coset_bits
-        # final polynomial at the folded point
-        fe = b.reduce_ext(b.to_ext(sx), final_poly) if len(final_poly) > 12 else b.reduce_with_powers_ext(final_poly, b.to_ext(sx))
-        b.connect_ext(fe, old_eval)
+    with b.parallel_sections() as region:
+        for q in range(fp.num_queries):
+            with region.section():  # the query rounds read the challenges and reduced openings above and nothing of each other
+                init, steps = rounds[q]
+                bits = b.split_le(query_indices[q], 64)[:lg]
+                cap_index = b.le_sum(bits[lg - fp.cap_height:lg])
+                for o in range(4):
+                    leaf, sib = init[o]
+                    verify_merkle_proof_to_cap(b, leaf, bits[:lg - fp.cap_height], cap_index, cap_t[o], sib)
+                # subgroup_x = g * w^(bit-reversed index)
+                sx = b.mul_const(MULT_GEN, b.exp_from_bits_const_base(w_lg, list(reversed(bits))))
+                # fri_combine_initial: (reduce(all leaf evals) - red0) / (x - zeta), shifted, + the g*zeta batch
+                leaf_all = [t for o in range(4) for t in init[o][0]]
+                sx_e = b.to_ext(sx)
+                num0 = b.sub_ext(b.reduce_base(fri_alpha, leaf_all), red[0])
+                q0 = b.div_ext(num0, b.sub_ext(sx_e, zeta))
+                num1 = b.sub_ext(b.reduce_base(fri_alpha, init[2][0][:nc]) if nc > 21 else
+                                 b.reduce_with_powers_ext([b.to_ext(t) for t in init[2][0][:nc]], fri_alpha), red[1])
+                q1 = b.div_ext(num1, b.sub_ext(sx_e, zeta_next))
+                old_eval = b.mul_add_ext(q0, alpha_pow_next, q1)
+                xbits = bits
+                clg = lg
+                for i in range(fp.n_layers):
+                    ab = fp.arity_bits[i]
+                    evals, sib = steps[i]
+                    within_bits, coset_bits = xbits[:ab], xbits[ab:]
+                    within = b.le_sum(within_bits)
+                    b.connect_ext(b.random_access_ext(within, evals), old_eval)
+                    # compute_evaluation: interpolate the coset at beta
+                    g_ab = root_of_unity(ab)
+                    rev = list(evals)
+                    rev = [rev[int(format(j, f"0{ab}b")[::-1], 2)] for j in range(1 << ab)]
+                    start = b.exp_from_bits_const_base(inv(g_ab), list(reversed(within_bits)))
+                    coset_start = b.mul(start, sx)
+                    old_eval = b.interpolate_coset(ab, coset_start, rev, fri_betas[i])
+                    clg -= ab
+                    leaf = [t for e in evals for t in (e.a, e.b)]
+                    verify_merkle_proof_to_cap(b, leaf, coset_bits[:clg - fp.cap_height], cap_index, commit_caps[i], sib)
+                    sx = b.exp_power_of_2(sx, ab)
+                    xbits = coset_bits
+                # final polynomial at the folded point
+                fe = b.reduce_ext(b.to_ext(sx), final_poly) if len(final_poly) > 12 else b.reduce_with_powers_ext(final_poly, b.to_ext(sx))
+                b.connect_ext(fe, old_eval)
     return pis
 
 
