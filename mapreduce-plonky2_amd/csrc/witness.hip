@@ -48,24 +48,40 @@ u32 op_len(u64 op, const u64* t) {
 
 // Poseidon2 linear layers on canonical values (poseidon.cuh keeps weak forms for the device; the witness wants the
 // intermediate states, canonical, as the gate's wires)
+// circ(2 M4, M4, M4) with M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]: M4 by its addition chain (t0 = x0 + x1, t1 = x2 + x3,
+// t2 = 2 x1 + t1, t3 = 2 x3 + t0, t4 = 4 t1 + t3, t5 = 4 t0 + t2, rows = t3 + t5, t5, t2 + t4, t4) in 128-bit integers -- every
+// entry of the layer stays below 2^70 -- and ONE reduction per output limb (a third of a host permutation was spent here on
+// 16 modular multiply-by-constant and 28 modular additions per block)
 void p2_external(u64 s[12]) {
-  static const u32 M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
-  u64 t[12];
-  for (int c = 0; c < 3; c++)
-    for (int i = 0; i < 4; i++) {
-      u64 acc = 0;
-      for (int j = 0; j < 4; j++) acc = gl_add(acc, gl_mul_small(s[4 * c + j], M4[i][j]));
-      t[4 * c + i] = acc;
-    }
+  typedef unsigned __int128 u128;
+  u128 t[12];
+  for (int c = 0; c < 3; c++) {
+    const u128 x0 = s[4 * c], x1 = s[4 * c + 1], x2 = s[4 * c + 2], x3 = s[4 * c + 3];
+    const u128 t0 = x0 + x1, t1 = x2 + x3, t2 = 2 * x1 + t1, t3 = 2 * x3 + t0, t4 = 4 * t1 + t3, t5 = 4 * t0 + t2;
+    t[4 * c] = t3 + t5; t[4 * c + 1] = t5; t[4 * c + 2] = t2 + t4; t[4 * c + 3] = t4;
+  }
   for (int i = 0; i < 4; i++) {
-    u64 sum = gl_add(gl_add(t[i], t[4 + i]), t[8 + i]);
-    for (int c = 0; c < 3; c++) s[4 * c + i] = gl_add(t[4 * c + i], sum);
+    const u128 sum = t[i] + t[4 + i] + t[8 + i];
+    for (int c = 0; c < 3; c++) {
+      const u128 v = t[4 * c + i] + sum;
+      s[4 * c + i] = gl_reduce128((u64)v, (u64)(v >> 64));
+    }
   }
 }
+// x_i <- mu_i x_i + sum_j x_j: the sum and each product in 128 bits, one reduction per limb
 void p2_internal(u64 s[12]) {
-  u64 sum = 0;
-  for (int i = 0; i < 12; i++) sum = gl_add(sum, s[i]);
-  for (int i = 0; i < 12; i++) s[i] = gl_add(gl_mul(s[i], POSEIDON2_DIAG_M1[i]), sum);
+  typedef unsigned __int128 u128;
+  u128 sum = 0;
+  for (int i = 0; i < 12; i++) sum += s[i];
+  const u64 sr = gl_reduce128((u64)sum, (u64)(sum >> 64));
+  for (int i = 0; i < 12; i++) {
+    const u128 v = (u128)s[i] * POSEIDON2_DIAG_M1[i];
+    // lo + hi 2^64 + sr: add sr into the low word with carry into hi (hi <= 2^64 - 2 for canonical factors)
+    u64 lo = (u64)v, hi = (u64)(v >> 64);
+    const u64 l2 = lo + sr;
+    hi += l2 < lo ? 1 : 0;
+    s[i] = gl_reduce128(l2, hi);
+  }
 }
 }  // namespace
 
