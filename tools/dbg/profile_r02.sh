@@ -13,7 +13,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/traffic_$c -- python3 $R/tools/dbg/traffic_run.py > /dev/null 2> $O/traffic_$c.err
 done
 python3 $R/bench.py --workload tree --steps 2 --warmup 1 > $O/tree.json 2> $O/tree.err
-python3 $R/bench.py --workload recursion --batch 64 --trees 8 --steps 3 --warmup 1 > $O/recursion.json 2> $O/recursion.err
+python3 $R/bench.py --workload recursion --batch 128 --trees 8 --steps 3 --warmup 1 > $O/recursion.json 2> $O/recursion.err
 python3 $R/bench.py --hasher poseidon --no-cpu-baseline > $O/bench_poseidon.json 2> $O/bench_poseidon.err
 # keep only the summaries (the raw traces exceed the merge limit)
 find $O -name "*kernel_trace.csv" -size +20M -delete
