@@ -148,6 +148,10 @@ class Context:
     def h2d_async(self, d_dst, host_ptr, nbytes, dst_offset=0):
         _ck(load().mp2g_h2d_async(self.h, ctypes.c_void_p(d_dst.ptr.value + dst_offset), host_ptr, ctypes.c_size_t(nbytes)))
 
+    def wires_from_rows_dev(self, d_rows, d_wires, log_n, batch, num_wires=135):
+        """[batch][n][num_wires] (the witness executor's row layout) -> [batch][num_wires][n] (the prover's), on the device"""
+        _ck(load().mp2g_wires_from_rows_dev(self.h, d_rows.ptr, d_wires.ptr, log_n, num_wires, batch))
+
     def timer_start(self):
         _ck(load().mp2g_timer_start(self.h))
 
@@ -549,13 +553,18 @@ class WitnessProgram:
         _ck(load().mp2g_witness_program_create(_p(tape), ctypes.c_size_t(tape.size), int(ckt.n_slots), int(ckt.log_n), _p(ins), int(ins.size),
                                                _p(cs), int(cs.shape[0]), ctypes.byref(self.h)))
 
-    def run(self, inputs, threads=0, out=None):
-        """inputs [batch][n_inputs] -> (wires [batch][135][n], pi_hash [batch][4], public_inputs [batch][n_pi])"""
+    def run(self, inputs, threads=0, out=None, rows=False):
+        """inputs [batch][n_inputs] -> (wires [batch][135][n], pi_hash [batch][4], public_inputs [batch][n_pi]);
+        rows=True: the wires as [batch][n][135] (one contiguous row per gate row: faster to fill; Context.wires_from_rows_dev
+        gives the prover's layout on the device)"""
         a = _arr(inputs).reshape(-1, self.n_inputs)
         B = a.shape[0]
-        wires = out if out is not None else np.empty((B, 135, 1 << self.log_n), dtype=np.uint64)
+        shape = (B, 1 << self.log_n, 135) if rows else (B, 135, 1 << self.log_n)
+        wires = out if out is not None else np.empty(shape, dtype=np.uint64)
+        assert wires.shape == shape
         probe = np.empty((B, self.probe.size), dtype=np.uint64)
-        _ck(load().mp2g_witness_program_run(self.h, _p(a), B, int(threads), _p(wires), _p(self.probe), int(self.probe.size), _p(probe)))
+        fn = load().mp2g_witness_program_run_rows if rows else load().mp2g_witness_program_run
+        _ck(fn(self.h, _p(a), B, int(threads), _p(wires), _p(self.probe), int(self.probe.size), _p(probe)))
         return wires, probe[:, :4], probe[:, 4:]
 
     def free(self):

@@ -119,6 +119,14 @@ int mp2g_h2d_async(mp2g_ctx* c, void* d_dst, const void* src, size_t bytes) {
   CK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
   return 0;
 }
+int mp2g_wires_from_rows_dev(mp2g_ctx* c, const uint64_t* d_rows, uint64_t* d_wires, uint32_t log_n, uint32_t num_wires, uint32_t batch) {
+  NEED(c && d_rows && d_wires && log_n >= 1 && log_n <= 24 && num_wires >= 1 && batch >= 1, "ctx / pointers / shape");
+  const u64 n = (u64)1 << log_n;
+  // rows [n][w] -> polynomials [w][n]: the 64 x 64 LDS tile transpose with the roles of the two indices exchanged
+  for (uint32_t b = 0; b < batch; b++)
+    CK(transpose_to_leaves(c->stream, d_rows + (u64)b * n * num_wires, (u32)n, num_wires, num_wires, d_wires + (u64)b * n * num_wires));
+  return 0;
+}
 int mp2g_timer_start(mp2g_ctx* c) { NEED(c, "ctx"); CK(hipEventRecord(c->ev0, c->stream)); return 0; }
 int mp2g_timer_stop(mp2g_ctx* c, float* ms) {
   NEED(c && ms, "ctx/ms");

@@ -97,9 +97,10 @@ namespace {
 // the instructions of [t, end). A parallel region (OP_PAR) is a run of sections that read what came before the region and each
 // other's nothing: the builder brackets the query rounds of a FRI verifier this way (28 per verified proof). With inner > 1 the
 // sections of a region are dealt to that many threads; every instruction writes value slots and wire cells of its own.
-void exec(const mp2g_witness_program& P, const u64* t, const u64* end, u64* vals, u64* wires, u32 inner) {
-  const u64 n = (u64)1 << P.log_n;
-#define W(col, row) wires[(u64)(col) * n + (row)]
+void exec(const mp2g_witness_program& P, const u64* t, const u64* end, u64* vals, u64* wires, u32 inner, u64 cs, u64 rs) {
+  // wire (col, row) sits at col * cs + row * rs: (n, 1) = the prover's polynomial-major matrix, (1, 135) = one contiguous row per
+  // gate row (what the host writes fastest: a Poseidon2 row is 135 consecutive words instead of 135 cache lines)
+#define W(col, row) wires[(u64)(col) * cs + (u64)(row) * rs]
   while (t < end) {
     const u64 op = *t++;
     switch (op) {
@@ -110,7 +111,7 @@ void exec(const mp2g_witness_program& P, const u64* t, const u64* end, u64* vals
         u64 total = 0;
         for (u32 i = 0; i < ns; i++) total += len[i];
         if (inner <= 1 || ns <= 1) {
-          exec(P, body, body + total, vals, wires, 1);
+          exec(P, body, body + total, vals, wires, 1, cs, rs);
         } else {
           std::vector<const u64*> start(ns + 1);
           start[0] = body;
@@ -120,7 +121,7 @@ void exec(const mp2g_witness_program& P, const u64* t, const u64* end, u64* vals
             for (;;) {
               const u32 i = next.fetch_add(1);
               if (i >= ns) return;
-              exec(P, start[i], start[i + 1], vals, wires, 1);
+              exec(P, start[i], start[i + 1], vals, wires, 1, cs, rs);
             }
           };
           const u32 nt = inner < ns ? inner : ns;
@@ -278,12 +279,12 @@ void exec(const mp2g_witness_program& P, const u64* t, const u64* end, u64* vals
 #undef W
 }
 // one proof: vals = scratch of n_slots words, wires = [135][n] (zero-filled here)
-void run_one(const mp2g_witness_program& P, const u64* inputs, u64* vals, u64* wires, u32 inner) {
+void run_one(const mp2g_witness_program& P, const u64* inputs, u64* vals, u64* wires, u32 inner, bool rows) {
   const u64 n = (u64)1 << P.log_n;
   memset(wires, 0, NUM_WIRES * n * sizeof(u64));
   for (size_t i = 0; i < P.consts.size(); i += 2) vals[P.consts[i]] = P.consts[i + 1];
   for (size_t i = 0; i < P.input_sids.size(); i++) vals[P.input_sids[i]] = inputs[i];
-  exec(P, P.tape.data(), P.tape.data() + P.tape.size(), vals, wires, inner);
+  exec(P, P.tape.data(), P.tape.data() + P.tape.size(), vals, wires, inner, rows ? 1 : n, rows ? NUM_WIRES : 1);
 }
 }  // namespace
 
@@ -364,8 +365,8 @@ int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t 
   return 0;
 }
 uint32_t mp2g_witness_program_num_inputs(const mp2g_witness_program* P) { return P ? (uint32_t)P->input_sids.size() : 0; }
-int mp2g_witness_program_run(const mp2g_witness_program* P, const uint64_t* inputs, uint32_t batch, uint32_t threads, uint64_t* wires,
-                             const uint32_t* probe_sids, uint32_t n_probe, uint64_t* probe_out) {
+static int witness_run(const mp2g_witness_program* P, const uint64_t* inputs, uint32_t batch, uint32_t threads, uint64_t* wires,
+                       const uint32_t* probe_sids, uint32_t n_probe, uint64_t* probe_out, bool rows) {
   NEED(P && inputs && wires && batch >= 1, "program / inputs / wires");
   NEED(!n_probe || (probe_sids && probe_out), "probe");
   for (uint32_t i = 0; i < n_probe; i++) NEED(probe_sids[i] < P->n_slots, "probe slot");
@@ -384,7 +385,7 @@ int mp2g_witness_program_run(const mp2g_witness_program* P, const uint64_t* inpu
       const uint32_t b = next.fetch_add(1);
       if (b >= batch) return;
       std::fill(vals.begin(), vals.end(), 0);
-      run_one(*P, inputs + (size_t)b * n_in, vals.data(), wires + (size_t)b * per, inner);
+      run_one(*P, inputs + (size_t)b * n_in, vals.data(), wires + (size_t)b * per, inner, rows);
       for (uint32_t i = 0; i < n_probe; i++) probe_out[(size_t)b * n_probe + i] = vals[probe_sids[i]];
     }
   };
@@ -393,6 +394,14 @@ int mp2g_witness_program_run(const mp2g_witness_program* P, const uint64_t* inpu
   worker();
   for (auto& th : pool) th.join();
   return 0;
+}
+int mp2g_witness_program_run(const mp2g_witness_program* P, const uint64_t* inputs, uint32_t batch, uint32_t threads, uint64_t* wires,
+                             const uint32_t* probe_sids, uint32_t n_probe, uint64_t* probe_out) {
+  return witness_run(P, inputs, batch, threads, wires, probe_sids, n_probe, probe_out, false);
+}
+int mp2g_witness_program_run_rows(const mp2g_witness_program* P, const uint64_t* inputs, uint32_t batch, uint32_t threads, uint64_t* rows,
+                                  const uint32_t* probe_sids, uint32_t n_probe, uint64_t* probe_out) {
+  return witness_run(P, inputs, batch, threads, rows, probe_sids, n_probe, probe_out, true);
 }
 void mp2g_witness_program_free(mp2g_witness_program* P) { delete P; }
 }  // extern "C"

@@ -224,9 +224,11 @@ class GpuProver:
         self.provers = {}
         self.pinned = {}  # data address of a pinned wire matrix -> its host pointer
 
+    rows_layout = True  # generate_proofs_batch fills [B][n][135] (rows) for this prover; prove_batch_launch transposes on the device
+
     def pinned_wires(self, shape):
-        """a [B][135][n] u64 wire matrix in pinned host memory: prove_batch_launch sends it up with an asynchronous copy on
-        the context's stream instead of a blocking pageable one"""
+        """a wire matrix ([B][135][n], or [B][n][135] in the row layout) in pinned host memory: prove_batch_launch sends it up with
+        an asynchronous copy on the context's stream instead of a blocking pageable one"""
         nbytes = int(np.prod(shape)) * 8
         view, hptr = self.ctx.host_alloc(nbytes)
         a = view.view(np.uint64).reshape(shape)
@@ -253,20 +255,27 @@ class GpuProver:
         return caps[0], openings[0], proofs[0]
 
     def prove_batch_launch(self, ckt, wires, pi_hash):
-        """upload B witnesses of one circuit (wires [B][135][n], pi_hash [B][4], host) and queue their prove() on the context's
-        stream; returns the handle prove_batch_finish waits on. One batch per (circuit, B) in flight at a time."""
-        B = wires.shape[0]
+        """upload B witnesses of one circuit (wires [B][135][n] or, in the witness executor's row layout, [B][n][135]; pi_hash
+        [B][4], host) and queue their prove() on the context's stream; returns the handle prove_batch_finish waits on. One
+        batch per (circuit, B) in flight at a time."""
+        B, n = wires.shape[0], 1 << ckt.log_n
+        rows = wires.shape[1:] == (n, 135) and n != 135
         key = (ckt.log_n, hash(ckt.pre.tobytes()), B)
         cp = self.provers.get(key)
         if cp is None:
             cp = self.provers[key] = CircuitProver(self.ctx, ckt, B, self.variant, witness_check=self.witness_check)
-            cp.d_w, cp.d_ph = self.ctx.alloc(wires.nbytes), self.ctx.alloc(B * 32)
+            cp.d_w, cp.d_ph, cp.d_rows = self.ctx.alloc(wires.nbytes), self.ctx.alloc(B * 32), None
+        if rows and cp.d_rows is None:
+            cp.d_rows = self.ctx.alloc(wires.nbytes)
         cp.d_ph.upload(np.ascontiguousarray(pi_hash, dtype=np.uint64))
+        dst = cp.d_rows if rows else cp.d_w
         hptr = self.pinned.get(wires.ctypes.data) if wires.flags["C_CONTIGUOUS"] else None
         if hptr is not None:
-            self.ctx.h2d_async(cp.d_w, hptr, wires.nbytes)  # ordered before the prove() kernels on the same stream
+            self.ctx.h2d_async(dst, hptr, wires.nbytes)  # ordered before the kernels below on the same stream
         else:
-            cp.d_w.upload(wires)
+            dst.upload(wires)
+        if rows:
+            self.ctx.wires_from_rows_dev(cp.d_rows, cp.d_w, ckt.log_n, B)
         cp.prove(cp.d_w, cp.d_ph)
         return cp, B
 

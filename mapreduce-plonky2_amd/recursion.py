@@ -1573,7 +1573,8 @@ def _generate_proofs_batch(self, name, jobs, threads=0, session=None):
     proofs = None
     for step, prog in enumerate(progs):
         assert cur.shape[1] == prog.n_inputs, f"{name} step {step}: {cur.shape[1]} inputs for a program of {prog.n_inputs}"
-        wires, pi_hash, pis = prog.run(cur, threads, out=sess.wire_buffer(name, step, cur.shape[0], prog.log_n))
+        rows = bool(getattr(sess.prover, "rows_layout", False))
+        wires, pi_hash, pis = prog.run(cur, threads, out=sess.wire_buffer(name, step, cur.shape[0], prog.log_n, rows), rows=rows)
         outs = sess.prover.prove_batch(self.chains[name][step][0], wires, pi_hash)
         proofs = [(c, o, p, pis[i]) for i, (c, o, p) in enumerate(outs)]
         if step + 1 < len(progs):
@@ -1589,11 +1590,11 @@ class ProofSession:
     def __init__(self, prover):
         self.prover, self.buffers = prover, {}
 
-    def wire_buffer(self, name, step, batch, log_n):
+    def wire_buffer(self, name, step, batch, log_n, rows=False):
         key = (name, step, batch)
         buf = self.buffers.get(key)
         if buf is None:
-            shape = (batch, 135, 1 << log_n)
+            shape = (batch, 1 << log_n, 135) if rows else (batch, 135, 1 << log_n)
             make = getattr(self.prover, "pinned_wires", None)
             buf = self.buffers[key] = make(shape) if make is not None else np.empty(shape, dtype=np.uint64)
         return buf

@@ -139,3 +139,14 @@ def test_verify_proof_with_fixed_circuit(ctx, mp2):
         bcp.prove(ctx.to_device(bad.wires[None]), ctx.to_device(bad.pi_hash[None]))
         with pytest.raises(Exception, match="witness"):
             bcp.pr.witness_status()
+
+
+def test_wires_from_rows_on_the_device(ctx, mp2):
+    """mp2g_wires_from_rows_dev: the witness executor's row layout [batch][n][135] becomes the prover's [batch][135][n]"""
+    for log_n, batch in ((6, 3), (12, 2), (13, 1)):
+        n = 1 << log_n
+        rows = O.rand_field((batch, n, 135), 700 + log_n)
+        d_rows, d_w = ctx.to_device(rows), ctx.alloc(rows.nbytes)
+        ctx.wires_from_rows_dev(d_rows, d_w, log_n, batch)
+        assert np.array_equal(d_w.download((batch, 135, n)), rows.transpose(0, 2, 1))
+        d_rows.free(); d_w.free()

@@ -301,6 +301,8 @@ def test_parallel_regions_of_a_witness_program():
     for batch, threads in ((1, 8), (3, 8), (3, 2), (3, 1)):
         w = prog.run(x[:batch], threads)[0]
         assert all(np.array_equal(w[i], wrap.wires) for i in range(batch))
+        rows = prog.run(x[:batch], threads, rows=True)[0]  # one contiguous row of 135 wires per gate row
+        assert rows.shape == (batch, 1 << wrap.log_n, 135) and all(np.array_equal(rows[i].T, wrap.wires) for i in range(batch))
 
     def refused(bad_tape):
         c = copy_of(wrap, bad_tape)
