@@ -114,6 +114,66 @@ def tape_instructions(tape):
             t += 1 + fixed[op]
 
 
+def instruction_slots(tape, pos):
+    """(slots read, slots written, (row, col) wire cells written, next position) of the instruction at tape[pos] -- the operand roles
+    of csrc/witness.hip's executor"""
+    op = int(tape[pos])
+    need = {OP_ARITH: 8, OP_ARITH_EXT: 12, OP_P2: 26, OP_BASE_SUM: 65, OP_RA: 20, OP_REDUCING: 50, OP_REDUCING_EXT: 71, OP_WIRE: 3,
+            OP_HINT_DIV_EXT: 6, OP_HINT_LO63: 2, OP_HINT_HI: 2, OP_HINT_SPLIT: 4}.get(op)
+    if need is None and op == OP_COSET:
+        need = 3 + (2 << int(tape[pos + 2])) + 4
+    t = tape[pos + 1:pos + 1 + (need or 0)]
+    if op == OP_ARITH:
+        return t[4:7], [t[7]], [(t[0], 4 * t[1] + k) for k in range(4)], pos + 9
+    if op == OP_ARITH_EXT:
+        return t[4:10], t[10:12], [(t[0], 8 * t[1] + k) for k in range(8)], pos + 13
+    if op == OP_P2:
+        return t[1:14], t[14:26], [(t[0], c) for c in range(135)], pos + 27
+    if op == OP_BASE_SUM:
+        return [t[1]], t[2:2 + 63], [(t[0], c) for c in range(64)], pos + 1 + 2 + 63
+    if op == OP_RA:
+        base = (2 + 16) * t[1]
+        return t[2:19], [t[19]], [(t[0], base + k) for k in range(18)] + [(t[0], (2 + 16) * 4 + 2 + 4 * t[1] + k) for k in range(4)], pos + 21
+    if op == OP_REDUCING:
+        return t[1:5 + 43], t[5 + 43:5 + 43 + 2], [(t[0], c) for c in range(135)], pos + 1 + 5 + 43 + 2
+    if op == OP_REDUCING_EXT:
+        return t[1:5 + 64], t[5 + 64:5 + 64 + 2], [(t[0], c) for c in range(135)], pos + 1 + 5 + 64 + 2
+    if op == OP_COSET:
+        npts = 1 << t[1]
+        return t[2:3 + 2 * npts + 2], t[3 + 2 * npts + 2:3 + 2 * npts + 4], [(t[0], c) for c in range(135)], pos + 1 + 3 + 2 * npts + 4
+    if op == OP_WIRE:
+        return [t[2]], [], [(t[0], t[1])], pos + 4
+    if op == OP_HINT_DIV_EXT:
+        return t[0:4], t[4:6], [], pos + 7
+    if op in (OP_HINT_LO63, OP_HINT_HI):
+        return [t[0]], [t[1]], [], pos + 3
+    if op == OP_HINT_SPLIT:
+        return [t[0]], t[2:4], [], pos + 5
+    raise ValueError(f"opcode {op}")
+
+
+def check_sections_independent(tape, start, lengths):
+    """the sections [start, start + lengths[0]), ... of a parallel region may run concurrently: no section reads a slot another
+    section writes, no two sections write the same slot or the same wire cell"""
+    slot_writer, cell_writer, reads = {}, {}, []
+    pos = start
+    for k, ln in enumerate(lengths):
+        end = pos + ln
+        rd = set()
+        while pos < end:
+            r, w, cells, pos = instruction_slots(tape, pos)
+            rd.update(r)
+            for sl in w:
+                assert slot_writer.setdefault(sl, k) == k, f"sections {slot_writer[sl]} and {k} both write slot {sl}"
+            for c in cells:
+                assert cell_writer.setdefault(c, k) == k, f"sections {cell_writer[c]} and {k} both write wire {c}"
+        assert pos == end, "a section ends inside an instruction"
+        reads.append(rd)
+    for k, rd in enumerate(reads):
+        for sl in rd:
+            assert slot_writer.get(sl, k) == k, f"section {k} reads slot {sl} written by section {slot_writer[sl]}"
+
+
 class _ParallelRegion:
     def __init__(self, b):
         self.b, self.lengths, self.at = b, [], None
@@ -132,6 +192,7 @@ class _ParallelRegion:
         if exc_type is None:
             assert len(self.b.tape) == self.at, "witness operations recorded between the sections of a parallel region"
             if len(self.lengths) > 1:
+                check_sections_independent(self.b.tape, self.start, self.lengths)
                 self.b.tape[self.start:self.start] = [OP_PAR, len(self.lengths)] + self.lengths
         return False
 

@@ -320,3 +320,23 @@ def test_parallel_regions_of_a_witness_program():
     t = list(tape)
     body = at + 2 + n_sections
     t[body:body] = [R.OP_PAR, 1, 0]; t[at + 2] += 3; refused(t)      # a region inside a region
+
+
+def test_parallel_sections_must_be_independent():
+    """the builder refuses a parallel region whose sections are not independent (one reading what another computed)"""
+    b = R.Builder()
+    x, y = b.add_virtual(3), b.add_virtual(5)
+    with b.parallel_sections() as region:
+        with region.section():
+            p = b.mul(x, y)
+        with region.section():
+            q = b.mul(x, x)
+    assert (p.v, q.v) == (15, 9) and R.OP_PAR in [op for _, op in R.tape_instructions(b.tape)]
+    b2 = R.Builder()
+    x, y = b2.add_virtual(3), b2.add_virtual(5)
+    with pytest.raises(AssertionError, match="reads slot"):
+        with b2.parallel_sections() as region:
+            with region.section():
+                p = b2.mul(x, y)
+            with region.section():
+                b2.mul(p, x)  # depends on the first section
