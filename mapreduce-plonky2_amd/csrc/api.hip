@@ -123,8 +123,11 @@ int mp2g_wires_from_rows_dev(mp2g_ctx* c, const uint64_t* d_rows, uint64_t* d_wi
   NEED(c && d_rows && d_wires && log_n >= 1 && log_n <= 24 && num_wires >= 1 && batch >= 1, "ctx / pointers / shape");
   const u64 n = (u64)1 << log_n;
   // rows [n][w] -> polynomials [w][n]: the 64 x 64 LDS tile transpose with the roles of the two indices exchanged
-  for (uint32_t b = 0; b < batch; b++)
-    CK(transpose_to_leaves(c->stream, d_rows + (u64)b * n * num_wires, (u32)n, num_wires, num_wires, d_wires + (u64)b * n * num_wires));
+  for (uint32_t b0 = 0; b0 < batch; b0 += 32768) {  // grid z limit
+    const uint32_t nb = batch - b0 < 32768 ? batch - b0 : 32768;
+    CK(transpose_to_leaves(c->stream, d_rows + (u64)b0 * n * num_wires, (u32)n, num_wires, num_wires, d_wires + (u64)b0 * n * num_wires, nb,
+                           n * num_wires, n * num_wires));
+  }
   return 0;
 }
 int mp2g_timer_start(mp2g_ctx* c) { NEED(c, "ctx"); CK(hipEventRecord(c->ev0, c->stream)); return 0; }

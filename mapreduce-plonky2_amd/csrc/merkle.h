@@ -25,5 +25,7 @@ hipError_t merkle_open(hipStream_t st, const u64* levels, u32 log_leaves, u32 ca
 // out[q][p] = values[p*stride + idx[q]]
 hipError_t gather_rows(hipStream_t st, const u64* values, u32 w, u64 stride, const u32* idx, u32 n_idx, u64* out);
 // out[i][p] = values[p*stride + i]  (leaf-major copy for hosts that want plonky2's layout)
-hipError_t transpose_to_leaves(hipStream_t st, const u64* values, u32 w, u64 stride, u64 n_leaves, u64* out);
+// in[p][i] (p < w, rows `stride` apart) -> out[i][p], for `batch` matrices in_bstride / out_bstride words apart
+hipError_t transpose_to_leaves(hipStream_t st, const u64* values, u32 w, u64 stride, u64 n_leaves, u64* out, u32 batch = 1, u64 in_bstride = 0,
+                               u64 out_bstride = 0);
 }  // namespace mp2g

@@ -172,8 +172,11 @@ __global__ void gather_rows_kernel(const u64* __restrict__ values, u32 w, u64 st
   out[t] = values[(u64)p * stride + idx[q]];
 }
 // 64x64 LDS tile transpose: in[p][i] -> out[i][p]
-__global__ void __launch_bounds__(256) transpose_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ out) {
+__global__ void __launch_bounds__(256) transpose_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ out,
+                                                        u64 in_bstride, u64 out_bstride) {
   __shared__ u64 tile[64][65];
+  values += blockIdx.z * in_bstride;  // one matrix per z
+  out += blockIdx.z * out_bstride;
   u64 i0 = (u64)blockIdx.x * 64;
   u32 p0 = blockIdx.y * 64;
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
@@ -244,9 +247,11 @@ hipError_t gather_rows(hipStream_t st, const u64* values, u32 w, u64 stride, con
   hipLaunchKernelGGL(gather_rows_kernel, grid1(total, 256), dim3(256), 0, st, values, w, stride, idx, n_idx, out);
   return hipGetLastError();
 }
-hipError_t transpose_to_leaves(hipStream_t st, const u64* values, u32 w, u64 stride, u64 n, u64* out) {
-  if (!n || !w) return hipSuccess;
-  hipLaunchKernelGGL(transpose_kernel, dim3((u32)((n + 63) / 64), (w + 63) / 64), dim3(256), 0, st, values, w, stride, n, out);
+hipError_t transpose_to_leaves(hipStream_t st, const u64* values, u32 w, u64 stride, u64 n, u64* out, u32 batch, u64 in_bstride,
+                               u64 out_bstride) {
+  if (!n || !w || !batch) return hipSuccess;
+  hipLaunchKernelGGL(transpose_kernel, dim3((u32)((n + 63) / 64), (w + 63) / 64, batch), dim3(256), 0, st, values, w, stride, n, out,
+                     in_bstride, out_bstride);
   return hipGetLastError();
 }
 }  // namespace mp2g
