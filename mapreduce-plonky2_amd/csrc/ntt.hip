@@ -4,10 +4,10 @@
 // `lde(rate_bits).coset_fft(g)` loop of plonky2 fri/oracle.rs PolynomialBatch::from_coeffs, as
 // reached from recursion-framework/src/circuit_builder.rs:308 and wrap_circuit.rs:143.
 //
-// Structure (HBM-bound op: 16 B of algorithmic traffic per point):
-//   * n <= 2^12 : one launch; a 256-thread block owns 4096 points in LDS (several small
-//     transforms per block), every global access is a contiguous 8 B/lane stream.
-//   * n  > 2^12 : Cooley-Tukey n = n1*n2 in two launches. Pass A transforms the strided
+// Structure (16 B of algorithmic traffic per point; in practice the butterflies' instruction stream is the limit):
+//   * n <= 2^13 : one launch; a block owns 4096 points in LDS (several small transforms per block; one 8192-point
+//     transform of 1024 lanes at 2^13), every global access is a contiguous 8 B/lane stream.
+//   * n  > 2^13 : Cooley-Tukey n = n1*n2 in two launches. Pass A transforms the strided
 //     dimension for a tile of 2^LC adjacent columns (>= 32..128 B contiguous per row), multiplies
 //     by w_n^(i2*k1) (streamed from a precomputed table: one multiply per point) and leaves row j
 //     in DIF order; pass B transforms contiguous rows in place.
@@ -18,8 +18,8 @@
 //     has no general twiddle at all. (radix-16 halves the LDS round trips but also the waves per tile
 //     and measured 15 % slower.) LDS indices are padded by 1/16 so the strided rounds are bank-conflict
 //     free; the twiddles of all rounds but the first are staged in LDS once per block.
-//   * a tile has ONE block barrier: the first round reads global memory directly, every later round stays inside
-//     the 512 points a wave owns ("one-barrier tiles" below; the barrier-per-round kernels remain for the shapes
+//   * a tile has ONE block barrier (two at 2^13): the first round reads global memory directly, every later round stays
+//     inside the 512 points a wave owns ("one-barrier tiles" below; the barrier-per-round kernels remain for the shapes
 //     that do not fit that scheme and for A/B runs with MP2G_NTT_V1=1).
 //   * LDE: the 2^r cosets of the blown-up domain are 2^r independent size-n transforms of the
 //     same coefficients scaled by (g w_{N}^j)^i; outputs land bit-reversed, i.e. already in
