@@ -1367,6 +1367,77 @@ class FrameworkCircuit:
         return b.build(min_log_n=6)
 
 
+def build_wrap_chain(prover, fri_params, base_vd):
+    """WrapCircuit::build_wrap_circuit (universal_verifier_gadget/wrap_circuit.rs:45-120): the circuits that re-prove a
+    proof of `base_vd` = (circuit, constants_sigmas cap, circuit digest) until the threshold size is reached, built over
+    dummy proofs; returns [(circuit, cap, digest)] per wrap step"""
+    chain = []
+    cur = base_vd
+    for _ in range(4):
+        inner = InnerCircuit(cur[0], fri_params(cur[0]), cur[1], cur[2], len(cur[0].public_inputs))
+        b = Builder(strict=False)
+        pis = verify_proof_circuit(b, inner, *dummy_proof(inner))
+        b.register_public_inputs(pis)
+        w = b.build(min_log_n=RECURSION_THRESHOLD)
+        cap, digest = prover.verifier_data(w)
+        cur = (w, cap, digest)
+        chain.append(cur)
+        if w.log_n == RECURSION_THRESHOLD:
+            return chain
+    raise AssertionError("the wrap chain does not reach the threshold size")
+
+
+def wrap_proof_chain(prover, fri_params, chain, base, proof):
+    """WrapCircuit::wrap_proof (wrap_circuit.rs:122-148): chain = [base verifier data] + build_wrap_chain(...); every step
+    fills the verifier circuit with the previous proof and proves it. A proof the step's verifier does not accept makes the
+    witness inconsistent: the strict builder raises, as the reference's prove() panics."""
+    cur_ckt, cur_proof = base, proof
+    for step, (wckt, wcap, wdig) in enumerate(chain[1:]):
+        prev = chain[step]
+        inner = InnerCircuit(cur_ckt, fri_params(cur_ckt), prev[1], prev[2], len(cur_ckt.public_inputs))
+        b = Builder()
+        pis = verify_proof_circuit(b, inner, *cur_proof)
+        b.register_public_inputs(pis)
+        w = b.build(min_log_n=RECURSION_THRESHOLD)
+        assert np.array_equal(w.pre, wckt.pre)
+        caps, openings, proof = prover.prove(w)
+        cur_ckt, cur_proof = w, (caps, openings, proof, w.public_inputs)
+    return cur_proof
+
+
+def dummy_proof(inner):
+    fp = inner.fp
+    n_open = sum(fp.oracle_w[o] for o in range(4)) + fp.zs_count
+    return (np.zeros((4, 4 << fp.cap_height), dtype=np.uint64), np.zeros((n_open, 2), dtype=np.uint64),
+            np.zeros(fp.proof_words, dtype=np.uint64), np.zeros(inner.n_public_inputs, dtype=np.uint64))
+
+
+def dummy_circuit(num_gates_log, num_public_inputs):
+    """universal_verifier_gadget/mod.rs:47-63: `num_public_inputs` free public inputs, padded with no-ops to 2^num_gates_log rows"""
+    b = Builder()
+    b.register_public_inputs([b.add_virtual(0) for _ in range(num_public_inputs)])
+    return b.build(min_log_n=num_gates_log)
+
+
+class WrapCircuit:
+    """universal_verifier_gadget/wrap_circuit.rs:29-155: the chain of circuits shrinking proofs of one base circuit to the
+    RECURSION_THRESHOLD size. prover / fri_params as for RecursiveCircuits."""
+
+    def __init__(self, base, prover, fri_params):
+        self.prover, self.fri_params = prover, fri_params
+        cap, digest = prover.verifier_data(base)
+        self.chain = [(base, cap, digest)] + build_wrap_chain(prover, fri_params, (base, cap, digest))
+
+    def final_proof_circuit_data(self):
+        """(circuit, constants_sigmas cap, circuit digest) of the last wrap step"""
+        return self.chain[-1]
+
+    def wrap_proof(self, base, proof):
+        """proof = (caps, openings, fri, public_inputs) of `base` (the witness-filled instance of the base circuit)"""
+        assert np.array_equal(base.pre, self.chain[0][0].pre), "not a proof of this wrap circuit's base circuit"
+        return wrap_proof_chain(self.prover, self.fri_params, self.chain, base, proof)
+
+
 class RecursiveCircuits:
     """framework.rs RecursiveCircuits + the per-circuit wrap chains: build every circuit's structure once (dummy
     witnesses), collect the digests of the final wrap circuits into the circuit set, then generate_proof().
@@ -1415,26 +1486,10 @@ class RecursiveCircuits:
         return (ckt, cap, digest)
 
     def _dummy_proof(self, inner):
-        fp = inner.fp
-        n_open = sum(fp.oracle_w[o] for o in range(4)) + fp.zs_count
-        return (np.zeros((4, 4 << fp.cap_height), dtype=np.uint64), np.zeros((n_open, 2), dtype=np.uint64),
-                np.zeros(fp.proof_words, dtype=np.uint64), np.zeros(inner.n_public_inputs, dtype=np.uint64))
+        return dummy_proof(inner)
 
     def _wrap_structure(self, base):
-        """the wrap chain of a circuit (WrapCircuit::build_wrap_circuit): wrap until the threshold shape is reached"""
-        chain = []
-        cur = self._verifier_data(base)
-        for _ in range(4):
-            inner = InnerCircuit(cur[0], self.fri_params(cur[0]), cur[1], cur[2], len(cur[0].public_inputs))
-            b = Builder(strict=False)
-            pis = verify_proof_circuit(b, inner, *self._dummy_proof(inner))
-            b.register_public_inputs(pis)
-            w = b.build(min_log_n=RECURSION_THRESHOLD)
-            cur = self._verifier_data(w)
-            chain.append(cur)
-            if w.log_n == RECURSION_THRESHOLD:
-                return chain
-        raise AssertionError("the wrap chain does not reach the threshold size")
+        return build_wrap_chain(self.prover, self.fri_params, self._verifier_data(base))
 
     def _set_tree(self, digests):
         size = 1 << max(0, (len(digests) - 1).bit_length())
@@ -1467,18 +1522,7 @@ class RecursiveCircuits:
         base = c.build_base(self, child_proofs, vds, mems, inputs, self.set_digest)
         assert np.array_equal(base.pre, self.chains[name][0][0].pre), "the circuit structure depends on the witness"
         caps, openings, proof = self.prover.prove(base)
-        cur_ckt, cur_proof = base, (caps, openings, proof, base.public_inputs)
-        for step, (wckt, wcap, wdig) in enumerate(self.chains[name][1:]):
-            prev = self.chains[name][step]
-            inner = InnerCircuit(cur_ckt, self.fri_params(cur_ckt), prev[1], prev[2], len(cur_ckt.public_inputs))
-            b = Builder()
-            pis = verify_proof_circuit(b, inner, *cur_proof)
-            b.register_public_inputs(pis)
-            w = b.build(min_log_n=RECURSION_THRESHOLD)
-            assert np.array_equal(w.pre, wckt.pre)
-            caps, openings, proof = self.prover.prove(w)
-            cur_ckt, cur_proof = w, (caps, openings, proof, w.public_inputs)
-        return cur_proof
+        return wrap_proof_chain(self.prover, self.fri_params, self.chains[name], base, (caps, openings, proof, base.public_inputs))
 
 
 def split_hash_element_to_low_high(b, element):

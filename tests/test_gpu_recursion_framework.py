@@ -66,16 +66,18 @@ def test_sixteen_leaf_tree_through_the_witness_programs(ctx, mp2):
     prover.free()
 
 
-def _hash_chain_leaf_logic(n_hashes):
-    """LeafCircuitWires::circuit_logic (recursion-framework/src/circuit_builder.rs:398-430, flag false): a chain of n_hashes
-    hashes over (state ++ generated), generated *= generator after every hash; the last state is the public input"""
+def _hash_chain_leaf_logic(n_hashes, reverse=False):
+    """LeafCircuitWires::circuit_logic (recursion-framework/src/circuit_builder.rs:398-430): a chain of n_hashes hashes over
+    (state ++ generated) -- reversed when the builder parameter's flag is set --, generated *= generator after every hash; the
+    last state is the public input"""
     def logic(b, child_pis, inputs):
         vals = inputs if inputs is not None else [0] * 9
         state = [b.add_virtual(int(x)) for x in vals[:8]]
         generator = b.add_virtual(int(vals[8]))
         generated = generator
         for _ in range(n_hashes):
-            state = b.hash_n_to_m_no_pad(state + [generated], 4)
+            hash_input = state + [generated]
+            state = b.hash_n_to_m_no_pad(hash_input[::-1] if reverse else hash_input, 4)
             generated = b.mul(generated, generator)
         return state
     return logic
@@ -140,6 +142,70 @@ def test_circuit_with_universal_verifiers(ctx, mp2, num_verifiers):
     (second,) = fw.generate_proofs_batch("rec", [(leaves[N:] + [first], ["leaf"] * (N - 1) + ["rec"], rand(8))])
     assert np.array_equal(second[3][4:], set_digest)
     assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(second[3], 4), *second[:3]) == 0
+    prover.free()
+
+
+def test_wrap_circuit_keys(ctx, mp2):
+    """recursion-framework/src/universal_verifier_gadget/wrap_circuit.rs:268-324: two base circuits of the same size that differ
+    only in the order of their hash inputs, each with its own wrap chain. Both wrapped proofs verify; the verifier data of the
+    base circuits and of the final wrap circuits differ; a proof of the variant does not go through the other circuit's chain."""
+    prover = FW.GpuProver(ctx)
+    rng = np.random.default_rng(0xC0FFEE21)
+    rand = lambda n: O.rand_field(n, int(rng.integers(1 << 30)))
+
+    def instance(reverse, inputs):
+        b = R.Builder()
+        b.register_public_inputs(_hash_chain_leaf_logic(1 << 12, reverse)(b, [], inputs))
+        return b.build()
+
+    def base_proof(base):
+        caps, openings, proof = prover.prove(base)
+        return (caps, openings, proof, base.public_inputs)
+
+    bases = [instance(False, rand(9)), instance(True, rand(9))]
+    wraps = [R.WrapCircuit(b, prover, FW.circuit_fri_params) for b in bases]
+    assert bases[0].log_n == bases[1].log_n == 13
+    for base, wc in zip(bases, wraps):
+        final = wc.wrap_proof(base, base_proof(base))
+        wckt, wcap, wdig = wc.final_proof_circuit_data()
+        assert wckt.log_n == R.RECURSION_THRESHOLD
+        assert np.array_equal(final[3], base.public_inputs)
+        assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(final[3], 4), *final[:3]) == 0
+    for level in (0, -1):
+        (_, cap_a, dig_a), (_, cap_b, dig_b) = wraps[0].chain[level], wraps[1].chain[level]
+        assert not np.array_equal(np.asarray(cap_a), np.asarray(cap_b)) and not np.array_equal(np.asarray(dig_a), np.asarray(dig_b))
+    # wrapping a proof with the wrong wrap circuit does not work: refused by shape, and -- past that check -- the verifier
+    # circuit built around the other circuit's verifier data is not satisfied by the proof
+    other = instance(True, rand(9))
+    other_proof = base_proof(other)
+    with pytest.raises(AssertionError, match="not a proof of this wrap circuit"):
+        wraps[0].wrap_proof(other, other_proof)
+    with pytest.raises(AssertionError):
+        R.wrap_proof_chain(prover, FW.circuit_fri_params, wraps[0].chain, other, other_proof)
+    prover.free()
+
+
+def test_common_data_for_recursion(ctx, mp2):
+    """recursion-framework/src/universal_verifier_gadget/mod.rs:66-113 (`build_data_for_universal_verifier`): a no-op circuit of
+    2^SHRINK_LIMIT = 2^15 rows with 3 + 4 public inputs needs exactly two wrap steps, the last one has RECURSION_THRESHOLD
+    degree bits, and its common data is the one every circuit of a framework with that many public inputs ends in."""
+    prover = FW.GpuProver(ctx)
+    base = R.dummy_circuit(15, 3 + 4)
+    assert base.log_n == 15
+    wc = R.WrapCircuit(base, prover, FW.circuit_fri_params)
+    assert [c[0].log_n for c in wc.chain] == [15, 13, 12]
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("leaf", 0, lambda b, c, i: _hash_chain_leaf_logic(4)(b, c, i)[:3], 3)], prover, FW.circuit_fri_params)
+    assert R.common_data(wc.final_proof_circuit_data()[0]) == fw.rec_common
+    # and a real proof of the 2^15-row circuit goes through the chain
+    b = R.Builder()
+    pis = [int(x) for x in O.rand_field(7, 99)]
+    b.register_public_inputs([b.add_virtual(v) for v in pis])
+    inst = b.build(min_log_n=15)
+    caps, openings, proof = prover.prove(inst)
+    final = wc.wrap_proof(inst, (caps, openings, proof, inst.public_inputs))
+    wckt, wcap, wdig = wc.final_proof_circuit_data()
+    assert [int(x) for x in final[3]] == pis
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(final[3], 4), *final[:3]) == 0
     prover.free()
 
 
