@@ -1525,6 +1525,92 @@ class RecursiveCircuits:
         return wrap_proof_chain(self.prover, self.fri_params, self.chains[name], base, (caps, openings, proof, base.public_inputs))
 
 
+# ---- parameter files: the built framework without rebuilding it (framework.rs derives Serialize / Deserialize for RecursiveCircuits;
+# the container here is numpy's .npz -- plain arrays, loaded with allow_pickle=False -- not bincode of plonky2's CircuitData)
+_CKT_ARRAYS = ("pre", "tape", "input_sids", "const_slots", "pi_hash_sids", "public_input_sids", "pi_hash", "public_inputs", "input_values")
+_CKT_SCALARS = ("log_n", "num_selectors", "num_constants", "pi_row", "n_slots", "n_used_rows")
+PARAMS_VERSION = 1
+
+
+def circuit_to_arrays(ckt, prefix, out):
+    """everything of a built circuit but its witness: preprocessed polynomials, gate table with selector groups, witness program"""
+    for k in _CKT_ARRAYS:
+        out[prefix + k] = np.asarray(getattr(ckt, k))
+    out[prefix + "scalars"] = np.array([int(getattr(ckt, k)) for k in _CKT_SCALARS], dtype=np.int64)
+    out[prefix + "gates"] = np.array([[g.kind, g.p0, g.p1, g.p2, g.selector_index, g.group_start, g.group_end] for g in ckt.gates],
+                                     dtype=np.uint32).reshape(-1, 7)
+    out[prefix + "instances"] = np.asarray(ckt.instances, dtype=np.uint32)
+    out[prefix + "domain_separator"] = np.asarray(ckt.domain_separator, dtype=np.uint64)
+
+
+def circuit_from_arrays(data, prefix):
+    ckt = C.Circuit()
+    for k in _CKT_ARRAYS:
+        setattr(ckt, k, data[prefix + k])
+    for k, v in zip(_CKT_SCALARS, data[prefix + "scalars"]):
+        setattr(ckt, k, int(v))
+    ckt.gates = [Gate(*(int(x) for x in row)) for row in data[prefix + "gates"]]
+    ckt.gate_array = (Gate * len(ckt.gates))(*ckt.gates)
+    ckt.instances = [int(x) for x in data[prefix + "instances"]]
+    ckt.domain_separator = [int(x) for x in data[prefix + "domain_separator"]]
+    ckt.luts, ckt.num_lookup_selectors, ckt.num_lookup_polys = [], 0, 0
+    ckt.wires = None  # a parameter file holds circuits, not witnesses
+    return ckt
+
+
+def _params_to_bytes(self):
+    """RecursiveCircuits -> bytes: every circuit's base + wrap chain (preprocessed polynomials, gate tables, witness programs),
+    their verifier data, the circuit set. The circuit logic (Python callables), the prover and the FRI parameter rule are not
+    part of the file: from_bytes takes them again."""
+    import io
+    out = {"version": np.array([PARAMS_VERSION, self.set_size], dtype=np.int64),
+           "names": np.array([n.encode() for n in self.circuits]),
+           "shape": np.array([[c.num_verifiers, c.num_public_inputs, len(self.chains[n])] for n, c in self.circuits.items()], dtype=np.int64),
+           "set_digest": np.asarray(self.set_digest, dtype=np.uint64)}
+    for n in self.circuits:
+        for step, (ckt, cap, digest) in enumerate(self.chains[n]):
+            pre = f"{n}/{step}/"
+            circuit_to_arrays(ckt, pre, out)
+            out[pre + "cap"], out[pre + "digest"] = np.asarray(cap, dtype=np.uint64), np.asarray(digest, dtype=np.uint64)
+    circuit_to_arrays(self.rec.ckt, "rec/", out)
+    out["rec/cap"], out["rec/digest"] = np.array(self.rec.cap, dtype=np.uint64), np.array(self.rec.circuit_digest, dtype=np.uint64)
+    buf = io.BytesIO()
+    np.savez_compressed(buf, **out)
+    return buf.getvalue()
+
+
+def _params_from_bytes(cls, data, circuits, prover, fri_params):
+    """bytes of to_bytes() -> RecursiveCircuits, without building a circuit: `circuits` are the FrameworkCircuit objects (names,
+    verifier counts and public-input counts must be the file's), prover / fri_params as for the constructor. The circuit set is
+    re-hashed by the prover and must give the file's digest (a file made with the other hasher fails here)."""
+    import io
+    z = np.load(io.BytesIO(data), allow_pickle=False)
+    version, set_size = (int(x) for x in z["version"])
+    if version != PARAMS_VERSION:
+        raise ValueError(f"parameter file version {version}, expected {PARAMS_VERSION}")
+    names = [n.decode() for n in z["names"]]
+    shape = z["shape"]
+    if names != [c.name for c in circuits] or any((c.num_verifiers, c.num_public_inputs) != (int(s[0]), int(s[1])) for c, s in zip(circuits, shape)):
+        raise ValueError("the parameter file was built for another set of circuits")
+    self = cls.__new__(cls)
+    self.prover, self.fri_params = prover, fri_params
+    self.circuits = {c.name: c for c in circuits}
+    self.set_size = set_size
+    self.chains, self.vds = {}, {}
+    for n, s in zip(names, shape):
+        self.chains[n] = [(circuit_from_arrays(z, f"{n}/{step}/"), z[f"{n}/{step}/cap"], z[f"{n}/{step}/digest"]) for step in range(int(s[2]))]
+        self.vds[n] = (self.chains[n][-1][1], self.chains[n][-1][2])
+    rec = circuit_from_arrays(z, "rec/")
+    self.rec = InnerCircuit(rec, fri_params(rec), z["rec/cap"], z["rec/digest"], circuits[0].num_public_inputs + 4)
+    self.rec_common = common_data(rec)
+    self.digests = [self.vds[n][1] for n in names]
+    self.set_levels = self._set_tree(self.digests)
+    self.set_digest = self.set_levels[-1][0]
+    if [int(x) for x in self.set_digest] != [int(x) for x in z["set_digest"]]:
+        raise ValueError("the circuit set of the parameter file does not hash to its digest with this prover")
+    return self
+
+
 def split_hash_element_to_low_high(b, element):
     """mp2-common/src/poseidon.rs:59-72: the low and the high 32 bits of a hash limb, with the check that makes the split unique for
     a CANONICAL field element: high = 2^32 - 1 forces low = 0 (p = 2^64 - 2^32 + 1)"""
@@ -1723,5 +1809,7 @@ def _witness_programs(self, name):
 
 
 RecursiveCircuits.default_session = _default_session
+RecursiveCircuits.to_bytes = _params_to_bytes
+RecursiveCircuits.from_bytes = classmethod(_params_from_bytes)
 RecursiveCircuits.witness_programs = _witness_programs
 RecursiveCircuits.generate_proofs_batch = _generate_proofs_batch

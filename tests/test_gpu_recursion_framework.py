@@ -209,6 +209,46 @@ def test_common_data_for_recursion(ctx, mp2):
     prover.free()
 
 
+def test_recursive_circuit_framework_serialization(ctx, mp2):
+    """recursion-framework/src/framework.rs:588-595: the framework written to a parameter file and read back (no circuit is
+    rebuilt: preprocessed polynomials, gate tables, witness programs and verifier data come from the file) runs the same test;
+    proofs made by the original framework are accepted as children by the restored one, and the results are identical."""
+    import time
+    prover = FW.GpuProver(ctx)
+    circs = [R.FrameworkCircuit("leaf", 0, _hash_chain_leaf_logic(1 << 7), 4), R.FrameworkCircuit("rec", 2, _recursive_logic, 4)]
+    t0 = time.perf_counter()
+    fw = R.RecursiveCircuits(circs, prover, FW.circuit_fri_params)
+    t_build = time.perf_counter() - t0
+    blob = fw.to_bytes()
+    prover2 = FW.GpuProver(ctx)
+    t0 = time.perf_counter()
+    fw2 = R.RecursiveCircuits.from_bytes(blob, circs, prover2, FW.circuit_fri_params)
+    t_load = time.perf_counter() - t0
+    print(f"parameter file {len(blob) / 1e6:.1f} MB; build {t_build:.2f} s, load {t_load:.2f} s")
+    assert [int(x) for x in fw2.set_digest] == [int(x) for x in fw.set_digest]
+    rng = np.random.default_rng(0xC0FFEE31)
+    rand = lambda n: O.rand_field(n, int(rng.integers(1 << 30)))
+    leaf_inputs, payload = [rand(9) for _ in range(2)], rand(8)
+    leaves = fw.generate_proofs_batch("leaf", [([], [], x) for x in leaf_inputs])
+    leaves2 = fw2.generate_proofs_batch("leaf", [([], [], x) for x in leaf_inputs])
+    assert all(np.array_equal(a, b) for p, q in zip(leaves, leaves2) for a, b in zip(p, q))
+    (root,) = fw.generate_proofs_batch("rec", [(leaves, ["leaf"] * 2, payload)])
+    (root2,) = fw2.generate_proofs_batch("rec", [(leaves, ["leaf"] * 2, payload)])  # children proved by the original framework
+    assert all(np.array_equal(a, b) for a, b in zip(root, root2))
+    one = fw2.generate_proof("rec", leaves2, ["leaf"] * 2, payload)  # and the builder path of the restored framework
+    assert all(np.array_equal(a, b) for a, b in zip(one, root))
+    wckt, wcap, wdig = fw2.chains["rec"][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(root2[3], 4), *root2[:3]) == 0
+    with pytest.raises(ValueError, match="another set of circuits"):
+        R.RecursiveCircuits.from_bytes(blob, circs[::-1], prover2, FW.circuit_fri_params)
+    # a file made with the other hasher does not load: the circuit set does not hash to its digest
+    prover3 = FW.GpuProver(ctx, variant=mp2.POSEIDON)
+    with pytest.raises(ValueError, match="does not hash to its digest"):
+        R.RecursiveCircuits.from_bytes(blob, circs, prover3, FW.circuit_fri_params)
+    for p in (prover, prover2, prover3):
+        p.free()
+
+
 def test_verifier_circuit_of_recursive_circuits_set(ctx, mp2):
     """recursion-framework/src/framework.rs:598-701: circuits OUTSIDE a set verify proofs of the set with the
     RecursiveCircuitsVerifierGadget. Set one: the hash-chain leaf and a 1-verifier recursive circuit; a leaf proof and a

@@ -140,6 +140,19 @@ def test_map_reduce_with_the_universal_verifier():
     assert all(np.array_equal(x, y) for x, y in zip(b0, p0)) and all(np.array_equal(x, y) for x, y in zip(b1, p1))
     (broot,) = fw.generate_proofs_batch("reduce", [([b0, b1], ["map", "map"], None)])
     assert all(np.array_equal(x, y) for x, y in zip(broot, root))
+    # framework.rs:588-595 test_recursive_circuit_framework_serialization: the framework read back from its parameter file
+    # (no circuit is rebuilt) produces the same proofs, through the builder and through the witness programs
+    blob = fw.to_bytes()
+    fw2 = R.RecursiveCircuits.from_bytes(blob, circs, OracleProver(), FWm.circuit_fri_params)
+    assert [int(x) for x in fw2.set_digest] == [int(x) for x in fw.set_digest] and fw2.rec_common == fw.rec_common
+    q0 = fw2.generate_proof("map", [], [], data[:4])
+    assert all(np.array_equal(x, y) for x, y in zip(q0, p0))
+    (qroot,) = fw2.generate_proofs_batch("reduce", [([b0, b1], ["map", "map"], None)])
+    assert all(np.array_equal(x, y) for x, y in zip(qroot, root))
+    with pytest.raises(ValueError, match="another set of circuits"):
+        R.RecursiveCircuits.from_bytes(blob, circs[::-1], OracleProver(), FWm.circuit_fri_params)
+    with pytest.raises(ValueError, match="another set of circuits"):
+        R.RecursiveCircuits.from_bytes(blob, [circs[0], R.FrameworkCircuit("reduce", 3, R.reduce_logic, 5)], OracleProver(), FWm.circuit_fri_params)
     # a proof of a circuit outside the set cannot be used: the membership proof does not exist
     with pytest.raises(KeyError, match="circuit digest not found"):
         fw.membership([1, 2, 3, 4])
