@@ -239,3 +239,31 @@ def test_ntt_and_lde_stay_inside_their_buffers(ctx, log_n, batch):
         assert (got[:guard] == sentinel).all() and (got[-guard:] == sentinel).all()
         assert np.array_equal(got[guard:-guard].reshape(batch, n * 8).T, ctx.lde_leaves(a, 3))
         d_c.free(); d_v.free()
+
+
+def test_degenerate_shapes(ctx, mp2):
+    """the empty and one-element cases of every batched entry point: defined results (the identity transform, no output rows,
+    the hash of the empty input, the neutral point), or the documented error -- never a crash or a launch with an empty grid"""
+    a1 = O.rand_field((3, 1), 1)
+    assert np.array_equal(ctx.ntt(a1), a1) and np.array_equal(ctx.ntt(a1, inverse=True), a1)  # n = 1: the identity
+    assert ctx.ntt(np.zeros((0, 8), dtype=np.uint64)).shape == (0, 8)
+    assert ctx.hash_no_pad_batch(np.zeros((0, 5), dtype=np.uint64)).shape == (0, 4)
+    assert np.array_equal(ctx.hash_no_pad_batch(np.zeros((2, 0), dtype=np.uint64)), np.stack([O.hash_n_to_m_no_pad([], 4)] * 2))
+    c = O.rand_field((2, 8), 3)
+    assert np.array_equal(ctx.lde_leaves(c, 0), O.lde_leaves(c, 0))  # rate_bits 0: the coset transform alone
+    for bad in (lambda: ctx.lde_leaves(O.rand_field((2, 1), 3), 3), lambda: mp2.PolynomialBatch.from_values(ctx, a1, 3, 0)):
+        with pytest.raises(mp2.Mp2gError, match="log_n"):
+            bad()
+    one = O.rand_field((1, 7), 4)
+    assert np.array_equal(mp2.MerkleTree(ctx, one, 0).cap, O.merkle_cap(O.merkle_build(one, 0), 0))  # a tree of one leaf
+    four = O.rand_field((4, 7), 4)
+    assert np.array_equal(mp2.MerkleTree(ctx, four, 2).cap, O.merkle_cap(O.merkle_build(four, 2), 2))  # cap = the leaf hashes
+    leaves, siblings = mp2.MerkleTree(ctx, four, 1).prove([])
+    assert leaves.shape == (0, 7) and siblings.shape[0] == 0
+    # Ecgfp5: empty sums are the neutral point (encoding 0, Weierstrass form with is_inf = 1), empty batches give no rows
+    neutral_w = np.zeros(5, dtype=np.uint64)
+    assert np.array_equal(mp2.curve_sum(ctx, np.zeros((0, 5), dtype=np.uint64)), neutral_w)
+    assert mp2.map_to_curve_batch(ctx, np.zeros((0, 9), dtype=np.uint64)).shape == (0, 5)
+    assert mp2.scalar_mul_batch(ctx, np.zeros((0, 5), dtype=np.uint64), []).shape == (0, 5)
+    w, wei = mp2.compute_table_row_digest(ctx, np.array([1, 2], dtype=np.uint64), np.zeros((0, 2, 8), dtype=np.uint32), np.zeros((0, 1, 8), dtype=np.uint32))
+    assert np.array_equal(w, neutral_w) and wei.tolist() == [0] * 10 + [1]
