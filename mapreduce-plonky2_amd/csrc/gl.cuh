@@ -128,7 +128,20 @@ GLHD u64 gl_reduce96w(u64 lo, u64 hi) {
 }
 GLHD u64 gl_reduce128(u64 lo, u64 hi) { return gl_canon(gl_reduce128w(lo, hi)); }
 GLHD void gl_mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_MULWIDE_CARRY)
+  // four independent 32x32->64 products (v_mad_u64_u32 with a zero addend), summed word by word with two carry chains:
+  // no 64-bit addend has to be assembled from 32-bit halves (tools/ubench A/B)
+  u64 p00 = (u64)(u32)a * (u32)b, x = (u64)(u32)a * (u32)(b >> 32), y = (u64)(u32)(a >> 32) * (u32)b, p11 = (u64)(u32)(a >> 32) * (u32)(b >> 32);
+  u32 c0, c1, c2;
+  u32 w1 = __builtin_addc((u32)(p00 >> 32), (u32)x, 0u, &c0);
+  u32 w2 = __builtin_addc((u32)p11, (u32)(x >> 32), c0, &c1);
+  u32 w3 = (u32)(p11 >> 32) + c1;
+  w1 = __builtin_addc(w1, (u32)y, 0u, &c0);
+  w2 = __builtin_addc(w2, (u32)(y >> 32), c0, &c2);
+  w3 += c2;
+  lo = gl_mk((u32)p00, w1);
+  hi = gl_mk(w2, w3);
+#elif defined(__HIP_DEVICE_COMPILE__)
   // four 32x32->64 products; hipcc lowers the accumulations to v_mad_u64_u32
   u64 a0 = (u32)a, a1 = a >> 32, b0 = (u32)b, b1 = b >> 32;
   u64 p00 = a0 * b0;
