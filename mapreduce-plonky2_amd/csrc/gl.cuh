@@ -59,6 +59,9 @@ GLHD u64 gl_addw(u64 a, u64 b) {
   u32 c0, c1, d0, d1;
   u32 s0 = __builtin_addc((u32)a, (u32)b, 0u, &c0);
   u32 s1 = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c0, &c1);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GL_REDUCE_CARRYCHAIN)
+  return gl_mk(s0, s1) + (u64)(c1 ? 0xFFFFFFFFu : 0u);
+#endif
   u32 m = c1 ? 0xFFFFFFFFu : 0u;
   u32 t0 = __builtin_addc(s0, m, 0u, &d0);
   u32 t1 = __builtin_addc(s1, 0u, d0, &d1);
@@ -78,6 +81,18 @@ GLHD u64 gl_reduce128w(u64 lo, u64 hi) {
   u64 t, c;
   asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(hl), "v"(lo));
   u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mb, mc;
+#ifndef GL_REDUCE_CARRYCHAIN
+  // both corrections as ONE signed 64-bit addend K = (c - b) EPS, added with a carry-less 64-bit add (v_lshl_add_u64): three
+  // carry-chain instructions instead of seven. K = [mc - mb, mb & ~mc] for the masks mc = -c, mb = -b.
+  asm("v_sub_co_u32 %0, vcc, %4, %6\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %0, %0, vcc\n\t"
+      "v_cndmask_b32 %3, 0, -1, %7"
+      : "=&v"(r0), "=&v"(r1), "=&v"(mb), "=&v"(mc)
+      : "v"(t0), "v"(t1), "v"(hh), "s"(c)
+      : "vcc");
+  return gl_mk(r0, r1) + gl_mk(mc - mb, mb & ~mc);
+#endif
   // Hazard discipline (gfx90a+: a VALU-written SGPR / VCC needs 2 wait states before another VALU reads it
   // as an explicit operand; the compiler cannot see inside asm): VCC is only consumed through the implicit
   // carry-in of VOP2 forms, the borrow mask is made by u0 - u0 - borrow, and the mad's carry pair %7 is
@@ -110,6 +125,14 @@ GLHD u64 gl_reduce96w(u64 lo, u64 hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
   u64 t, c;
   asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"((u32)hi), "v"(lo));
+#ifndef GL_REDUCE_CARRYCHAIN
+  {
+    u32 m;
+    asm("s_nop 1\n\t"
+        "v_cndmask_b32 %0, 0, -1, %1" : "=v"(m) : "s"(c));
+    return t + (u64)m;  // + c EPS cannot wrap (see gl_reduce128w): a carry-less 64-bit add
+  }
+#endif
   u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mc;
   asm("s_nop 1\n\t"  // 2 wait states between the mad's SGPR carry and its first VALU reader
       "v_cndmask_b32 %2, 0, -1, %5\n\t"
