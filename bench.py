@@ -534,10 +534,10 @@ def main(argv=None):
         step()
     sync_all()
 
-    # roofline leg: the 2^22 NTT, HIP events on the stream the kernels are launched on. 200 untimed transforms first: the leg is
-    # 60 us long and follows the clocks, which need ~10 ms of this kernel to settle after the prover's steps (tools/dbg/ntt_leg_burst.sh:
+    # roofline leg: the 2^22 NTT, HIP events on the stream the kernels are launched on. 1000 untimed transforms first: the leg is
+    # 55-60 us long and follows the clocks, which need tens of ms of this kernel to settle after the prover's steps (tools/dbg/ntt_leg_burst.sh:
     # 61 / 58 / 55 us as the median of 20 / 200 / 1000 back-to-back transforms); then 50 timed ones, each between its own events
-    for _ in range(200):
+    for _ in range(1000):
         ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
     ntt_ms = []
     for _ in range(50):
