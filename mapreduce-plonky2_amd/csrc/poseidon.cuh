@@ -56,6 +56,17 @@ GLHD void p2_external_rc(u64 s[12], const u64* rc) {
   for (int i = 0; i < 12; i++) { lo[i] = (u32)s[i]; hi[i] = s[i] >> 32; }
   p2_external_half(lo);
   p2_external_half(hi);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(P2_EXTERNAL_CARRY)
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    // value = lo + hi * 2^32 (+ rc), lo, hi < 2^39: carry-less 64-bit adds of the halves, the high part of the low half moves up
+    u64 L = lo[i], H = hi[i];
+    if (RC) { L += (u64)(u32)rc[i]; H += rc[i] >> 32; }
+    H += L >> 32;  // < 2^41
+    s[i] = gl_reduce96w(gl_mk((u32)L, (u32)H), H >> 32);
+  }
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < 12; i++) {
     // value = lo + hi * 2^32, lo, hi < 2^39
@@ -78,8 +89,25 @@ GLHD u64 p2_sbox0(u64 t) {
   u64 t2 = gl_mulw(t, t), t4 = gl_mulw(t2, t2), t3 = gl_mulw(t, t2);
   return gl_mulw(t3, t4);
 }
-// s_i <- d_i s_i + sum_j s_j, exactly: 128-bit product plus the 68-bit sum, one reduction
+// s_i <- d_i s_i + sum_j s_j. Device code: sum reduced once, then a weak multiply and a weak add per limb (2.60 -> 2.71 G perm/s against the
+// fused form below -- 128-bit product plus the 68-bit sum, one reduction --, whose carry chains cost more than the second reduction saves;
+// -DP2_INTERNAL_FUSED / -DP2_EXTERNAL_CARRY restore the carry-chain forms for A/B runs)
 GLHD void p2_internal(u64 s[12]) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(P2_INTERNAL_FUSED)
+  // the 68-bit sum from the 32-bit halves (each v_mad_u64_u32 adds a zero-extended word into a 64-bit accumulator: no carry
+  // chains), reduced ONCE to a canonical element; every limb is then weak multiply + weak add
+  u64 al = 0, ah = 0;
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    al += (u64)(u32)s[i];
+    ah += s[i] >> 32;
+  }
+  ah += al >> 32;  // < 2^37
+  const u64 sum = gl_canon(gl_reduce96w(gl_mk((u32)al, (u32)ah), ah >> 32));
+#pragma unroll
+  for (int i = 0; i < 12; i++) s[i] = gl_addw(gl_mulw(s[i], c_p2_diag[i]), sum);
+  return;
+#endif
   u64 acc = s[0];
   u64 top = 0;
 #pragma unroll
