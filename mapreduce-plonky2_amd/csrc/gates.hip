@@ -127,6 +127,32 @@ GLD u64 gl_subw(u64 a, u64 b) {
   bool br = __builtin_sub_overflow(a, b, &r);  // borrow: r = a - b + 2^64 >= 2^32, so -EPS cannot borrow again
   return r - (br ? GL_EPS : 0);
 }
+// sum_j alpha^j C_j as four 64-bit columns of 32-bit words (no carry chains: a 64-bit add without carry-out costs 1.6 issue slots on
+// gfx950, an add_co / addc pair with its hazard nop 4.4 -- DESIGN.md section 4); fewer than 2^32 terms, so no column overflows
+struct LazySum {
+  u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  GLD void add(u64 v, u64 alpha_pow) {
+    u64 pl, ph;
+    gl_mul_wide(v, alpha_pow, pl, ph);
+#ifdef GATES_CARRY_ACC
+    bool k0 = __builtin_add_overflow(c0, pl, &c0);
+    bool k1 = __builtin_add_overflow(c1, ph, &c1);
+    bool k2 = __builtin_add_overflow(c1, (u64)(k0 ? 1 : 0), &c1);
+    c2 += (k1 ? 1 : 0) + (k2 ? 1 : 0);
+#else
+    c0 += (u32)pl; c1 += pl >> 32; c2 += (u32)ph; c3 += ph >> 32;
+#endif
+  }
+  // the sum as a canonical element: lo + hi 2^64 + top 2^128, 2^128 = -2^32 (mod p)
+  GLD u64 value() const {
+#ifdef GATES_CARRY_ACC
+    return gl_sub(gl_reduce128(c0, c1), c2 << 32);
+#else
+    const u64 w1 = c1 + (c0 >> 32), w2 = c2 + (w1 >> 32), w3 = c3 + (w2 >> 32);
+    return gl_sub(gl_reduce128(gl_mk((u32)c0, (u32)w1), gl_mk((u32)w2, (u32)w3)), (w3 >> 32) << 32);
+#endif
+  }
+};
 // eval_unfiltered_base of one gate: wire(j) / cst(j) fetch local wire j / gate constant j (after the
 // selector prefix), emit(c) receives the constraints in plonky2's order. WEAK = true lets the Poseidon
 // gates hand over un-canonicalised representatives (the lazy accumulator of the LDE kernel takes any u64).
@@ -645,26 +671,16 @@ __global__ void __launch_bounds__(256) gate_constraints_lde_kernel(mp2g_gate g, 
       if (r != gi) f = gl_mul(f, gl_sub(r, s));
     if (num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
   }
-  u64 lo[2] = {0, 0}, hi[2] = {0, 0};
-  u32 top[2] = {0, 0};
+  LazySum acc[2];
   u32 j = 0;
   eval_gate<true>(g, wire, cst, pih, [&](u64 v) {
 #pragma unroll
-    for (u32 a = 0; a < 2; a++) {
-      u64 pl, ph;
-      gl_mul_wide(v, apw[a][j], pl, ph);
-      bool c0 = __builtin_add_overflow(lo[a], pl, &lo[a]);
-      bool c1 = __builtin_add_overflow(hi[a], ph, &hi[a]);
-      bool c2 = __builtin_add_overflow(hi[a], (u64)(c0 ? 1 : 0), &hi[a]);
-      top[a] += (c1 ? 1 : 0) + (c2 ? 1 : 0);
-    }
+    for (u32 a = 0; a < 2; a++) acc[a].add(v, apw[a][j]);
     j++;
   });
   const u32 i = bitrev32(p, lg);
   for (u32 a = 0; a < nc; a++) {
-    // lo + hi 2^64 + top 2^128, 2^128 = -2^32 (mod p)
-    u64 r = gl_sub(gl_reduce128(lo[a], hi[a]), (u64)top[a] << 32);
-    r = gl_mul(f, r);
+    u64 r = gl_mul(f, acc[a].value());
     u64* dst = q + (((u64)b * nc + a) << lg) + i;
     *dst = first ? r : gl_add(*dst, r);
   }
@@ -719,19 +735,11 @@ __global__ void __launch_bounds__(256) gate_constraints_lde_light_kernel(LightGa
         if (r != gi) f = gl_mul(f, gl_sub(r, s));
       if (num_selectors > 1) f = gl_mul(f, gl_sub(0xFFFFFFFFull, s));
     }
-    u64 lo[2] = {0, 0}, hi[2] = {0, 0};
-    u32 top[2] = {0, 0};
+    LazySum acc[2];
     u32 j = 0;
     auto emit = [&](u64 v) {
 #pragma unroll
-      for (u32 a = 0; a < 2; a++) {
-        u64 pl, ph;
-        gl_mul_wide(v, apw[a][j], pl, ph);
-        bool c0 = __builtin_add_overflow(lo[a], pl, &lo[a]);
-        bool c1 = __builtin_add_overflow(hi[a], ph, &hi[a]);
-        bool c2 = __builtin_add_overflow(hi[a], (u64)(c0 ? 1 : 0), &hi[a]);
-        top[a] += (c1 ? 1 : 0) + (c2 ? 1 : 0);
-      }
+      for (u32 a = 0; a < 2; a++) acc[a].add(v, apw[a][j]);
       j++;
     };
     switch (g.kind) {
@@ -745,10 +753,7 @@ __global__ void __launch_bounds__(256) gate_constraints_lde_light_kernel(LightGa
 #undef LIGHT_CASE
       default: break;
     }
-    for (u32 a = 0; a < nc; a++) {
-      u64 r = gl_sub(gl_reduce128(lo[a], hi[a]), (u64)top[a] << 32);
-      total[a] = gl_add(total[a], gl_mul(f, r));
-    }
+    for (u32 a = 0; a < nc; a++) total[a] = gl_add(total[a], gl_mul(f, acc[a].value()));
   }
   const u32 i = bitrev32(p, lg);
   for (u32 a = 0; a < nc; a++) {
