@@ -195,12 +195,17 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
 #pragma unroll
     for (u32 k = 0; k < 16; k++) buf[k] = k < count ? wire(first + k) : 0;
   };
-  auto range4 = [&](u64 limb) {  // limb (limb - 1)(limb - 2)(limb - 3)
-    u64 pr = limb;
-#pragma unroll
-    for (u32 x = 1; x < 4; x++) pr = mulx(pr, gl_sub(limb, x));
-    return pr;
+  auto range4 = [&](u64 limb) {  // limb (limb - 1)(limb - 2)(limb - 3) = z (z + 2) with z = limb (limb - 3): two products instead of three
+    const u64 z = mulx(limb, gl_sub(limb, 3));
+    return mulx(z, WEAK ? gl_addw(z, 2) : gl_add(z, 2));
   };
+  // Horner step in base 4 and the final difference: weak representatives where the caller takes them (4 acc as a 66-bit integer reduced
+  // without canonicalisation, limb / b canonical wire values)
+  auto horner4 = [](u64 acc, u64 limb) {
+    if (!WEAK) return gl_add(gl_mul_small(acc, 4), limb);
+    return gl_addw(gl_reduce96w(acc << 2, acc >> 62), limb);
+  };
+  auto subx = [](u64 a, u64 b) { return WEAK ? gl_subw(a, b) : gl_sub(a, b); };
   switch (g.kind) {
     case MP2G_GATE_CONSTANT:
       for (u32 i = 0; i < g.p0; i++) emit(gl_sub(cst(i), wire(i)));
@@ -418,12 +423,12 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         u64 clo = 0, chi = 0, lm[16];
         load16(6 * ops + 32 * i + 16, 16, lm);  // limbs 31..16: the high half
 #pragma unroll
-        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); chi = gl_add(gl_mul_small(chi, 4), lm[j]); }
+        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); chi = horner4(chi, lm[j]); }
         load16(6 * ops + 32 * i, 16, lm);       // limbs 15..0
 #pragma unroll
-        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); clo = gl_add(gl_mul_small(clo, 4), lm[j]); }
-        emit(gl_sub(clo, lo));
-        emit(gl_sub(chi, hi));
+        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); clo = horner4(clo, lm[j]); }
+        emit(subx(clo, lo));
+        emit(subx(chi, hi));
       }
       break;
     }
@@ -434,8 +439,8 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         load16(k + 16 * i, 16, lm);
         u64 acc = 0;
 #pragma unroll
-        for (int j = 15; j >= 0; j--) acc = gl_add(gl_mul_small(acc, 4), lm[j]);
-        emit(gl_sub(acc, wire(i)));
+        for (int j = 15; j >= 0; j--) acc = horner4(acc, lm[j]);
+        emit(subx(acc, wire(i)));
 #pragma unroll
         for (int j = 0; j < 16; j++) emit(range4(lm[j]));
       }
@@ -451,8 +456,8 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         u64 comb = 0, lm[16];
         load16(5 * ops + 16 * i, 16, lm);
 #pragma unroll
-        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); comb = gl_add(gl_mul_small(comb, 4), lm[j]); }
-        emit(gl_sub(comb, res));
+        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); comb = horner4(comb, lm[j]); }
+        emit(subx(comb, res));
         emit(gl_mul(bo, gl_sub(1, bo)));
       }
       break;
@@ -470,12 +475,12 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
           const u64 l17 = wire(per * ops + 18 * i + 17), l16 = wire(per * ops + 18 * i + 16);
           load16(per * ops + 18 * i, 16, lm);
           emit(range4(l17)); ccar = l17;
-          emit(range4(l16)); ccar = gl_add(gl_mul_small(ccar, 4), l16);
+          emit(range4(l16)); ccar = horner4(ccar, l16);
         }
 #pragma unroll
-        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); cres = gl_add(gl_mul_small(cres, 4), lm[j]); }
-        emit(gl_sub(cres, res));
-        emit(gl_sub(ccar, co));
+        for (int j = 15; j >= 0; j--) { emit(range4(lm[j])); cres = horner4(cres, lm[j]); }
+        emit(subx(cres, res));
+        emit(subx(ccar, co));
       }
       break;
     }
