@@ -1,6 +1,8 @@
 #!/bin/bash
-# per-kernel A/B of two library builds: rocprofv3 kernel stats of a single-stream bench run with each (MP2G_LIB), gate kernels listed
+# per-kernel A/B of two library builds: rocprofv3 kernel stats of a single-stream bench run with each (MP2G_LIB); kernels matching
+# the regex $2 are listed (default: the gate and permutation-quotient kernels)
 V=${1:-carryacc}
+export PAT=${2:-gate_constraints|quotient_perm}
 cd /tmp && export TMPDIR=/tmp
 for lib in mapreduce-plonky2_amd/libmp2gpu.so build_dbg/$V/libmp2gpu.so; do
   export MP2G_LIB=$GRAFT_REPO_ROOT/$lib
@@ -14,7 +16,8 @@ rows=list(csv.DictReader(open(f)))
 tot=0
 for r in rows:
     n=r['Name']
-    if 'gate_constraints' in n or 'quotient_perm' in n:
+    import re, os
+    if re.search(os.environ['PAT'], n):
         k=n.split('<')[1].split('>')[0] if '<' in n else 'light/perm'
         print(f"  {n.split('(')[0][-45:]:45s} calls {r['Calls']:>4s} avg {float(r['AverageNs'])/1e3:9.1f} us")
         tot+=int(r['TotalDurationNs'])
