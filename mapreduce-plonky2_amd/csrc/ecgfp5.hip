@@ -15,15 +15,14 @@
 //
 // ALU-bound: one lane owns one point in fractional coordinates (X:Z:U:T), x = X/Z, u = U/T,
 // using the complete 10M addition and 4M+5S doubling of the ecgfp5 paper (checked against the
-// affine chord/tangent law of the oracle). GF(p^5) products accumulate five 128-bit partial
-// products per output limb and reduce once. Encodings are canonical, so results are identical
+// affine chord/tangent law of the oracle). GF(p^5) products accumulate the five partial products of an
+// output limb in carry-free 64-bit columns (gl_cols) and reduce once. Encodings are canonical, so results are identical
 // to the reference's regardless of the coordinate system.
 #include "ecgfp5.h"
 #include "poseidon.cuh"
 
 namespace mp2g {
 
-typedef unsigned __int128 u128;
 // large bodies are real functions: the SWU / scalar-mul kernels call them hundreds of times
 #define GLN __device__ __noinline__
 struct gl5 { u64 c[5]; };
@@ -67,16 +66,6 @@ GLD gl5 gl5_mul_kz(const gl5& a, u32 k) {
   for (int i = 1; i < 5; i++) r.c[i] = gl_mul_small(a.c[i - 1], k);
   return r;
 }
-// lo + hi 2^64 + top 2^128 mod p  (2^128 = -2^32)
-GLD u64 gl_reduce160(u128 acc, u32 top) {
-  u64 r = gl_reduce128((u64)acc, (u64)(acc >> 64));
-  return gl_sub(r, (u64)top << 32);
-}
-GLD u128 mulw(u64 a, u64 b) {
-  u64 lo, hi;
-  gl_mul_wide(a, b, lo, hi);
-  return ((u128)hi << 64) | lo;
-}
 // The one out-of-line body of a GF(p^5) product takes its ten limbs as scalars: clang's AMDGPU ABI keeps at most 16 dwords of
 // aggregate arguments in registers and sends the rest through the stack, scalars all travel in VGPRs. (With both operands by
 // reference every 600-instruction multiplication began with six flat loads from the stack, and row_digest_kernel sat parked for
@@ -85,20 +74,17 @@ GLN gl5 gl5_mul_limbs(u64 x0, u64 x1, u64 x2, u64 x3, u64 x4, u64 y0, u64 y1, u6
   const u64 a[5] = {x0, x1, x2, x3, x4}, b[5] = {y0, y1, y2, y3, y4};
   u64 a3[5];
 #pragma unroll
-  for (int j = 1; j < 5; j++) a3[j] = gl_mul_small(a[j], 3);
+  for (int j = 1; j < 5; j++) a3[j] = gl_mul_small_w(a[j], 3);  // only ever a multiplicand: a weak representative will do
   a3[0] = 0;
   gl5 r;
 #pragma unroll
   for (int i = 0; i < 5; i++) {
-    u128 acc = 0;
-    u32 top = 0;
+    gl_cols acc;  // five partial products per output limb in carry-free columns, one reduction
 #pragma unroll
     for (int j = 0; j < 5; j++) {
-      u128 p = j <= i ? mulw(a[j], b[i - j]) : mulw(a3[j], b[i + 5 - j]);
-      acc += p;
-      top += acc < p ? 1 : 0;
+      if (j <= i) acc.add(a[j], b[i - j]); else acc.add(a3[j], b[i + 5 - j]);
     }
-    r.c[i] = gl_reduce160(acc, top);
+    r.c[i] = acc.value();
   }
   return r;
 }
@@ -142,15 +128,11 @@ GLN gl5 gl5_inv(gl5 a) {  // inverse_or_zero
   gl5 q = gl5_mul(f12, f34);           // a^(r-1)
   u64 n = 0;                           // norm = (a*q)[0]
   {
-    u128 acc = mulw(a.c[0], q.c[0]);
-    u32 top = 0;
+    gl_cols acc;
+    acc.add(a.c[0], q.c[0]);
 #pragma unroll
-    for (int j = 1; j < 5; j++) {
-      u128 p = mulw(gl_mul_small(a.c[j], 3), q.c[5 - j]);
-      acc += p;
-      top += acc < p ? 1 : 0;
-    }
-    n = gl_reduce160(acc, top);
+    for (int j = 1; j < 5; j++) acc.add(gl_mul_small_w(a.c[j], 3), q.c[5 - j]);
+    n = acc.value();
   }
   return gl5_scale(q, gl_inv_chain(n));
 }

@@ -127,32 +127,8 @@ GLD u64 gl_subw(u64 a, u64 b) {
   bool br = __builtin_sub_overflow(a, b, &r);  // borrow: r = a - b + 2^64 >= 2^32, so -EPS cannot borrow again
   return r - (br ? GL_EPS : 0);
 }
-// sum_j alpha^j C_j as four 64-bit columns of 32-bit words (no carry chains: a 64-bit add without carry-out costs 1.6 issue slots on
-// gfx950, an add_co / addc pair with its hazard nop 4.4 -- DESIGN.md section 4); fewer than 2^32 terms, so no column overflows
-struct LazySum {
-  u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  GLD void add(u64 v, u64 alpha_pow) {
-    u64 pl, ph;
-    gl_mul_wide(v, alpha_pow, pl, ph);
-#ifdef GATES_CARRY_ACC
-    bool k0 = __builtin_add_overflow(c0, pl, &c0);
-    bool k1 = __builtin_add_overflow(c1, ph, &c1);
-    bool k2 = __builtin_add_overflow(c1, (u64)(k0 ? 1 : 0), &c1);
-    c2 += (k1 ? 1 : 0) + (k2 ? 1 : 0);
-#else
-    c0 += (u32)pl; c1 += pl >> 32; c2 += (u32)ph; c3 += ph >> 32;
-#endif
-  }
-  // the sum as a canonical element: lo + hi 2^64 + top 2^128, 2^128 = -2^32 (mod p)
-  GLD u64 value() const {
-#ifdef GATES_CARRY_ACC
-    return gl_sub(gl_reduce128(c0, c1), c2 << 32);
-#else
-    const u64 w1 = c1 + (c0 >> 32), w2 = c2 + (w1 >> 32), w3 = c3 + (w2 >> 32);
-    return gl_sub(gl_reduce128(gl_mk((u32)c0, (u32)w1), gl_mk((u32)w2, (u32)w3)), (w3 >> 32) << 32);
-#endif
-  }
-};
+// sum_j alpha^j C_j: gl_cols (gl.cuh), carry-free columns
+typedef gl_cols LazySum;
 // eval_unfiltered_base of one gate: wire(j) / cst(j) fetch local wire j / gate constant j (after the
 // selector prefix), emit(c) receives the constraints in plonky2's order. WEAK = true lets the Poseidon
 // gates hand over un-canonicalised representatives (the lazy accumulator of the LDE kernel takes any u64).

@@ -190,6 +190,12 @@ GLHD u64 gl_mul_small(u64 a, u32 c) {
   u64 p1 = (a >> 32) * c + (p0 >> 32);
   return gl_canon(gl_reduce96w((p1 << 32) | (p0 & GL_EPS), p1 >> 32));
 }
+// the same for any u64 a, as some u64 representative (no canonicalisation)
+GLHD u64 gl_mul_small_w(u64 a, u32 c) {
+  u64 p0 = (u64)(u32)a * c;
+  u64 p1 = (a >> 32) * c + (p0 >> 32);
+  return gl_reduce96w((p1 << 32) | (p0 & GL_EPS), p1 >> 32);
+}
 GLHD u64 gl_pow7(u64 x) {
   u64 x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x, x2);
   return gl_mul(x3, x4);
@@ -224,6 +230,23 @@ GLHD u64 gl_mulw(u64 a, u64 b) {
   gl_mul_wide(a, b, lo, hi);
   return gl_reduce128w(lo, hi);
 }
+
+// ---- sums of products without carry chains ------------------------------------------------------------------------------
+// sum_k a_k b_k as four 64-bit columns of 32-bit words: on gfx950 a 64-bit add without carry-out costs 1.6 issue slots, an
+// add_co / addc pair with its hazard nop 4.4. Fewer than 2^32 terms, so no column overflows.
+struct gl_cols {
+  u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  GLHD void add(u64 a, u64 b) {
+    u64 pl, ph;
+    gl_mul_wide(a, b, pl, ph);
+    c0 += (u32)pl; c1 += pl >> 32; c2 += (u32)ph; c3 += ph >> 32;
+  }
+  // the sum as a canonical element: lo + hi 2^64 + top 2^128, 2^128 = -2^32 (mod p)
+  GLHD u64 value() const {
+    const u64 w1 = c1 + (c0 >> 32), w2 = c2 + (w1 >> 32), w3 = c3 + (w2 >> 32);
+    return gl_sub(gl_reduce128(gl_mk((u32)c0, (u32)w1), gl_mk((u32)w2, (u32)w3)), (w3 >> 32) << 32);
+  }
+};
 
 // ---- quadratic extension ------------------------------------------------------------------
 struct gl2 { u64 a, b; };
