@@ -91,9 +91,33 @@ __device__ __forceinline__ u64 gl_mul_2p72(u64 x) {
 template <int K> __device__ __forceinline__ u64 gl_mul_w8(u64 x) {  // x * w_8^K, K = 1..3
   return K == 1 ? gl_mul_2p24(x) : (K == 2 ? gl_mul_2p48(x) : gl_mul_2p72(x));
 }
+// (u - v) * 2^48 and (u - v) * 2^72 without canonicalising the difference first: with s = u - v mod 2^64 and the borrow b, the
+// difference is s - b 2^64, and -2^64 2^48 = -2^112 = +2^16, -2^64 2^72 = -2^136 = +2^40 (mod p, 2^96 = -1): the borrow becomes one
+// bit of the low word that the shift leaves empty (saves the second subtract chain of gl_sub)
+__device__ __forceinline__ u64 gl_sub_mul_2p48(u64 u, u64 v) {
+  u32 c0, c1;
+  const u32 s0 = __builtin_subc((u32)u, (u32)v, 0u, &c0);
+  const u32 s1 = __builtin_subc((u32)(u >> 32), (u32)(v >> 32), c0, &c1);
+  const u64 s = gl_mk(s0, s1);
+  return gl_reduce128(gl_mk(c1 ? 0x10000u : 0u, s0 << 16), s >> 16);
+}
+__device__ __forceinline__ u64 gl_sub_mul_2p72(u64 u, u64 v) {
+  u32 c0, c1;
+  const u32 s0 = __builtin_subc((u32)u, (u32)v, 0u, &c0);
+  const u32 s1 = __builtin_subc((u32)(u >> 32), (u32)(v >> 32), c0, &c1);
+  const u64 s = gl_mk(s0, s1);
+  return gl_sub(gl_reduce128(gl_mk(0u, c1 ? 0x100u : 0u), s << 8), (s >> 56) << 32);
+}
+template <int K> __device__ __forceinline__ u64 gl_sub_mul_w8(u64 u, u64 v) {  // (u - v) * w_8^K
+#ifdef NTT_UNFUSED_SUB
+  return gl_mul_w8<K>(gl_sub(u, v));
+#else
+  return K == 1 ? gl_mul_2p24(gl_sub(u, v)) : (K == 2 ? gl_sub_mul_2p48(u, v) : gl_sub_mul_2p72(u, v));
+#endif
+}
 // (u - v) * w_8^K for the forward transform, (u - v) * w_8^-K = (v - u) * w_8^(4-K) for the inverse (w_8^4 = -1)
 template <int K> __device__ __forceinline__ u64 bfly_lo(u64 u, u64 v, bool inverse) {
-  return inverse ? gl_mul_w8<4 - K>(gl_sub(v, u)) : gl_mul_w8<K>(gl_sub(u, v));
+  return inverse ? gl_sub_mul_w8<4 - K>(v, u) : gl_sub_mul_w8<K>(u, v);
 }
 // the 2^R-point DIF butterfly of one lane (R = 3: true radix-8 with the w_8 shifts; R < 3: the last, partial round) followed by
 // the round's general twiddles w_T^(E r), r = bitrev3(m), looked up at [r-1][below]
@@ -114,9 +138,14 @@ __device__ __forceinline__ void butterfly(u64* x, int below, const u64* tw, cons
       { u64 u = x[h], v = x[h + 2]; x[h] = gl_add(u, v); x[h + 2] = gl_sub(u, v); }
       { u64 u = x[h + 1], v = x[h + 3]; x[h + 1] = gl_add(u, v); x[h + 3] = bfly_lo<2>(u, v, inverse); }
     }
-    // stage 2: pairs (m, m + 1)
+    // stage 2: pairs (m, m + 1). A sum that goes straight into a general twiddle multiplication (LO > 0, m > 0) may stay a weak
+    // representative: gl_mul takes any u64 and returns the canonical product
 #pragma unroll
-    for (int m = 0; m < 8; m += 2) { u64 u = x[m], v = x[m + 1]; x[m] = gl_add(u, v); x[m + 1] = gl_sub(u, v); }
+    for (int m = 0; m < 8; m += 2) {
+      u64 u = x[m], v = x[m + 1];
+      x[m] = (LO > 0 && m > 0) ? gl_addw(u, v) : gl_add(u, v);
+      x[m + 1] = gl_sub(u, v);
+    }
     if constexpr (LO > 0) {
       const u64* tab = (TWG || RHO < R8Tw<LT>::GLOBAL_ROUNDS) ? twg + R8Tw<LT>::off(RHO) : tw + (R8Tw<LT>::off(RHO) - R8Tw<LT>::LDS_OFF);
 #pragma unroll
