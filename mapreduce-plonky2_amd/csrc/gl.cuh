@@ -178,6 +178,23 @@ GLHD void gl_mul_wide(u64 a, u64 b, u64& lo, u64& hi) {
   hi = (u64)(x >> 64);
 #endif
 }
+// a * b + c as a 128-bit integer (any u64 a, b, c; the sum is below 2^128): the halves of c ride in the addend slots of the first two
+// multiply-adds -- [c_lo, 0] where gl_mul_wide adds nothing, c_hi with the carry word of the first product (a0 b1 + 2^33 - 2 still
+// fits 64 bits) -- so the addition costs no carry chain at all
+GLHD void gl_mul_add_wide(u64 a, u64 b, u64 c, u64& lo, u64& hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  u64 a0 = (u32)a, a1 = a >> 32, b0 = (u32)b, b1 = b >> 32;
+  u64 p00 = a0 * b0 + (u64)(u32)c;
+  u64 m1 = a0 * b1 + ((p00 >> 32) + (c >> 32));
+  u64 m2 = a1 * b0 + (m1 & GL_EPS);
+  lo = (m2 << 32) | (p00 & GL_EPS);
+  hi = a1 * b1 + (m1 >> 32) + (m2 >> 32);
+#else
+  unsigned __int128 x = (unsigned __int128)a * b + c;
+  lo = (u64)x;
+  hi = (u64)(x >> 64);
+#endif
+}
 GLHD u64 gl_mul(u64 a, u64 b) {
   u64 lo, hi;
   gl_mul_wide(a, b, lo, hi);
@@ -225,6 +242,12 @@ GLHD u32 bitrev32(u32 x, unsigned bits) {
 #endif
 }
 
+// a * b + c as some u64 representative (any u64 a, b, c)
+GLHD u64 gl_mul_addw(u64 a, u64 b, u64 c) {
+  u64 lo, hi;
+  gl_mul_add_wide(a, b, c, lo, hi);
+  return gl_reduce128w(lo, hi);
+}
 GLHD u64 gl_mulw(u64 a, u64 b) {
   u64 lo, hi;
   gl_mul_wide(a, b, lo, hi);

@@ -103,9 +103,17 @@ GLHD void p2_internal(u64 s[12]) {
     ah += s[i] >> 32;
   }
   ah += al >> 32;  // < 2^37
+#ifdef P2_INTERNAL_ADDW
   const u64 sum = gl_canon(gl_reduce96w(gl_mk((u32)al, (u32)ah), ah >> 32));
+#else
+  const u64 sum = gl_reduce96w(gl_mk((u32)al, (u32)ah), ah >> 32);  // any representative will do below
+#endif
 #pragma unroll
+#ifdef P2_INTERNAL_ADDW
   for (int i = 0; i < 12; i++) s[i] = gl_addw(gl_mulw(s[i], c_p2_diag[i]), sum);
+#else
+  for (int i = 0; i < 12; i++) s[i] = gl_mul_addw(s[i], c_p2_diag[i], sum);  // the sum rides in the product's addend slots
+#endif
   return;
 #endif
   u64 acc = s[0];
