@@ -115,7 +115,7 @@ const char* gate_table_check(const GateTable& t, u32 num_constants, u32 wires_w)
 
 struct Alg { u64 a, b; };  // ExtensionAlgebra element over the evaluation field, X^2 = 7
 GLD Alg alg_mul(Alg x, Alg y) {
-  return Alg{gl_add(gl_mul(x.a, y.a), gl_mul_small(gl_mul(x.b, y.b), 7)), gl_add(gl_mul(x.a, y.b), gl_mul(x.b, y.a))};
+  return Alg{gl_mul_add(x.a, y.a, gl_mul_small_w(gl_mulw(x.b, y.b), 7)), gl_mul_add(x.a, y.b, gl_mulw(x.b, y.a))};
 }
 GLD Alg alg_add(Alg x, Alg y) { return Alg{gl_add(x.a, y.a), gl_add(x.b, y.b)}; }
 GLD Alg alg_sub(Alg x, Alg y) { return Alg{gl_sub(x.a, y.a), gl_sub(x.b, y.b)}; }
@@ -193,7 +193,7 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
       const u64 c0 = cst(0), c1 = cst(1);
       for (u32 i = 0; i < g.p0; i++) {
         u64 m0 = wire(4 * i), m1 = wire(4 * i + 1), ad = wire(4 * i + 2), o = wire(4 * i + 3);
-        emit(gl_sub(o, gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1))));
+        emit(gl_sub(o, gl_mul_add(gl_mulw(m0, m1), c0, gl_mulw(ad, c1))));
       }
       break;
     }
@@ -391,11 +391,11 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
       const u32 ops = g.p0;
       for (u32 i = 0; i < ops; i++) {
         const u32 b = 6 * i;
-        const u64 computed = gl_add(gl_mul(wire(b), wire(b + 1)), wire(b + 2));
+        const u64 computed = gl_mul_add(wire(b), wire(b + 1), wire(b + 2));
         const u64 lo = wire(b + 3), hi = wire(b + 4), inv = wire(b + 5);
         const u64 hi_not_max = gl_sub(gl_mul(inv, gl_sub(0xFFFFFFFFull, hi)), 1);
         emit(gl_mul(hi_not_max, lo));
-        emit(gl_sub(gl_add(gl_mul(hi, (u64)1 << 32), lo), computed));
+        emit(gl_sub(gl_mul_add(hi, (u64)1 << 32, lo), computed));
         u64 clo = 0, chi = 0, lm[16];
         load16(6 * ops + 32 * i + 16, 16, lm);  // limbs 31..16: the high half
 #pragma unroll
@@ -445,7 +445,7 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         u64 computed = wire(b + na);
         for (u32 j = 0; j < na; j++) computed = gl_add(computed, wire(b + j));
         const u64 res = wire(b + na + 1), co = wire(b + na + 2);
-        emit(gl_sub(gl_add(gl_mul(co, (u64)1 << 32), res), computed));
+        emit(gl_sub(gl_mul_add(co, (u64)1 << 32, res), computed));
         u64 cres = 0, ccar = 0, lm[16];
         {
           const u64 l17 = wire(per * ops + 18 * i + 17), l16 = wire(per * ops + 18 * i + 16);
@@ -497,7 +497,7 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
       for (u32 i = 0; i < nb; i++) {
         u64 prev = i == 0 ? 1 : gl_mul(prev_int, prev_int);
         u64 bit = wire(1 + (nb - 1 - i));
-        u64 mulby = gl_add(gl_mul(bit, base), gl_sub(1, bit));
+        u64 mulby = gl_mul_add(bit, base, gl_sub(1, bit));
         u64 cur = wire(nb + 2 + i);
         emit(gl_sub(gl_mul(prev, mulby), cur));
         prev_int = cur;

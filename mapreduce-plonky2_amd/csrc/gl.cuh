@@ -248,6 +248,7 @@ GLHD u64 gl_mul_addw(u64 a, u64 b, u64 c) {
   gl_mul_add_wide(a, b, c, lo, hi);
   return gl_reduce128w(lo, hi);
 }
+GLHD u64 gl_mul_add(u64 a, u64 b, u64 c) { return gl_canon(gl_mul_addw(a, b, c)); }  // canonical a b + c, any u64 inputs
 GLHD u64 gl_mulw(u64 a, u64 b) {
   u64 lo, hi;
   gl_mul_wide(a, b, lo, hi);
@@ -277,9 +278,8 @@ GLHD gl2 gl2_make(u64 a, u64 b) { gl2 r; r.a = a; r.b = b; return r; }
 GLHD gl2 gl2_add(gl2 x, gl2 y) { return gl2_make(gl_add(x.a, y.a), gl_add(x.b, y.b)); }
 GLHD gl2 gl2_sub(gl2 x, gl2 y) { return gl2_make(gl_sub(x.a, y.a), gl_sub(x.b, y.b)); }
 GLHD gl2 gl2_mul(gl2 x, gl2 y) {
-  u64 aa = gl_mul(x.a, y.a), bb = gl_mul(x.b, y.b);
-  u64 cross = gl_add(gl_mul(x.a, y.b), gl_mul(x.b, y.a));
-  return gl2_make(gl_add(aa, gl_mul_small(bb, 7)), cross);
+  // (a + b X)(c + d X) = ac + 7 bd + (ad + bc) X: the second product of each coefficient rides in the first one's addend slots
+  return gl2_make(gl_mul_add(x.a, y.a, gl_mul_small_w(gl_mulw(x.b, y.b), 7)), gl_mul_add(x.a, y.b, gl_mulw(x.b, y.a)));
 }
 GLHD gl2 gl2_scale(gl2 x, u64 s) { return gl2_make(gl_mul(x.a, s), gl_mul(x.b, s)); }
 GLHD gl2 gl2_inv(gl2 x) {

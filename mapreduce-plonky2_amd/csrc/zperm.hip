@@ -43,8 +43,9 @@ __global__ void __launch_bounds__(256) zpp_chunk_kernel(const u64* __restrict__ 
     u64 pn = 1, pd = 1;
     for (u32 t = 0; t < degree; t++, j++) {
       u64 wv = w[(u64)j << log_n];
-      pn = gl_mulw(pn, gl_addw(gl_addw(gl_mulw(bx, kis[j]), wv), gamma));
-      pd = gl_mulw(pd, gl_addw(gl_addw(gl_mulw(beta, sg[(u64)j << log_n]), wv), gamma));
+      const u64 wg = gl_addw(wv, gamma);  // shared by numerator and denominator; it rides in the products' addend slots
+      pn = gl_mulw(pn, gl_mul_addw(bx, kis[j], wg));
+      pd = gl_mulw(pd, gl_mul_addw(beta, sg[(u64)j << log_n], wg));
     }
     num[k] = pn; den[k] = gl_canon(pd);
   }
@@ -151,8 +152,9 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(const u64* __restric
       u64 num = 1, den = 1;
       for (u32 t = 0; t < degree; t++, j++) {
         u64 wv = w[(u64)j << lg];
-        num = gl_mulw(num, gl_addw(gl_addw(gl_mulw(bx, kis[j]), wv), gamma));  // weak running products
-        den = gl_mulw(den, gl_addw(gl_addw(gl_mulw(beta, sg[(u64)j << lg]), wv), gamma));
+        const u64 wg = gl_addw(wv, gamma);  // weak running products; w + gamma rides in the addend slots of beta k_j x / beta sigma_j
+        num = gl_mulw(num, gl_mul_addw(bx, kis[j], wg));
+        den = gl_mulw(den, gl_mul_addw(beta, sg[(u64)j << lg], wg));
       }
       u64 next = k == chunks - 1 ? z[((u64)c << lg) + pn] : pp[((u64)k << lg) + p];
       push(gl_sub(gl_mul(prev, num), gl_mul(next, den)));
