@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) quotient_perm_kernel(const u64* __restric
   for (u32 a = 0; a < nc; a++) al[a] = alphas[b * al_bstride + a];
   auto push = [&](u64 term) {
     for (u32 a = 0; a < nc; a++) {
-      acc[a] = gl_add(acc[a], gl_mul(term, apow[a]));
+      acc[a] = gl_mul_add(term, apow[a], acc[a]);  // term: any representative
       apow[a] = gl_mul(apow[a], al[a]);
     }
   };
