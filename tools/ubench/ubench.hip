@@ -132,6 +132,12 @@ __global__ void __launch_bounds__(256) kperm(u64* out, u64 seed, int reps) {
   for (int r = 0; r < reps; r++) poseidon2_perm(s);
   out[blockIdx.x * blockDim.x + threadIdx.x] = s[0];
 }
+__global__ void __launch_bounds__(256) kperm1(u64* out, u64 seed, int reps) {  // the original Poseidon permutation
+  u64 s[12];
+  for (int i = 0; i < 12; i++) s[i] = (seed * (threadIdx.x + 1 + i * 977) + blockIdx.x) % GL_P;
+  for (int r = 0; r < reps; r++) poseidon_perm(s);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s[0];
+}
 __global__ void kcheck(u64* bad, u64 seed) {
   u64 x = seed * (blockIdx.x * 256 + threadIdx.x + 1), y = x * 0xD1342543DE82EF95ull + 12345;
   for (int it = 0; it < 64; it++) {
@@ -190,6 +196,8 @@ int main() {
     int reps = 64;
     float ms = timeit([&] { hipLaunchKernelGGL(kperm, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull, reps); });
     printf("poseidon2_perm %8.3f ms  %8.3f Gperm/s\n", ms, (double)blocks * threads * reps / ms / 1e6);
+    ms = timeit([&] { hipLaunchKernelGGL(kperm1, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull, reps); });
+    printf("poseidon_perm  %8.3f ms  %8.3f Gperm/s\n", ms, (double)blocks * threads * reps / ms / 1e6);
   }
   return 0;
 }
