@@ -191,9 +191,13 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
       break;
     case MP2G_GATE_ARITHMETIC: {
       const u64 c0 = cst(0), c1 = cst(1);
-      for (u32 i = 0; i < g.p0; i++) {
-        u64 m0 = wire(4 * i), m1 = wire(4 * i + 1), ad = wire(4 * i + 2), o = wire(4 * i + 3);
-        emit(gl_sub(o, gl_mul_add(gl_mulw(m0, m1), c0, gl_mulw(ad, c1))));
+      u64 lm[16];
+      for (u32 i0 = 0; i0 < g.p0; i0 += 4) {  // four operations = sixteen wires in flight
+        const u32 cnt = g.p0 - i0 < 4 ? g.p0 - i0 : 4;
+        load16(4 * i0, 4 * cnt, lm);
+#pragma unroll
+        for (u32 k = 0; k < 4; k++)
+          if (k < cnt) emit(gl_sub(lm[4 * k + 3], gl_mul_add(gl_mulw(lm[4 * k], lm[4 * k + 1]), c0, gl_mulw(lm[4 * k + 2], c1))));
       }
       break;
     }
@@ -224,21 +228,37 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
     }
     case MP2G_GATE_ARITHMETIC_EXT: {
       const u64 c0 = cst(0), c1 = cst(1);
-      for (u32 i = 0; i < g.p0; i++) {
-        const u32 b = 8 * i;
-        Alg m0{wire(b), wire(b + 1)}, m1{wire(b + 2), wire(b + 3)}, ad{wire(b + 4), wire(b + 5)}, o{wire(b + 6), wire(b + 7)};
-        Alg d = alg_sub(o, alg_add(alg_scale(alg_mul(m0, m1), c0), alg_scale(ad, c1)));
-        emit(d.a); emit(d.b);
+      u64 lm[16];
+      for (u32 i0 = 0; i0 < g.p0; i0 += 2) {  // two operations = sixteen wires in flight
+        const u32 cnt = g.p0 - i0 < 2 ? g.p0 - i0 : 2;
+        load16(8 * i0, 8 * cnt, lm);
+#pragma unroll
+        for (u32 k = 0; k < 2; k++) {
+          if (k < cnt) {
+            const u64* w8 = lm + 8 * k;
+            Alg m0{w8[0], w8[1]}, m1{w8[2], w8[3]}, ad{w8[4], w8[5]}, o{w8[6], w8[7]};
+            Alg d = alg_sub(o, alg_add(alg_scale(alg_mul(m0, m1), c0), alg_scale(ad, c1)));
+            emit(d.a); emit(d.b);
+          }
+        }
       }
       break;
     }
     case MP2G_GATE_MUL_EXT: {
       const u64 c0 = cst(0);
-      for (u32 i = 0; i < g.p0; i++) {
-        const u32 b = 6 * i;
-        Alg m0{wire(b), wire(b + 1)}, m1{wire(b + 2), wire(b + 3)}, o{wire(b + 4), wire(b + 5)};
-        Alg d = alg_sub(o, alg_scale(alg_mul(m0, m1), c0));
-        emit(d.a); emit(d.b);
+      u64 lm[16];
+      for (u32 i0 = 0; i0 < g.p0; i0 += 2) {  // two operations = twelve wires in flight
+        const u32 cnt = g.p0 - i0 < 2 ? g.p0 - i0 : 2;
+        load16(6 * i0, 6 * cnt, lm);
+#pragma unroll
+        for (u32 k = 0; k < 2; k++) {
+          if (k < cnt) {
+            const u64* w6 = lm + 6 * k;
+            Alg m0{w6[0], w6[1]}, m1{w6[2], w6[3]}, o{w6[4], w6[5]};
+            Alg d = alg_sub(o, alg_scale(alg_mul(m0, m1), c0));
+            emit(d.a); emit(d.b);
+          }
+        }
       }
       break;
     }
