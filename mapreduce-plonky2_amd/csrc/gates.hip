@@ -294,9 +294,11 @@ __device__ __forceinline__ void eval_gate(const mp2g_gate g, WireF wire, ConstF 
         }
         p2_external(s);
       }
+      u64 nxt = wire(65);
 #pragma unroll 1
       for (int r = 0; r < 22; r++) {
-        u64 in = wire(65 + r);
+        const u64 in = nxt;
+        if (r < 21) nxt = wire(65 + r + 1);  // the next round's wire is on its way while this round computes
         emit(diff(s[0], c_p2_int[r], in));
         s[0] = p2_sbox(in, 0);
         p2_internal(s);
