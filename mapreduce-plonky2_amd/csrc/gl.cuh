@@ -20,9 +20,12 @@ typedef uint32_t u32;
 #define GLD __device__ __forceinline__
 #define GLHD __host__ __device__ __forceinline__
 
-// 64-bit values are handled as two 32-bit words with explicit carry chains: on gfx950 a
-// v_add_co/v_addc pair is two full-rate issue slots and hands the carry over for free, whereas a
-// 64-bit compare (v_cmp_*_u64) alone costs about four (profiles/r01/ubench_alu.txt).
+// What the operations cost on gfx950, in issue slots of a plain 32-bit add (tools/ubench, profiles/r02/ubench_alu.txt): register move
+// ~0.4, v_cndmask ~0.8, 64-bit add WITHOUT carry-out (v_lshl_add_u64) 1.6, v_mad_u64_u32 1.7, an add_co / addc pair with the hazard
+// nop hipcc puts between them 4.4, a compare ~2.5, a 64-bit compare + select + add 6.2. Hence the rules below: a carry (or borrow)
+// is taken from an add_co / addc pair or from the multiply-add's own carry-out only where the value really can wrap; every
+// correction that provably cannot wrap is a carry-less 64-bit add of a mask; sums of products go through carry-free columns
+// (gl_cols) or ride in the addend slots of the multiply-adds (gl_mul_add_wide); compares are avoided altogether.
 GLHD u64 gl_mk(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 // a in [0, 2^64) -> canonical: a >= p  <=>  a + EPS carries out of 64 bits
 GLHD u64 gl_canon(u64 a) {
