@@ -419,6 +419,39 @@ def run_ntt_leg(args, local_rank, clocks):
     return out
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU, `torch.distributed.run` on
+    127.0.0.1) as a CHILD process, before this process has imported torch or made any GPU call (a process that has
+    initialised the GPU must not exec or fork workers), pass their output through and leave with their exit code."""
+    import socket
+    import subprocess
+    if os.environ.get("MP2G_BENCH_BACKEND", "nccl") == "nccl":
+        import torch  # device_count() reads the driver's device list without initialising a device
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"bench.py: --gpus {n} needs {n} visible GPUs for the RCCL backend, this node shows {have} "
+                             "(MP2G_BENCH_BACKEND=gloo shares the devices among the ranks: a plumbing check, not a measurement)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    out = None
+    for line in p.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        if line.startswith("{"):
+            try:
+                out = json.loads(line)
+            except ValueError:
+                pass
+    rc = p.wait()
+    if rc:
+        raise SystemExit(rc)
+    return out
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -447,6 +480,8 @@ def main(argv=None):
                          "reduce circuits of recursion-framework/tests/integration.rs with universal verifiers, wrapped to the shared "
                          "shape; witnesses by the recorded witness programs on host threads, inside the timed region")
     args = ap.parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
     clocks = ClockReader()  # before anything initialises the GPU
 
     rank = int(os.environ.get("RANK", "0"))

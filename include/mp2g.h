@@ -205,6 +205,12 @@ int mp2g_map_to_curve_batch(mp2g_ctx* ctx, int variant, const uint64_t* in, uint
 /* add_curve_point (curve_add.rs:17-22) over `count` encoded points; fails on an invalid encoding */
 int mp2g_curve_sum(mp2g_ctx* ctx, const uint64_t* pts_w /* [count][5] */, uint32_t count, uint64_t out_w[5],
                    uint64_t out_weierstrass[11]);
+/* the same sum over n_ranges index ranges [start, end) of one point array at once: the accumulated digest of every node of a
+ * tree laid out in order (a subtree = one contiguous range) -- what SplitDigestPoint::accumulate (mp2-common/src/digest.rs:38-47)
+ * builds node by node up the cells tree / row tree (verifiable-db/src/cells_tree/full_node.rs:26-28,
+ * row_tree/full_node.rs:78-82). An empty range gives the neutral point. */
+int mp2g_curve_sum_ranges(mp2g_ctx* ctx, const uint64_t* pts_w /* [count][5] */, uint32_t count, const uint32_t* ranges /* [n_ranges][2] */,
+                          uint32_t n_ranges, uint64_t* out_w /* [n_ranges][5] */, uint64_t* out_weierstrass /* [n_ranges][11] */);
 /* scalar * point for 128-bit scalars given as 4 little-endian u32 limbs (hash_to_int_value,
  * mp2-common/src/poseidon.rs:120-133) */
 int mp2g_scalar_mul_batch(mp2g_ctx* ctx, const uint64_t* pts_w /* [count][5] */, const uint32_t* scalars /* [count][4] */,
@@ -220,6 +226,11 @@ int mp2g_field_hashed_scalar_mul(mp2g_ctx* ctx, int variant, const uint64_t* inp
 int mp2g_row_digest_batch(mp2g_ctx* ctx, int variant, const uint64_t* col_ids, uint32_t n_cols,
                           const uint32_t* values, const uint32_t* unique, uint32_t n_unique, uint32_t rows,
                           uint64_t out_w[5], uint64_t out_weierstrass[11]);
+/* the per-row terms of that sum, row_id * sum over columns of D(id_c || value_c): the individual digest a row-tree node
+ * contributes (verifiable-db/src/row_tree/secondary_index_cell.rs:99-139 with every cell individual) */
+int mp2g_row_digests(mp2g_ctx* ctx, int variant, const uint64_t* col_ids, uint32_t n_cols, const uint32_t* values,
+                     const uint32_t* unique, uint32_t n_unique, uint32_t rows, uint64_t* out_w /* [rows][5] */,
+                     uint64_t* out_weierstrass /* [rows][11] */);
 /* same with device-resident inputs; d_frac_out [20] receives the sum in fractional coordinates
  * (X:Z:U:T) for further accumulation, out_w / out_weierstrass are host pointers (may be NULL) */
 int mp2g_row_digest_batch_dev(mp2g_ctx* ctx, int variant, const uint64_t* d_col_ids, uint32_t n_cols,

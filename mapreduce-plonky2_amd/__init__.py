@@ -599,6 +599,17 @@ def curve_sum(ctx, pts_w, weierstrass=False):
     return (w, wei) if weierstrass else w
 
 
+def curve_sum_ranges(ctx, pts_w, ranges):
+    """the sum of pts_w[start:end] for every (start, end) of `ranges` in one call: the accumulated digest of every node of a
+    tree laid out in order. Returns (encodings [n][5], Weierstrass forms [n][11])."""
+    a = _arr(pts_w).reshape(-1, 5)
+    r = _arr(ranges, np.uint32).reshape(-1, 2)
+    w = np.empty((r.shape[0], 5), dtype=np.uint64)
+    wei = np.empty((r.shape[0], 11), dtype=np.uint64)
+    _ck(load().mp2g_curve_sum_ranges(ctx.h, _p(a), a.shape[0], _p(r), r.shape[0], _p(w), _p(wei)))
+    return w, wei
+
+
 def scalar_mul_batch(ctx, pts_w, scalars):
     """scalars: python ints < 2^128 (hash_to_int_value range)."""
     a = _arr(pts_w).reshape(-1, 5)
@@ -637,6 +648,19 @@ def compute_table_row_digest(ctx, col_ids, values, unique, variant=POSEIDON2):
     w = np.empty(5, dtype=np.uint64)
     wei = np.empty(11, dtype=np.uint64)
     _ck(load().mp2g_row_digest_batch(ctx.h, variant, _p(ids), n_cols, _p(v), _p(u), n_unique, rows, _p(w), _p(wei)))
+    return w, wei
+
+
+def row_digests(ctx, col_ids, values, unique, variant=POSEIDON2):
+    """the per-row terms of compute_table_row_digest, row_id * sum_c D(id_c || value_c): (encodings [rows][5], Weierstrass [rows][11])"""
+    ids = _arr(col_ids)
+    v = _arr(values, np.uint32)
+    u = _arr(unique, np.uint32)
+    rows, n_cols = v.shape[0], ids.size
+    n_unique = u.shape[1] if u.ndim == 3 else 0
+    w = np.empty((rows, 5), dtype=np.uint64)
+    wei = np.empty((rows, 11), dtype=np.uint64)
+    _ck(load().mp2g_row_digests(ctx.h, variant, _p(ids), n_cols, _p(v), _p(u), n_unique, rows, _p(w), _p(wei)))
     return w, wei
 
 

@@ -59,6 +59,24 @@ int mp2g_curve_sum(mp2g_ctx* c, const uint64_t* pts_w, uint32_t count, uint64_t 
   return copy_out(c, dw, dwei, 1, out_w, out_wei);
 }
 
+int mp2g_curve_sum_ranges(mp2g_ctx* c, const uint64_t* pts_w, uint32_t count, const uint32_t* ranges, uint32_t n_ranges,
+                          uint64_t* out_w, uint64_t* out_wei) {
+  NEED(c && (pts_w || !count) && (ranges || !n_ranges), "ctx/pts/ranges");
+  for (uint32_t i = 0; i < n_ranges; i++) NEED(ranges[2 * i] <= ranges[2 * i + 1] && ranges[2 * i + 1] <= count, "range outside the points");
+  if (!n_ranges) return 0;
+  DevBuf frac, dr, fout, dw, dwei;
+  int rc = decode_host(c, pts_w, count, frac);
+  if (rc) return rc;
+  CK(dr.alloc((size_t)n_ranges * 8));
+  CK(fout.alloc((size_t)n_ranges * 20 * sizeof(u64)));
+  CK(dw.alloc((size_t)n_ranges * 5 * sizeof(u64)));
+  CK(dwei.alloc((size_t)n_ranges * 11 * sizeof(u64)));
+  CK(hipMemcpyAsync(dr.p, ranges, (size_t)n_ranges * 8, hipMemcpyHostToDevice, c->stream));
+  CK(ec_sum_ranges(c->stream, frac.p, (const u32*)dr.p, n_ranges, fout.p));
+  CK(ec_emit(c->stream, fout.p, n_ranges, out_w ? dw.p : nullptr, out_wei ? dwei.p : nullptr));
+  return copy_out(c, dw, dwei, n_ranges, out_w, out_wei);
+}
+
 int mp2g_scalar_mul_batch(mp2g_ctx* c, const uint64_t* pts_w, const uint32_t* scalars, uint32_t count, uint64_t* out_w,
                           uint64_t* out_wei) {
   NEED(c && ((pts_w && scalars) || !count), "ctx/pts/scalars");
@@ -102,6 +120,27 @@ int mp2g_row_digest_batch_dev(mp2g_ctx* c, int variant, const uint64_t* d_col_id
   if (d_frac_out) CK(hipMemcpyAsync(d_frac_out, scratch.p, 20 * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
   if (out_w || out_wei) CK(ec_emit(c->stream, scratch.p, 1, out_w ? dw.p : nullptr, out_wei ? dwei.p : nullptr));
   return copy_out(c, dw, dwei, 1, out_w, out_wei);
+}
+
+int mp2g_row_digests(mp2g_ctx* c, int variant, const uint64_t* col_ids, uint32_t n_cols, const uint32_t* values, const uint32_t* unique,
+                     uint32_t n_unique, uint32_t rows, uint64_t* out_w, uint64_t* out_wei) {
+  NEED(c && (col_ids || !n_cols), "ctx/col_ids");
+  NEED(variant == 0 || variant == 1, "variant");
+  NEED((values || !n_cols || !rows) && (unique || !n_unique || !rows), "values/unique");
+  if (!rows) return 0;
+  DevBuf dc, dv, du, frac, dw, dwei;
+  CK(dc.alloc((size_t)n_cols * sizeof(u64)));
+  CK(dv.alloc((size_t)rows * n_cols * 32));
+  CK(du.alloc((size_t)rows * n_unique * 32));
+  CK(frac.alloc((size_t)rows * 20 * sizeof(u64)));
+  CK(dw.alloc((size_t)rows * 5 * sizeof(u64)));
+  CK(dwei.alloc((size_t)rows * 11 * sizeof(u64)));
+  if (n_cols) CK(hipMemcpyAsync(dc.p, col_ids, (size_t)n_cols * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  if (n_cols) CK(hipMemcpyAsync(dv.p, values, (size_t)rows * n_cols * 32, hipMemcpyHostToDevice, c->stream));
+  if (n_unique) CK(hipMemcpyAsync(du.p, unique, (size_t)rows * n_unique * 32, hipMemcpyHostToDevice, c->stream));
+  CK(ec_row_digest(c->stream, variant, (const u64*)dc.p, n_cols, (const u32*)dv.p, (const u32*)du.p, n_unique, rows, frac.p));
+  CK(ec_emit(c->stream, frac.p, rows, out_w ? dw.p : nullptr, out_wei ? dwei.p : nullptr));
+  return copy_out(c, dw, dwei, rows, out_w, out_wei);
 }
 
 int mp2g_row_digest_batch(mp2g_ctx* c, int variant, const uint64_t* col_ids, uint32_t n_cols, const uint32_t* values,

@@ -367,6 +367,25 @@ __global__ void __launch_bounds__(128) sum_kernel(const u64* pts, u32 count, u64
   }
   if (t < 20) out[20 * (u64)blockIdx.x + t] = sm[t];
 }
+// out[blockIdx] = sum of pts[ranges[blockIdx][0] .. ranges[blockIdx][1]): one 64-lane block per range (a subtree of a tree laid out in
+// order is one contiguous range), lanes stride through the range, then a tree over the wave through LDS
+__global__ void __launch_bounds__(64) sum_ranges_kernel(const u64* pts, const u32* ranges, u64* out) {
+  __shared__ u64 sm[64 * 20];
+  const u32 t = threadIdx.x, lo = ranges[2 * blockIdx.x], hi = ranges[2 * blockIdx.x + 1];
+  pt acc = pt_neutral();
+  for (u32 i = lo + t; i < hi; i += 64) acc = pt_add(acc, pt_load(pts + 20 * (u64)i));
+  pt_store(sm + 20 * t, acc);
+  __syncthreads();
+#pragma unroll 1
+  for (u32 s = 32; s > 0; s >>= 1) {
+    if (t < s && lo + t + s < hi) {  // lanes past the range hold the neutral point
+      pt a = pt_load(sm + 20 * t), b = pt_load(sm + 20 * (t + s));
+      pt_store(sm + 20 * t, pt_add(a, b));
+    }
+    __syncthreads();
+  }
+  if (t < 20) out[20 * (u64)blockIdx.x + t] = sm[t];
+}
 __global__ void emit_kernel(const u64* frac, u32 count, u64* w_out, u64* wei_out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -441,6 +460,11 @@ hipError_t ec_sum(hipStream_t s, const u64* frac, u32 count, u64* scratch) {
   } else {
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(128), 0, s, frac, count, scratch);
   }
+  return hipGetLastError();
+}
+hipError_t ec_sum_ranges(hipStream_t s, const u64* frac, const u32* ranges, u32 n_ranges, u64* frac_out) {
+  if (!n_ranges) return hipSuccess;
+  hipLaunchKernelGGL(sum_ranges_kernel, dim3(n_ranges), dim3(64), 0, s, frac, ranges, frac_out);
   return hipGetLastError();
 }
 hipError_t ec_emit(hipStream_t s, const u64* frac, u32 count, u64* w_out, u64* wei_out) {

@@ -1,0 +1,98 @@
+"""table.py on the CPU: the tree shapes against ryhope's sbbst, the circuit sets' shapes, and a one-row table (4 cells-tree proofs +
+1 row-tree proof, every one base + wrap) with the oracle as the proving back end; the root's public inputs are the off-circuit
+tree hash / digest / min / max."""
+import importlib
+
+import numpy as np
+import pytest
+
+import circuits as C
+import oracle as O
+from table_oracle import OracleTableWitness
+from test_recursion import OracleProver
+
+T = importlib.import_module("mapreduce-plonky2_amd.table")
+R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+
+
+def test_sbbst_shape_restates_ryhope():
+    """ryhope/src/tree/sbbst.rs: root = highest power of two <= n; a node's missing right child is replaced by the first
+    in-range node down its left spine; in-order spans are contiguous and partition under a node"""
+    assert [T.sbbst_root(n) for n in (1, 2, 3, 4, 5, 7, 8, 9)] == [1, 2, 2, 4, 4, 4, 8, 8]
+    assert T.sbbst_children(4, 4) == (2, None) and T.sbbst_children(4, 2) == (1, 3) and T.sbbst_children(4, 1) == (None, None)
+    assert T.sbbst_children(5, 4) == (2, 5) and T.sbbst_children(6, 4) == (2, 6) and T.sbbst_children(6, 6) == (5, None)
+    assert T.sbbst_children(9, 8) == (4, 9) and T.sbbst_children(11, 8) == (4, 10) and T.sbbst_children(11, 10) == (9, 11)
+    for n in range(1, 40):
+        seen = []
+
+        def walk(k):
+            l, r = T.sbbst_children(n, k)
+            lo, hi = T.sbbst_span(n, k)
+            if l is not None:
+                walk(l)
+            seen.append(k)
+            if r is not None:
+                walk(r)
+            under = [x for x in range(lo, hi + 1)]
+            assert k in under
+
+        walk(T.sbbst_root(n))
+        assert seen == list(range(1, n + 1))  # a BST over 1..n holding every position once
+
+
+def test_balanced_bst_spans():
+    for n in (1, 2, 3, 7, 8, 100):
+        root, nodes, spans = T.balanced_bst(n)
+        assert sorted(nodes) == list(range(n)) and spans[root] == (0, n)
+        for k, (l, r) in nodes.items():
+            lo, hi = spans[k]
+            assert (spans[l] == (lo, k) if l is not None else lo == k) and (spans[r] == (k + 1, hi) if r is not None else hi == k + 1)
+
+
+@pytest.fixture(scope="module")
+def params():
+    empty = O.hash_n_to_m_no_pad(np.zeros(0, dtype=np.uint64), 4)
+    return T.TableParams(OracleProver(), FW.circuit_fri_params, empty)
+
+
+def test_circuit_sets_have_the_reference_shapes(params):
+    """cells set of 4 (api.rs:143), row set of 3 (row_tree/api.rs:47); 28 / 43 public inputs + the set digest; every chain ends at
+    RECURSION_THRESHOLD; the row full node (two row proofs + the cells proof = three verifiers) needs 2^14 rows and two wrap steps"""
+    assert params.cells.set_size == 4 and params.rows.set_size == 3
+    sh = params.shapes()
+    assert all(v[-1] == R.RECURSION_THRESHOLD for v in sh.values())
+    assert sh["row_full"] == [14, 13, 12] and sh["cells_full"] == [13, 12] and sh["row_leaf"][0] == 12
+    assert len(params.cells.chains["cells_full"][0][0].public_inputs) == T.CELLS_IO + 4
+    assert len(params.rows.chains["row_full"][0][0].public_inputs) == T.ROWS_IO + 4
+    assert R.common_data(params.cells.chains["cells_leaf"][-1][0]) == params.cells.rec_common
+
+
+class _Ctx:
+    """the two calls expected_root_public_inputs makes on a context, by the oracle"""
+
+    def hash_no_pad_batch(self, inputs, out_len=4, variant=0):
+        a = np.asarray(inputs, dtype=np.uint64)
+        if a.shape[1] == 0:
+            return np.stack([O.hash_n_to_m_no_pad(np.zeros(0, dtype=np.uint64), out_len, variant)] * a.shape[0])
+        return O.hash_no_pad_batch(a, out_len, variant)
+
+
+def test_one_row_table_on_the_oracle_prover(params):
+    table = T.SyntheticTable(1, 4, seed=0xC0FFEE04)
+    root, nodes, spans = T.balanced_bst(1)
+    wit = OracleTableWitness(table, spans)
+    build = T.TableBuild(params, [R.ProofSession(OracleProver())], batch=4, subtree_size=1, host_threads=4)
+    proof, name = build.run(table, wit, root, nodes)
+    assert name == "row_leaf" and build.n_proofs == 5
+    pis = proof[3]
+    want = T.expected_root_public_inputs(_Ctx(), table, wit, root, nodes, spans)
+    assert np.array_equal(pis[:T.ROWS_IO], want)
+    assert np.array_equal(pis[T.ROWS_IO:], np.asarray(params.rows.set_digest, dtype=np.uint64))
+    # one row: its tree digest is the table's (compute_table_row_digest over the single row)
+    ow, owei = np.zeros(5, dtype=np.uint64), np.zeros(11, dtype=np.uint64)
+    O.lib().orc_row_digest_batch(0, O.p(O.arr(table.col_ids)), O.sz(5), O.p(O.arr(table.values, np.uint32)), O.p(O.arr(table.values[:, 0:1], np.uint32)),
+                                 O.sz(1), O.sz(1), O.p(ow), O.p(owei))
+    assert np.array_equal(pis[4:15], owei)
+    wckt, wcap, wdig = params.rows.chains["row_leaf"][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *proof[:3]) == 0
