@@ -419,6 +419,69 @@ def run_ntt_leg(args, local_rank, clocks):
     return out
 
 
+def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
+    """the kernel-level half of the metric, measured in the same process as the proving loop: the `roofline` object (configs[1]'s
+    2^22-point forward NTT, HIP events on the stream the kernels run on, algorithmic 16 B / point), the batched 2^12 shape the
+    prover runs, and the sponge rate. Returns the three JSON objects."""
+    n_ntt = 1 << LOG_NTT
+    d_poly = ctx.to_device(C.rand_field((1, n_ntt), 0xC0FFEE02 + rank))
+    d_out = ctx.alloc(n_ntt * 8)
+    # roofline leg: the 2^22 NTT, HIP events on the stream the kernels are launched on. 1000 untimed transforms first: the leg is
+    # 55-60 us long and follows the clocks, which need tens of ms of this kernel to settle after the prover's steps (tools/dbg/ntt_leg_burst.sh:
+    # 61 / 58 / 55 us as the median of 20 / 200 / 1000 back-to-back transforms); then 50 timed ones, each between its own events
+    for _ in range(1000):
+        ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
+    ntt_ms = []
+    for _ in range(50):
+        ctx.timer_start()
+        ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
+        ntt_ms.append(ctx.timer_stop())
+
+    # the same kernel family on the shape the prover actually runs: 8192 transforms of 2^12 points
+    # (LDE-sized batch, no tail effects); reported beside the roofline leg, not as `value`
+    nb12 = 8192
+    d_b12 = ctx.alloc(nb12 * 4096 * 8)
+    ctx.ntt_dev(d_b12, d_b12, 12, nb12, bitrev_out=True)
+    ctx.timer_start()
+    ctx.ntt_dev(d_b12, d_b12, 12, nb12, bitrev_out=True)
+    ntt12_ms = ctx.timer_stop()
+    d_b12.free()
+
+    # the sponge, the kernel that takes half of a step: 2^21 leaves of 136 limbs (17 permutations each), the rate
+    # of the instruction-bound Poseidon2 permutation (DESIGN.md section 4); reported beside the roofline leg
+    n_hash, limbs = 1 << 21, 136
+    d_hin = ctx.alloc(n_hash * limbs * 8)
+    d_hout = ctx.alloc(n_hash * 4 * 8)
+    hargs = (ctx.h, VARIANT, d_hin.ptr, limbs, n_hash, 4, d_hout.ptr)
+    mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
+    ctx.timer_start()
+    mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
+    hash_ms = ctx.timer_stop()
+    d_hin.free(); d_hout.free()
+
+    d_poly.free(); d_out.free()
+    # HBM-side bytes of the same two launches from the TCC counters (collected in separate
+    # --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/rNN/ntt_traffic.json)
+    traffic = None
+    for rnd in ("r03", "r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "ntt_traffic.json")) as f:
+                traffic = json.load(f)["ntt_2p22_forward_bitrev"]["traffic_bytes"]
+            break
+        except (OSError, KeyError, ValueError):
+            pass
+    ntt_s = float(np.median(ntt_ms)) / 1e3
+    achieved = 16.0 * n_ntt / ntt_s / 1e9
+    return {"roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, all launches)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "launch_ms": ntt_s * 1e3, "algorithmic_bytes": 16 * n_ntt},
+            "ntt_batched_2p12": {"transforms": nb12, "GBps": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9,
+                                 "frac_of_hbm_peak": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9 / HBM_PEAK_GBPS},
+            "sponge": {"hasher": hasher, "permutations_per_s": n_hash * (limbs // 8) / (hash_ms / 1e3), "bound": "VALU issue (integer ALU)",
+                       "input": f"{n_hash} x {limbs} limbs, hash_no_pad, resident"}}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU, `torch.distributed.run` on
     127.0.0.1) as a CHILD process, before this process has imported torch or made any GPU call (a process that has
@@ -473,8 +536,15 @@ def main(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the sampled proofs")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work for the cpu_baseline sample")
     ap.add_argument("--trees", type=int, default=8, help="--workload recursion: independent trees per rank and step, one host thread + GPU stream each")
-    ap.add_argument("--workload", choices=("leaves", "tree", "recursion", "ntt"), default="leaves",
-                    help="leaves (default, the headline): independent leaf proofs. tree: every step also proves the 2-to-1 aggregation "
+    ap.add_argument("--rows", type=int, default=512, help="--workload table: table rows per rank and step (5 framework proofs each)")
+    ap.add_argument("--workers", type=int, default=4, help="--workload table: concurrent work-plan items per rank, one host thread + GPU stream + prover set each")
+    ap.add_argument("--table-batch", type=int, default=32, help="--workload table: proofs per prove() launch sequence of a worker")
+    ap.add_argument("--subtree", type=int, default=64, help="--workload table: into_batched_workplan(subtree_size), the rows of one work-plan item")
+    ap.add_argument("--no-leaves-leg", action="store_true", help="--workload table: skip the short prove()-only leg reported beside the headline")
+    ap.add_argument("--workload", choices=("table", "leaves", "tree", "recursion", "ntt"), default="table",
+                    help="table (default, the headline): BASELINE configs[3] sampled -- per row 4 cells-tree + 1 row-tree REAL framework proofs, work-plan "
+                         "scheduled, witness generation inside the timed region (run_table). leaves: prove() only on synthetic circuits with resident witnesses "
+                         "(last round's headline). tree: every step also proves the 2-to-1 aggregation "
                          "levels above the leaves -- locally below the shard boundary, then log2(ranks) levels whose child proofs move "
                          "between ranks with point-to-point send/recv (RCCL on device tensors). recursion: REAL circuits -- the map / "
                          "reduce circuits of recursion-framework/tests/integration.rs with universal verifiers, wrapped to the shared "
@@ -510,6 +580,237 @@ def main(argv=None):
         out = run_ntt_leg(args, local_rank, clocks)
         clocks.close()
         return out
+    if args.workload == "table":
+        return run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks)
+    return run_leaves(args, rank, local_rank, world, dist, torch, VARIANT, clocks)
+
+
+def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
+    """--workload table (the default, the headline): BASELINE configs[3] as a sample of `--rows` table rows per rank and step.
+    Per row the reference proves C = 4 cells-tree nodes (ryhope sbbst over the value columns: two leaves, a full node, a partial
+    node) and one row-tree node that verifies the cells root against the cells circuit set and its 0 / 1 / 2 row children
+    (mapreduce-plonky2_amd/table.py; verifiable-db/src/cells_tree/api.rs, row_tree/api.rs; mp2-v1/tests/common/celltree.rs:54-189,
+    rowtree.rs:78-337). Every one of the 5 x rows framework proofs of a step is REAL: witness generation from its recorded witness
+    program (host threads), upload, base prove() with the device-side witness check, the wrap chain down to 2^12 rows (one wrap,
+    two for the three-verifier row full node: 2^14 -> 2^13 -> 2^12), download of what the parent verifies. The row tree of the rank's
+    block (a BST over the secondary index, every node a row) is scheduled by ryhope's batched work plan (mp2g_update_plan_*,
+    updatetree.rs:154-163,449-531): an item = a spun-off subtree = the unit one worker (GPU stream + provers + pinned wire
+    matrices) proves bottom-up, `--workers` of them concurrently. The off-circuit side of the same rows -- value digests, their
+    accumulation up both trees, row ids (mp2g_map_to_curve_batch, mp2g_row_digests, mp2g_curve_sum_ranges) -- is inside the timed
+    region too. With several ranks every rank builds its own block and log2(ranks) join levels follow: the owner of a parent
+    receives the other block's root proof (bincode bytes, point to point) and proves the separator row between the blocks.
+    value = framework proofs per second. After the timed region: the root's public inputs are compared with the off-circuit tree
+    hash / digest / min / max; sampled framework proofs of the last step (one of every circuit kind that occurred) are re-proved
+    from their captured witnesses by the CPU oracle -- bit-exact and verified; those oracle proofs are the cpu_baseline sample --
+    and the whole-table multiset digest of 2^20 rows is timed once for the extrapolation."""
+    assert VARIANT == 0, "the recursive verifier circuit of recursion.py hashes with Poseidon2 gates (the reference's default config)"
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+    FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+    C = importlib.import_module("mapreduce-plonky2_amd.circuits")
+    T = importlib.import_module("mapreduce-plonky2_amd.table")
+    IX = importlib.import_module("mapreduce-plonky2_amd.indexing")
+    sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
+    n_workers, n_rows, n_cols = max(1, args.workers), args.rows, 4
+    ctxs = [mp2.Context(local_rank) for _ in range(n_workers)]
+    ctx = ctxs[0]
+    provers = [FW.GpuProver(c, VARIANT, witness_check=True, capacity=args.table_batch) for c in ctxs]
+    sessions = [R.ProofSession(p) for p in provers]
+    t_setup = time.perf_counter()
+    params = T.TableParams(provers[0], lambda ckt: FW.circuit_fri_params(ckt, VARIANT), IX.empty_poseidon_hash(ctx, VARIANT))
+    t_setup = time.perf_counter() - t_setup
+    ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    host_threads = max(1, (os.cpu_count() or 1) // (n_workers * ranks_here))
+    build = T.TableBuild(params, sessions, batch=args.table_batch, subtree_size=args.subtree, host_threads=host_threads)
+    table = T.SyntheticTable(n_rows, n_cols, seed=0xC0FFEE04, block=2 * rank)
+    root, nodes, spans = T.balanced_bst(n_rows)
+    nccl = dist is not None and dist.get_backend() == "nccl"
+    dev = torch.device("cuda", local_rank) if nccl else None
+    final_ckt = params.rows.chains["row_leaf"][-1][0]  # every final proof of the row set has this shape (the shared common data)
+    final_fp = FW.circuit_fri_params(final_ckt, VARIANT)
+    n_pis = T.ROWS_IO + 4
+    names = list(params.rows.circuits)
+    last = {}
+
+    def step():
+        wit = T.TableWitness(ctx, table, spans, VARIANT)
+        proof, name = build.run(table, wit, root, nodes)
+        last["wit"], last["block_root"] = wit, (proof, name)
+        cur = (proof, name, wit.root_digest_w[root])
+        for lvl in range(world.bit_length() - 1):  # above the shard boundary: the separator rows between the ranks' blocks
+            bit = 1 << lvl
+            if rank & (bit - 1):
+                break
+            if rank & bit:
+                blob = mp2.serialize_proof(final_fp, final_ckt.num_constants, *cur[0])
+                sharding.exchange_bytes(dist, bytes([names.index(cur[1])]) + np.asarray(cur[2], dtype=np.uint64).tobytes() + blob, rank, rank - bit, dev)
+                break
+            got = sharding.exchange_bytes(dist, None, rank + bit, rank, dev)
+            other = mp2.deserialize_proof(final_fp, final_ckt.num_constants, got[41:], n_pis)
+            cur = T.join_blocks(build, ctx, cur, (tuple(other), names[got[0]], np.frombuffer(got[1:41], dtype=np.uint64)), 2 * (rank + bit) - 1, n_cols, 0xC0FFEE04, VARIANT)
+        return cur
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.sync()
+
+    for _ in range(max(1, args.warmup)):  # the first pass creates the provers of every (circuit, batch width)
+        cur = step()
+    barrier()
+    n0 = build.n_proofs
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cur = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    n_local = build.n_proofs - n0
+    if dist is not None:
+        t = torch.tensor([dt, float(n_local)], device="cuda" if nccl else "cpu", dtype=torch.float64)
+        dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:2], op=dist.ReduceOp.SUM)
+        dt, n_total = float(t[0].item()), int(t[1].item())
+    else:
+        n_total = n_local
+
+    # ---- checks (outside the timed region) ---------------------------------------------------------------------------------
+    # every rank: its block's root exposes the off-circuit tree hash, multiset digest, min / max of the block
+    wit = last["wit"]
+    block_pis = last["block_root"][0][3]
+    want = T.expected_root_public_inputs(ctx, table, wit, root, nodes, spans, VARIANT)
+    assert np.array_equal(block_pis[:T.ROWS_IO], want), "the block root's public inputs differ from the off-circuit tree hash / digest / min / max"
+    assert np.array_equal(block_pis[T.ROWS_IO:], np.asarray(params.rows.set_digest, dtype=np.uint64)), "circuit-set digest"
+    w_all, wei_all = mp2.compute_table_row_digest(ctx, table.col_ids, table.values, table.values[:, 0:1])
+    assert np.array_equal(wei_all, block_pis[4:15]), "individual digest != compute_table_row_digest of the block"
+    verified, cpu_base, sample_desc = 0, None, ""
+    if rank == 0:
+        root_pis = cur[0][3]
+        if world > 1:  # the joined tree: digest = the whole table's (blocks and separators), min of block 0, max of the last block
+            ws = [w_all]
+            for r in range(1, world):
+                tb = T.SyntheticTable(n_rows, n_cols, 0xC0FFEE04, 2 * r)
+                ws.append(mp2.compute_table_row_digest(ctx, tb.col_ids, tb.values, tb.values[:, 0:1])[0])
+            for s_ in range(world - 1):
+                tb = T.SyntheticTable(1, n_cols, 0xC0FFEE04, 2 * s_ + 1)
+                ws.append(mp2.compute_table_row_digest(ctx, tb.col_ids, tb.values, tb.values[:, 0:1])[0])
+            assert np.array_equal(mp2.curve_sum(ctx, np.stack(ws), weierstrass=True)[1], root_pis[4:15]), "root digest != digest of the whole table"
+            assert np.array_equal(root_pis[26:34], want[26:34]), "root min != min of block 0"
+    if not args.no_verify:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import circuits as OC
+        # one framework proof of every circuit kind of the last step, re-proved with capture from the inputs the timed run used
+        cap = []
+        sess = sessions[0]
+        row0 = 0
+        cells = {}
+        Cn = table.n_cols
+        for k in sorted(range(1, Cn + 1), key=lambda k: ((k & -k).bit_length(), k)):
+            kids = [c for c in T.sbbst_children(Cn, k) if c is not None]
+            name = ("cells_leaf", "cells_partial", "cells_full")[len(kids)]
+            flat = T._u64cat([table.col_ids[k]], table.values[row0, k], [0], wit.cell_digest[row0, k - 1], T.NEUTRAL_FIELDS)
+            (pr,) = params.cells.generate_proofs_batch(name, [([cells[c][0] for c in kids], [cells[c][1] for c in kids], flat)], session=sess, capture=cap)
+            cells[k] = (pr, name)
+        root_cells = cells[T.sbbst_root(Cn)]
+        assert all(np.array_equal(a, b) for a, b in zip(root_cells[0], build.cells_roots[row0][0])), "re-proved cells root != the timed run's"
+        seen = set()
+        for k in [row0] + sorted(nodes, key=lambda k: -(spans[k][1] - spans[k][0])):
+            kind = sum(c is not None for c in nodes[k])
+            if kind in seen:
+                continue
+            seen.add(kind)
+            name, job = build.row_job(table, wit, nodes, k, build.cells_roots[k], build.row_proofs)
+            (pr,) = params.rows.generate_proofs_batch(name, [job], session=sess, capture=cap)
+            assert all(np.array_equal(a, b) for a, b in zip(pr, build.row_proofs[k][0])), f"re-proved {name} != the timed run's"
+        # group the captured prove() calls by framework proof (a chain of steps), all mandatory
+        samples, chain = [], []
+        for (name, stp, ckt, digest, wires, ph, caps, openings, proof) in cap:
+            if stp == 0 and chain:
+                samples.append(chain)
+                chain = []
+            chain.append((f"{name} step {stp}", ckt, OC.oracle_params(ckt), np.asarray(digest, dtype=np.uint64), (lambda w=wires: w), ph, caps, openings, proof, True))
+        samples.append(chain)
+        timed = world == 1 and not args.no_cpu_baseline
+        verified, cpu_base = check_against_oracle(samples, args.cpu_budget, timed, ranks_here)
+        if cpu_base is not None:
+            kinds = [c[0][0].rsplit(" step", 1)[0] for c in samples]
+            cpu_base["unit"] = "proofs/s"
+            cpu_base["sample"] = (f"{len(samples)} framework proofs of the last step ({', '.join(kinds)}: {sum(len(c) for c in samples)} prove() calls of 2^6..2^14 rows) re-proved "
+                                  "from their captured witnesses by oracle/ (our C restatement, not the Rust prover); every one compared bit for bit with the GPU's and verified")
+    if dist is not None:
+        v = torch.tensor([verified], device="cuda" if nccl else "cpu", dtype=torch.int64)
+        dist.all_reduce(v)
+        verified = int(v.item())
+
+    # the whole-table multiset digest at BASELINE size (2^20 rows x 5 columns), device resident, timed once
+    digest_ms = None
+    if rank == 0:
+        big = 1 << 20
+        rng = np.random.default_rng(0xC0FFEE04)
+        d_ids = ctx.to_device(table.col_ids)
+        d_values = ctx.to_device(rng.integers(0, 1 << 32, size=(big, n_cols + 1, 8), dtype=np.uint32))
+        d_unique = ctx.to_device(rng.integers(0, 1 << 32, size=(big, 1, 8), dtype=np.uint32))
+        mp2.compute_table_row_digest_dev(ctx, d_ids, n_cols + 1, d_values, d_unique, 1, 1 << 12)
+        t1 = time.perf_counter()
+        mp2.compute_table_row_digest_dev(ctx, d_ids, n_cols + 1, d_values, d_unique, 1, big)
+        digest_ms = (time.perf_counter() - t1) * 1e3
+        for b_ in (d_ids, d_values, d_unique):
+            b_.free()
+
+    legs = kernel_legs(ctx, mp2, C, VARIANT, args.hasher, rank) if rank == 0 else None
+    shapes = params.shapes()
+    for p_ in provers:
+        p_.free()
+    for c in reversed(ctxs):
+        c.close()
+    # the prove()-only loop on synthetic circuits (last round's headline) beside it, briefly
+    leaves = None
+    if not args.no_leaves_leg:
+        import copy
+        a2 = copy.copy(args)
+        a2.steps, a2.warmup, a2.batch = 3, 1, 128
+        leaves = run_leaves(a2, rank, local_rank, world, dist, torch, VARIANT, clocks, brief=True)
+    out = None
+    if rank == 0:
+        rows_per_s = world * n_rows * args.steps / dt
+        out = {"metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build, 1/2/4/8 GPU",
+               "value": n_total / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u64 (Goldilocks field)", "data": "synthetic", "verified": verified,
+               "rows_per_s": rows_per_s,
+               "table_2p20_rows_extrapolated_s": (1 << 20) / rows_per_s + (digest_ms or 0) / 1e3,
+               "table_digest_2p20_rows_ms": digest_ms,
+               "config": {"workload": f"table: configs[3] sampled at {n_rows} rows per rank and step -- per row {n_cols} cells-tree proofs (2 leaves, 1 full, 1 partial) + 1 "
+                                      "row-tree proof (leaf / partial / full + the cells root through the cells-set verifier gadget), all REAL framework proofs = witness "
+                                      "program + base prove() + wrap chain to 2^12 rows, witness check on; row tree scheduled by the batched UpdateTree work plan; the rows' "
+                                      "multiset digests (map-to-curve, row ids, accumulation up both trees) inside the timed region; value = framework proofs/s "
+                                      "(5 per row); roofline leg = configs[1] 2^22-point NTT",
+                          "rows_per_rank_and_step": n_rows, "value_columns": n_cols, "workers": n_workers, "batch": args.table_batch, "subtree_size": args.subtree,
+                          "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "shapes": shapes,
+                          "setup_s": round(t_setup, 1), "hasher": "Poseidon2",
+                          "sharding": f"{world} rank(s): one block of rows each, no collective below the block roots; {world.bit_length() - 1} join level(s) move a root proof point to point",
+                          "root_public_inputs": [int(x) for x in cur[0][3]],
+                          "verified": f"{verified} prove() calls of sampled framework proofs (one of every circuit kind of the last step, on every rank) equal the CPU "
+                                      "oracle's proofs of the same witnesses bit for bit and pass its verifier; the block roots expose the off-circuit tree hash, "
+                                      "digest (= compute_table_row_digest of the block), min, max and the circuit-set digest"},
+               "clocks": clocks.read(local_rank)}
+        if leaves is not None:
+            out["leaves_prove_only"] = {"value": leaves["value"], "unit": "leaf proofs/s (base 2^13 + wrap 2^12 prove() on synthetic circuits, resident witnesses: "
+                                        "`--workload leaves`, last round's headline)", "ms_per_step": leaves["ms_per_step"], "batch": 128}
+        out.update(legs)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
+        print(json.dumps(out))
+    clocks.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return out
+
+
+def run_leaves(args, rank, local_rank, world, dist, torch, VARIANT, clocks, brief=False):
+    """--workload leaves: prove() only, on synthetic circuits with resident witnesses (the module docstring's first paragraph). With
+    `brief` (the table workload's side leg) nothing is verified or printed and the kernel legs are skipped: returns the line's dict."""
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
     C = importlib.import_module("mapreduce-plonky2_amd.circuits")  # synthetic circuit + witness generator (pure Python)
@@ -551,10 +852,6 @@ def main(argv=None):
             view[:] = np.frombuffer(d_w.download((d_w.nbytes // 8,)).tobytes(), dtype=np.uint8)
             staging.append((d_w, hptr, d_w.nbytes))
         provers.append((cp, d_w, d_ph, cx, staging, wseed, pi_hash, role))
-    n_ntt = 1 << LOG_NTT
-    d_poly = ctx.to_device(C.rand_field((1, n_ntt), 0xC0FFEE02 + rank))
-    d_out = ctx.alloc(n_ntt * 8)
-
     def step():
         for cp, d_w, d_ph, cx, staging, *_ in provers:
             for buf, hptr, nbytes in staging:
@@ -569,38 +866,7 @@ def main(argv=None):
         step()
     sync_all()
 
-    # roofline leg: the 2^22 NTT, HIP events on the stream the kernels are launched on. 1000 untimed transforms first: the leg is
-    # 55-60 us long and follows the clocks, which need tens of ms of this kernel to settle after the prover's steps (tools/dbg/ntt_leg_burst.sh:
-    # 61 / 58 / 55 us as the median of 20 / 200 / 1000 back-to-back transforms); then 50 timed ones, each between its own events
-    for _ in range(1000):
-        ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
-    ntt_ms = []
-    for _ in range(50):
-        ctx.timer_start()
-        ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
-        ntt_ms.append(ctx.timer_stop())
-
-    # the same kernel family on the shape the prover actually runs: 8192 transforms of 2^12 points
-    # (LDE-sized batch, no tail effects); reported beside the roofline leg, not as `value`
-    nb12 = 8192
-    d_b12 = ctx.alloc(nb12 * 4096 * 8)
-    ctx.ntt_dev(d_b12, d_b12, 12, nb12, bitrev_out=True)
-    ctx.timer_start()
-    ctx.ntt_dev(d_b12, d_b12, 12, nb12, bitrev_out=True)
-    ntt12_ms = ctx.timer_stop()
-    d_b12.free()
-
-    # the sponge, the kernel that takes half of a step: 2^21 leaves of 136 limbs (17 permutations each), the rate
-    # of the instruction-bound Poseidon2 permutation; reported beside the roofline leg
-    n_hash, limbs = 1 << 21, 136
-    d_hin = ctx.alloc(n_hash * limbs * 8)
-    d_hout = ctx.alloc(n_hash * 4 * 8)
-    hargs = (ctx.h, VARIANT, d_hin.ptr, limbs, n_hash, 4, d_hout.ptr)
-    mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
-    ctx.timer_start()
-    mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
-    hash_ms = ctx.timer_stop()
-    d_hin.free(); d_hout.free()
+    legs = None if brief else kernel_legs(ctx, mp2, C, VARIANT, args.hasher, rank)
 
     def barrier():
         if dist is not None:
@@ -626,7 +892,7 @@ def main(argv=None):
 
     # ---- self-check: sampled proofs of the LAST timed step vs the CPU oracle (also the cpu_baseline sample) ------
     verified, cpu_base = 0, None
-    if not args.no_verify:
+    if not args.no_verify and not brief:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle as O
         results = [cp.results() for cp, *_ in provers]
@@ -663,7 +929,7 @@ def main(argv=None):
 
     # per-stage split of one batch per shape, each prover alone on the GPU (outside the timed region)
     stages = {}
-    if rank == 0:
+    if rank == 0 and not brief:
         seen_shapes = set()
         for (role, k, cx, nb), (cp, d_w, d_ph, *_rest) in zip(plan, provers):
             if role in seen_shapes:
@@ -678,7 +944,7 @@ def main(argv=None):
 
     # the per-rank multiset digest (2^16 rows x 4 value columns, device resident) meets in one
     # all_gather of one encoded point per rank, outside the per-proof path
-    rows, n_cols = 1 << 16, 4
+    rows, n_cols = (1 << 16, 4) if not brief else (256, 4)
     rng = np.random.default_rng(0xC0FFEE04 + rank)
     d_ids = ctx.to_device(C.rand_field(n_cols, 0xC0FFEE04))
     d_values = ctx.to_device(rng.integers(0, 1 << 32, size=(rows, n_cols, 8), dtype=np.uint32))
@@ -687,7 +953,7 @@ def main(argv=None):
     t1 = time.perf_counter()
     w = mp2.compute_table_row_digest_dev(ctx, d_ids, n_cols, d_values, d_unique, 1, rows)
     digest_s = time.perf_counter() - t1
-    if dist is not None:
+    if dist is not None and not brief:
         allw = sharding.all_gather_words(dist, w, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else None)
         w = mp2.curve_sum(ctx, allw)
         v = torch.tensor([verified], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.int64)
@@ -696,18 +962,6 @@ def main(argv=None):
 
     out = None
     if rank == 0:
-        # HBM-side bytes of the same two launches from the TCC counters (collected in separate
-        # --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/rNN/ntt_traffic.json)
-        traffic = None
-        for rnd in ("r02", "r01"):
-            try:
-                with open(os.path.join(ROOT, "profiles", rnd, "ntt_traffic.json")) as f:
-                    traffic = json.load(f)["ntt_2p22_forward_bitrev"]["traffic_bytes"]
-                break
-            except (OSError, KeyError, ValueError):
-                pass
-        ntt_s = float(np.median(ntt_ms)) / 1e3
-        achieved = 16.0 * n_ntt / ntt_s / 1e9
         out = {
             "metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build, 1/2/4/8 GPU",
             "value": world * args.steps * B / dt,
@@ -728,25 +982,23 @@ def main(argv=None):
                        "sharding": f"{world} rank(s), leaf proofs independent, digest all_gather 160 B",
                        "verified": f"{verified} sampled GPU proofs (first and last of every prover's batch on every rank, then more while the CPU budget "
                                    "lasts) equal the CPU oracle's proofs of the same witnesses bit for bit and pass its verifier"},
-            "roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, all launches)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "launch_ms": ntt_s * 1e3, "algorithmic_bytes": 16 * n_ntt},
-            "ntt_batched_2p12": {"transforms": nb12, "GBps": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9,
-                                 "frac_of_hbm_peak": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9 / HBM_PEAK_GBPS},
-            "sponge": {"hasher": args.hasher, "permutations_per_s": n_hash * (limbs // 8) / (hash_ms / 1e3), "bound": "VALU issue (integer ALU)",
-                       "input": f"{n_hash} x {limbs} limbs, hash_no_pad, resident"},
             "stage_ms": stages,
             "clocks": clocks.read(local_rank),
             "digest_rows_per_s": rows / digest_s,
             "digest_check": [int(x) for x in w],
         }
+        if legs is not None:
+            out.update(legs)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
-        print(json.dumps(out))
-    clocks.close()
-    if dist is not None:
-        dist.destroy_process_group()
+        if not brief:
+            print(json.dumps(out))
+    for cp, *_ in provers:
+        cp.free()
+    if not brief:
+        clocks.close()
+        if dist is not None:
+            dist.destroy_process_group()
     for c in reversed(ctxs):
         c.close()
     return out

@@ -293,6 +293,9 @@ int mp2g_prover_bind_public_inputs(mp2g_prover* pr, int64_t row);
  * a message naming the first offending proof. flags (may be NULL) receives one word per proof: bit 0 a
  * copy constraint, bit 1 a gate constraint, bit 2 the lookup argument (a looked-up pair that is not in its table). The proof itself is still produced (it does not verify). */
 int mp2g_prover_enable_witness_check(mp2g_prover* pr, int on);
+/* prove only the first n <= batch witnesses from the next call on (every buffer is proof-major, so a prover created for `batch`
+ * proofs serves any smaller batch without new allocations: the narrow levels of a tree reuse the wide levels' prover) */
+int mp2g_prover_set_active(mp2g_prover* pr, uint32_t n);
 int mp2g_prover_witness_status(mp2g_prover* pr, uint32_t* flags);
 /* Replay the prover's launch sequence (several hundred small kernels per call) as a hipGraph: the
  * first call after enabling runs normally (it creates the cached twiddle tables), the second is captured,

@@ -497,6 +497,11 @@ class BatchedProver:
         """Check gate and copy constraints of every witness on the device (plonky2 panics on a bad one)."""
         _ck(load().mp2g_prover_enable_witness_check(self.h, int(on)))
 
+    def set_active(self, n):
+        """prove only the first n <= batch witnesses from the next prove() on (no reallocation: every buffer is proof-major)"""
+        _ck(load().mp2g_prover_set_active(self.h, int(n)))
+        self.active = int(n)
+
     def witness_status(self):
         """Per-proof flags of the last prove() (bit 0 copy constraint, bit 1 gate constraint); raises
         Mp2gError naming the first bad proof, like prove()'s panic in the reference."""
@@ -530,7 +535,7 @@ class BatchedProver:
                                          self.d_openings.ptr, self.d_proof.ptr))
 
     def results(self):
-        fp, B = self.fp, self.batch
+        fp, B = self.fp, getattr(self, "active", self.batch)
         return (self.d_caps.download((B, fp.n_oracles, fp.cap_words)), self.d_openings.download((B, fp.n_openings, 2)),
                 self.d_proof.download((B, fp.proof_words)))
 

@@ -28,7 +28,8 @@ struct mp2g_challenger {
 struct mp2g_prover {
   mp2g_ctx* ctx = nullptr;
   mp2g_fri_params P{};
-  uint32_t B = 0;
+  uint32_t B = 0;     // proofs per prove() call (mp2g_prover_set_active: 1 .. Bcap)
+  uint32_t Bcap = 0;  // proofs the buffers were allocated for
   bool have_pre = false;
   size_t capw = 0, levels_words = 0, proof_words = 0, q_words = 0, q_off = 0, final_off = 0, final_len = 0, n_open = 0;
   DevBuf coeffs[8], values[8], levels[8];
@@ -232,7 +233,7 @@ static int prover_create_impl(mp2g_ctx* c, const mp2g_fri_params* params, uint32
   if (rc) return rc;
   mp2g_prover* pr = new (std::nothrow) mp2g_prover();
   if (!pr) return fail("out of memory");
-  pr->ctx = c; pr->P = *params; pr->B = batch;
+  pr->ctx = c; pr->P = *params; pr->B = pr->Bcap = batch;
   const mp2g_fri_params& P = pr->P;
   const size_t n = (size_t)1 << P.log_n, N = n << P.rate_bits, B = batch;
   const uint32_t lg = P.log_n + P.rate_bits;
@@ -324,10 +325,10 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
   NEED(P.zs_count >= 1 && P.zs_count <= 2, "1 or 2 challenges");
   NEED(P.oracle_w[2] == P.zs_count * (num_routed / degree + P.num_lookup_polys), "oracle_w[2] must be zs_count * (num_routed/degree + num_lookup_polys)");
   const size_t n = (size_t)1 << P.log_n;
-  CK(pr->zs_values.alloc((size_t)pr->B * P.oracle_w[2] * n * sizeof(u64)));
-  CK(pr->chunk_q.alloc((size_t)pr->B * P.zs_count * (num_routed / degree) * n * sizeof(u64)));
-  CK(pr->bg.alloc((size_t)pr->B * 8 * sizeof(u64)));  // betas, gammas (+ the 2 * num_challenges extra lookup challenges)
-  CK(pr->alphas.alloc((size_t)pr->B * 2 * sizeof(u64)));
+  CK(pr->zs_values.alloc((size_t)pr->Bcap * P.oracle_w[2] * n * sizeof(u64)));
+  CK(pr->chunk_q.alloc((size_t)pr->Bcap * P.zs_count * (num_routed / degree) * n * sizeof(u64)));
+  CK(pr->bg.alloc((size_t)pr->Bcap * 8 * sizeof(u64)));  // betas, gammas (+ the 2 * num_challenges extra lookup challenges)
+  CK(pr->alphas.alloc((size_t)pr->Bcap * 2 * sizeof(u64)));
   pr->num_routed = num_routed; pr->degree = degree;
   pr->drop_graph();
   return 0;
@@ -338,7 +339,7 @@ int mp2g_prover_enable_quotient(mp2g_prover* pr) {
   NEED(P.n_oracles == 4 && P.rate_bits == 3, "needs the four plonky2 oracles and rate_bits 3 (quotient degree factor 8)");
   NEED(P.oracle_w[3] == P.zs_count * 8, "oracle_w[3] must be zs_count * 8 quotient chunks");
   NEED(P.log_n + 3 <= 24, "log_n <= 21");
-  CK(pr->qvals.alloc((size_t)pr->B * P.zs_count * ((size_t)8 << P.log_n) * sizeof(u64)));
+  CK(pr->qvals.alloc((size_t)pr->Bcap * P.zs_count * ((size_t)8 << P.log_n) * sizeof(u64)));
   pr->quotient = true;
   pr->drop_graph();
   return 0;
@@ -615,7 +616,7 @@ int mp2g_prover_set_lookups(mp2g_prover* pr, const mp2g_lookup* luts, uint32_t n
     total += (size_t)u.table_len * 2;
   }
   CK(pr->lut_tables.alloc(total * sizeof(uint16_t)));
-  CK(pr->lut_eval.alloc((size_t)pr->B * P.zs_count * MP2G_MAX_LUTS * sizeof(u64)));
+  CK(pr->lut_eval.alloc((size_t)pr->Bcap * P.zs_count * MP2G_MAX_LUTS * sizeof(u64)));
   size_t off = 0;
   for (uint32_t r = 0; r < n_luts; r++) {
     const mp2g_lookup& u = luts[r];
@@ -641,9 +642,15 @@ int mp2g_prover_bind_public_inputs(mp2g_prover* pr, int64_t row) {
   pr->drop_graph();
   return 0;
 }
+int mp2g_prover_set_active(mp2g_prover* pr, uint32_t n) {
+  NEED(pr && n >= 1 && n <= pr->Bcap, "1 <= n <= the batch the prover was created for");
+  if (n != pr->B) pr->drop_graph();
+  pr->B = n;
+  return 0;
+}
 int mp2g_prover_enable_witness_check(mp2g_prover* pr, int on) {
   NEED(pr && pr->num_routed, "call mp2g_prover_enable_permutation first");
-  if (on && !pr->wflags.p) CK(pr->wflags.alloc((size_t)pr->B * sizeof(u32)));
+  if (on && !pr->wflags.p) CK(pr->wflags.alloc((size_t)pr->Bcap * sizeof(u32)));
   pr->wcheck = on != 0;
   pr->drop_graph();
   return 0;

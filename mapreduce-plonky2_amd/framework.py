@@ -219,8 +219,11 @@ class GpuProver:
     the device, the circuit's verifier data from the preprocessed commitment, and the Merkle node hash of the circuit
     set. One CircuitProver (preprocessed oracle, gate table) per distinct circuit, kept for reuse."""
 
-    def __init__(self, ctx, variant=POSEIDON2, witness_check=True):
-        self.ctx, self.variant, self.witness_check = ctx, variant, witness_check
+    def __init__(self, ctx, variant=POSEIDON2, witness_check=True, capacity=0):
+        """capacity > 0: one prover per circuit, created for `capacity` proofs and used for every batch width up to that
+        (mp2g_prover_set_active) -- the narrow levels of a tree then cost no device memory of their own; 0: one prover per
+        (circuit, batch width)."""
+        self.ctx, self.variant, self.witness_check, self.capacity = ctx, variant, witness_check, capacity
         self.provers = {}
         self.pinned = {}  # data address of a pinned wire matrix -> its host pointer
 
@@ -235,8 +238,25 @@ class GpuProver:
         self.pinned[a.ctypes.data] = hptr
         return a
 
+    @staticmethod
+    def circuit_key(ckt):
+        """identity of a circuit for the prover cache: a 128-bit digest of everything a CircuitProver is built from (preprocessed
+        polynomials, gate table with selector groups, lookup tables, public-input row, domain separator)"""
+        key = getattr(ckt, "_prover_key", None)
+        if key is None:
+            import hashlib
+            h = hashlib.blake2b(digest_size=16)
+            h.update(np.ascontiguousarray(ckt.pre).tobytes())
+            h.update(repr((ckt.log_n, ckt.num_selectors, [(g.kind, g.p0, g.p1, g.p2, g.selector_index, g.group_start, g.group_end) for g in ckt.gates],
+                           getattr(ckt, "pi_row", None), list(getattr(ckt, "domain_separator", ())))).encode())
+            for lut in (getattr(ckt, "luts", None) or []):
+                h.update(repr((lut["last_lu_row"], lut["last_lut_row"], lut["first_lut_row"])).encode())
+                h.update(np.ascontiguousarray(lut["table"], dtype=np.uint16).tobytes())
+            key = ckt._prover_key = h.hexdigest()
+        return key
+
     def _prover(self, ckt):
-        key = (ckt.log_n, hash(ckt.pre.tobytes()))
+        key = (ckt.log_n, self.circuit_key(ckt))
         cp = self.provers.get(key)
         if cp is None:
             cp = self.provers[key] = CircuitProver(self.ctx, ckt, 1, self.variant, witness_check=self.witness_check)
@@ -260,20 +280,24 @@ class GpuProver:
         batch per (circuit, B) in flight at a time."""
         B, n = wires.shape[0], 1 << ckt.log_n
         rows = wires.shape[1:] == (n, 135) and n != 135
-        key = (ckt.log_n, hash(ckt.pre.tobytes()), B)
+        cap = max(B, self.capacity) if self.capacity else B
+        key = (ckt.log_n, self.circuit_key(ckt), cap)
         cp = self.provers.get(key)
+        per = wires.nbytes // B
         if cp is None:
-            cp = self.provers[key] = CircuitProver(self.ctx, ckt, B, self.variant, witness_check=self.witness_check)
-            cp.d_w, cp.d_ph, cp.d_rows = self.ctx.alloc(wires.nbytes), self.ctx.alloc(B * 32), None
+            cp = self.provers[key] = CircuitProver(self.ctx, ckt, cap, self.variant, witness_check=self.witness_check)
+            cp.d_w, cp.d_ph, cp.d_rows = self.ctx.alloc(cap * per), self.ctx.alloc(cap * 32), None
         if rows and cp.d_rows is None:
-            cp.d_rows = self.ctx.alloc(wires.nbytes)
-        cp.d_ph.upload(np.ascontiguousarray(pi_hash, dtype=np.uint64))
+            cp.d_rows = self.ctx.alloc(cap * per)
+        if cap != B or getattr(cp.pr, "active", cap) != B:
+            cp.pr.set_active(B)
+        cp.d_ph.upload_at(np.ascontiguousarray(pi_hash, dtype=np.uint64), 0)
         dst = cp.d_rows if rows else cp.d_w
         hptr = self.pinned.get(wires.ctypes.data) if wires.flags["C_CONTIGUOUS"] else None
         if hptr is not None:
             self.ctx.h2d_async(dst, hptr, wires.nbytes)  # ordered before the kernels below on the same stream
         else:
-            dst.upload(wires)
+            dst.upload_at(wires, 0)
         if rows:
             self.ctx.wires_from_rows_dev(cp.d_rows, cp.d_w, ckt.log_n, B)
         cp.prove(cp.d_w, cp.d_ph)

@@ -1742,13 +1742,15 @@ def universal_inputs(proof, vd, membership):
                            np.asarray(bits, dtype=np.uint64).ravel(), np.asarray(sib, dtype=np.uint64).ravel()])
 
 
-def _generate_proofs_batch(self, name, jobs, threads=0, session=None):
+def _generate_proofs_batch(self, name, jobs, threads=0, session=None, capture=None):
     """RecursiveCircuits.generate_proof for a batch of nodes of circuit `name`: jobs = [(child_proofs, child_names, inputs)].
     Witnesses come from the circuits' recorded programs (csrc/witness.hip: host threads, one proof each), proving from
     prover.prove_batch(circuit, wires [B][135][n], pi_hash [B][4]). Returns the final proofs, one per job.
     `session` (ProofSession): the prover and the host wire matrices to use instead of the framework's own -- independent trees
     (the reference's independent rows / blocks) run in one thread each with a session of their own, so that one tree's witness
-    generation fills the time another's prove() spends on the GPU; circuits, verifier data and witness programs are shared."""
+    generation fills the time another's prove() spends on the GPU; circuits, verifier data and witness programs are shared.
+    `capture` (a list): receives, per job and chain step, (name, step, circuit, circuit digest, wire matrix [135][n], pi_hash, caps,
+    openings, proof) -- what a checker needs to prove the same witness again."""
     sess = session if session is not None else self.default_session()
     progs = self.witness_programs(name)
     rows = []
@@ -1768,6 +1770,11 @@ def _generate_proofs_batch(self, name, jobs, threads=0, session=None):
         wires, pi_hash, pis = prog.run(cur, threads, out=sess.wire_buffer(name, step, cur.shape[0], prog.log_n, rows), rows=rows)
         outs = sess.prover.prove_batch(self.chains[name][step][0], wires, pi_hash)
         proofs = [(c, o, p, pis[i]) for i, (c, o, p) in enumerate(outs)]
+        if capture is not None:
+            ckt, _, digest = self.chains[name][step]
+            for i, (c, o, p) in enumerate(outs):
+                w = np.ascontiguousarray(wires[i].T) if rows else wires[i].copy()
+                capture.append((name, step, ckt, digest, w, pi_hash[i].copy(), c, o, p))
         if step + 1 < len(progs):
             cur = np.stack([proof_inputs(p) for p in proofs])
     return proofs
@@ -1782,13 +1789,14 @@ class ProofSession:
         self.prover, self.buffers = prover, {}
 
     def wire_buffer(self, name, step, batch, log_n, rows=False):
-        key = (name, step, batch)
+        cap = max(batch, getattr(self.prover, "capacity", 0) or 0)  # a prover with a capacity serves every narrower batch from one matrix
+        key = (name, step, cap)
         buf = self.buffers.get(key)
         if buf is None:
-            shape = (batch, 1 << log_n, 135) if rows else (batch, 135, 1 << log_n)
+            shape = (cap, 1 << log_n, 135) if rows else (cap, 135, 1 << log_n)
             make = getattr(self.prover, "pinned_wires", None)
             buf = self.buffers[key] = make(shape) if make is not None else np.empty(shape, dtype=np.uint64)
-        return buf
+        return buf[:batch]
 
 
 def _default_session(self):

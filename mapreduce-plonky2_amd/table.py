@@ -332,6 +332,7 @@ class TableBuild:
         try:
             keyset = set(keys)
             cells = self.cells_proofs(table, wit, sorted(keys), sess)
+            self.cells_roots.update(cells)
             height = {}
 
             def h(k):
@@ -356,9 +357,16 @@ class TableBuild:
         ut = W.UpdateTree.from_map(0, root, nodes)
         plan = ut.into_batched_workplan(self.subtree_size) if self.subtree_size > 1 else ut.into_workplan()
         row_proofs, pending = {}, {}
+        self.row_proofs, self.cells_roots = row_proofs, {}  # kept after the run: what a checker re-proves sampled nodes from
         with ThreadPoolExecutor(max_workers=len(self.sessions)) as ex:
+            issued = set()
             while True:
                 for it in W.drain_wave(plan):
+                    if it.k in issued:  # handed out before and still being proved: the plan repeats an item until it is done
+                        if it.subtree is not None:
+                            it.subtree.free()
+                        continue
+                    issued.add(it.k)
                     if it.subtree is not None:
                         keys = [int(k) for k in it.subtree.nodes()]
                         it.subtree.free()
@@ -374,6 +382,25 @@ class TableBuild:
         assert plan.completed()
         plan.free()
         return row_proofs[root]
+
+
+def join_blocks(build, ctx, left, right, sep_block, n_cols=4, seed=0xC0FFEE04, variant=0):
+    """the row-tree node above two ranks' blocks: the separator row between them (a one-row table with the odd prefix sep_block)
+    with the blocks' root proofs as its children. left / right = (root proof, circuit name, accumulated digest encoding [5]).
+    Proves the separator's cells tree and its full node; returns (proof, name, digest encoding) of the joined tree."""
+    from . import curve_sum
+    table = SyntheticTable(1, n_cols, seed, sep_block)
+    wit = TableWitness(ctx, table, {0: (0, 1)}, variant)
+    w, wei = curve_sum(ctx, np.stack([wit.row_w[0], np.asarray(left[2], dtype=np.uint64), np.asarray(right[2], dtype=np.uint64)]), weierstrass=True)
+    wit.row_digest[0] = wei
+    sess = build.pool.get()
+    try:
+        cells = build.cells_proofs(table, wit, [0], sess)
+        name, job = build.row_job(table, wit, {0: ("L", "R")}, 0, cells[0], {"L": left[:2], "R": right[:2]})
+        (proof,) = build._batched(build.p.rows, name, [job], sess)
+    finally:
+        build.pool.put(sess)
+    return proof, name, w
 
 
 def expected_root_public_inputs(ctx, table, wit, root, nodes, spans, variant=0):

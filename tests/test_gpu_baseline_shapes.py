@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_bench_step_is_self_verifying():
     """one bench step at the headline shape: 128 leaf proofs = 2 x 64 base (2^13 rows, 19 gates) + 2 x 64 wrap
     (2^12 rows, 13 gates) on 4 contexts; first and last proof of every prover equal the oracle's and verify"""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "128", "--streams", "4",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "leaves", "--steps", "1", "--warmup", "1", "--batch", "128", "--streams", "4",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])

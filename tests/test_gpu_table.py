@@ -1,0 +1,172 @@
+"""BASELINE configs[3] on the GPU: the table-creation flow of mapreduce-plonky2_amd/table.py (cells-tree + row-tree framework
+proofs scheduled by the batched work plan) through the HIP prover, its off-circuit side against the oracle, and bench.py's
+default workload including its self-launch on two ranks."""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import circuits as C
+import oracle as O
+from table_oracle import OracleTableWitness, o_sum
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = importlib.import_module("mapreduce-plonky2_amd.table")
+R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+IX = importlib.import_module("mapreduce-plonky2_amd.indexing")
+
+
+def test_curve_sum_ranges_vs_oracle(ctx, mp2):
+    w = mp2.map_to_curve_batch(ctx, O.rand_field((150, 9), 77))
+    ranges = [(0, 150), (0, 1), (3, 3), (5, 70), (64, 129), (149, 150), (10, 75), (0, 64), (1, 66)]
+    gw, gwei = mp2.curve_sum_ranges(ctx, w, ranges)
+    for (lo, hi), a, b in zip(ranges, gw, gwei):
+        ow, owei = o_sum(w[lo:hi]) if hi > lo else (np.zeros(5, dtype=np.uint64), np.array([0] * 10 + [1], dtype=np.uint64))
+        assert np.array_equal(a, ow) and np.array_equal(b, owei), (lo, hi)
+    with pytest.raises(mp2.Mp2gError, match="range"):
+        mp2.curve_sum_ranges(ctx, w, [(0, 151)])
+    # no ranges, no points
+    assert mp2.curve_sum_ranges(ctx, w, np.zeros((0, 2), dtype=np.uint32))[0].shape == (0, 5)
+
+
+def test_row_digests_sum_to_the_table_digest(ctx, mp2):
+    """the per-row terms: each equals the oracle's one-row digest, and their sum is compute_table_row_digest"""
+    rng = np.random.default_rng(5)
+    ids = O.rand_field(5, 0xC0FFEE04)
+    values = rng.integers(0, 1 << 32, size=(70, 5, 8), dtype=np.uint32)
+    w, wei = mp2.row_digests(ctx, ids, values, values[:, 0:1])
+    tw, twei = mp2.compute_table_row_digest(ctx, ids, values, values[:, 0:1])
+    assert np.array_equal(mp2.curve_sum(ctx, w), tw)
+    for r in (0, 1, 69):
+        ow, owei = np.zeros(5, dtype=np.uint64), np.zeros(11, dtype=np.uint64)
+        O.lib().orc_row_digest_batch(0, O.p(ids), O.sz(5), O.p(O.arr(values[r:r + 1], np.uint32)), O.p(O.arr(values[r:r + 1, 0:1], np.uint32)), O.sz(1), O.sz(1), O.p(ow), O.p(owei))
+        assert np.array_equal(w[r], ow) and np.array_equal(wei[r], owei)
+
+
+def test_table_witness_matches_the_oracle(ctx, mp2):
+    table = T.SyntheticTable(7, 4, seed=0xC0FFEE04, block=2)
+    assert all(table.secondary_int(i) < table.secondary_int(i + 1) for i in range(6)) and int(table.values[0, 0, 0]) >> 16 == 2
+    root, nodes, spans = T.balanced_bst(7)
+    g, o = T.TableWitness(ctx, table, spans), OracleTableWitness(table, spans)
+    assert np.array_equal(g.cell_digest, o.cell_digest) and np.array_equal(g.unique, o.unique)
+    assert np.array_equal(g.row_w, o.row_w) and np.array_equal(g.row_own, o.row_own)
+    for k in spans:
+        assert np.array_equal(g.row_digest[k], o.row_digest[k]) and np.array_equal(g.root_digest_w[k], o.root_digest_w[k])
+
+
+def test_prover_serves_narrower_batches(ctx, mp2):
+    """mp2g_prover_set_active: a prover created for 6 proofs proving 2 gives what a prover created for 2 gives, and goes back to 6"""
+    ckt = C.build(7, C.VERIFIER_KINDS, 3)
+    wide, narrow = FW.CircuitProver(ctx, ckt, 6, bind_public_inputs=True), FW.CircuitProver(ctx, ckt, 2, bind_public_inputs=True)
+    d_w = FW.tile_witness(ctx, ckt, 6, 11)
+    ph = O.rand_field((6, 4), 12)
+    d_ph = ctx.to_device(ph)
+    wide.prove(d_w, d_ph)
+    full = wide.results()
+    wide.pr.set_active(2)
+    wide.prove(d_w, d_ph)
+    narrow.prove(d_w, d_ph)
+    a, b = wide.results(), narrow.results()
+    assert a[0].shape[0] == 2 and all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert all(np.array_equal(x[:2], y) for x, y in zip(full, a))
+    wide.pr.set_active(6)
+    wide.prove(d_w, d_ph)
+    assert all(np.array_equal(x, y) for x, y in zip(full, wide.results()))
+    with pytest.raises(mp2.Mp2gError):
+        wide.pr.set_active(7)
+    wide.free(); narrow.free()
+
+
+@pytest.fixture(scope="module")
+def params(ctx):
+    prover = FW.GpuProver(ctx, capacity=8)
+    p = T.TableParams(prover, FW.circuit_fri_params, IX.empty_poseidon_hash(ctx))
+    yield p
+    prover.free()
+
+
+def test_table_build_of_eleven_rows(ctx, mp2, params):
+    """11 rows x (4 cells-tree proofs + 1 row-tree proof) = 55 real framework proofs, scheduled by the batched work plan over two
+    workers; the row tree has leaves, partial and full nodes. The root exposes the off-circuit tree hash, the table's multiset
+    digest, min / max, and passes the oracle's verifier; a cells proof made by the Python builder equals the batch path's."""
+    n = 11
+    table = T.SyntheticTable(n, 4, seed=0xC0FFEE04)
+    root, nodes, spans = T.balanced_bst(n)
+    kinds = sorted({sum(c is not None for c in nodes[k]) for k in nodes})
+    assert kinds == [0, 1, 2]
+    ctx2 = mp2.Context(0)
+    provers = [params.cells.prover, FW.GpuProver(ctx2, capacity=8)]
+    build = T.TableBuild(params, [R.ProofSession(p) for p in provers], batch=8, subtree_size=4, host_threads=8)
+    wit = T.TableWitness(ctx, table, spans)
+    proof, name = build.run(table, wit, root, nodes)
+    assert name == "row_full" and build.n_proofs == 5 * n
+    pis = proof[3]
+    want = T.expected_root_public_inputs(ctx, table, wit, root, nodes, spans)
+    assert np.array_equal(pis[:T.ROWS_IO], want)
+    assert np.array_equal(pis[T.ROWS_IO:], np.asarray(params.rows.set_digest, dtype=np.uint64))
+    assert np.array_equal(pis[4:15], mp2.compute_table_row_digest(ctx, table.col_ids, table.values, table.values[:, 0:1])[1])
+    wckt, wcap, wdig = params.rows.chains["row_full"][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *proof[:3]) == 0
+    # every row's cells root exposes the row's cells-tree hash (indexing.cells hashes are part of expected_root_public_inputs) and 4 cells
+    for r in (0, n - 1):
+        cp = build.cells_roots[r][0][3]
+        assert int(cp[26]) == 4 and int(cp[27]) == 0 and np.array_equal(cp[4:15], wit.cell_digest[r, 3])
+    # the builder path (eager Python circuit) of one cells leaf = the witness-program path
+    flat = T._u64cat([table.col_ids[1]], table.values[0, 1], [0], wit.cell_digest[0, 0], T.NEUTRAL_FIELDS)
+    one = params.cells.generate_proof("cells_leaf", [], [], flat)
+    (two,) = params.cells.generate_proofs_batch("cells_leaf", [([], [], flat)])
+    assert all(np.array_equal(a, b) for a, b in zip(one, two))
+    provers[1].free()
+    ctx2.close()
+
+
+def test_row_node_refuses_a_foreign_cells_proof(ctx, mp2, params):
+    """a row-tree proof is verified in place of the cells-tree proof: its digest is not in the cells circuit set (the reference's
+    set_circuit_membership_target fails the same way)"""
+    table = T.SyntheticTable(1, 4, seed=7)
+    root, nodes, spans = T.balanced_bst(1)
+    wit = T.TableWitness(ctx, table, spans)
+    build = T.TableBuild(params, [R.ProofSession(params.cells.prover)], batch=8, subtree_size=1, host_threads=4)
+    row_proof, name = build.run(table, wit, root, nodes)
+    with pytest.raises(KeyError):
+        params.cells.membership(params.rows.vds[name][1])
+    # and a cells proof with a tampered public input makes the row node's witness inconsistent: prove() refuses it
+    cells = build.cells_roots[0]
+    bad = (cells[0][0], cells[0][1], cells[0][2], cells[0][3].copy())
+    bad[3][0] ^= np.uint64(1)
+    name, job = build.row_job(table, wit, nodes, 0, (bad, cells[1]), {})
+    with pytest.raises(Exception, match="witness"):
+        params.rows.generate_proofs_batch(name, [job])
+
+
+def _bench(args, env=None, timeout=2400):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_default_workload_is_the_table_build():
+    """python bench.py (no --workload): the table build, self-verifying, with roofline and cpu_baseline objects"""
+    line = _bench(["--rows", "16", "--steps", "1", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "8", "--cpu-budget", "1"])
+    assert line["config"]["workload"].startswith("table:") and line["unit"] == "proofs/s" and line["n_gpus"] == 1
+    assert line["config"]["shapes"]["row_full"] == [14, 13, 12]
+    assert line["value"] > 0 and line["verified"] >= 15 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+    assert line["leaves_prove_only"]["value"] > 0 and len(line["config"]["root_public_inputs"]) == T.ROWS_IO + 4
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: two ranks (gloo rendezvous, both on this box's GPU), one block of rows each, the
+    separator row between them proved by rank 0 over both block roots; the run itself asserts that the root's digest is the whole
+    table's and its min the first block's"""
+    line = _bench(["--gpus", "2", "--rows", "8", "--steps", "1", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "4", "--no-leaves-leg",
+                   "--no-cpu-baseline"], env={"MP2G_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["config"]["workload"].startswith("table:")
+    assert "1 join level" in line["config"]["sharding"]
+    # 2 x 8 rows + the separator row, 5 proofs each
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * 17) < 1e-6
