@@ -414,6 +414,15 @@ typedef struct mp2g_witness_program mp2g_witness_program;
 int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t n_slots, uint32_t log_n, const uint32_t* input_sids,
                                 uint32_t n_inputs, const uint64_t* const_slots, uint32_t n_consts, mp2g_witness_program** out);
 uint32_t mp2g_witness_program_num_inputs(const mp2g_witness_program* p);
+/* The same replay ON THE DEVICE, for a batch of proofs of one circuit, stream ordered on ctx's stream and without a host copy of
+ * anything: one block per proof walks the program's dependency levels (csrc/witness_dev.hip). d_inputs [batch][n_inputs] and
+ * d_wires [batch][135][2^log_n] (zero-filled here, then written: what mp2g_prover_prove_dev takes as d_values[0]) are device
+ * pointers; d_probe_out [batch][n_probe] receives the slots registered with set_probe (the public-inputs hash and the public inputs,
+ * which prove() and the parent's witness need), set once before the first device run. Bit-identical to the host replay. */
+uint32_t mp2g_witness_program_num_levels(const mp2g_witness_program* p);
+int mp2g_witness_program_set_probe(mp2g_witness_program* p, const uint32_t* probe_sids, uint32_t n_probe);
+int mp2g_witness_program_run_dev(mp2g_witness_program* p, mp2g_ctx* ctx, const uint64_t* d_inputs, uint32_t batch, uint64_t* d_wires,
+                                 uint64_t* d_probe_out);
 /* inputs [batch][n_inputs] canonical field elements -> wires [batch][135][2^log_n] (host memory, the layout of
  * mp2g_prover_prove_dev's d_values[0]); `threads` host threads (0 = all), one proof per thread at a time.
  * probe_sids (may be NULL): slots whose final values are also returned, probe_out [batch][n_probe] -- the circuit's

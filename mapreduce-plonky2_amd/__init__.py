@@ -557,6 +557,13 @@ class WitnessProgram:
         self.h = ctypes.c_void_p()
         _ck(load().mp2g_witness_program_create(_p(tape), ctypes.c_size_t(tape.size), int(ckt.n_slots), int(ckt.log_n), _p(ins), int(ins.size),
                                                _p(cs), int(cs.shape[0]), ctypes.byref(self.h)))
+        _ck(load().mp2g_witness_program_set_probe(self.h, _p(self.probe), int(self.probe.size)))
+        self.n_levels = int(load().mp2g_witness_program_num_levels(self.h))
+
+    def run_dev(self, ctx, d_inputs, batch, d_wires, d_probe):
+        """the same replay on the device, stream ordered on ctx's stream: d_inputs [batch][n_inputs] -> d_wires [batch][135][n] (the
+        prover's layout) and d_probe [batch][4 + n_public_inputs] (public-inputs hash, then the public inputs); asynchronous"""
+        _ck(load().mp2g_witness_program_run_dev(self.h, ctx.h, d_inputs.ptr, int(batch), d_wires.ptr, d_probe.ptr))
 
     def run(self, inputs, threads=0, out=None, rows=False):
         """inputs [batch][n_inputs] -> (wires [batch][135][n], pi_hash [batch][4], public_inputs [batch][n_pi]);

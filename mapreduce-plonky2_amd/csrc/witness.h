@@ -1,0 +1,37 @@
+// Shared by witness.hip (host executor, program validation, level schedule) and witness_dev.hip (device executor).
+#pragma once
+#include <cstdint>
+#include <mutex>
+#include <vector>
+#include "ctx.h"
+
+namespace mp2g {
+enum { OP_ARITH = 1, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
+       OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR, OP_END };
+const u32 BASE_SUM_LIMBS = 63, RA_BITS = 4, RA_COPIES = 4, RED_COEFFS = 43, RED_EXT_COEFFS = 32, NUM_WIRES = 135;
+
+// the program's read-only data on one device (uploaded at the first device run there)
+struct WitnessDev {
+  int device = -1;
+  DevBuf tape, sched, level_off, input_sids, consts, domtab, probe;
+};
+// device executor (witness_dev.hip): one block per proof walks the level schedule
+hipError_t witness_exec_launch(hipStream_t s, const WitnessDev& d, u32 n_levels, u32 n_slots, u32 log_n, u32 n_inputs, u32 n_consts,
+                               u32 n_probe, const u64* d_inputs, u32 batch, u64* d_vals, u64* d_wires, u64* d_probe_out);
+}  // namespace mp2g
+
+struct mp2g_witness_program {
+  std::vector<u64> tape;
+  std::vector<u32> input_sids;
+  std::vector<u64> consts;  // (sid, value) pairs
+  u32 n_slots = 0, log_n = 0;
+  u64 dom[6][32], bw[6][32];  // two-adic subgroup of 2^bits points and its barycentric weights, bits <= 5
+  // level schedule for the device executor: instruction offsets ordered by (dependency level, opcode); a level's instructions
+  // read only slots written at lower levels (every slot is written once: the builder's programs are in SSA form)
+  std::vector<u32> sched, level_off;
+  bool ssa = true;
+  std::vector<u32> probe;  // slots returned next to the wires by the device run (mp2g_witness_program_set_probe)
+  std::mutex dev_mu;
+  std::vector<mp2g::WitnessDev*> dev;  // per device
+  ~mp2g_witness_program() { for (auto* d : dev) delete d; }
+};

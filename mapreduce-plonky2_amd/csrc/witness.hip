@@ -12,6 +12,8 @@
 #include "gl.cuh"
 #include "perm_constants.h"
 #include "ctx.h"
+#include "witness.h"
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <new>
@@ -22,10 +24,6 @@ using namespace mp2g;
 #define NEED(c, msg) do { if (!(c)) return fail("invalid argument: %s", msg); } while (0)
 
 namespace {
-enum { OP_ARITH = 1, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
-       OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR, OP_END };
-const u32 BASE_SUM_LIMBS = 63, RA_BITS = 4, RA_COPIES = 4, RED_COEFFS = 43, RED_EXT_COEFFS = 32, NUM_WIRES = 135;
-
 // operand count after the opcode; 0 = variable (OP_COSET: 3 + 2 * 2^bits + 4)
 u32 op_len(u64 op, const u64* t) {
   switch (op) {
@@ -84,14 +82,6 @@ void p2_internal(u64 s[12]) {
   }
 }
 }  // namespace
-
-struct mp2g_witness_program {
-  std::vector<u64> tape;
-  std::vector<u32> input_sids;
-  std::vector<u64> consts;  // (sid, value) pairs
-  u32 n_slots = 0, log_n = 0;
-  u64 dom[6][32], bw[6][32];  // two-adic subgroup of 2^bits points and its barycentric weights, bits <= 5
-};
 
 namespace {
 // the instructions of [t, end). A parallel region (OP_PAR) is a run of sections that read what came before the region and each
@@ -361,10 +351,122 @@ int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t 
       P->bw[bits][i] = gl_inv(pr);
     }
   }
+  // level schedule for the device executor (witness_dev.hip): level(i) = 1 + max level of the slots i reads
+  {
+    struct Ins { u32 off, lvl, op; };
+    std::vector<Ins> ins;
+    std::vector<u32> lvl(n_slots, 0);
+    std::vector<uint8_t> written(n_slots, 0);
+    for (uint32_t i = 0; i < n_inputs; i++) written[input_sids[i]] = 1;
+    for (uint32_t i = 0; i < n_consts; i++) written[const_slots[2 * i]] = 1;
+    const u64* base = P->tape.data();
+    u32 max_lvl = 0;
+    for (const u64* q = base; q < end;) {
+      const u64 op = *q;
+      const u64* a = q + 1;
+      const u32 len = op_len(op, a);
+      if (op == OP_PAR) { q = a + len; continue; }  // the sections follow as ordinary instructions
+      u32 r0 = 0, nr = 0, w0 = 0, nw = 0;
+      switch (op) {
+        case OP_ARITH: r0 = 4; nr = 3; w0 = 7; nw = 1; break;
+        case OP_ARITH_EXT: r0 = 4; nr = 6; w0 = 10; nw = 2; break;
+        case OP_P2: r0 = 1; nr = 13; w0 = 14; nw = 12; break;
+        case OP_BASE_SUM: r0 = 1; nr = 1; w0 = 2; nw = BASE_SUM_LIMBS; break;
+        case OP_RA: r0 = 2; nr = 17; w0 = 19; nw = 1; break;
+        case OP_REDUCING: r0 = 1; nr = 4 + RED_COEFFS; w0 = 5 + RED_COEFFS; nw = 2; break;
+        case OP_REDUCING_EXT: r0 = 1; nr = 4 + 2 * RED_EXT_COEFFS; w0 = 5 + 2 * RED_EXT_COEFFS; nw = 2; break;
+        case OP_COSET: r0 = 2; nr = 3 + (2u << a[1]); w0 = 5 + (2u << a[1]); nw = 2; break;
+        case OP_WIRE: r0 = 2; nr = 1; break;
+        case OP_HINT_DIV_EXT: r0 = 0; nr = 4; w0 = 4; nw = 2; break;
+        case OP_HINT_LO63: case OP_HINT_HI: r0 = 0; nr = 1; w0 = 1; nw = 1; break;
+        case OP_HINT_SPLIT: r0 = 0; nr = 1; w0 = 2; nw = 2; break;
+        default: break;
+      }
+      u32 l = 0;
+      for (u32 i = 0; i < nr; i++) { const u32 sl = (u32)a[r0 + i]; if (lvl[sl] > l) l = lvl[sl]; }
+      l += 1;
+      for (u32 i = 0; i < nw; i++) {
+        const u32 sl = (u32)a[w0 + i];
+        if (written[sl]) P->ssa = false;  // a slot written twice: the level schedule would reorder the writes
+        written[sl] = 1;
+        lvl[sl] = l;
+      }
+      if ((size_t)(q - base) > 0xFFFFFFFFu) return bad("tape too long");
+      ins.push_back({(u32)(q - base), l, (u32)op});
+      if (l > max_lvl) max_lvl = l;
+      q = a + len;
+    }
+    std::stable_sort(ins.begin(), ins.end(), [](const Ins& x, const Ins& y) { return x.lvl != y.lvl ? x.lvl < y.lvl : x.op < y.op; });
+    P->sched.resize(ins.size());
+    P->level_off.assign(max_lvl + 1, 0);
+    for (size_t i = 0; i < ins.size(); i++) { P->sched[i] = ins[i].off; P->level_off[ins[i].lvl]++; }
+    // counts per level (index 1..max_lvl) -> offsets: level l's instructions are sched[level_off[l-1] .. level_off[l])
+    u32 acc = 0;
+    for (u32 l = 0; l <= max_lvl; l++) { acc += P->level_off[l]; P->level_off[l] = acc; }
+  }
   *out = P;
   return 0;
 }
 uint32_t mp2g_witness_program_num_inputs(const mp2g_witness_program* P) { return P ? (uint32_t)P->input_sids.size() : 0; }
+uint32_t mp2g_witness_program_num_levels(const mp2g_witness_program* P) { return P && !P->level_off.empty() ? (uint32_t)P->level_off.size() - 1 : 0; }
+int mp2g_witness_program_set_probe(mp2g_witness_program* P, const uint32_t* probe_sids, uint32_t n_probe) {
+  NEED(P && (probe_sids || !n_probe), "program / probe");
+  for (uint32_t i = 0; i < n_probe; i++) NEED(probe_sids[i] < P->n_slots, "probe slot");
+  std::lock_guard<std::mutex> g(P->dev_mu);
+  NEED(P->dev.empty(), "set the probe before the first device run");
+  P->probe.assign(probe_sids, probe_sids + n_probe);
+  return 0;
+}
+#define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+// the program's read-only data on the context's device, uploaded once
+static int witness_dev_data(mp2g_witness_program* P, mp2g_ctx* c, WitnessDev** out) {
+  std::lock_guard<std::mutex> g(P->dev_mu);
+  for (auto* d : P->dev)
+    if (d->device == c->device) { *out = d; return 0; }
+  WitnessDev* d = new (std::nothrow) WitnessDev();
+  if (!d) return fail("out of memory");
+  d->device = c->device;
+  auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = b.alloc(bytes);
+    if (e == hipSuccess && bytes) e = hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+    return e;
+  };
+  hipError_t e = up(d->tape, P->tape.data(), P->tape.size() * 8);
+  if (e == hipSuccess) e = up(d->sched, P->sched.data(), P->sched.size() * 4);
+  if (e == hipSuccess) e = up(d->level_off, P->level_off.data(), P->level_off.size() * 4);
+  if (e == hipSuccess) e = up(d->input_sids, P->input_sids.data(), P->input_sids.size() * 4);
+  if (e == hipSuccess) e = up(d->consts, P->consts.data(), P->consts.size() * 8);
+  if (e == hipSuccess) e = up(d->probe, P->probe.data(), P->probe.size() * 4);
+  if (e == hipSuccess) {
+    std::vector<u64> tab(2 * 6 * 32, 0);
+    memcpy(tab.data(), P->dom, sizeof(P->dom));
+    memcpy(tab.data() + 6 * 32, P->bw, sizeof(P->bw));
+    e = up(d->domtab, tab.data(), tab.size() * 8);
+  }
+  if (e != hipSuccess) { delete d; return fail("witness program upload: %s", hipGetErrorString(e)); }
+  P->dev.push_back(d);
+  *out = d;
+  return 0;
+}
+int mp2g_witness_program_run_dev(mp2g_witness_program* P, mp2g_ctx* c, const uint64_t* d_inputs, uint32_t batch, uint64_t* d_wires,
+                                 uint64_t* d_probe_out) {
+  NEED(P && c && d_inputs && d_wires && batch >= 1, "program / ctx / inputs / wires");
+  NEED(P->probe.empty() || d_probe_out, "probe output");
+  if (!P->ssa) return fail("the witness program writes a slot twice: it cannot be level-scheduled for the device");
+  WitnessDev* d = nullptr;
+  int rc = witness_dev_data(P, c, &d);
+  if (rc) return rc;
+  const size_t vals_words = (size_t)batch * P->n_slots;
+  if (c->wit_vals.bytes < vals_words * 8) {
+    CKH(hipStreamSynchronize(c->stream));  // a kernel queued earlier may still use the old buffer
+    CKH(c->wit_vals.alloc(vals_words * 8));
+  }
+  CKH(hipMemsetAsync(c->wit_vals.p, 0, vals_words * 8, c->stream));
+  CKH(hipMemsetAsync(d_wires, 0, ((size_t)batch * NUM_WIRES << P->log_n) * 8, c->stream));
+  CKH(witness_exec_launch(c->stream, *d, (u32)P->level_off.size() - 1, P->n_slots, P->log_n, (u32)P->input_sids.size(), (u32)(P->consts.size() / 2),
+                          (u32)P->probe.size(), (const u64*)d_inputs, batch, c->wit_vals.p, (u64*)d_wires, (u64*)d_probe_out));
+  return 0;
+}
 static int witness_run(const mp2g_witness_program* P, const uint64_t* inputs, uint32_t batch, uint32_t threads, uint64_t* wires,
                        const uint32_t* probe_sids, uint32_t n_probe, uint64_t* probe_out, bool rows) {
   NEED(P && inputs && wires && batch >= 1, "program / inputs / wires");

@@ -29,7 +29,7 @@ curve gadgets on top).
 """
 import queue
 import threading
-from concurrent.futures import FIRST_COMPLETED, ThreadPoolExecutor, wait
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -356,29 +356,28 @@ class TableBuild:
         """drain the batched work plan of the row tree (rowtree.rs:78-337 with into_batched_workplan): returns (root proof, name)"""
         ut = W.UpdateTree.from_map(0, root, nodes)
         plan = ut.into_batched_workplan(self.subtree_size) if self.subtree_size > 1 else ut.into_workplan()
-        row_proofs, pending = {}, {}
+        row_proofs = {}
         self.row_proofs, self.cells_roots = row_proofs, {}  # kept after the run: what a checker re-proves sampled nodes from
         with ThreadPoolExecutor(max_workers=len(self.sessions)) as ex:
-            issued = set()
             while True:
-                for it in W.drain_wave(plan):
-                    if it.k in issued:  # handed out before and still being proved: the plan repeats an item until it is done
-                        if it.subtree is not None:
-                            it.subtree.free()
-                        continue
-                    issued.add(it.k)
+                # one wave = every item that is Ready now; its items are disjoint subtrees and run concurrently. The plan is only
+                # polled again once the whole wave is done: polled with items outstanding it re-cuts the subtrees around them
+                # and hands out nodes a second time (updatetree.rs:479-515 builds an item from whatever is ready at the moment)
+                wave = W.drain_wave(plan)
+                if not wave:
+                    break
+                futures = []
+                for it in wave:
                     if it.subtree is not None:
                         keys = [int(k) for k in it.subtree.nodes()]
                         it.subtree.free()
                     else:
                         keys = [int(it.k)]
-                    pending[ex.submit(self.prove_item, table, wit, nodes, keys, row_proofs)] = it.k
-                if not pending:
-                    break
-                done, _ = wait(list(pending), return_when=FIRST_COMPLETED)
-                for f in done:
+                    futures.append(ex.submit(self.prove_item, table, wit, nodes, keys, row_proofs))
+                for f in futures:
                     f.result()  # re-raises a worker's failure (an unsatisfied witness makes prove() refuse, as the reference panics)
-                    plan.done(pending.pop(f))
+                for it in wave:
+                    plan.done(it.k)
         assert plan.completed()
         plan.free()
         return row_proofs[root]

@@ -75,3 +75,47 @@ def test_full_scale_properties(ctx, mp2):
             acc = (acc * g + c) % O.P
         assert acc == int(leaves[0][p])
     b.free()
+
+
+def test_device_witness_replay_equals_the_host_replay(ctx, mp2):
+    """mp2g_witness_program_run_dev (one block per proof walking the program's dependency levels) against
+    mp2g_witness_program_run (host threads) and the Python builder, word for word: a map circuit (2^6 rows), its wrap circuit
+    (2^12 rows: the whole recursive verifier -- every opcode of the tape) and a reduce base circuit (two universal verifiers, 2^13
+    rows) for a batch of different inputs"""
+    import importlib
+    R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+    FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+    prover = FW.GpuProver(ctx)
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover, FW.circuit_fri_params)
+    B = 5
+    data = O.rand_field(4 * B, 0xC0FFEE03)
+    jobs = [([], [], data[4 * i:4 * i + 4]) for i in range(B)]
+    cap = []
+    leaves = fw.generate_proofs_batch("map", jobs, capture=cap)
+    (root,) = fw.generate_proofs_batch("reduce", [([leaves[0], leaves[1]], ["map", "map"], None)], capture=cap)
+    # the inputs of every captured witness, rebuilt as generate_proofs_batch builds them
+    set_digest = np.asarray(fw.set_digest, dtype=np.uint64)
+    map_in = np.stack([np.concatenate([set_digest, data[4 * i:4 * i + 4]]) for i in range(B)])
+    base_proofs = [(c[6], c[7], c[8]) for c in cap if c[0] == "map" and c[1] == 0]
+    map_pis = [np.concatenate([[sum(int(x) for x in data[4 * i:4 * i + 4] if int(x) % 2 == 0) % O.P], O.hash_n_to_m_no_pad(data[4 * i:4 * i + 4], 4), set_digest]).astype(np.uint64) for i in range(B)]
+    wrap_in = np.stack([R.proof_inputs((*base_proofs[i], map_pis[i])) for i in range(B)])
+    vd = fw.vds["map"]
+    red_in = np.concatenate([set_digest] + [R.universal_inputs(leaves[i], vd, fw.membership(vd[1])) for i in range(2)])[None]
+    for name, step, inputs in (("map", 0, map_in), ("map", 1, wrap_in), ("reduce", 0, red_in)):
+        prog = fw.witness_programs(name)[step]
+        assert prog.n_levels > 0
+        n = 1 << prog.log_n
+        hw, hph, hpis = prog.run(inputs, threads=4)
+        want = [c[4] for c in cap if c[0] == name and c[1] == step]
+        assert all(np.array_equal(hw[i], want[i]) for i in range(len(want)))  # the run that was proved
+        nb = inputs.shape[0]
+        d_in, d_w, d_pr = ctx.to_device(inputs), ctx.alloc(nb * 135 * n * 8), ctx.alloc(nb * prog.probe.size * 8)
+        prog.run_dev(ctx, d_in, nb, d_w, d_pr)
+        gw = d_w.download((nb, 135, n))
+        gp = d_pr.download((nb, prog.probe.size))
+        assert np.array_equal(gw, hw), f"{name} step {step}: device wires differ from the host replay"
+        assert np.array_equal(gp[:, :4], hph) and np.array_equal(gp[:, 4:], hpis)
+        # a second run into the same buffers (slot tables and wires are re-initialised)
+        prog.run_dev(ctx, d_in, nb, d_w, d_pr)
+        assert np.array_equal(d_w.download((nb, 135, n)), hw)
+    prover.free()
