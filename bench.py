@@ -276,7 +276,7 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
     C = importlib.import_module("mapreduce-plonky2_amd.circuits")
     import threading
     ctx = mp2.Context(local_rank)
-    prover = FW.GpuProver(ctx, VARIANT, witness_check=True)
+    prover = FW.GpuProver(ctx, VARIANT, witness_check=True, device_witness=not args.host_witness)
     fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover,
                              lambda ckt: FW.circuit_fri_params(ckt, VARIANT))
     n_leaves = args.batch
@@ -285,7 +285,7 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
     # prover each: one tree's witness programs run on the host while another's prove() occupies the GPU
     n_trees = max(1, args.trees)
     ctxs = [ctx] + [mp2.Context(local_rank) for _ in range(n_trees - 1)]
-    provers = [prover] + [FW.GpuProver(c, VARIANT, witness_check=True) for c in ctxs[1:]]
+    provers = [prover] + [FW.GpuProver(c, VARIANT, witness_check=True, device_witness=not args.host_witness) for c in ctxs[1:]]
     sessions = [R.ProofSession(p) for p in provers]
     for name in ("map", "reduce"):
         fw.witness_programs(name)  # shared and read-only from here on
@@ -376,7 +376,7 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
                "dtype": "u64 (Goldilocks field)", "data": "synthetic",
                "framework_proofs_per_s": n_trees * (world * n_nodes + world - 1) * args.steps / dt,
                "config": {"workload": f"recursion: per rank {n_trees} independent {n_leaves}-leaf map-reduce tree(s) of REAL framework proofs, one host thread and GPU stream each ({n_nodes} per tree = map: base 2^6 + wrap 2^12 "
-                                      "rows; reduce: two universal verifiers, base 2^13 + wrap 2^12 rows), witness generation on the host threads, "
+                                      "rows; reduce: two universal verifiers, base 2^13 + wrap 2^12 rows), witness generation " + ("on the host threads, " if args.host_witness else "on the device (level-scheduled witness programs), ") +
                                       "witness check on, every level inside the timed region",
                           "shapes": {k: [c[0].log_n for c in v] for k, v in fw.chains.items()}, "host_threads": os.cpu_count(),
                           "hasher": "Poseidon2" if VARIANT == 0 else "Poseidon", "root_public_inputs": [int(x) for x in pis]}}
@@ -540,6 +540,8 @@ def main(argv=None):
     ap.add_argument("--workers", type=int, default=4, help="--workload table: concurrent work-plan items per rank, one host thread + GPU stream + prover set each")
     ap.add_argument("--table-batch", type=int, default=32, help="--workload table: proofs per prove() launch sequence of a worker")
     ap.add_argument("--subtree", type=int, default=64, help="--workload table: into_batched_workplan(subtree_size), the rows of one work-plan item")
+    ap.add_argument("--host-witness", action="store_true", help="--workload table / recursion: replay the witness programs on host threads (mp2g_witness_program_run_rows) "
+                    "instead of on the device (mp2g_witness_program_run_dev, the default): the A/B switch")
     ap.add_argument("--no-leaves-leg", action="store_true", help="--workload table: skip the short prove()-only leg reported beside the headline")
     ap.add_argument("--workload", choices=("table", "leaves", "tree", "recursion", "ntt"), default="table",
                     help="table (default, the headline): BASELINE configs[3] sampled -- per row 4 cells-tree + 1 row-tree REAL framework proofs, work-plan "
@@ -614,7 +616,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     n_workers, n_rows, n_cols = max(1, args.workers), args.rows, 4
     ctxs = [mp2.Context(local_rank) for _ in range(n_workers)]
     ctx = ctxs[0]
-    provers = [FW.GpuProver(c, VARIANT, witness_check=True, capacity=args.table_batch) for c in ctxs]
+    provers = [FW.GpuProver(c, VARIANT, witness_check=True, capacity=args.table_batch, device_witness=not args.host_witness) for c in ctxs]
     sessions = [R.ProofSession(p) for p in provers]
     t_setup = time.perf_counter()
     params = T.TableParams(provers[0], lambda ckt: FW.circuit_fri_params(ckt, VARIANT), IX.empty_poseidon_hash(ctx, VARIANT))
@@ -787,6 +789,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                                       "multiset digests (map-to-curve, row ids, accumulation up both trees) inside the timed region; value = framework proofs/s "
                                       "(5 per row); roofline leg = configs[1] 2^22-point NTT",
                           "rows_per_rank_and_step": n_rows, "value_columns": n_cols, "workers": n_workers, "batch": args.table_batch, "subtree_size": args.subtree,
+                          "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "shapes": shapes,
                           "setup_s": round(t_setup, 1), "hasher": "Poseidon2",
                           "sharding": f"{world} rank(s): one block of rows each, no collective below the block roots; {world.bit_length() - 1} join level(s) move a root proof point to point",

@@ -45,6 +45,9 @@ int mp2g_dev_alloc(mp2g_ctx* ctx, size_t bytes, void** d_ptr);
 int mp2g_dev_free(mp2g_ctx* ctx, void* d_ptr);
 int mp2g_h2d(mp2g_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 int mp2g_d2h(mp2g_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+/* stream-ordered strided device-to-device copy: `rows` pieces of width_bytes, the i-th from d_src + i * src_pitch to
+ * d_dst + i * dst_pitch (how a batch of proofs becomes the next witness program's input vectors without leaving the device) */
+int mp2g_d2d_2d(mp2g_ctx* ctx, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch, size_t width_bytes, size_t rows);
 /* pinned host staging memory and stream-ordered uploads (a host that feeds witness matrices from
  * its own memory overlaps the PCIe copy of batch k+1 with the proving of batch k) */
 int mp2g_host_alloc(mp2g_ctx* ctx, size_t bytes, void** ptr);

@@ -148,6 +148,11 @@ class Context:
     def h2d_async(self, d_dst, host_ptr, nbytes, dst_offset=0):
         _ck(load().mp2g_h2d_async(self.h, ctypes.c_void_p(d_dst.ptr.value + dst_offset), host_ptr, ctypes.c_size_t(nbytes)))
 
+    def d2d_2d(self, d_dst, dst_offset, dst_pitch, d_src, src_offset, src_pitch, width, rows):
+        """stream-ordered strided device copy (all sizes in bytes): `rows` pieces of `width` bytes"""
+        _ck(load().mp2g_d2d_2d(self.h, ctypes.c_void_p(d_dst.ptr.value + dst_offset), ctypes.c_size_t(dst_pitch),
+                               ctypes.c_void_p(d_src.ptr.value + src_offset), ctypes.c_size_t(src_pitch), ctypes.c_size_t(width), ctypes.c_size_t(rows)))
+
     def wires_from_rows_dev(self, d_rows, d_wires, log_n, batch, num_wires=135):
         """[batch][n][num_wires] (the witness executor's row layout) -> [batch][num_wires][n] (the prover's), on the device"""
         _ck(load().mp2g_wires_from_rows_dev(self.h, d_rows.ptr, d_wires.ptr, log_n, num_wires, batch))

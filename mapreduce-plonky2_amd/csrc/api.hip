@@ -103,6 +103,12 @@ int mp2g_d2h(mp2g_ctx* c, void* dst, const void* d_src, size_t bytes) {
   CK(hipStreamSynchronize(c->stream));
   return 0;
 }
+int mp2g_d2d_2d(mp2g_ctx* c, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch, size_t width_bytes, size_t rows) {
+  NEED(c && d_dst && d_src && dst_pitch >= width_bytes && src_pitch >= width_bytes, "ctx / pointers / pitches");
+  if (!width_bytes || !rows) return 0;
+  CK(hipMemcpy2DAsync(d_dst, dst_pitch, d_src, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
 int mp2g_host_alloc(mp2g_ctx* c, size_t bytes, void** ptr) {
   NEED(c && ptr, "ctx/ptr");
   CK(hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocDefault));

@@ -219,11 +219,15 @@ class GpuProver:
     the device, the circuit's verifier data from the preprocessed commitment, and the Merkle node hash of the circuit
     set. One CircuitProver (preprocessed oracle, gate table) per distinct circuit, kept for reuse."""
 
-    def __init__(self, ctx, variant=POSEIDON2, witness_check=True, capacity=0):
+    def __init__(self, ctx, variant=POSEIDON2, witness_check=True, capacity=0, device_witness=True):
         """capacity > 0: one prover per circuit, created for `capacity` proofs and used for every batch width up to that
         (mp2g_prover_set_active) -- the narrow levels of a tree then cost no device memory of their own; 0: one prover per
         (circuit, batch width)."""
         self.ctx, self.variant, self.witness_check, self.capacity = ctx, variant, witness_check, capacity
+        # device_witness: generate_proofs_batch replays the witness programs on the device (prove_chain: mp2g_witness_program_run_dev,
+        # the whole base + wrap chain queued on the stream, proofs handed from step to step by device copies); off: host threads
+        # (mp2g_witness_program_run_rows) and an upload per step -- kept for A/B runs and as the second opinion of the parity tests
+        self.device_witness = device_witness
         self.provers = {}
         self.pinned = {}  # data address of a pinned wire matrix -> its host pointer
 
@@ -302,6 +306,65 @@ class GpuProver:
             self.ctx.wires_from_rows_dev(cp.d_rows, cp.d_w, ckt.log_n, B)
         cp.prove(cp.d_w, cp.d_ph)
         return cp, B
+
+    def _chain_prover(self, ckt, prog, B):
+        """the CircuitProver of a chain step with its device-side witness buffers: program inputs, wires, probe (pi hash + public inputs)"""
+        n = 1 << ckt.log_n
+        cap = max(B, self.capacity) if self.capacity else B
+        key = (ckt.log_n, self.circuit_key(ckt), cap)
+        cp = self.provers.get(key)
+        if cp is None:
+            cp = self.provers[key] = CircuitProver(self.ctx, ckt, cap, self.variant, witness_check=self.witness_check)
+            cp.d_w, cp.d_ph, cp.d_rows = self.ctx.alloc(cap * 135 * n * 8), self.ctx.alloc(cap * 32), None
+        if getattr(cp, "d_in", None) is None:
+            cp.d_in, cp.d_probe = self.ctx.alloc(cap * prog.n_inputs * 8), self.ctx.alloc(cap * prog.probe.size * 8)
+        if cap != B or getattr(cp.pr, "active", cap) != B:
+            cp.pr.set_active(B)
+        return cp
+
+    def prove_chain(self, ckts, progs, cur, capture=None, name=""):
+        """generate_proof's chain for B nodes without the host in the loop: `cur` [B][n_inputs] (host) are the base circuit's witness
+        inputs; per step the witness program runs on the device into the prover's wire matrix, prove() follows on the same
+        stream, and the next step's inputs (public inputs, caps, openings, FRI proof: recursion.proof_inputs order) are
+        gathered from the prover's outputs by device copies. One synchronisation at the end. Returns [(caps, openings, proof,
+        public_inputs)] of the last step."""
+        ctx, B = self.ctx, cur.shape[0]
+        cps, prev = [], None
+        for step, (ckt, prog) in enumerate(zip(ckts, progs)):
+            cp = self._chain_prover(ckt, prog, B)
+            n_in, n_pr = prog.n_inputs, int(prog.probe.size)
+            if prev is None:
+                assert cur.shape[1] == n_in
+                cp.d_in.upload_at(np.ascontiguousarray(cur, dtype=np.uint64), 0)
+            else:
+                pcp, pprog = prev
+                fp, n_pi, ppr = pcp.fp, pprog.n_public_inputs, int(pprog.probe.size)
+                cw, ow, pw = 3 * fp.cap_words, fp.n_openings * 2, fp.proof_words
+                assert n_in == n_pi + cw + ow + pw, f"{name} step {step}: {n_in} inputs for a proof of {n_pi + cw + ow + pw} words"
+                ctx.d2d_2d(cp.d_in, 0, n_in * 8, pcp.d_probe, 4 * 8, ppr * 8, n_pi * 8, B)
+                ctx.d2d_2d(cp.d_in, n_pi * 8, n_in * 8, pcp.pr.d_caps, fp.cap_words * 8, fp.n_oracles * fp.cap_words * 8, cw * 8, B)
+                ctx.d2d_2d(cp.d_in, (n_pi + cw) * 8, n_in * 8, pcp.pr.d_openings, 0, ow * 8, ow * 8, B)
+                ctx.d2d_2d(cp.d_in, (n_pi + cw + ow) * 8, n_in * 8, pcp.pr.d_proof, 0, pw * 8, pw * 8, B)
+            prog.run_dev(ctx, cp.d_in, B, cp.d_w, cp.d_probe)
+            ctx.d2d_2d(cp.d_ph, 0, 32, cp.d_probe, 0, n_pr * 8, 32, B)
+            cp.prove(cp.d_w, cp.d_ph)
+            cps.append(cp)
+            prev = (cp, prog)
+        if self.witness_check:
+            for cp in cps:
+                cp.pr.witness_status()  # raises like plonky2's prove() on an unsatisfied witness
+        last, lprog = prev
+        caps, openings, proofs = last.results()
+        pis = last.d_probe.download((B, int(lprog.probe.size)))[:, 4:]
+        if capture is not None:
+            for step, (cp, ckt) in enumerate(zip(cps, ckts)):
+                n = 1 << ckt.log_n
+                w = cp.d_w.download((B, 135, n))
+                c, o, p = cp.results()
+                ph = cp.d_probe.download((B, int(progs[step].probe.size)))[:, :4]
+                for b in range(B):
+                    capture.append((name, step, ckt, cp.circuit_digest, w[b].copy(), ph[b].copy(), c[b], o[b], p[b]))
+        return [(caps[b], openings[b], proofs[b], pis[b].copy()) for b in range(B)]
 
     def prove_batch_finish(self, handle):
         cp, B = handle

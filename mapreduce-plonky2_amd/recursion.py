@@ -1763,6 +1763,9 @@ def _generate_proofs_batch(self, name, jobs, threads=0, session=None, capture=No
             parts.append(np.asarray(inputs, dtype=np.uint64).ravel())
         rows.append(np.concatenate(parts))
     cur = np.stack(rows)
+    if getattr(sess.prover, "device_witness", False):
+        assert cur.shape[1] == progs[0].n_inputs, f"{name}: {cur.shape[1]} inputs for a program of {progs[0].n_inputs}"
+        return sess.prover.prove_chain([c[0] for c in self.chains[name]], progs, cur, capture=capture, name=name)
     proofs = None
     for step, prog in enumerate(progs):
         assert cur.shape[1] == prog.n_inputs, f"{name} step {step}: {cur.shape[1]} inputs for a program of {prog.n_inputs}"

@@ -97,8 +97,7 @@ def test_device_witness_replay_equals_the_host_replay(ctx, mp2):
     set_digest = np.asarray(fw.set_digest, dtype=np.uint64)
     map_in = np.stack([np.concatenate([set_digest, data[4 * i:4 * i + 4]]) for i in range(B)])
     base_proofs = [(c[6], c[7], c[8]) for c in cap if c[0] == "map" and c[1] == 0]
-    map_pis = [np.concatenate([[sum(int(x) for x in data[4 * i:4 * i + 4] if int(x) % 2 == 0) % O.P], O.hash_n_to_m_no_pad(data[4 * i:4 * i + 4], 4), set_digest]).astype(np.uint64) for i in range(B)]
-    wrap_in = np.stack([R.proof_inputs((*base_proofs[i], map_pis[i])) for i in range(B)])
+    wrap_in = np.stack([R.proof_inputs((*base_proofs[i], leaves[i][3])) for i in range(B)])  # a wrap proof carries its base proof's public inputs
     vd = fw.vds["map"]
     red_in = np.concatenate([set_digest] + [R.universal_inputs(leaves[i], vd, fw.membership(vd[1])) for i in range(2)])[None]
     for name, step, inputs in (("map", 0, map_in), ("map", 1, wrap_in), ("reduce", 0, red_in)):
