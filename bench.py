@@ -266,9 +266,9 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
     generate_proof does is inside the timed region: witness generation (mp2g_witness_program_run on the host's threads),
     upload, prove() with the device-side witness check, download of the proofs the next level verifies. With several
     ranks the tree continues above the shard boundary: log2(world) levels in which the owner of a parent receives the
-    other child's final proof as the reference moves proofs between tree levels -- bincode bytes of
-    ProofWithPublicInputs (mp2g_proof_serialize / mp2g_proof_deserialize; mp2-common/src/proof.rs:42-57) over a
-    point-to-point send/recv -- and proves the reduce node whose universal verifiers check both children in-circuit."""
+    other child's final proof -- the word ranges of the sender's prover outputs as device tensors over RCCL, copied on the
+    device into the parent's witness inputs (recursion.DeviceProof; host tensors over gloo) -- and proves the reduce node
+    whose universal verifiers check both children in-circuit."""
     assert VARIANT == 0, "the recursive verifier circuit of recursion.py hashes with Poseidon2 gates (the reference's default config)"
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     R = importlib.import_module("mapreduce-plonky2_amd.recursion")
@@ -323,21 +323,27 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
                 th.join()
             if any(r is None for r in local):
                 raise SystemExit("bench.py: a tree thread failed")
-        return [above_shards(*local[t]) for t in range(n_trees)]
+        return [above_shards(*local[t], t=t) for t in range(n_trees)]
 
-    def above_shards(root, root_name):
+    proof_sizes = [n_pis, 3 * final_fp.cap_words, final_fp.n_openings * 2, final_fp.proof_words]
+
+    def above_shards(root, root_name, t=0):
+        sess = sessions[t]
         for lvl in range(world.bit_length() - 1):  # above the shard boundary
             bit = 1 << lvl
             if rank & (bit - 1):
                 break
             if rank & bit:
-                blob = mp2.serialize_proof(final_fp, final_ckt.num_constants, root[0], root[1], root[2], root[3])
-                sharding.exchange_bytes(dist, bytes([0 if root_name == "map" else 1]) + blob, rank, rank - bit, dev)
+                # the root proof leaves from the prover's output buffers (device tensors over RCCL; mp2g_proof_serialize is the
+                # wire format for hosts that store proofs, mp2-common/src/proof.rs:42-57 -- not needed between GPUs)
+                tag = torch.tensor([0 if root_name == "map" else 1], dtype=torch.int64)
+                dist.send(tag.to(dev) if nccl else tag, rank - bit)
+                sharding.send_device_proof(dist, sess.prover.ctx, sess.prover.last_device_proof(0), rank - bit, dev)
                 break
-            got = sharding.exchange_bytes(dist, None, rank + bit, rank, dev)
-            c_caps, c_open, c_fri, c_pis = mp2.deserialize_proof(final_fp, final_ckt.num_constants, got[1:], n_pis)
-            child = (c_caps, c_open, c_fri, c_pis)
-            (root,) = fw.generate_proofs_batch("reduce", [([root, child], [root_name, "map" if got[0] == 0 else "reduce"], None)])
+            tag = torch.zeros(1, dtype=torch.int64, device=dev)
+            dist.recv(tag, rank + bit)
+            child = sharding.recv_device_proof(dist, proof_sizes, rank + bit, dev)
+            (root,) = fw.generate_proofs_batch("reduce", [([root, child], [root_name, "map" if int(tag.item()) == 0 else "reduce"], None)], session=sess)
             root_name = "reduce"
         return root
 
@@ -631,6 +637,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     final_ckt = params.rows.chains["row_leaf"][-1][0]  # every final proof of the row set has this shape (the shared common data)
     final_fp = FW.circuit_fri_params(final_ckt, VARIANT)
     n_pis = T.ROWS_IO + 4
+    proof_sizes = [n_pis, 3 * final_fp.cap_words, final_fp.n_openings * 2, final_fp.proof_words]
     names = list(params.rows.circuits)
     last = {}
 
@@ -644,12 +651,17 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
             if rank & (bit - 1):
                 break
             if rank & bit:
-                blob = mp2.serialize_proof(final_fp, final_ckt.num_constants, *cur[0])
-                sharding.exchange_bytes(dist, bytes([names.index(cur[1])]) + np.asarray(cur[2], dtype=np.uint64).tobytes() + blob, rank, rank - bit, dev)
+                # the root proof goes to the parent's rank from where the prover left it: device to device over RCCL
+                head = torch.from_numpy(np.concatenate([[names.index(cur[1])], np.asarray(cur[2], dtype=np.uint64).view(np.int64)]).astype(np.int64))
+                dist.send(head.to(dev) if nccl else head, rank - bit)
+                sess = build.last_session
+                sharding.send_device_proof(dist, sess.prover.ctx, sess.prover.last_device_proof(0), rank - bit, dev)
                 break
-            got = sharding.exchange_bytes(dist, None, rank + bit, rank, dev)
-            other = mp2.deserialize_proof(final_fp, final_ckt.num_constants, got[41:], n_pis)
-            cur = T.join_blocks(build, ctx, cur, (tuple(other), names[got[0]], np.frombuffer(got[1:41], dtype=np.uint64)), 2 * (rank + bit) - 1, n_cols, 0xC0FFEE04, VARIANT)
+            head = torch.zeros(6, dtype=torch.int64, device=dev)
+            dist.recv(head, rank + bit)
+            head = head.cpu().numpy()
+            other = sharding.recv_device_proof(dist, proof_sizes, rank + bit, dev)
+            cur = T.join_blocks(build, ctx, cur, (other, names[int(head[0])], head[1:6].view(np.uint64)), 2 * (rank + bit) - 1, n_cols, 0xC0FFEE04, VARIANT)
         return cur
 
     def barrier():
@@ -792,7 +804,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "shapes": shapes,
                           "setup_s": round(t_setup, 1), "hasher": "Poseidon2",
-                          "sharding": f"{world} rank(s): one block of rows each, no collective below the block roots; {world.bit_length() - 1} join level(s) move a root proof point to point",
+                          "sharding": f"{world} rank(s): one block of rows each, no collective below the block roots; {world.bit_length() - 1} join level(s) move a root proof point to point "
+                                      f"({sum(proof_sizes) * 8} B, " + ("device to device over RCCL into the parent's device-side witness inputs)" if nccl else "host tensors over gloo)"),
                           "root_public_inputs": [int(x) for x in cur[0][3]],
                           "verified": f"{verified} prove() calls of sampled framework proofs (one of every circuit kind of the last step, on every rank) equal the CPU "
                                       "oracle's proofs of the same witnesses bit for bit and pass its verifier; the block roots expose the off-circuit tree hash, "

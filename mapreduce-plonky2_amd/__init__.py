@@ -153,6 +153,11 @@ class Context:
         _ck(load().mp2g_d2d_2d(self.h, ctypes.c_void_p(d_dst.ptr.value + dst_offset), ctypes.c_size_t(dst_pitch),
                                ctypes.c_void_p(d_src.ptr.value + src_offset), ctypes.c_size_t(src_pitch), ctypes.c_size_t(width), ctypes.c_size_t(rows)))
 
+    def d2d_raw(self, d_dst, dst_offset, src_ptr, nbytes):
+        """stream-ordered device copy of nbytes from a raw device address into a DeviceBuffer"""
+        _ck(load().mp2g_d2d_2d(self.h, ctypes.c_void_p(d_dst.ptr.value + dst_offset), ctypes.c_size_t(nbytes), ctypes.c_void_p(int(src_ptr)),
+                               ctypes.c_size_t(nbytes), ctypes.c_size_t(nbytes), ctypes.c_size_t(1)))
+
     def wires_from_rows_dev(self, d_rows, d_wires, log_n, batch, num_wires=135):
         """[batch][n][num_wires] (the witness executor's row layout) -> [batch][num_wires][n] (the prover's), on the device"""
         _ck(load().mp2g_wires_from_rows_dev(self.h, d_rows.ptr, d_wires.ptr, log_n, num_wires, batch))

@@ -322,7 +322,7 @@ class GpuProver:
             cp.pr.set_active(B)
         return cp
 
-    def prove_chain(self, ckts, progs, cur, capture=None, name=""):
+    def prove_chain(self, ckts, progs, cur, capture=None, name="", patches=()):
         """generate_proof's chain for B nodes without the host in the loop: `cur` [B][n_inputs] (host) are the base circuit's witness
         inputs; per step the witness program runs on the device into the prover's wire matrix, prove() follows on the same
         stream, and the next step's inputs (public inputs, caps, openings, FRI proof: recursion.proof_inputs order) are
@@ -336,6 +336,11 @@ class GpuProver:
             if prev is None:
                 assert cur.shape[1] == n_in
                 cp.d_in.upload_at(np.ascontiguousarray(cur, dtype=np.uint64), 0)
+                for j, off, dp in patches:  # child proofs that live on the device (recursion.DeviceProof): copied in place, no host visit
+                    at = (j * n_in + off) * 8
+                    for ptr, nw in dp.parts:
+                        ctx.d2d_raw(cp.d_in, at, ptr, nw * 8)
+                        at += nw * 8
             else:
                 pcp, pprog = prev
                 fp, n_pi, ppr = pcp.fp, pprog.n_public_inputs, int(pprog.probe.size)
@@ -354,6 +359,7 @@ class GpuProver:
             for cp in cps:
                 cp.pr.witness_status()  # raises like plonky2's prove() on an unsatisfied witness
         last, lprog = prev
+        self.last_chain = (last, lprog, B)
         caps, openings, proofs = last.results()
         pis = last.d_probe.download((B, int(lprog.probe.size)))[:, 4:]
         if capture is not None:
@@ -365,6 +371,18 @@ class GpuProver:
                 for b in range(B):
                     capture.append((name, step, ckt, cp.circuit_digest, w[b].copy(), ph[b].copy(), c[b], o[b], p[b]))
         return [(caps[b], openings[b], proofs[b], pis[b].copy()) for b in range(B)]
+
+    def last_device_proof(self, b=0):
+        """proof b of the last prove_chain as a recursion.DeviceProof over the prover's output buffers: valid until this prover's next
+        chain of the same circuit (hand it on -- to a parent's generate_proofs_batch or to another rank -- before that)"""
+        from .recursion import DeviceProof
+        cp, prog, B = self.last_chain
+        assert 0 <= b < B
+        fp, n_pr, n_pi = cp.fp, int(prog.probe.size), prog.n_public_inputs
+        cw, ow, pw = fp.cap_words, fp.n_openings * 2, fp.proof_words
+        parts = [(cp.d_probe.ptr.value + (b * n_pr + 4) * 8, n_pi), (cp.pr.d_caps.ptr.value + (b * fp.n_oracles + 1) * cw * 8, 3 * cw),
+                 (cp.pr.d_openings.ptr.value + b * ow * 8, ow), (cp.pr.d_proof.ptr.value + b * pw * 8, pw)]
+        return DeviceProof(parts, keep=cp)
 
     def prove_batch_finish(self, handle):
         cp, B = handle

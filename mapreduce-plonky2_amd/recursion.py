@@ -1742,6 +1742,30 @@ def universal_inputs(proof, vd, membership):
                            np.asarray(bits, dtype=np.uint64).ravel(), np.asarray(sib, dtype=np.uint64).ravel()])
 
 
+class DeviceProof:
+    """a final framework proof that stays in device memory: the address and length (u64 words) of its public inputs, its three proof
+    caps, its openings and its FRI proof words, in recursion.proof_inputs order. A parent's generate_proofs_batch copies them into
+    its witness inputs on the device (GpuProver.prove_chain); between ranks they travel as device tensors (sharding.send_device_proof).
+    `keep` holds whatever owns the memory."""
+
+    def __init__(self, parts, keep=None):
+        self.parts, self.keep = [(int(p), int(n)) for p, n in parts], keep
+        self.n_words = sum(n for _, n in self.parts)
+
+    def to_host(self, ctx):
+        """(caps [4][cap words], openings [n][2], fri words, public inputs): the host form of the same proof"""
+        import ctypes
+        from . import _ck, load
+        out = []
+        for ptr, n in self.parts:
+            a = np.empty(n, dtype=np.uint64)
+            _ck(load().mp2g_d2h(ctx.h, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(n * 8)))
+            out.append(a)
+        pis, caps3, openings, fri = out
+        caps = np.concatenate([np.zeros(caps3.size // 3, dtype=np.uint64), caps3]).reshape(4, -1)  # oracle 0's cap is verifier data, not proof
+        return caps, openings.reshape(-1, 2), fri, pis
+
+
 def _generate_proofs_batch(self, name, jobs, threads=0, session=None, capture=None):
     """RecursiveCircuits.generate_proof for a batch of nodes of circuit `name`: jobs = [(child_proofs, child_names, inputs)].
     Witnesses come from the circuits' recorded programs (csrc/witness.hip: host threads, one proof each), proving from
@@ -1753,19 +1777,28 @@ def _generate_proofs_batch(self, name, jobs, threads=0, session=None, capture=No
     openings, proof) -- what a checker needs to prove the same witness again."""
     sess = session if session is not None else self.default_session()
     progs = self.witness_programs(name)
-    rows = []
-    for child_proofs, child_names, inputs in jobs:
+    on_device = bool(getattr(sess.prover, "device_witness", False))
+    rows, patches = [], []
+    for j, (child_proofs, child_names, inputs) in enumerate(jobs):
         parts = [np.asarray(self.set_digest, dtype=np.uint64)]
         for pr, cn in zip(child_proofs, child_names):
             vd = self.vds[cn]
-            parts.append(universal_inputs(pr, vd, self.membership(vd[1])))
+            if isinstance(pr, DeviceProof) and not on_device:
+                pr = pr.to_host(sess.prover.ctx)
+            if isinstance(pr, DeviceProof):  # the proof words are copied in on the device; the host fills what surrounds them
+                bits, sib = self.membership(vd[1])
+                head = np.concatenate([np.asarray(vd[0], dtype=np.uint64).ravel(), np.asarray(vd[1], dtype=np.uint64).ravel()])
+                patches.append((j, sum(p.size for p in parts) + head.size, pr))
+                parts += [head, np.zeros(pr.n_words, dtype=np.uint64), np.asarray(bits, dtype=np.uint64).ravel(), np.asarray(sib, dtype=np.uint64).ravel()]
+            else:
+                parts.append(universal_inputs(pr, vd, self.membership(vd[1])))
         if inputs is not None:
             parts.append(np.asarray(inputs, dtype=np.uint64).ravel())
         rows.append(np.concatenate(parts))
     cur = np.stack(rows)
     if getattr(sess.prover, "device_witness", False):
         assert cur.shape[1] == progs[0].n_inputs, f"{name}: {cur.shape[1]} inputs for a program of {progs[0].n_inputs}"
-        return sess.prover.prove_chain([c[0] for c in self.chains[name]], progs, cur, capture=capture, name=name)
+        return sess.prover.prove_chain([c[0] for c in self.chains[name]], progs, cur, capture=capture, name=name, patches=patches)
     proofs = None
     for step, prog in enumerate(progs):
         assert cur.shape[1] == prog.n_inputs, f"{name} step {step}: {cur.shape[1]} inputs for a program of {prog.n_inputs}"

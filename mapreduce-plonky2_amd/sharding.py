@@ -140,6 +140,43 @@ def recv_proof_words(dist, sizes, src, device=None):
     return out
 
 
+class _RawView:
+    def __init__(self, ptr, n_words, keep):
+        self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+        self._keep = keep
+
+
+def send_device_proof(dist, ctx, dp, dst, device=None):
+    """hand a final proof (recursion.DeviceProof) to the rank that proves its parent. RCCL (device given): the word ranges of the
+    prover's output buffers are sent as they are, device to device; gloo: through host tensors. The context's stream is drained
+    first: the collective runs on torch's stream."""
+    import torch
+    ctx.sync()
+    if device is not None:
+        parts = [torch.as_tensor(_RawView(ptr, n, dp.keep), device=device) for ptr, n in dp.parts]
+    else:
+        caps, openings, fri, pis = dp.to_host(ctx)
+        parts = [torch.from_numpy(np.ascontiguousarray(a).view(np.int64).ravel().copy()) for a in (pis, caps[1:4], openings, fri)]
+    for t in parts:
+        dist.send(t, dst)
+    if device is not None:
+        torch.cuda.synchronize()
+
+
+def recv_device_proof(dist, sizes, src, device=None):
+    """the receiving side: sizes = words of (public inputs, three caps, openings, FRI proof). Returns a recursion.DeviceProof over
+    the received device tensors (RCCL) or the host proof tuple (gloo)."""
+    import torch
+    from .recursion import DeviceProof
+    ts = recv_proof_words(dist, sizes, src, device)
+    if device is not None:
+        torch.cuda.synchronize()
+        return DeviceProof([(t.data_ptr(), t.numel()) for t in ts], keep=ts)
+    pis, caps3, openings, fri = [t.numpy().view(np.uint64) for t in ts]
+    caps = np.concatenate([np.zeros(caps3.size // 3, dtype=np.uint64), caps3]).reshape(4, -1)
+    return caps, openings.reshape(-1, 2), fri, pis
+
+
 def all_gather_bytes(dist, payload, device=None):
     """all_gather of one variable-length byte string per rank (serialized root proofs of a wave):
     lengths first, then bodies padded to the longest. Returns [bytes per rank]."""

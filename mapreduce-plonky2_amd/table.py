@@ -289,6 +289,7 @@ class TableBuild:
             out += fw.generate_proofs_batch(name, jobs[lo:lo + self.batch], threads=self.host_threads, session=sess)
         with self.lock:
             self.n_proofs += len(jobs)
+            self.last_session = sess  # whose prover holds the most recent final proofs on the device (the root's, after run())
         return out
 
     def cells_proofs(self, table, wit, rows, sess):

@@ -407,8 +407,8 @@ def test_independent_trees_in_parallel_sessions(ctx, mp2):
 
 def test_two_ranks_real_recursion_with_proof_handoff():
     """bench.py --workload recursion on two ranks (gloo rendezvous, both on the test box's GPU): each rank proves an 8-leaf
-    tree of real framework proofs, then rank 1's root proof travels as bincode bytes (mp2g_proof_serialize ->
-    send/recv -> mp2g_proof_deserialize) to rank 0, whose reduce node verifies both roots in-circuit; the run itself
+    tree of real framework proofs, then rank 1's root proof travels to rank 0 (sharding.send_device_proof / recv_device_proof: device
+    tensors over RCCL, host tensors in this gloo run), whose reduce node verifies both roots in-circuit; the run itself
     asserts that the final public input is the sum of the even elements of both ranks' data."""
     import json
     import os
@@ -422,3 +422,81 @@ def test_two_ranks_real_recursion_with_proof_handoff():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["shapes"] == {"map": [6, 12], "reduce": [13, 12]}
     assert line["framework_proofs_per_s"] > 0 and len(line["config"]["root_public_inputs"]) == 9
+
+
+def test_1024_leaf_aggregation_of_real_framework_proofs(ctx, mp2):
+    """BASELINE configs[2] on the REAL circuits (recursion-framework/tests/integration.rs:138-261 at 1024 leaves): 1024 map proofs and
+    the 1023 reduce proofs above them (two universal verifiers each), level by level in batches of 128 through generate_proofs_batch
+    -- device-side witness programs, base prove() + wrap, witness check on: 2047 framework proofs. The root's public inputs are (sum
+    of the even elements, hash tree of the chunks, circuit-set digest) as integration.rs:224-228; the first and the last node of
+    every level pass the oracle's verifier; one node per level is re-proved from its captured witness by the oracle, bit for bit."""
+    prover = FW.GpuProver(ctx, capacity=128)
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover, FW.circuit_fri_params)
+    n_leaves, chunk = 1024, 128
+    data = O.rand_field(4 * n_leaves, 0xC0FFEE03)
+
+    def batched(name, jobs):
+        out = []
+        for lo in range(0, len(jobs), chunk):
+            out += fw.generate_proofs_batch(name, jobs[lo:lo + chunk])
+        return out
+
+    level = batched("map", [([], [], data[4 * i:4 * i + 4]) for i in range(n_leaves)])
+    names, n_proofs, levels = ["map"] * n_leaves, n_leaves, [("map", level)]
+    while len(level) > 1:
+        level = batched("reduce", [([level[2 * i], level[2 * i + 1]], [names[2 * i], names[2 * i + 1]], None) for i in range(len(level) // 2)])
+        names = ["reduce"] * len(level)
+        n_proofs += len(level)
+        levels.append(("reduce", level))
+    assert n_proofs == 2047 and len(levels) == 11
+    pis = level[0][3]
+    assert int(pis[0]) == sum(int(x) for x in data if int(x) % 2 == 0) % O.P
+    hs = O.hash_no_pad_batch(data.reshape(n_leaves, 4), 4)
+    while len(hs) > 1:
+        hs = O.hash_no_pad_batch(hs.reshape(len(hs) // 2, 8), 4)
+    assert np.array_equal(pis[1:5], hs[0]) and np.array_equal(pis[5:], np.asarray(fw.set_digest, dtype=np.uint64))
+    for name, lv in levels:
+        wckt, wcap, wdig = fw.chains[name][-1]
+        ofp = C.oracle_params(wckt)
+        for pr in {0: lv[0], len(lv) - 1: lv[-1]}.values():
+            assert C.verify(wckt, ofp, wdig, O.hash_n_to_m_no_pad(pr[3], 4), *pr[:3]) == 0
+    # one node per level (cycling through the positions) again with capture: the same final proof, and every prove() of its chain
+    # equals the oracle's proof of the captured witness. Three levels are enough for the CPU budget: leaves, the middle, the root.
+    for li in (0, 5, 10):
+        name, lv = levels[li]
+        i = (7 * li) % len(lv)
+        job = ([], [], data[4 * i:4 * i + 4]) if li == 0 else ([levels[li - 1][1][2 * i], levels[li - 1][1][2 * i + 1]], [levels[li - 1][0]] * 2, None)
+        cap = []
+        (again,) = fw.generate_proofs_batch(name, [job], capture=cap)
+        assert all(np.array_equal(a, b) for a, b in zip(again, lv[i]))
+        for (nm, step, ckt, digest, wires, ph, caps, openings, proof) in cap:
+            oc, oo, op, _ = C.prove_witness(ckt, C.oracle_params(ckt), np.asarray(digest, dtype=np.uint64), wires, ph)
+            assert np.array_equal(oc, caps) and np.array_equal(oo, openings) and np.array_equal(op, proof), f"level {li} {nm} step {step}"
+    prover.free()
+
+
+def test_device_resident_child_proofs(ctx, mp2):
+    """recursion.DeviceProof: a parent proved over children that never left the device (the word ranges of the children's prover
+    outputs, copied into the parent's witness inputs by device copies -- how proofs cross ranks over RCCL) is the parent proved over
+    the downloaded children, word for word; and the host form of a DeviceProof is the proof."""
+    prover = FW.GpuProver(ctx)
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover, FW.circuit_fri_params)
+    data = O.rand_field(8, 0xC0FFEE05)
+    leaves = fw.generate_proofs_batch("map", [([], [], data[:4]), ([], [], data[4:])])
+    dps = [prover.last_device_proof(b) for b in range(2)]
+    for dp, leaf in zip(dps, leaves):
+        caps, openings, fri, pis = dp.to_host(ctx)
+        assert np.array_equal(caps[1:4], leaf[0][1:4]) and np.array_equal(openings, leaf[1]) and np.array_equal(fri, leaf[2]) and np.array_equal(pis, leaf[3])
+    (on_device,) = fw.generate_proofs_batch("reduce", [(dps, ["map", "map"], None)])
+    (on_host,) = fw.generate_proofs_batch("reduce", [(leaves, ["map", "map"], None)])
+    assert all(np.array_equal(a, b) for a, b in zip(on_device, on_host))
+    # mixed: one child on the device, one on the host; and the host-witness back end downloads a DeviceProof by itself
+    dps = None
+    leaves2 = fw.generate_proofs_batch("map", [([], [], data[:4])])
+    (mixed,) = fw.generate_proofs_batch("reduce", [([prover.last_device_proof(0), leaves[1]], ["map", "map"], None)])
+    assert all(np.array_equal(a, b) for a, b in zip(mixed, on_host))
+    host_prover = FW.GpuProver(ctx, device_witness=False)
+    (via_host,) = fw.generate_proofs_batch("reduce", [([prover.last_device_proof(0), leaves[1]], ["map", "map"], None)], session=R.ProofSession(host_prover))
+    assert all(np.array_equal(a, b) for a, b in zip(via_host, on_host))
+    host_prover.free()
+    prover.free()
