@@ -493,10 +493,11 @@ def test_device_resident_child_proofs(ctx, mp2):
     # mixed: one child on the device, one on the host; and the host-witness back end downloads a DeviceProof by itself
     dps = None
     leaves2 = fw.generate_proofs_batch("map", [([], [], data[:4])])
-    (mixed,) = fw.generate_proofs_batch("reduce", [([prover.last_device_proof(0), leaves[1]], ["map", "map"], None)])
+    dp = prover.last_device_proof(0)  # the map proof, in the outputs of the map chain's last prover (the reduce chains below use others)
+    (mixed,) = fw.generate_proofs_batch("reduce", [([dp, leaves[1]], ["map", "map"], None)])
     assert all(np.array_equal(a, b) for a, b in zip(mixed, on_host))
     host_prover = FW.GpuProver(ctx, device_witness=False)
-    (via_host,) = fw.generate_proofs_batch("reduce", [([prover.last_device_proof(0), leaves[1]], ["map", "map"], None)], session=R.ProofSession(host_prover))
+    (via_host,) = fw.generate_proofs_batch("reduce", [([dp, leaves[1]], ["map", "map"], None)], session=R.ProofSession(host_prover))
     assert all(np.array_equal(a, b) for a, b in zip(via_host, on_host))
     host_prover.free()
     prover.free()
