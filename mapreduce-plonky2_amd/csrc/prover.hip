@@ -615,6 +615,10 @@ int mp2g_prover_set_lookups(mp2g_prover* pr, const mp2g_lookup* luts, uint32_t n
     NEED((uint64_t)(u.first_lut_row - u.last_lut_row + 1) * L.num_lut_slots >= u.table_len, "the table does not fit its LookupTableGate rows");
     total += (size_t)u.table_len * 2;
   }
+  // from here on the old tables are gone: no captured graph and no LookupDev may point into them if a later step fails
+  pr->drop_graph();
+  pr->lookups = LookupDev{};
+  pr->gates.num_lookup_selectors = 0;
   CK(pr->lut_tables.alloc(total * sizeof(uint16_t)));
   CK(pr->lut_eval.alloc((size_t)pr->Bcap * P.zs_count * MP2G_MAX_LUTS * sizeof(u64)));
   size_t off = 0;

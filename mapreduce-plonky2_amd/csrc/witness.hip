@@ -116,7 +116,11 @@ void exec(const mp2g_witness_program& P, const u64* t, const u64* end, u64* vals
           };
           const u32 nt = inner < ns ? inner : ns;
           std::vector<std::thread> pool;
-          for (u32 i = 1; i < nt; i++) pool.emplace_back(worker);
+          try {
+            for (u32 i = 1; i < nt; i++) pool.emplace_back(worker);
+          } catch (...) {
+            // fewer threads than hoped for: the sections are dealt from a shared counter
+          }
           worker();
           for (auto& th : pool) th.join();
         }
@@ -279,8 +283,8 @@ void run_one(const mp2g_witness_program& P, const u64* inputs, u64* vals, u64* w
 }  // namespace
 
 extern "C" {
-int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t n_slots, uint32_t log_n, const uint32_t* input_sids,
-                                uint32_t n_inputs, const uint64_t* const_slots, uint32_t n_consts, mp2g_witness_program** out) {
+static int witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t n_slots, uint32_t log_n, const uint32_t* input_sids,
+                                  uint32_t n_inputs, const uint64_t* const_slots, uint32_t n_consts, mp2g_witness_program** out) {
   NEED(out && (tape || !tape_len) && (input_sids || !n_inputs) && (const_slots || !n_consts), "pointers");
   NEED(log_n >= 1 && log_n <= 20 && n_slots >= 1, "log_n / n_slots");
   mp2g_witness_program* P = new (std::nothrow) mp2g_witness_program();
@@ -407,6 +411,17 @@ int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t 
   *out = P;
   return 0;
 }
+// no C++ exception crosses the C ABI: allocation and thread-creation failures become error returns
+int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t n_slots, uint32_t log_n, const uint32_t* input_sids,
+                                uint32_t n_inputs, const uint64_t* const_slots, uint32_t n_consts, mp2g_witness_program** out) {
+  try {
+    return witness_program_create(tape, tape_len, n_slots, log_n, input_sids, n_inputs, const_slots, n_consts, out);
+  } catch (const std::bad_alloc&) {
+    return fail("out of memory while building the witness program");
+  } catch (...) {
+    return fail("witness program creation failed");
+  }
+}
 uint32_t mp2g_witness_program_num_inputs(const mp2g_witness_program* P) { return P ? (uint32_t)P->input_sids.size() : 0; }
 uint32_t mp2g_witness_program_num_levels(const mp2g_witness_program* P) { return P && !P->level_off.empty() ? (uint32_t)P->level_off.size() - 1 : 0; }
 int mp2g_witness_program_set_probe(mp2g_witness_program* P, const uint32_t* probe_sids, uint32_t n_probe) {
@@ -491,10 +506,19 @@ static int witness_run(const mp2g_witness_program* P, const uint64_t* inputs, ui
       for (uint32_t i = 0; i < n_probe; i++) probe_out[(size_t)b * n_probe + i] = vals[probe_sids[i]];
     }
   };
+  std::atomic<int> failed{0};
+  auto guarded = [&]() {
+    try { worker(); } catch (...) { failed.store(1); }  // bad_alloc of a slot table / an inner pool: report, do not terminate
+  };
   std::vector<std::thread> pool;
-  for (uint32_t i = 1; i < threads; i++) pool.emplace_back(worker);
-  worker();
+  try {
+    for (uint32_t i = 1; i < threads; i++) pool.emplace_back(guarded);
+  } catch (...) {
+    // the host refuses more threads: go on with the ones that started (the work queue is shared)
+  }
+  guarded();
   for (auto& th : pool) th.join();
+  if (failed.load()) return fail("witness replay: out of memory or thread creation failed");
   return 0;
 }
 int mp2g_witness_program_run(const mp2g_witness_program* P, const uint64_t* inputs, uint32_t batch, uint32_t threads, uint64_t* wires,

@@ -1355,6 +1355,10 @@ class FrameworkCircuit:
         self.name, self.num_verifiers, self.logic, self.num_public_inputs = name, num_verifiers, logic, num_public_inputs
 
     def build_base(self, fw, child_proofs, child_vds, memberships, inputs, set_digest, strict=True):
+        if self.num_verifiers and fw.rec.fp.num_lookup_polys:
+            # verify_proof_circuit has no in-circuit lookup argument (check_lookup_constraints_circuit): a circuit with lookup
+            # tables can be proved by prove() but not wrapped or checked by the universal verifier (Limits)
+            raise NotImplementedError("the in-circuit verifier does not check the lookup argument: circuits with lookup tables cannot enter the framework")
         b = Builder(strict)
         set_t = [b.add_virtual(int(x)) for x in set_digest]  # CircuitSetTarget::build_target: a virtual cap of height 0
         child_pis = []
