@@ -311,7 +311,20 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
             names = ["reduce"] * len(level)
         out[t] = (level[0], names[0])
 
+    # the proof that leaves the framework: verifiable-db/src/api.rs:148-214, a PoseidonGoldilocksConfig circuit verifying the root
+    wrap_prover = FW.GpuProver(ctx, mp2.POSEIDON, witness_check=True, device_witness=not args.host_witness)
+    fin = R.FinalWrapCircuit(fw, wrap_prover, lambda ckt: FW.circuit_fri_params(ckt, mp2.POSEIDON))
+    fin.program()
+
     def step():
+        roots = tree_roots()
+        if rank == 0:  # the last step of the pipeline: the final Poseidon wrap of every tree's root
+            final[:] = fin.generate_proofs_batch(roots, ["reduce" if (n_leaves > 1 or world > 1) else "map"] * len(roots))
+        return roots
+
+    final = []
+
+    def tree_roots():
         local = [None] * n_trees
         if n_trees == 1:
             local_tree(0, local)
@@ -380,7 +393,9 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
                "value": world * n_trees * n_leaves * args.steps / dt, "unit": "leaf proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u64 (Goldilocks field)", "data": "synthetic",
-               "framework_proofs_per_s": n_trees * (world * n_nodes + world - 1) * args.steps / dt,
+               "framework_proofs_per_s": n_trees * (world * n_nodes + world - 1 + 1) * args.steps / dt,
+               "final_wrap": {"circuit": "PoseidonGoldilocksConfig wrap of every root (verifiable-db/src/api.rs:148-214), variant = Poseidon prove()", "rows_log2": fin.ckt.log_n,
+                              "public_inputs": [int(x) for x in final[0][3]]},
                "config": {"workload": f"recursion: per rank {n_trees} independent {n_leaves}-leaf map-reduce tree(s) of REAL framework proofs, one host thread and GPU stream each ({n_nodes} per tree = map: base 2^6 + wrap 2^12 "
                                       "rows; reduce: two universal verifiers, base 2^13 + wrap 2^12 rows), witness generation " + ("on the host threads, " if args.host_witness else "on the device (level-scheduled witness programs), ") +
                                       "witness check on, every level inside the timed region",
@@ -389,6 +404,7 @@ def run_recursion(args, rank, local_rank, world, dist, torch, VARIANT):
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    wrap_prover.free()
     for p in provers:
         p.free()
     for c in ctxs:

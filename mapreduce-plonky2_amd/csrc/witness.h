@@ -7,7 +7,7 @@
 
 namespace mp2g {
 enum { OP_ARITH = 1, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
-       OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR, OP_END };
+       OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR, OP_POSEIDON, OP_END };
 const u32 BASE_SUM_LIMBS = 63, RA_BITS = 4, RA_COPIES = 4, RED_COEFFS = 43, RED_EXT_COEFFS = 32, NUM_WIRES = 135;
 
 // the program's read-only data on one device (uploaded at the first device run there)

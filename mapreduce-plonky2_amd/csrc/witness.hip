@@ -29,7 +29,7 @@ u32 op_len(u64 op, const u64* t) {
   switch (op) {
     case OP_ARITH: return 8;
     case OP_ARITH_EXT: return 12;
-    case OP_P2: return 1 + 12 + 1 + 12;
+    case OP_P2: case OP_POSEIDON: return 1 + 12 + 1 + 12;
     case OP_BASE_SUM: return 2 + BASE_SUM_LIMBS;
     case OP_RA: return 3 + 16 + 1;
     case OP_REDUCING: return 5 + RED_COEFFS + 2;
@@ -80,6 +80,18 @@ void p2_internal(u64 s[12]) {
     hi += l2 < lo ? 1 : 0;
     s[i] = gl_reduce128(l2, hi);
   }
+}
+// Poseidon's MDS layer on canonical values: circ [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,...]; entries < 2^6, so a row sum
+// stays below 2^74: one reduction per output limb
+void poseidon_mds_host(u64 s[12]) {
+  typedef unsigned __int128 u128;
+  u64 out[12];
+  for (int r = 0; r < 12; r++) {
+    u128 acc = (u128)s[r] * POSEIDON_MDS_DIAG[r];
+    for (int i = 0; i < 12; i++) acc += (u128)s[(i + r) % 12] * POSEIDON_MDS_CIRC[i];
+    out[r] = gl_reduce128((u64)acc, (u64)(acc >> 64));
+  }
+  for (int i = 0; i < 12; i++) s[i] = out[i];
 }
 }  // namespace
 
@@ -178,6 +190,34 @@ void exec(const mp2g_witness_program& P, const u64* t, const u64* end, u64* vals
           for (int i = 0; i < 12; i++) { s[i] = gl_add(s[i], POSEIDON2_RC_EXT[12 * (4 + r) + i]); W(87 + 12 * r + i, row) = s[i]; }
           for (int i = 0; i < 12; i++) s[i] = gl_pow7(s[i]);
           p2_external(s);
+        }
+        for (int i = 0; i < 12; i++) { W(12 + i, row) = s[i]; vals[t[14 + i]] = s[i]; }
+        t += 26;
+        break;
+      }
+      case OP_POSEIDON: {  // PoseidonGate: the wire layout of the Poseidon2 gate, the original permutation (30 rounds, 4 + 22 + 4)
+        const u64 row = t[0];
+        u64 in[12], s[12];
+        for (int i = 0; i < 12; i++) { in[i] = vals[t[1 + i]]; W(i, row) = in[i]; }
+        const u64 swap = vals[t[13]];
+        W(24, row) = swap;
+        for (int i = 0; i < 4; i++) {
+          const u64 delta = gl_mul(swap, gl_sub(in[i + 4], in[i]));
+          W(25 + i, row) = delta;
+          s[i] = gl_add(in[i], delta);
+          s[i + 4] = gl_sub(in[i + 4], delta);
+        }
+        for (int i = 8; i < 12; i++) s[i] = in[i];
+        for (int r = 0; r < 30; r++) {
+          for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], POSEIDON_RC[12 * r + i]);
+          if (r >= 4 && r < 26) {
+            W(65 + r - 4, row) = s[0];
+            s[0] = gl_pow7(s[0]);
+          } else {
+            if (r) { const int base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26); for (int i = 0; i < 12; i++) W(base + i, row) = s[i]; }
+            for (int i = 0; i < 12; i++) s[i] = gl_pow7(s[i]);
+          }
+          poseidon_mds_host(s);
         }
         for (int i = 0; i < 12; i++) { W(12 + i, row) = s[i]; vals[t[14 + i]] = s[i]; }
         t += 26;
@@ -332,7 +372,7 @@ static int witness_program_create(const uint64_t* tape, size_t tape_len, uint32_
     u32 first_slot = 0;
     switch (op) {
       case OP_ARITH: case OP_ARITH_EXT: if (t[0] >= n || t[1] >= (op == OP_ARITH ? 20u : 10u) || t[2] >= GL_P || t[3] >= GL_P) return bad("arithmetic operands"); first_slot = 4; break;
-      case OP_P2: case OP_BASE_SUM: case OP_REDUCING: case OP_REDUCING_EXT: if (t[0] >= n) return bad("row"); first_slot = 1; break;
+      case OP_P2: case OP_POSEIDON: case OP_BASE_SUM: case OP_REDUCING: case OP_REDUCING_EXT: if (t[0] >= n) return bad("row"); first_slot = 1; break;
       case OP_RA: if (t[0] >= n || t[1] >= RA_COPIES) return bad("random access operands"); first_slot = 2; break;
       case OP_COSET: if (t[0] >= n) return bad("row"); first_slot = 2; break;
       case OP_WIRE: if (t[0] >= n || t[1] >= NUM_WIRES) return bad("wire"); first_slot = 2; break;
@@ -374,7 +414,7 @@ static int witness_program_create(const uint64_t* tape, size_t tape_len, uint32_
       switch (op) {
         case OP_ARITH: r0 = 4; nr = 3; w0 = 7; nw = 1; break;
         case OP_ARITH_EXT: r0 = 4; nr = 6; w0 = 10; nw = 2; break;
-        case OP_P2: r0 = 1; nr = 13; w0 = 14; nw = 12; break;
+        case OP_P2: case OP_POSEIDON: r0 = 1; nr = 13; w0 = 14; nw = 12; break;
         case OP_BASE_SUM: r0 = 1; nr = 1; w0 = 2; nw = BASE_SUM_LIMBS; break;
         case OP_RA: r0 = 2; nr = 17; w0 = 19; nw = 1; break;
         case OP_REDUCING: r0 = 1; nr = 4 + RED_COEFFS; w0 = 5 + RED_COEFFS; nw = 2; break;

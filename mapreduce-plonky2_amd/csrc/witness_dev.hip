@@ -64,6 +64,44 @@ GLD void exec_p2(const u64* t, u64* vals, u64* wires, u64 n) {
   for (int i = 0; i < 12; i++) { const u64 o = gl_canon(s[i]); W(12 + i, row) = o; vals[t[14 + i]] = o; }
 }
 
+GLD void exec_poseidon(const u64* t, u64* vals, u64* wires, u64 n) {
+  // PoseidonGate ([dep] gates/poseidon.rs): the wire layout of the Poseidon2 gate, the original permutation (4 + 22 + 4 rounds)
+  const u64 row = t[0];
+  u64 s[12];
+#pragma unroll
+  for (int i = 0; i < 12; i++) { s[i] = vals[t[1 + i]]; W(i, row) = s[i]; }
+  const u64 swap = vals[t[13]];
+  W(24, row) = swap;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const u64 delta = gl_mul(swap, gl_sub(s[i + 4], s[i]));
+    W(25 + i, row) = delta;
+    s[i] = gl_add(s[i], delta);
+    s[i + 4] = gl_sub(s[i + 4], delta);
+  }
+#pragma unroll 1
+  for (int r = 0; r < 30; r++) {
+    if (r >= 4 && r < 26) {
+#pragma unroll
+      for (int i = 1; i < 12; i++) s[i] = gl_addw(s[i], c_p_rc[12 * r + i]);
+      const u64 x = gl_canon(gl_addw(s[0], c_p_rc[12 * r]));
+      W(65 + r - 4, row) = x;
+      s[0] = p2_sbox0(x);
+    } else {
+      const int base = r < 4 ? 29 + 12 * (r - 1) : 87 + 12 * (r - 26);
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        const u64 x = gl_canon(gl_addw(s[i], c_p_rc[12 * r + i]));
+        if (r) W(base + i, row) = x;
+        s[i] = p2_sbox0(x);
+      }
+    }
+    poseidon_mds(s);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) { const u64 o = gl_canon(s[i]); W(12 + i, row) = o; vals[t[14 + i]] = o; }
+}
+
 GLD void exec_one(const u64* t, u64* vals, u64* wires, u64 n, const u64* domtab) {
   const u64 op = *t++;
   switch (op) {
@@ -87,6 +125,7 @@ GLD void exec_one(const u64* t, u64* vals, u64* wires, u64 n, const u64* domtab)
       break;
     }
     case OP_P2: exec_p2(t, vals, wires, n); break;
+    case OP_POSEIDON: exec_poseidon(t, vals, wires, n); break;
     case OP_BASE_SUM: {
       const u64 row = t[0], x = vals[t[1]];
       W(0, row) = x;

@@ -74,7 +74,7 @@ class T:
 # (plonky2's generate_partial_witness for this circuit): csrc/witness.hip replays it for a batch of input vectors.
 # Every instruction: opcode, then its operands (row / slot indices, u64 constants), fixed length per opcode.
 (OP_ARITH, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
- OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR) = range(1, 15)
+ OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR, OP_POSEIDON) = range(1, 16)
 
 
 class E:
@@ -100,7 +100,7 @@ class Row:
 
 def tape_instructions(tape):
     """(position, opcode) of every instruction of a recorded witness program (the lengths csrc/witness.hip's op_len gives)"""
-    fixed = {OP_ARITH: 8, OP_ARITH_EXT: 12, OP_P2: 26, OP_BASE_SUM: 2 + 63, OP_RA: 20, OP_REDUCING: 5 + 43 + 2, OP_REDUCING_EXT: 5 + 64 + 2,
+    fixed = {OP_ARITH: 8, OP_ARITH_EXT: 12, OP_P2: 26, OP_POSEIDON: 26, OP_BASE_SUM: 2 + 63, OP_RA: 20, OP_REDUCING: 5 + 43 + 2, OP_REDUCING_EXT: 5 + 64 + 2,
              OP_WIRE: 3, OP_HINT_DIV_EXT: 6, OP_HINT_LO63: 2, OP_HINT_HI: 2, OP_HINT_SPLIT: 4}
     t, n = 0, len(tape)
     while t < n:
@@ -118,7 +118,7 @@ def instruction_slots(tape, pos):
     """(slots read, slots written, (row, col) wire cells written, next position) of the instruction at tape[pos] -- the operand roles
     of csrc/witness.hip's executor"""
     op = int(tape[pos])
-    need = {OP_ARITH: 8, OP_ARITH_EXT: 12, OP_P2: 26, OP_BASE_SUM: 65, OP_RA: 20, OP_REDUCING: 50, OP_REDUCING_EXT: 71, OP_WIRE: 3,
+    need = {OP_ARITH: 8, OP_ARITH_EXT: 12, OP_P2: 26, OP_POSEIDON: 26, OP_BASE_SUM: 65, OP_RA: 20, OP_REDUCING: 50, OP_REDUCING_EXT: 71, OP_WIRE: 3,
             OP_HINT_DIV_EXT: 6, OP_HINT_LO63: 2, OP_HINT_HI: 2, OP_HINT_SPLIT: 4}.get(op)
     if need is None and op == OP_COSET:
         need = 3 + (2 << int(tape[pos + 2])) + 4
@@ -127,7 +127,7 @@ def instruction_slots(tape, pos):
         return t[4:7], [t[7]], [(t[0], 4 * t[1] + k) for k in range(4)], pos + 9
     if op == OP_ARITH_EXT:
         return t[4:10], t[10:12], [(t[0], 8 * t[1] + k) for k in range(8)], pos + 13
-    if op == OP_P2:
+    if op in (OP_P2, OP_POSEIDON):
         return t[1:14], t[14:26], [(t[0], c) for c in range(135)], pos + 27
     if op == OP_BASE_SUM:
         return [t[1]], t[2:2 + 63], [(t[0], c) for c in range(64)], pos + 1 + 2 + 63
@@ -220,7 +220,11 @@ class Builder:
     REDUCING_COEFFS = 43
     REDUCING_EXT_COEFFS = 32
 
-    def __init__(self, strict=True):
+    def __init__(self, strict=True, hasher=0):
+        # hasher: the circuit's config hasher (0 = Poseidon2GoldilocksConfig, the reference's C; 1 = PoseidonGoldilocksConfig, its
+        # WrapC): what build() hashes the public inputs with (C::InnerHasher) -- Poseidon2Gate or PoseidonGate rows. The prover of
+        # the circuit must commit and draw challenges with the same hasher (CircuitProver(variant=...)).
+        self.hasher = hasher
         # strict: connect() asserts equal values (a wrong witness fails where it is produced). Off, the builder records
         # the copy constraint anyway and the witness simply violates it -- what a dishonest prover would hand to prove()
         self.strict = strict
@@ -545,22 +549,54 @@ class Builder:
     def permute(self, inputs):
         return self.permute_swapped(inputs, self.zero())
 
-    def hash_n_to_m_no_pad(self, inputs, m):
-        """hashing.rs hash_n_to_m_no_pad: overwrite-mode absorb (rate 8), squeeze from the front"""
+    def permute_poseidon_swapped(self, inputs, swap):
+        """one PoseidonGate row ([dep] plonky2 gates/poseidon.rs: the original Poseidon permutation, same wire layout as the Poseidon2
+        gate: inputs 0..11, outputs 12..23, swap 24, deltas 25..28, full-round S-box inputs 29.. and 87.., partial-round ones 65..)"""
+        row = self._new_row(C.POSEIDON)
+        w = self.rows[row].wires
+        for i, t in enumerate(inputs):
+            self._put(row, i, t)
+        self._put(row, 24, swap)
+        Kc = K2()
+        s = [0] * 12
+        for i in range(4):
+            delta = swap.v * (inputs[i + 4].v - inputs[i].v) % P
+            w[25 + i] = delta
+            s[i], s[i + 4] = (inputs[i].v + delta) % P, (inputs[i + 4].v - delta) % P
+        for i in range(8, 12):
+            s[i] = inputs[i].v
+        for r in range(30):
+            s = [(s[i] + Kc["POSEIDON_RC"][12 * r + i]) % P for i in range(12)]
+            if 4 <= r < 26:
+                w[65 + r - 4] = s[0]
+                s[0] = pow(s[0], 7, P)
+            else:
+                if r:
+                    base = 29 + 12 * (r - 1) if r < 4 else 87 + 12 * (r - 26)
+                    w[base:base + 12] = s
+                s = [pow(x, 7, P) for x in s]
+            s = C.poseidon_mds(s)
+        outs = [self._out(row, 12 + i, s[i]) for i in range(12)]
+        self.tape += [OP_POSEIDON, row] + [t.sid for t in inputs] + [swap.sid] + [t.sid for t in outs]
+        return outs
+
+    def hash_n_to_m_no_pad(self, inputs, m, hasher=0):
+        """hashing.rs hash_n_to_m_no_pad: overwrite-mode absorb (rate 8), squeeze from the front; hasher 1 = PoseidonHash (PoseidonGate rows)"""
         z = self.zero()
+        perm = self.permute if hasher == 0 else (lambda st: self.permute_poseidon_swapped(st, z))
         state = [z] * 12
         for i in range(0, len(inputs), 8):
             chunk = inputs[i:i + 8]
-            state = self.permute(list(chunk) + state[len(chunk):])
+            state = perm(list(chunk) + state[len(chunk):])
         if not inputs:
-            state = self.permute(state)
+            state = perm(state)
         out = []
         while True:
             for t in state[:8]:
                 out.append(t)
                 if len(out) == m:
                     return out
-            state = self.permute(state)
+            state = perm(state)
 
     def hash_or_noop(self, inputs):
         if len(inputs) <= 4:
@@ -756,7 +792,7 @@ class Builder:
     def build(self, min_log_n=6):
         """CircuitBuilder::build: the public-inputs hash bound to a PublicInputGate, rows padded with Noops to a
         power of two, selectors, sigma polynomials from the copy classes. Returns a circuits.Circuit."""
-        pi_hash = self.hash_n_to_m_no_pad(self.public_inputs, 4)
+        pi_hash = self.hash_n_to_m_no_pad(self.public_inputs, 4, self.hasher)  # C::InnerHasher of the circuit's config
         pi_row = self._new_row(C.PUBLIC_INPUT)
         for i, t in enumerate(pi_hash):
             self._put(pi_row, i, t)
@@ -1709,6 +1745,59 @@ class RecursiveCircuitsVerifierGadget:
         for x, y in zip(set_t, pis[len(pis) - 4:]):
             b.connect(x, y)
         return pis
+
+
+class FinalWrapCircuit:
+    """verifiable-db/src/api.rs:148-214 WrapCircuitParams: the one circuit whose proofs leave the framework (towards the Groth16
+    wrapper). Built over PoseidonGoldilocksConfig (`type WrapC`): it verifies a proof of ANY circuit of the set `fw` with the
+    universal verifier gadget (verify_proof_in_circuit_set: Poseidon2 hashing in-circuit, since the inner proof is the default
+    config's) and re-exposes the verified proof's own public inputs; the circuit itself is committed, challenged and digested with
+    the ORIGINAL Poseidon, and its public inputs are hashed by PoseidonGate rows (C::InnerHasher of WrapC). `prover` must be a
+    Poseidon-variant back end (framework.GpuProver(ctx, variant=POSEIDON)); fri_params(ckt) the FRI shape under that hasher."""
+
+    def __init__(self, fw, prover, fri_params, num_public_inputs=None):
+        self.fw, self.prover, self.fri_params = fw, prover, fri_params
+        self.gadget = RecursiveCircuitsVerifierGadget(fw)
+        self.n_pi = num_public_inputs if num_public_inputs is not None else fw.rec.n_public_inputs - 4
+        self.ckt = self._build(self.gadget.dummy_inputs(), strict=False)
+        self.cap, self.digest = prover.verifier_data(self.ckt)
+
+    def _build(self, inputs, strict=True):
+        b = Builder(strict, hasher=1)
+        pis = self.gadget.verify_proof_in_circuit_set(b, *inputs)
+        b.register_public_inputs(pis[:self.n_pi])  # get_public_input_targets::<F, N>: the verified proof's own public inputs
+        return b.build(min_log_n=RECURSION_THRESHOLD)
+
+    def program(self):
+        from . import WitnessProgram
+        if not hasattr(self, "_prog"):
+            self._prog = WitnessProgram(self.ckt)
+        return self._prog
+
+    def generate_proof(self, proof, name):
+        """WrapCircuitParams::generate_proof by the eager builder: (caps, openings, fri, public_inputs) of the wrap proof"""
+        vd = self.fw.vds[name]
+        w = self._build((proof, vd, self.fw.membership(vd[1])))
+        assert np.array_equal(w.pre, self.ckt.pre)
+        caps, openings, fri = self.prover.prove(w)
+        return caps, openings, fri, w.public_inputs
+
+    def generate_proofs_batch(self, proofs, names, capture=None):
+        """the same for a batch through the recorded witness program (device replay with a GPU prover)"""
+        rows = []
+        for pr, name in zip(proofs, names):
+            vd = self.fw.vds[name]
+            rows.append(universal_inputs(pr, vd, self.fw.membership(vd[1])))
+        cur = np.stack(rows)
+        prog = self.program()
+        if getattr(self.prover, "device_witness", False):
+            return self.prover.prove_chain([self.ckt], [prog], cur, capture=capture, name="final wrap")
+        wires, pi_hash, pis = prog.run(cur)
+        outs = self.prover.prove_batch(self.ckt, wires, pi_hash)
+        if capture is not None:
+            for i, (c, o, p) in enumerate(outs):
+                capture.append(("final wrap", 0, self.ckt, self.digest, wires[i].copy(), pi_hash[i].copy(), c, o, p))
+        return [(c, o, p, pis[i]) for i, (c, o, p) in enumerate(outs)]
 
 
 def map_logic(b, child_pis, inputs):

@@ -501,3 +501,38 @@ def test_device_resident_child_proofs(ctx, mp2):
     assert all(np.array_equal(a, b) for a, b in zip(via_host, on_host))
     host_prover.free()
     prover.free()
+
+
+def test_final_poseidon_wrap_on_the_gpu(ctx, mp2):
+    """verifiable-db/src/api.rs:148-214,198-209: the final wrap -- a PoseidonGoldilocksConfig circuit that verifies a Poseidon2
+    proof of the framework (here a reduce proof over two map proofs) in the circuit set and re-exposes its public inputs -- on the
+    HIP prover with variant = Poseidon (Merkle caps, challenger, circuit digest by the original Poseidon; the public inputs hashed
+    by PoseidonGate rows of the device-side witness program). Bit-exact against the oracle's variant-1 prover on the captured
+    witness, accepted by its variant-1 verifier, refused under Poseidon2; the builder path gives the same proof."""
+    prover = FW.GpuProver(ctx)
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover, FW.circuit_fri_params)
+    data = O.rand_field(8, 0xC0FFEE06)
+    leaves = fw.generate_proofs_batch("map", [([], [], data[:4]), ([], [], data[4:])])
+    (root,) = fw.generate_proofs_batch("reduce", [(leaves, ["map", "map"], None)])
+    wrap_prover = FW.GpuProver(ctx, variant=mp2.POSEIDON)
+    fin = R.FinalWrapCircuit(fw, wrap_prover, lambda ckt: FW.circuit_fri_params(ckt, mp2.POSEIDON))
+    assert fin.ckt.log_n == R.RECURSION_THRESHOLD
+    cap = []
+    outs = fin.generate_proofs_batch([root, leaves[0]], ["reduce", "map"], capture=cap)  # any circuit of the set
+    for out, inner in zip(outs, (root, leaves[0])):
+        assert np.array_equal(out[3], inner[3][:5])
+        ph = O.hash_n_to_m_no_pad(out[3], 4, 1)
+        ofp = C.oracle_params(fin.ckt, variant=1)
+        assert C.verify(fin.ckt, ofp, fin.digest, ph, *out[:3]) == 0
+        assert C.verify(fin.ckt, C.oracle_params(fin.ckt, variant=0), fin.digest, ph, *out[:3]) != 0
+    (nm, step, ckt, digest, wires, ph, caps, openings, proof) = cap[0]
+    oc, oo, op, _ = C.prove_witness(ckt, C.oracle_params(ckt, variant=1), np.asarray(digest, dtype=np.uint64), wires, ph)
+    assert np.array_equal(oc, caps) and np.array_equal(oo, openings) and np.array_equal(op, proof)
+    one = fin.generate_proof(root, "reduce")
+    assert all(np.array_equal(a, b) for a, b in zip(one, outs[0]))
+    # the host replay of the same program (PoseidonGate rows by the host executor) fills the same wires
+    vd = fw.vds["reduce"]
+    hw, hph, _ = fin.program().run(R.universal_inputs(root, vd, fw.membership(vd[1]))[None])
+    assert np.array_equal(hw[0], wires) and np.array_equal(hph[0], ph)
+    wrap_prover.free()
+    prover.free()

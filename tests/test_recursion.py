@@ -353,3 +353,50 @@ def test_parallel_sections_must_be_independent():
                 p = b2.mul(x, y)
             with region.section():
                 b2.mul(p, x)  # depends on the first section
+
+
+class PoseidonOracleProver(OracleProver):
+    """the oracle as a PoseidonGoldilocksConfig back end (variant 1): caps, transcript and circuit digest by the original Poseidon"""
+
+    def verifier_data(self, ckt):
+        cap = O.merkle_cap(O.merkle_build(O.lde_leaves(O.fft(ckt.pre, inverse=True), 3), 4, 1), 4)
+        dom = O.hash_n_to_m_no_pad([1, 0, 0, 0, 0, 0, 0, 1], 4, 1)
+        return cap, O.hash_n_to_m_no_pad(list(cap.reshape(-1)) + list(dom) + [ckt.log_n], 4, 1)
+
+    def prove(self, ckt):
+        cap, cd = self.verifier_data(ckt)
+        fp = C.oracle_params(ckt, variant=1)
+        caps, openings, proof, _ = C.prove(ckt, fp, cd)
+        assert C.verify(ckt, fp, cd, ckt.pi_hash, caps, openings, proof) == 0
+        return caps, openings, proof
+
+    def prove_batch(self, ckt, wires, pi_hash):
+        cap, cd = self.verifier_data(ckt)
+        fp = C.oracle_params(ckt, variant=1)
+        out = []
+        for w, ph in zip(wires, pi_hash):
+            caps, openings, proof, _ = C.prove_witness(ckt, fp, cd, w, ph)
+            assert C.verify(ckt, fp, cd, ph, caps, openings, proof) == 0
+            out.append((caps, openings, proof))
+        return out
+
+
+def test_final_poseidon_wrap_of_a_framework_proof():
+    """verifiable-db/src/api.rs:148-214 (WrapCircuitParams, `type WrapC = PoseidonGoldilocksConfig`): a circuit over the ORIGINAL
+    Poseidon config that verifies a Poseidon2 proof of the framework with the universal verifier gadget and re-exposes its public
+    inputs. The public inputs are hashed by PoseidonGate rows (their hash = the Poseidon sponge of the oracle); the proof is made and
+    accepted under variant 1; the builder path and the witness-program path agree; a Poseidon2 verifier does not accept it."""
+    FWm = importlib.import_module("mapreduce-plonky2_amd.framework")
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5)], OracleProver(), FWm.circuit_fri_params)
+    data = O.rand_field(4, 31)
+    inner = fw.generate_proof("map", [], [], data)
+    fin = R.FinalWrapCircuit(fw, PoseidonOracleProver(), lambda ckt: FWm.circuit_fri_params(ckt, 1))
+    assert fin.ckt.log_n == R.RECURSION_THRESHOLD and any(g.kind == C.POSEIDON for g in fin.ckt.gates)
+    out = fin.generate_proof(inner, "map")
+    assert np.array_equal(out[3], inner[3][:5])
+    (out2,) = fin.generate_proofs_batch([inner], ["map"])
+    assert all(np.array_equal(a, b) for a, b in zip(out, out2))
+    ph = O.hash_n_to_m_no_pad(out[3], 4, 1)  # C::InnerHasher = PoseidonHash
+    assert C.verify(fin.ckt, C.oracle_params(fin.ckt, variant=1), fin.digest, ph, *out[:3]) == 0
+    assert C.verify(fin.ckt, C.oracle_params(fin.ckt, variant=0), fin.digest, ph, *out[:3]) != 0
+    assert C.verify(fin.ckt, C.oracle_params(fin.ckt, variant=1), fin.digest, O.hash_n_to_m_no_pad(out[3], 4, 0), *out[:3]) != 0
