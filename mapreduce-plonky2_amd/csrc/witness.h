@@ -13,7 +13,7 @@ const u32 BASE_SUM_LIMBS = 63, RA_BITS = 4, RA_COPIES = 4, RED_COEFFS = 43, RED_
 // the program's read-only data on one device (uploaded at the first device run there)
 struct WitnessDev {
   int device = -1;
-  DevBuf tape, sched, level_off, input_sids, consts, domtab, probe;
+  DevBuf tape, sched, level_off, level_p2, input_sids, consts, domtab, probe;
 };
 // device executor (witness_dev.hip): one block per proof walks the level schedule
 hipError_t witness_exec_launch(hipStream_t s, const WitnessDev& d, u32 n_levels, u32 n_slots, u32 log_n, u32 n_inputs, u32 n_consts,
@@ -29,6 +29,7 @@ struct mp2g_witness_program {
   // level schedule for the device executor: instruction offsets ordered by (dependency level, opcode); a level's instructions
   // read only slots written at lower levels (every slot is written once: the builder's programs are in SSA form)
   std::vector<u32> sched, level_off;
+  std::vector<u32> level_p2;  // per level: first schedule index and count of its Poseidon2 rows (one opcode = one contiguous run)
   bool ssa = true;
   std::vector<u32> probe;  // slots returned next to the wires by the device run (mp2g_witness_program_set_probe)
   std::mutex dev_mu;

@@ -447,6 +447,13 @@ static int witness_program_create(const uint64_t* tape, size_t tape_len, uint32_
     // counts per level (index 1..max_lvl) -> offsets: level l's instructions are sched[level_off[l-1] .. level_off[l])
     u32 acc = 0;
     for (u32 l = 0; l <= max_lvl; l++) { acc += P->level_off[l]; P->level_off[l] = acc; }
+    P->level_p2.assign(2 * (size_t)max_lvl, 0);
+    for (size_t i = 0; i < ins.size(); i++)
+      if (ins[i].op == OP_P2) {
+        u32* e = &P->level_p2[2 * (ins[i].lvl - 1)];
+        if (!e[1]) e[0] = (u32)i;
+        e[1]++;
+      }
   }
   *out = P;
   return 0;
@@ -489,6 +496,7 @@ static int witness_dev_data(mp2g_witness_program* P, mp2g_ctx* c, WitnessDev** o
   hipError_t e = up(d->tape, P->tape.data(), P->tape.size() * 8);
   if (e == hipSuccess) e = up(d->sched, P->sched.data(), P->sched.size() * 4);
   if (e == hipSuccess) e = up(d->level_off, P->level_off.data(), P->level_off.size() * 4);
+  if (e == hipSuccess) e = up(d->level_p2, P->level_p2.data(), P->level_p2.size() * 4);
   if (e == hipSuccess) e = up(d->input_sids, P->input_sids.data(), P->input_sids.size() * 4);
   if (e == hipSuccess) e = up(d->consts, P->consts.data(), P->consts.size() * 8);
   if (e == hipSuccess) e = up(d->probe, P->probe.data(), P->probe.size() * 4);

@@ -11,6 +11,7 @@
 // representatives of the sponge kernels, canonicalised where they become wires.
 #include "gl.cuh"
 #include "poseidon.cuh"
+#include "poseidon_wave.cuh"
 #include "witness.h"
 
 namespace mp2g {
@@ -62,6 +63,52 @@ GLD void exec_p2(const u64* t, u64* vals, u64* wires, u64 n) {
   }
 #pragma unroll
   for (int i = 0; i < 12; i++) { const u64 o = gl_canon(s[i]); W(12 + i, row) = o; vals[t[14 + i]] = o; }
+}
+
+// The same gate with its state spread over lanes 0..11 of an aligned 16-lane group (poseidon_wave.cuh): a level that holds only a
+// few Poseidon2 rows -- the Fiat-Shamir chain, the upper part of a Merkle path -- is a chain of dependent permutations, and one
+// permutation takes a lone lane ~45 us but a 12-lane group ~12 us. Every lane of the group calls; l = lane & 15.
+GLD void exec_p2_coop(const u64* t, u64* vals, u64* wires, u64 n, int l) {
+  const u64 row = t[0];
+  const bool on = l < 12;
+  const int li = on ? l : 0;
+  u64 x = on ? vals[t[1 + li]] : 0;
+  if (on) W(l, row) = x;
+  const u64 swap = vals[t[13]];
+  if (l == 0) W(24, row) = swap;
+  {  // the swap of inputs[0..4) and [4..8): delta_i = swap (in[i + 4] - in[i]), lanes i and i + 4 both form it
+    const u64 other = wp_shfl(x, (l ^ 4) & 15);
+    const u64 lo_v = l < 4 ? x : other, hi_v = l < 4 ? other : x;
+    const u64 delta = gl_mul(swap, gl_sub(hi_v, lo_v));
+    if (l < 4) { W(25 + l, row) = delta; x = gl_add(x, delta); }
+    else if (l < 8) x = gl_sub(x, delta);
+  }
+  u64 rc[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) rc[r] = c_p2_ext[12 * r + li];
+  const u64 d = c_p2_diag[li];
+  x = wp2_external(x, l);
+#pragma unroll 1
+  for (int r = 0; r < 4; r++) {
+    const u64 k = r == 0 ? rc[0] : (r == 1 ? rc[1] : (r == 2 ? rc[2] : rc[3]));
+    const u64 in = gl_canon(gl_addw(x, k));
+    if (r && on) W(29 + 12 * (r - 1) + l, row) = in;
+    x = wp2_external(p2_sbox0(in), l);
+  }
+#pragma unroll 1
+  for (int r = 0; r < 22; r++) {
+    const u64 in = gl_canon(gl_addw(x, c_p2_int[r]));
+    if (l == 0) W(65 + r, row) = in;
+    x = wp2_internal(l == 0 ? p2_sbox0(in) : x, l, d);
+  }
+#pragma unroll 1
+  for (int r = 4; r < 8; r++) {
+    const u64 k = r == 4 ? rc[4] : (r == 5 ? rc[5] : (r == 6 ? rc[6] : rc[7]));
+    const u64 in = gl_canon(gl_addw(x, k));
+    if (on) W(87 + 12 * (r - 4) + l, row) = in;
+    x = wp2_external(p2_sbox0(in), l);
+  }
+  if (on) { const u64 o = gl_canon(x); W(12 + l, row) = o; vals[t[14 + l]] = o; }
 }
 
 GLD void exec_poseidon(const u64* t, u64* vals, u64* wires, u64 n) {
@@ -219,7 +266,7 @@ GLD void exec_one(const u64* t, u64* vals, u64* wires, u64 n, const u64* domtab)
 
 constexpr int WIT_LANES = 512;
 __global__ void __launch_bounds__(WIT_LANES) witness_exec_kernel(const u64* __restrict__ tape, const u32* __restrict__ sched,
-                                                                const u32* __restrict__ level_off, u32 n_levels, u32 n_slots, u32 log_n,
+                                                                const u32* __restrict__ level_off, const u32* __restrict__ level_p2, u32 n_levels, u32 n_slots, u32 log_n,
                                                                 const u32* __restrict__ input_sids, u32 n_inputs, const u64* __restrict__ consts,
                                                                 u32 n_consts, const u64* __restrict__ domtab, const u32* __restrict__ probe,
                                                                 u32 n_probe, const u64* __restrict__ inputs, u64* vals_all, u64* wires_all,
@@ -233,7 +280,19 @@ __global__ void __launch_bounds__(WIT_LANES) witness_exec_kernel(const u64* __re
   __syncthreads();
   for (u32 l = 0; l < n_levels; l++) {
     const u32 lo = level_off[l], hi = level_off[l + 1];
-    for (u32 i = lo + tid; i < hi; i += WIT_LANES) exec_one(tape + sched[i], vals, wires, n, domtab);
+    const u32 p2_lo = level_p2[2 * l], p2_n = level_p2[2 * l + 1];  // the level's Poseidon2 rows are sched[p2_lo .. p2_lo + p2_n)
+    if (p2_n && p2_n * 16 <= WIT_LANES) {
+      // few Poseidon2 rows: one 16-lane group each (latency), the level's other instructions one lane each
+      const u32 g = tid >> 4;
+      if (g < p2_n) exec_p2_coop(tape + sched[p2_lo + g] + 1, vals, wires, n, (int)(tid & 15));
+      const u32 rest = (hi - lo) - p2_n;
+      for (u32 i = tid; i < rest; i += WIT_LANES) {
+        const u32 j = lo + i;
+        exec_one(tape + sched[j < p2_lo ? j : j + p2_n], vals, wires, n, domtab);
+      }
+    } else {
+      for (u32 i = lo + tid; i < hi; i += WIT_LANES) exec_one(tape + sched[i], vals, wires, n, domtab);
+    }
     __syncthreads();  // the level's slot writes (global memory, this block's) are visible to the next level's reads
   }
   for (u32 i = tid; i < n_probe; i += WIT_LANES) probe_out[(u64)b * n_probe + i] = vals[probe[i]];
@@ -243,7 +302,7 @@ __global__ void __launch_bounds__(WIT_LANES) witness_exec_kernel(const u64* __re
 hipError_t witness_exec_launch(hipStream_t s, const WitnessDev& d, u32 n_levels, u32 n_slots, u32 log_n, u32 n_inputs, u32 n_consts,
                                u32 n_probe, const u64* d_inputs, u32 batch, u64* d_vals, u64* d_wires, u64* d_probe_out) {
   hipLaunchKernelGGL(witness_exec_kernel, dim3(batch), dim3(WIT_LANES), 0, s, d.tape.p, (const u32*)d.sched.p, (const u32*)d.level_off.p,
-                     n_levels, n_slots, log_n, (const u32*)d.input_sids.p, n_inputs, d.consts.p, n_consts, d.domtab.p,
+                     (const u32*)d.level_p2.p, n_levels, n_slots, log_n, (const u32*)d.input_sids.p, n_inputs, d.consts.p, n_consts, d.domtab.p,
                      (const u32*)d.probe.p, n_probe, d_inputs, d_vals, d_wires, d_probe_out);
   return hipGetLastError();
 }
