@@ -16,12 +16,30 @@ namespace mp2g {
 // value of `v` held by lane `src` (0..15) of this lane's 16-lane group
 GLD u64 wp_shfl(u64 v, int src) { return __shfl(v, src, 16); }
 
+// Cross-lane moves as DPP operands (a 16-lane group = one DPP row): no LDS round trip. A ds_bpermute costs an LDS instruction and
+// its latency (~100 cycles) per 32-bit half, and a permutation needs ~580 of them (tools/dbg/lone_proof.sh: ~15 us per permutation,
+// most of it these); a DPP move is one VALU instruction. quad_perm serves the exchanges inside a quad (one M4 block), row_ror the
+// rotations by whole quads. -DWP_BPERMUTE restores the __shfl forms for A/B runs.
+template <int CTRL> GLD u64 wp_dpp(u64 v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(u32)v, CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), CTRL, 0xF, 0xF, false);
+  return gl_mk((u32)lo, (u32)hi);
+}
+#define WP_QUAD(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+#define WP_ROR(n) (0x120 + (n))  // lane i takes the value of lane (i - n) mod 16: WP_ROR(16 - k) reads lane i + k
+
 // external layer circ(2 M4, M4, M4) on lanes: l = lane & 15 (< 12 meaningful)
 GLD u64 wp2_external(u64 x, int l) {
-  const int cb = l & 12, r = l & 3;
+  const int r = l & 3;
   u64 a[4];
+#ifdef WP_BPERMUTE
+  const int cb = l & 12;
 #pragma unroll
   for (int j = 0; j < 4; j++) a[j] = wp_shfl(x, cb + j);
+#else
+  a[0] = wp_dpp<WP_QUAD(0, 0, 0, 0)>(x); a[1] = wp_dpp<WP_QUAD(1, 1, 1, 1)>(x);
+  a[2] = wp_dpp<WP_QUAD(2, 2, 2, 2)>(x); a[3] = wp_dpp<WP_QUAD(3, 3, 3, 3)>(x);
+#endif
   // row r of M4 = [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]]
   const u32 c0 = r == 0 ? 5u : (r == 1 ? 4u : 1u);
   const u32 c1 = r == 0 ? 7u : (r == 1 ? 6u : (r == 2 ? 3u : 1u));
@@ -30,9 +48,17 @@ GLD u64 wp2_external(u64 x, int l) {
   u64 tl = (u64)(u32)a[0] * c0 + (u64)(u32)a[1] * c1 + (u64)(u32)a[2] * c2 + (u64)(u32)a[3] * c3;
   u64 th = (a[0] >> 32) * c0 + (a[1] >> 32) * c1 + (a[2] >> 32) * c2 + (a[3] >> 32) * c3;  // each < 2^36
   // same row of the two other chunks
+#ifdef WP_BPERMUTE
   const int s1 = l < 8 ? l + 4 : l - 8, s2 = l < 4 ? l + 8 : l - 4;
   u64 yl = 2 * tl + wp_shfl(tl, s1 & 15) + wp_shfl(tl, s2 & 15);
   u64 yh = 2 * th + wp_shfl(th, s1 & 15) + wp_shfl(th, s2 & 15);  // < 2^39
+#else
+  // with the fourth quad (lanes 12..15) contributing zero, the sum over the other chunks' row is the sum over ALL quads' row
+  // minus the lane's own: three rotations by whole quads
+  const u64 zl = l < 12 ? tl : 0, zh = l < 12 ? th : 0;
+  u64 yl = 2 * tl + wp_dpp<WP_ROR(4)>(zl) + wp_dpp<WP_ROR(8)>(zl) + wp_dpp<WP_ROR(12)>(zl);
+  u64 yh = 2 * th + wp_dpp<WP_ROR(4)>(zh) + wp_dpp<WP_ROR(8)>(zh) + wp_dpp<WP_ROR(12)>(zh);  // < 2^39
+#endif
   u64 lo;
   bool c = __builtin_add_overflow(yl, yh << 32, &lo);
   return gl_reduce96w(lo, (yh >> 32) + (c ? 1 : 0));
@@ -41,6 +67,7 @@ GLD u64 wp2_external(u64 x, int l) {
 GLD u64 wp2_internal(u64 x, int l, u64 d) {
   // 68-bit sum of the 12 lanes as (lo64, top): quad butterflies, then the two other quads
   u64 lo = l < 12 ? x : 0, top = 0;
+#ifdef WP_BPERMUTE
 #pragma unroll
   for (int m = 1; m <= 2; m <<= 1) {
     u64 olo = wp_shfl(lo, l ^ m), otop = wp_shfl(top, l ^ m);
@@ -57,6 +84,17 @@ GLD u64 wp2_internal(u64 x, int l, u64 d) {
     bool c3 = __builtin_add_overflow(lo, l3, &lo);
     top += t1 + t2 + t3 + (c1 ? 1 : 0) + (c2 ? 1 : 0) + (c3 ? 1 : 0);
   }
+#else
+  // the sum as two 64-bit columns of 32-bit halves (carry-free: 12 terms < 2^32 each): quad butterflies and quad rotations by DPP
+  u64 sl = (u32)lo, sh = lo >> 32;
+  sl += wp_dpp<WP_QUAD(1, 0, 3, 2)>(sl); sh += wp_dpp<WP_QUAD(1, 0, 3, 2)>(sh);
+  sl += wp_dpp<WP_QUAD(2, 3, 0, 1)>(sl); sh += wp_dpp<WP_QUAD(2, 3, 0, 1)>(sh);
+  sl += wp_dpp<WP_ROR(4)>(sl) + wp_dpp<WP_ROR(8)>(sl) + wp_dpp<WP_ROR(12)>(sl);  // lanes 12..15 hold zeros
+  sh += wp_dpp<WP_ROR(4)>(sh) + wp_dpp<WP_ROR(8)>(sh) + wp_dpp<WP_ROR(12)>(sh);
+  sh += sl >> 32;  // < 2^37
+  lo = gl_mk((u32)sl, (u32)sh);
+  top = sh >> 32;
+#endif
   u64 plo, phi;
   gl_mul_wide(x, d, plo, phi);
   bool c = __builtin_add_overflow(plo, lo, &plo);

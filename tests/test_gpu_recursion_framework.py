@@ -536,3 +536,42 @@ def test_final_poseidon_wrap_on_the_gpu(ctx, mp2):
     assert np.array_equal(hw[0], wires) and np.array_equal(hph[0], ph)
     wrap_prover.free()
     prover.free()
+
+
+def test_device_proof_through_torch_tensors_and_rccl(ctx, mp2):
+    """the RCCL leg of the cross-rank hand-off on the one GPU of the test box: a world-size-1 "nccl" process group (= RCCL) is
+    initialised the way bench.py does it, a final proof's word ranges are wrapped as torch device tensors without a copy
+    (sharding._RawView, what send_device_proof sends), pass through an RCCL collective, and the tensors a receiver would hold
+    (recv_device_proof builds a DeviceProof over their addresses) feed a parent's device-side witness: the parent proof equals the
+    one proved from the downloaded child. (Two ranks on two GPUs differ from this only in send / recv replacing the collective.)"""
+    import os
+    import torch
+    import torch.distributed as dist
+    sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
+    prover = FW.GpuProver(ctx)
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover, FW.circuit_fri_params)
+    data = O.rand_field(8, 0xC0FFEE07)
+    leaves = fw.generate_proofs_batch("map", [([], [], data[:4]), ([], [], data[4:])])
+    dp = prover.last_device_proof(1)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        ctx.sync()
+        views = [torch.as_tensor(sharding._RawView(ptr, n, dp.keep), device=dev) for ptr, n in dp.parts]
+        assert [v.numel() for v in views] == [n for _, n in dp.parts] and all(v.data_ptr() == ptr for v, (ptr, _) in zip(views, dp.parts))
+        received = [v.clone() for v in views]  # what the other rank's recv buffers would hold
+        for t in received:
+            dist.all_reduce(t)  # RCCL touches the buffers (sum over one rank = identity)
+        torch.cuda.synchronize()
+        child = R.DeviceProof([(t.data_ptr(), t.numel()) for t in received], keep=received)
+        host = child.to_host(ctx)
+        assert np.array_equal(host[3], leaves[1][3]) and np.array_equal(host[2], leaves[1][2]) and np.array_equal(host[1], leaves[1][1])
+        (a,) = fw.generate_proofs_batch("reduce", [([leaves[0], child], ["map", "map"], None)])
+        (b,) = fw.generate_proofs_batch("reduce", [(leaves, ["map", "map"], None)])
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    finally:
+        dist.destroy_process_group()
+    prover.free()
