@@ -1,38 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json metric ("leaf proofs/sec (whole node) + NTT GB/s vs HBM peak") on MI355X.
+"""bench.py -- BASELINE.json metric ("leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build") on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload. The metric is quoted on the 2^20-row table build (configs[3]); its unit of work is the
-framework leaf proof, which the recursion framework always produces as one base `prove()` plus
-one wrap `prove()` down to 2^12 rows (recursion-framework/src/circuit_builder.rs:286-311,
-wrap_circuit.rs:122-148). One step = one batch of `--batch` such leaf proofs, shaped as SURVEY
-8(d) config 3 says (base 2^13 + wrap 2^12, standard_recursion_config: constants + 80 sigmas,
-135 wires, 20 Z/partial products, 16 quotient chunks, rate 1/8, cap 16, FRI [4,4], 16-bit PoW, 28
-queries), on synthetic witness matrices that are resident in HBM before the timed region. What
-runs per proof is everything `prove()` does after witness generation -- wires commitment, Z / partial
-products, quotient polynomials (permutation terms and the gate constraints), their commitments,
-Fiat-Shamir, openings, FRI (HOT LOOPS 1-3 of SURVEY 3.1) -- for satisfied synthetic circuits composed
-as the reference composes them (mapreduce-plonky2_amd/circuits.py): the wrap circuit has the gate set of
-plonky2's recursive verifier (13 gates), the base (leaf) circuit adds the user-logic gates (u32 arithmetic,
-range checks, comparisons: 19 gates); as in plonky2 every gate of a circuit is evaluated at every LDE point,
-so the cost depends on the gate set, not on the row mix. Every proof of a batch has its own public inputs
-(bound to the PublicInputGate row on the device) and its own free cells; witness generation stays on the host.
-This is a steady-state "prove() after witness generation" rate: no 2^20-row build, no tree reduction
-(`--workload tree` times the aggregation levels too).
+Default workload (`--workload table`, run_table below): BASELINE configs[3] sampled at `--rows` table rows per rank and step.
+Per row the reference proves 4 cells-tree nodes and 1 row-tree node, each a framework proof (witness generation, base prove(),
+wrap chain to 2^12 rows: recursion-framework/src/circuit_builder.rs:286-311, wrap_circuit.rs:122-148); here they are REAL
+circuits with the reference's tree logic (mapreduce-plonky2_amd/table.py), their witnesses replayed on the device
+(mp2g_witness_program_run_dev), the row tree scheduled by ryhope's batched work plan (mp2g_update_plan_*), the rows' multiset
+digests computed inside the timed region. value = framework proofs per second (5 per row); the line also extrapolates the
+2^20-row build and carries last round's headline (`--workload leaves`: prove() only, synthetic circuits, resident witnesses) as
+`leaves_prove_only`.
 
-Self-check. After the timed loop the first and the last proof of every prover's batch are downloaded and
-compared, bit for bit, with the CPU oracle's proof of the same witness (caps, openings, FRI proof), and
-run through the oracle's verifier (transcript, PLONK identity with the gate terms, FRI). The JSON line
-carries "verified": k; any mismatch makes the run fail. The oracle proofs of that leg are the `cpu_baseline`
-sample at N=1.
+Self-check. After the timed loop: the block root's public inputs = the off-circuit tree hash / multiset digest / min / max; one
+framework proof of every circuit kind of the last step is re-proved from its captured witness by the CPU oracle -- caps, openings
+and FRI proof bit for bit, and accepted by its verifier (transcript, PLONK identity with the gate terms, FRI). "verified": k counts
+those prove() calls; any mismatch makes the run fail. The oracle proofs of that leg are the `cpu_baseline` sample at N=1.
 
-Leaf proofs shard across ranks with no data-path collective ("scaling": "weak"); the per-rank
-multiset digests meet in one 160-byte all_gather outside the per-proof path.
+Rows shard across ranks as blocks with no data-path collective ("scaling": "weak"); log2(N) join levels above the block roots
+move one final proof each, device to device over RCCL.
 
-The NTT half of the metric is the `roofline` object: BASELINE configs[1]'s 2^22-point forward NTT,
-timed with HIP events on the context's stream in this same run, algorithmic 16 B/point.
+The NTT half of the metric is the `roofline` object: BASELINE configs[1]'s 2^22-point forward NTT, timed with HIP events on the
+context's stream in this same run, algorithmic 16 B/point.
+
+Other workloads: leaves (above), tree (synthetic circuits + aggregation levels), recursion (map-reduce trees of real proofs + the
+final Poseidon wrap), ntt (the roofline leg alone, for rocprof).
 """
 import argparse
 import ctypes
@@ -558,7 +551,7 @@ def main(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the sampled proofs")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work for the cpu_baseline sample")
     ap.add_argument("--trees", type=int, default=8, help="--workload recursion: independent trees per rank and step, one host thread + GPU stream each")
-    ap.add_argument("--rows", type=int, default=512, help="--workload table: table rows per rank and step (5 framework proofs each)")
+    ap.add_argument("--rows", type=int, default=1024, help="--workload table: table rows per rank and step (5 framework proofs each)")
     ap.add_argument("--workers", type=int, default=4, help="--workload table: concurrent work-plan items per rank, one host thread + GPU stream + prover set each")
     ap.add_argument("--table-batch", type=int, default=32, help="--workload table: proofs per prove() launch sequence of a worker")
     ap.add_argument("--subtree", type=int, default=64, help="--workload table: into_batched_workplan(subtree_size), the rows of one work-plan item")

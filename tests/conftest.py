@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:  # a process that uses both torch's GPU side and libmp2gpu must load torch (and with it torch's own HIP runtime) FIRST, as bench.py
+    import torch  # noqa: F401  # does: loaded after libmp2gpu's libamdhip64, torch.cuda finds no device ("No HIP GPUs are available")
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
