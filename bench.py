@@ -814,7 +814,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "shapes": shapes,
                           "setup_s": round(t_setup, 1), "hasher": "Poseidon2",
                           "sharding": f"{world} rank(s): one block of rows each, no collective below the block roots; {world.bit_length() - 1} join level(s) move a root proof point to point "
-                                      f"({sum(proof_sizes) * 8} B, " + ("device to device over RCCL into the parent's device-side witness inputs)" if nccl else "host tensors over gloo)"),
+                                      f"({sum(proof_sizes) * 8} B" + (")" if world == 1 else ", device to device over RCCL into the parent's device-side witness inputs)" if nccl else ", host tensors over gloo)"),
                           "root_public_inputs": [int(x) for x in cur[0][3]],
                           "verified": f"{verified} prove() calls of sampled framework proofs (one of every circuit kind of the last step, on every rank) equal the CPU "
                                       "oracle's proofs of the same witnesses bit for bit and pass its verifier; the block roots expose the off-circuit tree hash, "
