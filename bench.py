@@ -467,6 +467,11 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
     n_hash, limbs = 1 << 21, 136
     d_hin = ctx.alloc(n_hash * limbs * 8)
     d_hout = ctx.alloc(n_hash * 4 * 8)
+    # random field elements, not a zero buffer: the permutation's power draw (and with it the clock) depends on its data
+    # (tools/dbg/sponge_ab.py: zeros hash 4.5 % faster)
+    part = C.rand_field((1 << 17, limbs), 0xC0FFEE05 + rank)
+    for k in range(n_hash >> 17):
+        d_hin.upload_at(part, k * part.nbytes)
     hargs = (ctx.h, VARIANT, d_hin.ptr, limbs, n_hash, 4, d_hout.ptr)
     mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
     ctx.timer_start()
@@ -494,7 +499,7 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
             "ntt_batched_2p12": {"transforms": nb12, "GBps": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9,
                                  "frac_of_hbm_peak": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9 / HBM_PEAK_GBPS},
             "sponge": {"hasher": hasher, "permutations_per_s": n_hash * (limbs // 8) / (hash_ms / 1e3), "bound": "VALU issue (integer ALU)",
-                       "input": f"{n_hash} x {limbs} limbs, hash_no_pad, resident"}}
+                       "input": f"{n_hash} x {limbs} limbs of random field elements, hash_no_pad, resident"}}
 
 
 def launch_ranks(n, argv):

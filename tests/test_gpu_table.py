@@ -170,3 +170,23 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert "1 join level" in line["config"]["sharding"]
     # 2 x 8 rows + the separator row, 5 proofs each
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * 17) < 1e-6
+
+
+@pytest.mark.parametrize("n_cols,rows", [(1, 2), (6, 3)])
+def test_other_column_counts(ctx, mp2, params, n_cols, rows):
+    """the cells tree follows ryhope's sbbst for any number of value columns: one column = a lone leaf; six columns = leaves 1, 3, 5, a
+    full node 2, a partial node 6 whose child is 5, the root 4 over 2 and 6 (sbbst.rs:301-333: the missing right child is replaced by
+    the first in-range node down its left spine). Off-circuit data against the oracle, root public inputs against the off-circuit tree."""
+    table = T.SyntheticTable(rows, n_cols, seed=0xC0FFEE04 + n_cols)
+    root, nodes, spans = T.balanced_bst(rows)
+    wit = T.TableWitness(ctx, table, spans)
+    o = OracleTableWitness(table, spans)
+    assert np.array_equal(wit.cell_digest, o.cell_digest) and all(np.array_equal(wit.row_digest[k], o.row_digest[k]) for k in spans)
+    build = T.TableBuild(params, [R.ProofSession(params.cells.prover)], batch=8, subtree_size=2, host_threads=4)
+    proof, name = build.run(table, wit, root, nodes)
+    assert build.n_proofs == rows * (n_cols + 1)
+    pis = proof[3]
+    assert np.array_equal(pis[:T.ROWS_IO], T.expected_root_public_inputs(ctx, table, wit, root, nodes, spans))
+    assert np.array_equal(pis[4:15], mp2.compute_table_row_digest(ctx, table.col_ids, table.values, table.values[:, 0:1])[1])
+    cells_root = build.cells_roots[0]
+    assert cells_root[1] == ("cells_leaf" if n_cols == 1 else "cells_full") and int(cells_root[0][3][26]) == n_cols
