@@ -300,6 +300,7 @@ int mp2g_prover_enable_witness_check(mp2g_prover* pr, int on);
  * proofs serves any smaller batch without new allocations: the narrow levels of a tree reuse the wide levels' prover) */
 int mp2g_prover_set_active(mp2g_prover* pr, uint32_t n);
 int mp2g_prover_witness_status(mp2g_prover* pr, uint32_t* flags);
+int mp2g_prover_witness_check_enabled(const mp2g_prover* pr);
 /* Replay the prover's launch sequence (several hundred small kernels per call) as a hipGraph: the
  * first call after enabling runs normally (it creates the cached twiddle tables), the second is captured,
  * later calls with the same buffer addresses launch the instantiated graph. A call with different
@@ -439,6 +440,32 @@ int mp2g_witness_program_run_rows(const mp2g_witness_program* p, const uint64_t*
                                   const uint32_t* probe_sids, uint32_t n_probe, uint64_t* probe_out);
 int mp2g_wires_from_rows_dev(mp2g_ctx* ctx, const uint64_t* d_rows, uint64_t* d_wires, uint32_t log_n, uint32_t num_wires, uint32_t batch);
 void mp2g_witness_program_free(mp2g_witness_program* p);
+
+/* ---- generate_proof for a batch of nodes of one framework circuit, on the device (csrc/chain.hip) ------------------------------
+ * Replaces the bodies of CircuitWithUniversalVerifier::generate_proof (recursion-framework/src/circuit_builder.rs:286-311) and
+ * WrapCircuit::wrap_proof (universal_verifier_gadget/wrap_circuit.rs:122-148): step 0 = the base circuit, steps 1.. = its wrap
+ * circuits, each given as its prover (mp2g_prover with the circuit's preprocessed polynomials, gate table, permutation / quotient /
+ * witness check switched on), its witness program (probe set: public-inputs hash, then the public inputs), its FRI parameters and
+ * its circuit digest (device pointer, 4 words). `capacity` = the widest batch; every narrower one runs in the same buffers.
+ * mp2g_chain_run: inputs [batch][n_inputs of step 0] (host) = the base circuit's witness inputs (circuit-set digest, per child the
+ * verifier data, the proof, the membership proof; the circuit's own inputs); patches copy child proofs that already live on the
+ * device into them in place. Per step: witness replay, prove(), gather of the next step's inputs -- all queued on the context's
+ * stream, one synchronisation at the end. Outputs (host, may be NULL): the LAST step's caps [batch][4][cap words], openings
+ * [batch][n_openings][2], FRI proof [batch][proof_words], public inputs [batch][n_pi]. A witness that violates a constraint makes
+ * the call fail when the provers' witness check is on, as plonky2's prove() panics. */
+typedef struct mp2g_chain mp2g_chain;
+typedef struct { uint32_t job; uint32_t offset; uint32_t n_words; uint32_t pad_; const uint64_t* d_src; } mp2g_chain_patch;
+int mp2g_chain_create(mp2g_ctx* ctx, uint32_t n_steps, mp2g_prover* const* provers, mp2g_witness_program* const* programs,
+                      const mp2g_fri_params* params, const uint64_t* const* d_circuit_digests, uint32_t capacity, mp2g_chain** out);
+int mp2g_chain_run(mp2g_chain* chain, const uint64_t* inputs, uint32_t batch, const mp2g_chain_patch* patches, uint32_t n_patches,
+                   uint64_t* caps, uint64_t* openings, uint64_t* proof, uint64_t* public_inputs);
+/* the device buffers of a step after a run (a checker downloads the wires it re-proves; any pointer may be NULL) */
+int mp2g_chain_step_buffers(const mp2g_chain* chain, uint32_t step, uint64_t** d_wires, uint64_t** d_probe, uint64_t** d_caps,
+                            uint64_t** d_openings, uint64_t** d_proof);
+/* proof b of the last run where the chain left it: address and length (words) of its public inputs, its three proof caps, its openings
+ * and its FRI proof words -- what a parent's mp2g_chain_patch entries (or a send to another rank) take; valid until the next run */
+int mp2g_chain_device_proof(const mp2g_chain* chain, uint32_t b, const uint64_t* d_parts[4], uint32_t n_words[4]);
+void mp2g_chain_free(mp2g_chain* chain);
 
 /* ---- work plan: the reference's only scheduler --------------------------------------
  * Host-side, no GPU involved. Replaces ryhope/src/storage/updatetree.rs: UpdateTree (:19-242, arena

@@ -153,6 +153,12 @@ class Context:
         _ck(load().mp2g_d2d_2d(self.h, ctypes.c_void_p(d_dst.ptr.value + dst_offset), ctypes.c_size_t(dst_pitch),
                                ctypes.c_void_p(d_src.ptr.value + src_offset), ctypes.c_size_t(src_pitch), ctypes.c_size_t(width), ctypes.c_size_t(rows)))
 
+    def d2h_raw(self, src_ptr, shape, dtype=np.uint64):
+        """download from a raw device address"""
+        out = np.empty(shape, dtype=dtype)
+        _ck(load().mp2g_d2h(self.h, _p(out), ctypes.c_void_p(int(src_ptr)), ctypes.c_size_t(out.nbytes)))
+        return out
+
     def d2d_raw(self, d_dst, dst_offset, src_ptr, nbytes):
         """stream-ordered device copy of nbytes from a raw device address into a DeviceBuffer"""
         _ck(load().mp2g_d2d_2d(self.h, ctypes.c_void_p(d_dst.ptr.value + dst_offset), ctypes.c_size_t(nbytes), ctypes.c_void_p(int(src_ptr)),
@@ -592,6 +598,66 @@ class WitnessProgram:
     def free(self):
         if self.h:
             load().mp2g_witness_program_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ChainPatch(ctypes.Structure):
+    _fields_ = [("job", ctypes.c_uint32), ("offset", ctypes.c_uint32), ("n_words", ctypes.c_uint32), ("pad_", ctypes.c_uint32), ("d_src", ctypes.c_void_p)]
+
+
+class ProofChain:
+    """mp2g_chain: generate_proof (base prove() + wrap chain) for batches of nodes of one framework circuit, on the device.
+    provers: BatchedProver per step (set up for its circuit), programs: WitnessProgram per step, d_digests: DeviceBuffer per step."""
+
+    def __init__(self, ctx, provers, programs, d_digests, capacity):
+        n = len(provers)
+        self.ctx, self.n_steps, self.capacity = ctx, n, capacity
+        self.provers, self.programs, self.d_digests = list(provers), list(programs), list(d_digests)  # keep the handles alive
+        self.fps = [p.fp for p in provers]
+        pr = (ctypes.c_void_p * n)(*[p.h for p in provers])
+        pg = (ctypes.c_void_p * n)(*[p.h for p in programs])
+        fp = (FriParams * n)(*self.fps)
+        dg = (ctypes.c_void_p * n)(*[d.ptr for d in d_digests])
+        self.h = ctypes.c_void_p()
+        _ck(load().mp2g_chain_create(ctx.h, n, pr, pg, fp, dg, int(capacity), ctypes.byref(self.h)))
+        ctx._adopt(self)
+
+    def run(self, inputs, patches=()):
+        """inputs [B][n_inputs] (host); patches [(job, word offset, device address, n words)] -> (caps [B][4][cap words], openings
+        [B][n][2], FRI proofs [B][words], public inputs [B][n_pi]) of the last step; raises on an unsatisfied witness"""
+        a = _arr(inputs)
+        B = a.shape[0]
+        fp, prog = self.fps[-1], self.programs[-1]
+        caps = np.empty((B, fp.n_oracles, fp.cap_words), dtype=np.uint64)
+        openings = np.empty((B, fp.n_openings, 2), dtype=np.uint64)
+        proofs = np.empty((B, fp.proof_words), dtype=np.uint64)
+        pis = np.empty((B, prog.n_public_inputs), dtype=np.uint64)
+        arr = (ChainPatch * max(1, len(patches)))(*[ChainPatch(int(j), int(off), int(n), 0, int(ptr)) for j, off, ptr, n in patches])
+        _ck(load().mp2g_chain_run(self.h, _p(a), B, arr, len(patches), _p(caps), _p(openings), _p(proofs), _p(pis)))
+        self.last_batch = B
+        return caps, openings, proofs, pis
+
+    def step_buffers(self, step):
+        """raw device addresses of a step's (wires, probe, caps, openings, proof) after a run"""
+        ptrs = [ctypes.c_void_p() for _ in range(5)]
+        _ck(load().mp2g_chain_step_buffers(self.h, int(step), *[ctypes.byref(p) for p in ptrs]))
+        return [p.value for p in ptrs]
+
+    def device_proof(self, b=0):
+        """[(device address, words)] x 4 of proof b of the last run: public inputs, the three caps, openings, FRI proof"""
+        parts, words = (ctypes.c_void_p * 4)(), (ctypes.c_uint32 * 4)()
+        _ck(load().mp2g_chain_device_proof(self.h, int(b), parts, words))
+        return [(int(parts[i]), int(words[i])) for i in range(4)]
+
+    def free(self):
+        if self.h and self.ctx.h:
+            load().mp2g_chain_free(self.h)
         self.h = None
 
     def __del__(self):

@@ -659,6 +659,7 @@ int mp2g_prover_enable_witness_check(mp2g_prover* pr, int on) {
   pr->drop_graph();
   return 0;
 }
+int mp2g_prover_witness_check_enabled(const mp2g_prover* pr) { return pr && pr->wcheck ? 1 : 0; }
 int mp2g_prover_witness_status(mp2g_prover* pr, uint32_t* flags) {
   NEED(pr && pr->wcheck, "call mp2g_prover_enable_witness_check first");
   std::vector<uint32_t> h(pr->B);

@@ -229,6 +229,7 @@ class GpuProver:
         # (mp2g_witness_program_run_rows) and an upload per step -- kept for A/B runs and as the second opinion of the parity tests
         self.device_witness = device_witness
         self.provers = {}
+        self.chains = {}
         self.pinned = {}  # data address of a pinned wire matrix -> its host pointer
 
     rows_layout = True  # generate_proofs_batch fills [B][n][135] (rows) for this prover; prove_batch_launch transposes on the device
@@ -307,82 +308,51 @@ class GpuProver:
         cp.prove(cp.d_w, cp.d_ph)
         return cp, B
 
-    def _chain_prover(self, ckt, prog, B):
-        """the CircuitProver of a chain step with its device-side witness buffers: program inputs, wires, probe (pi hash + public inputs)"""
-        n = 1 << ckt.log_n
+    def _chain(self, ckts, progs, B):
+        """the mp2g_chain of a framework circuit (base + wraps) on this context, created for `capacity` proofs (or B when no capacity
+        is set) and kept: every narrower batch runs in the same device buffers"""
+        from . import ProofChain
         cap = max(B, self.capacity) if self.capacity else B
-        key = (ckt.log_n, self.circuit_key(ckt), cap)
-        cp = self.provers.get(key)
-        if cp is None:
-            cp = self.provers[key] = CircuitProver(self.ctx, ckt, cap, self.variant, witness_check=self.witness_check)
-            cp.d_w, cp.d_ph, cp.d_rows = self.ctx.alloc(cap * 135 * n * 8), self.ctx.alloc(cap * 32), None
-        if getattr(cp, "d_in", None) is None:
-            cp.d_in, cp.d_probe = self.ctx.alloc(cap * prog.n_inputs * 8), self.ctx.alloc(cap * prog.probe.size * 8)
-        if cap != B or getattr(cp.pr, "active", cap) != B:
-            cp.pr.set_active(B)
-        return cp
+        key = ("chain", tuple(self.circuit_key(c) for c in ckts), cap)
+        ch = self.chains.get(key)
+        if ch is None:
+            cps = [CircuitProver(self.ctx, ckt, cap, self.variant, witness_check=self.witness_check) for ckt in ckts]
+            ch = self.chains[key] = ProofChain(self.ctx, [cp.pr for cp in cps], progs, [cp.d_circuit_digest for cp in cps], cap)
+            ch.cps = cps
+        return ch
 
     def prove_chain(self, ckts, progs, cur, capture=None, name="", patches=()):
-        """generate_proof's chain for B nodes without the host in the loop: `cur` [B][n_inputs] (host) are the base circuit's witness
-        inputs; per step the witness program runs on the device into the prover's wire matrix, prove() follows on the same
-        stream, and the next step's inputs (public inputs, caps, openings, FRI proof: recursion.proof_inputs order) are
-        gathered from the prover's outputs by device copies. One synchronisation at the end. Returns [(caps, openings, proof,
-        public_inputs)] of the last step."""
-        ctx, B = self.ctx, cur.shape[0]
-        cps, prev = [], None
-        for step, (ckt, prog) in enumerate(zip(ckts, progs)):
-            cp = self._chain_prover(ckt, prog, B)
-            n_in, n_pr = prog.n_inputs, int(prog.probe.size)
-            if prev is None:
-                assert cur.shape[1] == n_in
-                cp.d_in.upload_at(np.ascontiguousarray(cur, dtype=np.uint64), 0)
-                for j, off, dp in patches:  # child proofs that live on the device (recursion.DeviceProof): copied in place, no host visit
-                    at = (j * n_in + off) * 8
-                    for ptr, nw in dp.parts:
-                        ctx.d2d_raw(cp.d_in, at, ptr, nw * 8)
-                        at += nw * 8
-            else:
-                pcp, pprog = prev
-                fp, n_pi, ppr = pcp.fp, pprog.n_public_inputs, int(pprog.probe.size)
-                cw, ow, pw = 3 * fp.cap_words, fp.n_openings * 2, fp.proof_words
-                assert n_in == n_pi + cw + ow + pw, f"{name} step {step}: {n_in} inputs for a proof of {n_pi + cw + ow + pw} words"
-                ctx.d2d_2d(cp.d_in, 0, n_in * 8, pcp.d_probe, 4 * 8, ppr * 8, n_pi * 8, B)
-                ctx.d2d_2d(cp.d_in, n_pi * 8, n_in * 8, pcp.pr.d_caps, fp.cap_words * 8, fp.n_oracles * fp.cap_words * 8, cw * 8, B)
-                ctx.d2d_2d(cp.d_in, (n_pi + cw) * 8, n_in * 8, pcp.pr.d_openings, 0, ow * 8, ow * 8, B)
-                ctx.d2d_2d(cp.d_in, (n_pi + cw + ow) * 8, n_in * 8, pcp.pr.d_proof, 0, pw * 8, pw * 8, B)
-            prog.run_dev(ctx, cp.d_in, B, cp.d_w, cp.d_probe)
-            ctx.d2d_2d(cp.d_ph, 0, 32, cp.d_probe, 0, n_pr * 8, 32, B)
-            cp.prove(cp.d_w, cp.d_ph)
-            cps.append(cp)
-            prev = (cp, prog)
-        if self.witness_check:
-            for cp in cps:
-                cp.pr.witness_status()  # raises like plonky2's prove() on an unsatisfied witness
-        last, lprog = prev
-        self.last_chain = (last, lprog, B)
-        caps, openings, proofs = last.results()
-        pis = last.d_probe.download((B, int(lprog.probe.size)))[:, 4:]
+        """generate_proof's chain for B nodes without the host in the loop (csrc/chain.hip, mp2g_chain_run): `cur` [B][n_inputs] (host) are
+        the base circuit's witness inputs, `patches` [(job, word offset, recursion.DeviceProof)] the child proofs that stay on the
+        device. Per step the witness program runs on the device into the step's wire matrix, prove() follows on the same stream,
+        and the next step's inputs are gathered from the prover's outputs by device copies. One synchronisation at the end. Returns
+        [(caps, openings, proof, public_inputs)] of the last step; raises like plonky2's prove() on an unsatisfied witness."""
+        B = cur.shape[0]
+        ch = self._chain(ckts, progs, B)
+        flat = []
+        for j, off, dp in patches:
+            for ptr, nw in dp.parts:
+                flat.append((j, off, ptr, nw))
+                off += nw
+        caps, openings, proofs, pis = ch.run(np.ascontiguousarray(cur, dtype=np.uint64), flat)
+        self.last_chain = ch
         if capture is not None:
-            for step, (cp, ckt) in enumerate(zip(cps, ckts)):
-                n = 1 << ckt.log_n
-                w = cp.d_w.download((B, 135, n))
-                c, o, p = cp.results()
-                ph = cp.d_probe.download((B, int(progs[step].probe.size)))[:, :4]
+            for step, (cp, ckt) in enumerate(zip(ch.cps, ckts)):
+                n, fp, n_pr = 1 << ckt.log_n, cp.fp, int(progs[step].probe.size)
+                d_w, d_probe, d_caps, d_open, d_proof = ch.step_buffers(step)
+                w = self.ctx.d2h_raw(d_w, (B, 135, n))
+                ph = self.ctx.d2h_raw(d_probe, (B, n_pr))[:, :4]
+                c, o, p = (self.ctx.d2h_raw(d_caps, (B, fp.n_oracles, fp.cap_words)), self.ctx.d2h_raw(d_open, (B, fp.n_openings, 2)),
+                           self.ctx.d2h_raw(d_proof, (B, fp.proof_words)))
                 for b in range(B):
                     capture.append((name, step, ckt, cp.circuit_digest, w[b].copy(), ph[b].copy(), c[b], o[b], p[b]))
-        return [(caps[b], openings[b], proofs[b], pis[b].copy()) for b in range(B)]
+        return [(caps[b], openings[b], proofs[b], pis[b]) for b in range(B)]
 
     def last_device_proof(self, b=0):
-        """proof b of the last prove_chain as a recursion.DeviceProof over the prover's output buffers: valid until this prover's next
-        chain of the same circuit (hand it on -- to a parent's generate_proofs_batch or to another rank -- before that)"""
+        """proof b of the last prove_chain as a recursion.DeviceProof over the chain's output buffers: valid until the next run of
+        that chain (hand it on -- to a parent's generate_proofs_batch or to another rank -- before that)"""
         from .recursion import DeviceProof
-        cp, prog, B = self.last_chain
-        assert 0 <= b < B
-        fp, n_pr, n_pi = cp.fp, int(prog.probe.size), prog.n_public_inputs
-        cw, ow, pw = fp.cap_words, fp.n_openings * 2, fp.proof_words
-        parts = [(cp.d_probe.ptr.value + (b * n_pr + 4) * 8, n_pi), (cp.pr.d_caps.ptr.value + (b * fp.n_oracles + 1) * cw * 8, 3 * cw),
-                 (cp.pr.d_openings.ptr.value + b * ow * 8, ow), (cp.pr.d_proof.ptr.value + b * pw * 8, pw)]
-        return DeviceProof(parts, keep=cp)
+        return DeviceProof(self.last_chain.device_proof(b), keep=self.last_chain)
 
     def prove_batch_finish(self, handle):
         cp, B = handle
@@ -400,6 +370,11 @@ class GpuProver:
         return [int(x) for x in self.ctx.hash_no_pad(list(left) + list(right), self.variant)]
 
     def free(self):
+        for ch in self.chains.values():
+            ch.free()
+            for cp in ch.cps:
+                cp.free()
+        self.chains = {}
         for cp in self.provers.values():
             cp.free()
         self.provers = {}

@@ -29,10 +29,19 @@ def build_prove_circuit():
     return exe
 
 
+def build_generate_proof():
+    exe = os.path.join(ROOT, "examples", "c_generate_proof")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_generate_proof.c"), "-L" + os.path.join(ROOT, "mapreduce-plonky2_amd"),
+                           "-lmp2gpu", "-Wl,-rpath," + os.path.join(ROOT, "mapreduce-plonky2_amd"), "-o", exe])
+    return exe
+
+
 def test_header_compiles_as_c():
     """No GPU needed: the header is valid C11 and the demos link against the library."""
     build_demo()
     build_prove_circuit()
+    build_generate_proof()
 
 
 @pytest.mark.gpu
@@ -104,3 +113,59 @@ def test_c_client_proves_a_gate_level_circuit(ctx, mp2, tmp_path):
     write(bad, w)
     out = subprocess.run([exe, bad], capture_output=True, text=True, timeout=120)
     assert out.returncode == 3 and "violates a gate constraint" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_c_client_generates_framework_proofs(ctx, mp2, tmp_path):
+    """examples/c_generate_proof.c: CircuitWithUniversalVerifier::generate_proof (witness generation on the device, base prove(), wrap
+    chain) for a batch of nodes through the C ABI alone (mp2g_chain_*): a reduce circuit with two universal verifiers over two map
+    proofs, three nodes at once. Same final proofs and public inputs as the Python host; a child proof with an altered public input
+    makes generate_proof fail the way the reference's prove() panics."""
+    import importlib
+    R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+    FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+    exe = build_generate_proof()
+    prover = FW.GpuProver(ctx)
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover, FW.circuit_fri_params)
+    data = O.rand_field(16, 0xC0FFEE08)
+    leaves = fw.generate_proofs_batch("map", [([], [], data[4 * i:4 * i + 4]) for i in range(4)])
+    jobs = [([leaves[0], leaves[1]], ["map", "map"], None), ([leaves[2], leaves[3]], ["map", "map"], None), ([leaves[1], leaves[2]], ["map", "map"], None)]
+    want = fw.generate_proofs_batch("reduce", jobs)
+    vd = fw.vds["map"]
+    rows = np.stack([np.concatenate([np.asarray(fw.set_digest, dtype=np.uint64)] + [R.universal_inputs(p, vd, fw.membership(vd[1])) for p in kids]) for kids, _, _ in jobs])
+
+    def write(path, inputs):
+        with open(path, "wb") as f:
+            f.write(np.array([len(fw.chains["reduce"]), inputs.shape[0], inputs.shape[1]], dtype=np.uint32).tobytes())
+            for step, (ckt, cap, digest) in enumerate(fw.chains["reduce"]):
+                prog = fw.witness_programs("reduce")[step]
+                fp = FW.circuit_fri_params(ckt)
+                cs = np.ascontiguousarray(ckt.const_slots, dtype=np.uint64).reshape(-1, 2)
+                tape = np.ascontiguousarray(ckt.tape, dtype=np.uint64)
+                f.write(np.array([ckt.log_n, ckt.num_constants, len(ckt.gates), ckt.num_selectors, fp.pow_bits, fp.num_queries, ckt.n_slots, len(ckt.input_sids),
+                                  cs.shape[0], prog.probe.size, tape.size & 0xFFFFFFFF, tape.size >> 32], dtype=np.uint32).tobytes())
+                f.write(bytes(ckt.gate_array))
+                f.write(O.arr(digest).tobytes() + O.arr(ckt.pre).tobytes() + tape.tobytes())
+                f.write(np.ascontiguousarray(ckt.input_sids, dtype=np.uint32).tobytes() + cs.tobytes() + np.ascontiguousarray(prog.probe, dtype=np.uint32).tobytes())
+            f.write(O.arr(inputs).tobytes())
+
+    def fnv(a):
+        h = 1469598103934665603
+        for b in np.ascontiguousarray(a).tobytes():
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return f"{h:016x}"
+
+    good, bad = str(tmp_path / "reduce.bin"), str(tmp_path / "reduce_bad.bin")
+    write(good, rows)
+    out = subprocess.run([exe, good], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.startswith("node ")]
+    assert len(lines) == 3
+    for b, (line, pr) in enumerate(zip(lines, want)):
+        assert f"proof_fnv1a={fnv(pr[2])}" in line and f"openings_fnv1a={fnv(pr[1])}" in line and f"caps_fnv1a={fnv(pr[0])}" in line and f"pis_fnv1a={fnv(pr[3])}" in line, (b, line)
+    tampered = rows.copy()
+    tampered[1, 4 + 64 + 4] ^= np.uint64(1)  # first public input of node 1's first child (after the set digest and the child's verifier data)
+    write(bad, tampered)
+    out = subprocess.run([exe, bad], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 3 and "invalid witness" in out.stdout, out.stdout + out.stderr
+    prover.free()
