@@ -11,6 +11,7 @@
 // from another rank) are copied into the base step's inputs in place (mp2g_chain_patch). One synchronisation at the end.
 #include "ctx.h"
 #include "witness.h"
+#include <cstring>
 #include <new>
 
 using namespace mp2g;
@@ -30,6 +31,14 @@ struct mp2g_chain {
   };
   Step steps[8];  // DevBuf owns device memory and does not move
   uint32_t n_steps = 0;
+  // pinned staging for the inputs on the way up and the last step's outputs on the way down (pageable copies would be staged by
+  // the runtime in small synchronous pieces)
+  u64* h_in = nullptr;
+  u64* h_out = nullptr;
+  ~mp2g_chain() {
+    if (h_in) (void)hipHostFree(h_in);
+    if (h_out) (void)hipHostFree(h_out);
+  }
 };
 
 extern "C" {
@@ -63,6 +72,11 @@ int mp2g_chain_create(mp2g_ctx* c, uint32_t n_steps, mp2g_prover* const* provers
     A(st.in, B * st.n_in); A(st.wires, (B * NUM_WIRES) << P.log_n); A(st.probe, B * st.n_probe); A(st.pi_hash, B * 4);
     A(st.caps, B * P.n_oracles * st.cap_words); A(st.openings, B * st.n_open * 2); A(st.proof, B * st.proof_words);
   }
+  if (e == hipSuccess) e = hipHostMalloc((void**)&ch->h_in, (size_t)capacity * ch->steps[0].n_in * sizeof(u64), hipHostMallocDefault);
+  if (e == hipSuccess) {
+    const mp2g_chain::Step& L = ch->steps[n_steps - 1];
+    e = hipHostMalloc((void**)&ch->h_out, (size_t)capacity * (L.P.n_oracles * L.cap_words + 2 * L.n_open + L.proof_words + L.n_probe) * sizeof(u64), hipHostMallocDefault);
+  }
   if (e != hipSuccess) { delete ch; return fail("chain_create: %s", hipGetErrorString(e)); }
   *out = ch;
   return 0;
@@ -75,7 +89,8 @@ int mp2g_chain_run(mp2g_chain* ch, const uint64_t* inputs, uint32_t batch, const
   mp2g_chain::Step& s0 = ch->steps[0];
   for (uint32_t i = 0; i < n_patches; i++)
     NEED(patches[i].job < batch && patches[i].d_src && (size_t)patches[i].offset + patches[i].n_words <= s0.n_in, "patch outside the inputs");
-  CK(hipMemcpyAsync(s0.in.p, inputs, (size_t)batch * s0.n_in * sizeof(u64), hipMemcpyHostToDevice, s));
+  memcpy(ch->h_in, inputs, (size_t)batch * s0.n_in * sizeof(u64));
+  CK(hipMemcpyAsync(s0.in.p, ch->h_in, (size_t)batch * s0.n_in * sizeof(u64), hipMemcpyHostToDevice, s));
   for (uint32_t i = 0; i < n_patches; i++)
     CK(hipMemcpyAsync(s0.in.p + (size_t)patches[i].job * s0.n_in + patches[i].offset, patches[i].d_src, (size_t)patches[i].n_words * sizeof(u64),
                       hipMemcpyDeviceToDevice, s));
@@ -100,11 +115,21 @@ int mp2g_chain_run(mp2g_chain* ch, const uint64_t* inputs, uint32_t batch, const
   }
   ch->last_batch = batch;
   mp2g_chain::Step& L = ch->steps[ch->n_steps - 1];
-  if (caps) CK(hipMemcpyAsync(caps, L.caps.p, (size_t)batch * L.P.n_oracles * L.cap_words * 8, hipMemcpyDeviceToHost, s));
-  if (openings) CK(hipMemcpyAsync(openings, L.openings.p, (size_t)batch * L.n_open * 2 * 8, hipMemcpyDeviceToHost, s));
-  if (proof) CK(hipMemcpyAsync(proof, L.proof.p, (size_t)batch * L.proof_words * 8, hipMemcpyDeviceToHost, s));
-  if (public_inputs) CK(hipMemcpy2DAsync(public_inputs, (L.n_probe - 4) * 8, L.probe.p + 4, L.n_probe * 8, (L.n_probe - 4) * 8, batch, hipMemcpyDeviceToHost, s));
+  const size_t n_caps = (size_t)batch * L.P.n_oracles * L.cap_words, n_op = (size_t)batch * L.n_open * 2, n_pf = (size_t)batch * L.proof_words,
+               n_pi = L.n_probe - 4;
+  u64* hc = ch->h_out;
+  u64* ho = hc + n_caps;
+  u64* hp = ho + n_op;
+  u64* hi = hp + n_pf;
+  if (caps) CK(hipMemcpyAsync(hc, L.caps.p, n_caps * 8, hipMemcpyDeviceToHost, s));
+  if (openings) CK(hipMemcpyAsync(ho, L.openings.p, n_op * 8, hipMemcpyDeviceToHost, s));
+  if (proof) CK(hipMemcpyAsync(hp, L.proof.p, n_pf * 8, hipMemcpyDeviceToHost, s));
+  if (public_inputs) CK(hipMemcpy2DAsync(hi, n_pi * 8, L.probe.p + 4, L.n_probe * 8, n_pi * 8, batch, hipMemcpyDeviceToHost, s));
   CK(hipStreamSynchronize(s));
+  if (caps) memcpy(caps, hc, n_caps * 8);
+  if (openings) memcpy(openings, ho, n_op * 8);
+  if (proof) memcpy(proof, hp, n_pf * 8);
+  if (public_inputs) memcpy(public_inputs, hi, (size_t)batch * n_pi * 8);
   // plonky2's prove() panics on a witness that violates a constraint: with the provers' witness check on, so does the chain
   for (size_t k = 0; k < ch->n_steps; k++)
     if (mp2g_prover_witness_check_enabled(ch->steps[k].pr)) {

@@ -264,8 +264,14 @@ GLD void exec_one(const u64* t, u64* vals, u64* wires, u64 n, const u64* domtab)
 }
 #undef W
 
-constexpr int WIT_LANES = 512;
-__global__ void __launch_bounds__(WIT_LANES) witness_exec_kernel(const u64* __restrict__ tape, const u32* __restrict__ sched,
+#ifndef WIT_LANES_N
+#define WIT_LANES_N 512
+#endif
+#ifndef WIT_BOUNDS
+#define WIT_BOUNDS WIT_LANES_N
+#endif
+constexpr int WIT_LANES = WIT_LANES_N;
+__global__ void __launch_bounds__(WIT_BOUNDS) witness_exec_kernel(const u64* __restrict__ tape, const u32* __restrict__ sched,
                                                                 const u32* __restrict__ level_off, const u32* __restrict__ level_p2, u32 n_levels, u32 n_slots, u32 log_n,
                                                                 const u32* __restrict__ input_sids, u32 n_inputs, const u64* __restrict__ consts,
                                                                 u32 n_consts, const u64* __restrict__ domtab, const u32* __restrict__ probe,

@@ -190,3 +190,32 @@ def test_other_column_counts(ctx, mp2, params, n_cols, rows):
     assert np.array_equal(pis[4:15], mp2.compute_table_row_digest(ctx, table.col_ids, table.values, table.values[:, 0:1])[1])
     cells_root = build.cells_roots[0]
     assert cells_root[1] == ("cells_leaf" if n_cols == 1 else "cells_full") and int(cells_root[0][3][26]) == n_cols
+
+
+def test_table_build_of_128_rows(ctx, mp2, params):
+    """a block of 128 rows (640 real framework proofs) the way bench.py runs it: three workers with provers of capacity 32, the row tree
+    cut into spun-off subtrees of <= 16 rows by the batched work plan (two waves: eight bottom subtrees, then the top of the tree).
+    Root = off-circuit tree hash, the block's multiset digest, min / max; the root proof passes the oracle's verifier."""
+    n = 128
+    table = T.SyntheticTable(n, 4, seed=0xC0FFEE04, block=6)
+    root, nodes, spans = T.balanced_bst(n)
+    ctxs = [mp2.Context(0) for _ in range(3)]
+    provers = [FW.GpuProver(c, capacity=32) for c in ctxs]
+    build = T.TableBuild(params, [R.ProofSession(p) for p in provers], batch=32, subtree_size=16, host_threads=8)
+    wit = T.TableWitness(ctx, table, spans)
+    proof, name = build.run(table, wit, root, nodes)
+    assert build.n_proofs == 5 * n and len(build.row_proofs) == n and len(build.cells_roots) == n
+    kinds = {}
+    for k, (_, nm) in build.row_proofs.items():
+        kinds[nm] = kinds.get(nm, 0) + 1
+    assert kinds == {"row_leaf": 64, "row_full": 63, "row_partial": 1}
+    pis = proof[3]
+    assert np.array_equal(pis[:T.ROWS_IO], T.expected_root_public_inputs(ctx, table, wit, root, nodes, spans))
+    assert np.array_equal(pis[4:15], mp2.compute_table_row_digest(ctx, table.col_ids, table.values, table.values[:, 0:1])[1])
+    assert int(table.values[0, 0, 0]) >> 16 == 6 and np.array_equal(pis[26:34], table.values[0, 0].astype(np.uint64)) and np.array_equal(pis[34:42], table.values[n - 1, 0].astype(np.uint64))
+    wckt, wcap, wdig = params.rows.chains[name][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *proof[:3]) == 0
+    for p in provers:
+        p.free()
+    for c in ctxs:
+        c.close()
