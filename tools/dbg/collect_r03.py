@@ -13,7 +13,9 @@ for tag, name in (("prof4", "table_4workers"), ("prof1", "table_1worker"), ("pro
 summary = {}
 for a, b in (("bench.json", "bench_r03.json"), ("prof4.json", "bench_r03_under_rocprof_4workers.json"), ("prof1.json", "bench_r03_under_rocprof_1worker.json"),
              ("recursion.json", "bench_r03_recursion.json"), ("bench_host_witness.json", "bench_r03_host_witness.json"), ("leaves.json", "bench_r03_leaves.json"),
-             ("ntt.json", "bench_r03_ntt_under_rocprof.json")):
+             ("ntt.json", "bench_r03_ntt_under_rocprof.json"), ("bench_4096rows.json", "bench_r03_4096rows.json")):
+    if not os.path.exists(f"{src}/{a}"):
+        continue
     line = [l for l in open(f"{src}/{a}").read().splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     open(f"{dst}/{b}", "w").write(json.dumps(d, indent=1) + "\n")

@@ -20,6 +20,7 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --kernel-trace --o
 python3 $R/bench.py --workload recursion --batch 128 --trees 8 --steps 3 --warmup 1 > $O/recursion.json 2> $O/recursion.err
 python3 $R/bench.py --steps 2 --warmup 1 --host-witness --no-leaves-leg --no-verify > $O/bench_host_witness.json 2> $O/bench_host_witness.err
 python3 $R/bench.py --workload leaves > $O/leaves.json 2> $O/leaves.err
+python3 $R/bench.py --rows 4096 --steps 1 --warmup 1 --no-leaves-leg --no-verify > $O/bench_4096rows.json 2> $O/bench_4096rows.err
 python3 $R/tools/dbg/witness_dev_timing.py > $O/witness_dev_timing.txt 2>&1
 # keep only the summaries (the raw traces exceed the merge limit)
 find $O -name "*kernel_trace.csv" -size +20M -delete
