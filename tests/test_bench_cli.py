@@ -1,0 +1,21 @@
+"""bench.py's command line on a box without GPUs: `--gpus N` starts its own ranks only when N devices are visible, and says so
+otherwise (before anything touches a GPU)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gpus_n_without_devices_is_refused_with_a_message():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MP2G_BENCH_BACKEND")}
+    env["HIP_VISIBLE_DEVICES"] = ""  # also on a GPU box: no device visible to this child
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "--gpus 2 needs 2 visible GPUs" in r.stderr + r.stdout
+
+
+def test_default_workload_is_the_table_build():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "table (default, the headline)" in " ".join(r.stdout.split())

@@ -118,3 +118,53 @@ def test_device_witness_replay_equals_the_host_replay(ctx, mp2):
         prog.run_dev(ctx, d_in, nb, d_w, d_pr)
         assert np.array_equal(d_w.download((nb, 135, n)), hw)
     prover.free()
+
+
+def test_device_witness_and_chain_error_paths(ctx, mp2):
+    """what the new entry points refuse: a device run of a program that writes a slot twice (it cannot be level-scheduled), a probe
+    changed after the first device run, a chain whose steps do not fit together, a batch wider than the chain's capacity, a patch
+    outside the inputs; and a chain keeps working after a refused call."""
+    import ctypes
+    import importlib
+    R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+    FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+    L = mp2.load()
+    # a two-instruction program: slot 2 = slot 0 * slot 1, then slot 2 again = slot 0 + slot 1 (same destination: not SSA)
+    tape = np.array([R.OP_ARITH, 0, 0, 1, 0, 0, 1, 0, 2, R.OP_ARITH, 0, 1, 0, 1, 0, 1, 0, 2], dtype=np.uint64)
+    h = ctypes.c_void_p()
+    ins = np.array([0, 1], dtype=np.uint32)
+    assert L.mp2g_witness_program_create(mp2._p(tape), ctypes.c_size_t(tape.size), 3, 3, mp2._p(ins), 2, None, 0, ctypes.byref(h)) == 0
+    d_in, d_w, d_pr = ctx.to_device(np.array([[3, 4]], dtype=np.uint64)), ctx.alloc(135 * 8 * 8), ctx.alloc(64)
+    assert L.mp2g_witness_program_run_dev(h, ctx.h, d_in.ptr, 1, d_w.ptr, d_pr.ptr) != 0
+    assert b"writes a slot twice" in L.mp2g_last_error()
+    host = np.zeros((1, 135, 8), dtype=np.uint64)
+    assert L.mp2g_witness_program_run(h, mp2._p(np.array([[3, 4]], dtype=np.uint64)), 1, 1, mp2._p(host), None, 0, None) == 0  # the host replay runs it in order
+    assert int(host[0, 3, 0]) == 12 and int(host[0, 7, 0]) == 3  # 3 * 4, then 0 * (3 * 4) + 1 * 3
+    L.mp2g_witness_program_free(h)
+    # chains
+    prover = FW.GpuProver(ctx, capacity=2)
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], prover, FW.circuit_fri_params)
+    data = O.rand_field(12, 0xC0FFEE09)
+    jobs = [([], [], data[4 * i:4 * i + 4]) for i in range(3)]
+    two = fw.generate_proofs_batch("map", jobs[:2])
+    one = fw.generate_proofs_batch("map", jobs[2:])
+    chain = prover.last_chain
+    assert chain.capacity == 2
+    prog = fw.witness_programs("map")[0]
+    rows3 = np.stack([np.concatenate([np.asarray(fw.set_digest, dtype=np.uint64), data[4 * i:4 * i + 4]]) for i in range(3)])
+    with pytest.raises(mp2.Mp2gError, match="capacity"):
+        chain.run(rows3)  # three nodes through a chain created for two
+    with pytest.raises(mp2.Mp2gError, match="before the first device run"):
+        mp2._ck(L.mp2g_witness_program_set_probe(prog.h, mp2._p(prog.probe), int(prog.probe.size)))
+    row = np.concatenate([np.asarray(fw.set_digest, dtype=np.uint64), data[:4]])[None]
+    with pytest.raises(mp2.Mp2gError, match="patch outside"):
+        chain.run(row, [(0, row.shape[1] - 1, chain.device_proof(0)[3][0], 8)])
+    with pytest.raises(mp2.Mp2gError, match="patch outside"):
+        chain.run(row, [(1, 0, chain.device_proof(0)[3][0], 1)])  # job 1 of a batch of one
+    # steps that do not follow each other: the map chain's wrap step in front of its base step
+    cps, progs = chain.cps, fw.witness_programs("map")
+    with pytest.raises(mp2.Mp2gError, match="takes .* inputs"):
+        mp2.ProofChain(ctx, [cps[1].pr, cps[0].pr], [progs[1], progs[0]], [cps[1].d_circuit_digest, cps[0].d_circuit_digest], 2)
+    again = fw.generate_proofs_batch("map", jobs[:2])
+    assert all(np.array_equal(a, b) for p, q in zip(two, again) for a, b in zip(p, q)) and len(one) == 1
+    prover.free()

@@ -400,3 +400,31 @@ def test_final_poseidon_wrap_of_a_framework_proof():
     assert C.verify(fin.ckt, C.oracle_params(fin.ckt, variant=1), fin.digest, ph, *out[:3]) == 0
     assert C.verify(fin.ckt, C.oracle_params(fin.ckt, variant=0), fin.digest, ph, *out[:3]) != 0
     assert C.verify(fin.ckt, C.oracle_params(fin.ckt, variant=1), fin.digest, O.hash_n_to_m_no_pad(out[3], 4, 0), *out[:3]) != 0
+
+
+def test_level_schedule_of_a_witness_program(base_and_proof):
+    """the device executor's schedule (csrc/witness.hip, built at mp2g_witness_program_create, no GPU needed): the number of dependency
+    levels of the wrap circuit's program equals the depth computed here from the tape (level = 1 + max level of the slots read), and a
+    program that writes a slot twice is still accepted by the host executor but marked unschedulable (its device run refuses it)."""
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    data, base, fp, cap, cd, caps, openings, proof = base_and_proof
+    inner = R.InnerCircuit(base, fp, cap, cd, len(base.public_inputs))
+    w = R.wrap_circuit(inner, caps, openings, proof, base.public_inputs)
+    prog = mp2.WitnessProgram(w)
+    tape = [int(x) for x in w.tape]
+    level, depth, pos = {}, 0, 0
+    while pos < len(tape):
+        if tape[pos] == R.OP_PAR:
+            pos += 2 + tape[pos + 1]
+            continue
+        r, wr, _, nxt = R.instruction_slots(tape, pos)
+        lv = 1 + max([level.get(int(s), 0) for s in r], default=0)
+        for s in wr:
+            assert int(s) not in level, "the builder's programs are in SSA form"
+            level[int(s)] = lv
+        depth = max(depth, lv)
+        pos = nxt
+    assert prog.n_levels == depth and 100 < depth < 1000
+    # the host replay of the scheduled program still fills the builder's wires
+    wires, _, _ = prog.run(w.input_values[None])
+    assert np.array_equal(wires[0], w.wires)
