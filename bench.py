@@ -764,6 +764,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         if cpu_base is not None:
             kinds = [c[0][0].rsplit(" step", 1)[0] for c in samples]
             cpu_base["unit"] = "proofs/s"
+            cpu_base["sample_wall_s"] = cpu_base.pop("single_leaf_latency_s")
             cpu_base["sample"] = (f"{len(samples)} framework proofs of the last step ({', '.join(kinds)}: {sum(len(c) for c in samples)} prove() calls of 2^6..2^14 rows) re-proved "
                                   "from their captured witnesses by oracle/ (our C restatement, not the Rust prover); every one compared bit for bit with the GPU's and verified")
     if dist is not None:
