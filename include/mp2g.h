@@ -39,6 +39,10 @@ int mp2g_device_count(void);
 int mp2g_ctx_create(int device, mp2g_ctx** out);
 void mp2g_ctx_destroy(mp2g_ctx* ctx);
 int mp2g_ctx_sync(mp2g_ctx* ctx);
+/* HIP's current device is a property of the calling THREAD (0 until set). mp2g_ctx_create sets it for the creating thread; a worker thread
+ * that drives a context of another device (one process per GPU with several proving threads, rank > 0 of a node) calls this once before
+ * its first call: allocations and launches follow the thread's current device. */
+int mp2g_ctx_make_current(mp2g_ctx* ctx);
 void* mp2g_ctx_stream(mp2g_ctx* ctx);                 /* hipStream_t the context launches on */
 int mp2g_ctx_set_stream(mp2g_ctx* ctx, void* stream); /* adopt a caller-owned hipStream_t     */
 int mp2g_dev_alloc(mp2g_ctx* ctx, size_t bytes, void** d_ptr);

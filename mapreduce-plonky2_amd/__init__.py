@@ -122,6 +122,10 @@ class Context:
         except Exception:
             pass
 
+    def make_current(self):
+        """select this context's device for the calling thread (HIP's current device is per thread; call at the start of a worker thread)"""
+        _ck(load().mp2g_ctx_make_current(self.h))
+
     def sync(self):
         _ck(load().mp2g_ctx_sync(self.h))
 

@@ -91,6 +91,11 @@ int mp2g_dev_free(mp2g_ctx* c, void* d_ptr) {
   CK(hipFree(d_ptr));
   return 0;
 }
+int mp2g_ctx_make_current(mp2g_ctx* c) {
+  NEED(c, "ctx");
+  CK(hipSetDevice(c->device));
+  return 0;
+}
 int mp2g_h2d(mp2g_ctx* c, void* d_dst, const void* src, size_t bytes) {
   NEED(c, "ctx");
   CK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));

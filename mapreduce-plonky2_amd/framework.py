@@ -261,6 +261,7 @@ class GpuProver:
         return key
 
     def _prover(self, ckt):
+        self.ctx.make_current()
         key = (ckt.log_n, self.circuit_key(ckt))
         cp = self.provers.get(key)
         if cp is None:
@@ -284,6 +285,7 @@ class GpuProver:
         [B][4], host) and queue their prove() on the context's stream; returns the handle prove_batch_finish waits on. One
         batch per (circuit, B) in flight at a time."""
         B, n = wires.shape[0], 1 << ckt.log_n
+        self.ctx.make_current()
         rows = wires.shape[1:] == (n, 135) and n != 135
         cap = max(B, self.capacity) if self.capacity else B
         key = (ckt.log_n, self.circuit_key(ckt), cap)
@@ -328,6 +330,7 @@ class GpuProver:
         and the next step's inputs are gathered from the prover's outputs by device copies. One synchronisation at the end. Returns
         [(caps, openings, proof, public_inputs)] of the last step; raises like plonky2's prove() on an unsatisfied witness."""
         B = cur.shape[0]
+        self.ctx.make_current()  # worker threads of a rank whose GPU is not device 0
         ch = self._chain(ckts, progs, B)
         flat = []
         for j, off, dp in patches:

@@ -331,6 +331,7 @@ class TableBuild:
         outside the subtree were proved by earlier items (row_proofs)."""
         sess = self.pool.get()
         try:
+            getattr(getattr(sess.prover, "ctx", None), "make_current", lambda: None)()  # this worker thread drives the session's GPU
             keyset = set(keys)
             cells = self.cells_proofs(table, wit, sorted(keys), sess)
             self.cells_roots.update(cells)
