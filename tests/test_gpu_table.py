@@ -117,6 +117,10 @@ def test_table_build_of_eleven_rows(ctx, mp2, params):
     for r in (0, n - 1):
         cp = build.cells_roots[r][0][3]
         assert int(cp[26]) == 4 and int(cp[27]) == 0 and np.array_equal(cp[4:15], wit.cell_digest[r, 3])
+    # scheduling does not change a proof: one worker, batches of three, the plain (node by node) work plan -> the same root, word for word
+    plain = T.TableBuild(params, [R.ProofSession(provers[0])], batch=3, subtree_size=1, host_threads=8)
+    proof2, name2 = plain.run(table, wit, root, nodes)
+    assert name2 == name and plain.n_proofs == 5 * n and all(np.array_equal(a, b) for a, b in zip(proof, proof2))
     # the builder path (eager Python circuit) of one cells leaf = the witness-program path
     flat = T._u64cat([table.col_ids[1]], table.values[0, 1], [0], wit.cell_digest[0, 0], T.NEUTRAL_FIELDS)
     one = params.cells.generate_proof("cells_leaf", [], [], flat)
