@@ -67,6 +67,12 @@ class ClockReader:
 
     def __init__(self):
         import subprocess
+        # under a counter-collecting profiler the preloaded library has initialised the GPU before this program's first line: no child
+        # process may be started then (the pool's boxes refuse an exec after GPU initialisation)
+        preload = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD", "")
+        if "rocprof" in preload.lower():
+            self.p = None
+            return
         try:
             self.p = subprocess.Popen([sys.executable, "-c", _CLOCK_HELPER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
         except Exception:

@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/st1
-timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/st1 -- python3 ${@:-$R/bench.py --steps 1 --warmup 0 --streams 1 --batch 64 --no-cpu-baseline --no-verify} > /dev/null 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/st1 -- python3 ${@:-$R/bench.py --workload leaves --steps 1 --warmup 0 --streams 1 --batch 64 --no-cpu-baseline --no-verify} > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob, statistics
 res = {}
