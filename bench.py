@@ -69,8 +69,7 @@ class ClockReader:
         import subprocess
         # under a counter-collecting profiler the preloaded library has initialised the GPU before this program's first line: no child
         # process may be started then (the pool's boxes refuse an exec after GPU initialisation)
-        preload = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "") + os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD", "")
-        if "rocprof" in preload.lower():
+        if "rocprofiler" in os.environ.get("LD_PRELOAD", "").lower() and os.environ.get("ROCPROF_COUNTER_COLLECTION", "0") not in ("", "0"):
             self.p = None
             return
         try:
