@@ -567,6 +567,8 @@ def main(argv=None):
     ap.add_argument("--subtree", type=int, default=64, help="--workload table: into_batched_workplan(subtree_size), the rows of one work-plan item")
     ap.add_argument("--host-witness", action="store_true", help="--workload table / recursion: replay the witness programs on host threads (mp2g_witness_program_run_rows) "
                     "instead of on the device (mp2g_witness_program_run_dev, the default): the A/B switch")
+    ap.add_argument("--lean", action="store_true", help="--workload table: keep only the frontier of the row tree in host memory (automatic above 16384 rows); the "
+                    "self-check is then the root's public inputs and the oracle's verifier on the root, not the re-proving of sampled nodes")
     ap.add_argument("--no-leaves-leg", action="store_true", help="--workload table: skip the short prove()-only leg reported beside the headline")
     ap.add_argument("--workload", choices=("table", "leaves", "tree", "recursion", "ntt"), default="table",
                     help="table (default, the headline): BASELINE configs[3] sampled -- per row 4 cells-tree + 1 row-tree REAL framework proofs, work-plan "
@@ -648,7 +650,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     t_setup = time.perf_counter() - t_setup
     ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     host_threads = max(1, (os.cpu_count() or 1) // (n_workers * ranks_here))
-    build = T.TableBuild(params, sessions, batch=args.table_batch, subtree_size=args.subtree, host_threads=host_threads)
+    lean = args.lean or n_rows > 16384  # a block this large keeps only the frontier of the tree in host memory (no per-node re-proving afterwards)
+    build = T.TableBuild(params, sessions, batch=args.table_batch, subtree_size=args.subtree, host_threads=host_threads, keep_proofs=not lean)
     table = T.SyntheticTable(n_rows, n_cols, seed=0xC0FFEE04, block=2 * rank)
     root, nodes, spans = T.balanced_bst(n_rows)
     nccl = dist is not None and dist.get_backend() == "nccl"
@@ -690,7 +693,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         for c in ctxs:
             c.sync()
 
-    for _ in range(max(1, args.warmup)):  # the first pass creates the provers of every (circuit, batch width)
+    for _ in range(args.warmup):  # the first pass creates the provers of every circuit (with --warmup 0 that falls into the timed region)
         cur = step()
     barrier()
     n0 = build.n_proofs
@@ -730,7 +733,16 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                 ws.append(mp2.compute_table_row_digest(ctx, tb.col_ids, tb.values, tb.values[:, 0:1])[0])
             assert np.array_equal(mp2.curve_sum(ctx, np.stack(ws), weierstrass=True)[1], root_pis[4:15]), "root digest != digest of the whole table"
             assert np.array_equal(root_pis[26:34], want[26:34]), "root min != min of block 0"
-    if not args.no_verify:
+    if lean and not args.no_verify:  # the oracle's verifier on the block root (transcript, PLONK identity with the gate terms, FRI)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import circuits as OC
+        import oracle as O
+        wckt, _, wdig = params.rows.chains[last["block_root"][1]][-1]
+        rc = OC.verify(wckt, OC.oracle_params(wckt), np.asarray(wdig, dtype=np.uint64), O.hash_n_to_m_no_pad(block_pis, 4), *last["block_root"][0][:3])
+        if rc:
+            raise SystemExit(f"bench.py self-check FAILED: the oracle's verifier rejects the block root (code {rc})")
+        verified = 1
+    elif not args.no_verify:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import circuits as OC
         # one framework proof of every circuit kind of the last step, re-proved with capture from the inputs the timed run used

@@ -274,8 +274,11 @@ class TableBuild:
     subtree's row nodes bottom-up, level by level in batches, and returns. Workers run concurrently; the plan hands out an item once
     the subtrees below it are done."""
 
-    def __init__(self, params, sessions, batch=32, subtree_size=64, host_threads=0):
-        self.p, self.sessions, self.batch, self.subtree_size = params, sessions, batch, subtree_size
+    def __init__(self, params, sessions, batch=32, subtree_size=64, host_threads=0, keep_proofs=True):
+        """keep_proofs: retain every row proof and cells-tree root after the run (what a checker re-proves sampled nodes from: ~130 KB
+        per row); off, a proof is dropped as soon as its parent is proved -- the live set is the frontier of the tree, which is
+        what a 2^17-row block needs"""
+        self.p, self.sessions, self.batch, self.subtree_size, self.keep_proofs = params, sessions, batch, subtree_size, keep_proofs
         self.host_threads = host_threads
         self.pool = queue.Queue()
         for s in sessions:
@@ -334,7 +337,8 @@ class TableBuild:
             getattr(getattr(sess.prover, "ctx", None), "make_current", lambda: None)()  # this worker thread drives the session's GPU
             keyset = set(keys)
             cells = self.cells_proofs(table, wit, sorted(keys), sess)
-            self.cells_roots.update(cells)
+            if self.keep_proofs:
+                self.cells_roots.update(cells)
             height = {}
 
             def h(k):
@@ -351,6 +355,13 @@ class TableBuild:
                 for name, kj in by_name.items():
                     for (k, _), pr in zip(kj, self._batched(self.p.rows, name, [j for _, j in kj], sess)):
                         row_proofs[k] = (pr, name)
+                if not self.keep_proofs:  # this level's nodes have consumed their children and their cells roots
+                    for k in keys:
+                        if height[k] == lvl:
+                            cells.pop(k, None)
+                            for c in nodes[k]:
+                                if c is not None:
+                                    row_proofs.pop(c, None)
         finally:
             self.pool.put(sess)
 
