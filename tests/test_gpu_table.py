@@ -121,6 +121,10 @@ def test_table_build_of_eleven_rows(ctx, mp2, params):
     plain = T.TableBuild(params, [R.ProofSession(provers[0])], batch=3, subtree_size=1, host_threads=8)
     proof2, name2 = plain.run(table, wit, root, nodes)
     assert name2 == name and plain.n_proofs == 5 * n and all(np.array_equal(a, b) for a, b in zip(proof, proof2))
+    # ... and neither does dropping every proof as soon as its parent is proved (what a 2^17-row block does): only the root stays
+    lean = T.TableBuild(params, [R.ProofSession(p) for p in provers], batch=8, subtree_size=4, host_threads=8, keep_proofs=False)
+    proof3, _ = lean.run(table, wit, root, nodes)
+    assert all(np.array_equal(a, b) for a, b in zip(proof, proof3)) and list(lean.row_proofs) == [root] and not lean.cells_roots
     # the builder path (eager Python circuit) of one cells leaf = the witness-program path
     flat = T._u64cat([table.col_ids[1]], table.values[0, 1], [0], wit.cell_digest[0, 0], T.NEUTRAL_FIELDS)
     one = params.cells.generate_proof("cells_leaf", [], [], flat)
