@@ -88,19 +88,47 @@ __global__ void __launch_bounds__(64) lookup_rows_kernel(LookupDev L, const u64*
     out[(u64)(p + 1) << log_n] = table_row ? sum : gl_sub(0, sum);  // Sum adds mult / (alpha - combo), LDC subtracts 1 / (alpha - combo)
   }
 }
-// grid (n_luts, nc, B), one lane: walk the table's rows downwards, carrying RE (Horner in delta^slots) and the
-// running Sum - LDC value through the partial polynomials of each row and on to the next row
-__global__ void lookup_scan_kernel(LookupDev L, u32 log_n, const u64* __restrict__ deltas, u64 d_bstride, u32 nc, u64* __restrict__ polys,
-                                   u64 p_bstride, const u64* __restrict__ lut_eval, u32* __restrict__ flags) {
-  if (threadIdx.x) return;
-  const u32 r = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+// grid (n_luts, nc, B), one 64-lane wave per (table, challenge round, proof): the table's rows are walked downwards, carrying RE
+// (Horner in delta^slots over the LookupTable rows: re <- re dpow + chunk) and the running Sum - LDC value through the partial
+// polynomials of each row and on to the next row. Both are scans: the RE recurrence composes as affine maps (a, b): re -> a re + b,
+// the running value is a plain prefix sum over the (row, partial polynomial) cells in walk order. Each lane takes a run of
+// consecutive rows, folds it, the wave scans the lanes' folds, and each lane walks its run again with its carry-in (a 65536-entry
+// table spans ~2500 rows: 40 per lane instead of 2500 dependent steps on one lane).
+__global__ void __launch_bounds__(64) lookup_scan_kernel(LookupDev L, u32 log_n, const u64* __restrict__ deltas, u64 d_bstride, u32 nc,
+                                                        u64* __restrict__ polys, u64 p_bstride, const u64* __restrict__ lut_eval,
+                                                        u32* __restrict__ flags) {
+  const u32 lane = threadIdx.x, r = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
   const u64 n = (u64)1 << log_n;
   const u32 ns = L.num_sldc, nlp = ns + 1;
   u64* out = polys + b * p_bstride + (u64)c * nlp * n;
   const u64 dpow = gl_pow(deltas[b * d_bstride + 4 * c + 3], L.num_lut_slots);
-  u64 re = 0, run = 0;
-  for (u32 row = L.first_lut_row[r] + 1; row-- > L.last_lu_row[r];) {
-    if (row >= L.last_lut_row[r]) {
+  // walk position t = 0 .. total-1 visits row first_lut_row - t
+  const u32 top = L.first_lut_row[r], bottom = L.last_lu_row[r], lut_end = L.last_lut_row[r];
+  const u32 total = top - bottom + 1, per = (total + 63) / 64;
+  const u32 t0 = lane * per < total ? lane * per : total, t1 = t0 + per < total ? t0 + per : total;
+  // fold of this lane's run: RE map (A, Bc) over its LookupTable rows, sum of its Sum / LDC cells
+  u64 A = 1, Bc = 0, tot = 0;
+  for (u32 t = t0; t < t1; t++) {
+    const u32 row = top - t;
+    if (row >= lut_end) { Bc = gl_add(gl_mul(Bc, dpow), out[row]); A = gl_mul(A, dpow); }
+    for (u32 p = 0; p < ns; p++) tot = gl_add(tot, out[((u64)(p + 1) << log_n) + row]);
+  }
+  // exclusive scans over the lanes (lane 0 walks first): carry-in RE = composition of the earlier lanes' maps applied to 0
+  u64 cA = A, cB = Bc, cT = tot;  // inclusive
+  for (u32 d = 1; d < 64; d <<= 1) {
+    const u64 pA = __shfl_up(cA, d), pB = __shfl_up(cB, d), pT = __shfl_up(cT, d);
+    if (lane >= d) {
+      // earlier map (pA, pB) first, then this one (cA, cB): re -> cA (pA re + pB) + cB
+      cB = gl_add(gl_mul(cA, pB), cB);
+      cA = gl_mul(cA, pA);
+      cT = gl_add(cT, pT);
+    }
+  }
+  u64 re = __shfl_up(cB, 1), run = __shfl_up(cT, 1);  // applied to re = 0: the map's constant term
+  if (lane == 0) { re = 0; run = 0; }
+  for (u32 t = t0; t < t1; t++) {
+    const u32 row = top - t;
+    if (row >= lut_end) {
       re = gl_add(gl_mul(re, dpow), out[row]);
       out[row] = re;
     }
@@ -112,9 +140,11 @@ __global__ void lookup_scan_kernel(LookupDev L, u32 log_n, const u64* __restrict
     // witness check (what the LastLdc and the table-end constraints enforce): every looked-up pair is in the table
     // with the stated multiplicities iff Sum - LDC returns to zero; the table rows hold the registered table iff RE
     // ends at the table's polynomial
-    if (flags && row == L.last_lut_row[r] && re != lut_eval[((u64)b * nc + c) * MP2G_MAX_LUTS + r]) atomicOr(&flags[b], 4u);
+    if (flags && row == lut_end && re != lut_eval[((u64)b * nc + c) * MP2G_MAX_LUTS + r]) atomicOr(&flags[b], 4u);
   }
-  if (flags && run != 0) atomicOr(&flags[b], 4u);
+  // the running value after the last cell of the walk: held by the lane that walked the end
+  const u64 final_run = __shfl(cT, 63);
+  if (flags && lane == 0 && final_run != 0) atomicOr(&flags[b], 4u);
 }
 
 // The lookup terms of the vanishing polynomial at every LDE point, alpha-reduced and folded in front of the gate
