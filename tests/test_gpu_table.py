@@ -227,3 +227,13 @@ def test_table_build_of_128_rows(ctx, mp2, params):
         p.free()
     for c in ctxs:
         c.close()
+
+
+def test_bench_gpus_4_two_join_levels():
+    """four ranks (gloo, sharing this box's GPU): the blocks meet in two join levels -- ranks 1 and 3 hand their roots to 0 and 2, which prove
+    the separator rows 1 and 5, then rank 2 hands the joined tree to rank 0, which proves separator 3 over two joined trees. The run asserts
+    the root's digest = the digest of all 4 x 6 + 3 rows and its min = block 0's; every rank checks its block root and its sampled proofs."""
+    line = _bench(["--gpus", "4", "--rows", "6", "--steps", "1", "--warmup", "1", "--workers", "1", "--table-batch", "8", "--subtree", "4", "--no-leaves-leg",
+                   "--no-cpu-baseline"], env={"MP2G_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 4 and "2 join level" in line["config"]["sharding"]
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * (4 * 6 + 3)) < 1e-6 and line["verified"] >= 4 * 13
