@@ -284,9 +284,20 @@ __global__ void __launch_bounds__(WIT_BOUNDS) witness_exec_kernel(const u64* __r
   for (u32 i = tid; i < n_consts; i += WIT_LANES) vals[consts[2 * i]] = consts[2 * i + 1];
   for (u32 i = tid; i < n_inputs; i += WIT_LANES) vals[input_sids[i]] = inputs[(u64)b * n_inputs + i];
   __syncthreads();
+#ifdef WIT_PROF
+  // tools/dbg/witness_prof.sh: shader cycles of block 0 per class of level (0 narrow Poseidon2, 1 wide Poseidon2, 2 reducing / interpolation /
+  // inverse, 3 the rest), accumulated in the last 8 words of proof 0's probe row... of a side buffer: probe_out[n_probe * gridDim.x ..]
+  u64 prof[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
+#endif
   for (u32 l = 0; l < n_levels; l++) {
     const u32 lo = level_off[l], hi = level_off[l + 1];
     const u32 p2_lo = level_p2[2 * l], p2_n = level_p2[2 * l + 1];  // the level's Poseidon2 rows are sched[p2_lo .. p2_lo + p2_n)
+#ifdef WIT_PROF
+    const u64 t_start = __builtin_readcyclecounter();
+    u32 cls = p2_n ? (p2_n * 16 <= WIT_LANES ? 0 : 1) : 3;
+    if (!p2_n)
+      for (u32 i = lo; i < hi; i++) { const u64 op = tape[sched[i]]; if (op == OP_REDUCING || op == OP_REDUCING_EXT || op == OP_COSET || op == OP_HINT_DIV_EXT) { cls = 2; break; } }
+#endif
     if (p2_n && p2_n * 16 <= WIT_LANES) {
       // few Poseidon2 rows: one 16-lane group each (latency), the level's other instructions one lane each
       const u32 g = tid >> 4;
@@ -300,8 +311,15 @@ __global__ void __launch_bounds__(WIT_BOUNDS) witness_exec_kernel(const u64* __r
       for (u32 i = lo + tid; i < hi; i += WIT_LANES) exec_one(tape + sched[i], vals, wires, n, domtab);
     }
     __syncthreads();  // the level's slot writes (global memory, this block's) are visible to the next level's reads
+#ifdef WIT_PROF
+    prof[cls] += __builtin_readcyclecounter() - t_start; cnt[cls]++;
+#endif
   }
   for (u32 i = tid; i < n_probe; i += WIT_LANES) probe_out[(u64)b * n_probe + i] = vals[probe[i]];
+#ifdef WIT_PROF
+  if (b == 0 && tid == 0)
+    for (int k = 0; k < 4; k++) { probe_out[(u64)gridDim.x * n_probe + 2 * k] = prof[k]; probe_out[(u64)gridDim.x * n_probe + 2 * k + 1] = cnt[k]; }
+#endif
 }
 }  // namespace
 
