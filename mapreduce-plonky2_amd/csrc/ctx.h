@@ -31,6 +31,7 @@ struct mp2g_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   mp2g::NttEngine ntt;
   mp2g::DevBuf wit_vals;  // slot tables of the device witness executor (mp2g_witness_program_run_dev), grown on demand
+  mp2g::DevBuf wit_rows;  // its row-major staging wire matrices
 };
 struct mp2g_tree {
   mp2g_ctx* ctx = nullptr;

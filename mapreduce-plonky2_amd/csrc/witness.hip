@@ -519,15 +519,22 @@ int mp2g_witness_program_run_dev(mp2g_witness_program* P, mp2g_ctx* c, const uin
   WitnessDev* d = nullptr;
   int rc = witness_dev_data(P, c, &d);
   if (rc) return rc;
-  const size_t vals_words = (size_t)batch * P->n_slots;
-  if (c->wit_vals.bytes < vals_words * 8) {
-    CKH(hipStreamSynchronize(c->stream));  // a kernel queued earlier may still use the old buffer
-    CKH(c->wit_vals.alloc(vals_words * 8));
+  const size_t vals_words = (size_t)batch * P->n_slots, wire_words = (size_t)batch * NUM_WIRES << P->log_n;
+  if (c->wit_vals.bytes < vals_words * 8 || c->wit_rows.bytes < wire_words * 8) {
+    CKH(hipStreamSynchronize(c->stream));  // a kernel queued earlier may still use the old buffers
+    if (c->wit_vals.bytes < vals_words * 8) CKH(c->wit_vals.alloc(vals_words * 8));
+    if (c->wit_rows.bytes < wire_words * 8) CKH(c->wit_rows.alloc(wire_words * 8));
   }
   CKH(hipMemsetAsync(c->wit_vals.p, 0, vals_words * 8, c->stream));
-  CKH(hipMemsetAsync(d_wires, 0, ((size_t)batch * NUM_WIRES << P->log_n) * 8, c->stream));
+  CKH(hipMemsetAsync(c->wit_rows.p, 0, wire_words * 8, c->stream));
+  // the executor fills a row-major staging matrix (one contiguous run of words per gate row); the prover's polynomial-major
+  // [batch][135][n] is made from it by the tiled transpose (every word of d_wires is written)
   CKH(witness_exec_launch(c->stream, *d, (u32)P->level_off.size() - 1, P->n_slots, P->log_n, (u32)P->input_sids.size(), (u32)(P->consts.size() / 2),
-                          (u32)P->probe.size(), (const u64*)d_inputs, batch, c->wit_vals.p, (u64*)d_wires, (u64*)d_probe_out));
+                          (u32)P->probe.size(), (const u64*)d_inputs, batch, c->wit_vals.p, c->wit_rows.p, (u64*)d_probe_out));
+  {
+    int rc2 = mp2g_wires_from_rows_dev(c, c->wit_rows.p, d_wires, P->log_n, NUM_WIRES, batch);
+    if (rc2) return rc2;
+  }
   return 0;
 }
 static int witness_run(const mp2g_witness_program* P, const uint64_t* inputs, uint32_t batch, uint32_t threads, uint64_t* wires,

@@ -6,8 +6,8 @@
 // dependency levels; ~300 levels for a 10-20 k instruction verifier circuit, the long ones being the Merkle paths and leaf
 // hashes of the 28 FRI query rounds) and replayed by one 512-lane block per proof: at every level lane i takes the level's
 // i-th instruction (instructions of a level are ordered by opcode so that waves stay uniform), one block barrier between
-// levels. Values live in a per-proof slot table in global memory (written once each: SSA), wires go straight into the prover's
-// polynomial-major [B][135][n] matrix. Arithmetic is gl.cuh / poseidon.cuh: the Poseidon2 gate's S-box inputs are the weak
+// levels. Values live in a per-proof slot table in global memory (written once each: SSA), wires go into a row-major staging
+// matrix [B][n][135] (a gate row's wires are one contiguous run) that witness.hip transposes into the prover's [B][135][n]. Arithmetic is gl.cuh / poseidon.cuh: the Poseidon2 gate's S-box inputs are the weak
 // representatives of the sponge kernels, canonicalised where they become wires.
 #include "gl.cuh"
 #include "poseidon.cuh"
@@ -16,7 +16,9 @@
 
 namespace mp2g {
 namespace {
-#define W(col, row) wires[(u64)(col) * n + (u64)(row)]
+// wires: this proof's staging matrix in ROW-major order [n][135] (a gate row's wires are consecutive words: a Poseidon2 row's 135 stores
+// touch 17 sectors instead of 135; witness.hip transposes the batch into the prover's polynomial-major layout afterwards)
+#define W(col, row) wires[(u64)(row) * NUM_WIRES + (u64)(col)]
 
 GLD void exec_p2(const u64* t, u64* vals, u64* wires, u64 n) {
   // Poseidon2Gate: inputs 0..11, outputs 12..23, swap 24, deltas 25..28, S-box inputs 29.., 65.., 87..
@@ -294,14 +296,14 @@ __global__ void __launch_bounds__(WIT_BOUNDS) witness_exec_kernel(const u64* __r
     const u32 p2_lo = level_p2[2 * l], p2_n = level_p2[2 * l + 1];  // the level's Poseidon2 rows are sched[p2_lo .. p2_lo + p2_n)
 #ifdef WIT_PROF
     const u64 t_start = __builtin_readcyclecounter();
-    u32 cls = p2_n ? (p2_n * 16 <= WIT_LANES ? 0 : 1) : 3;
+    u32 cls = p2_n ? (p2_n * 16 <= 2 * WIT_LANES ? 0 : 1) : 3;
     if (!p2_n)
       for (u32 i = lo; i < hi; i++) { const u64 op = tape[sched[i]]; if (op == OP_REDUCING || op == OP_REDUCING_EXT || op == OP_COSET || op == OP_HINT_DIV_EXT) { cls = 2; break; } }
 #endif
-    if (p2_n && p2_n * 16 <= WIT_LANES) {
-      // few Poseidon2 rows: one 16-lane group each (latency), the level's other instructions one lane each
-      const u32 g = tid >> 4;
-      if (g < p2_n) exec_p2_coop(tape + sched[p2_lo + g] + 1, vals, wires, n, (int)(tid & 15));
+    if (p2_n && p2_n * 16 <= 2 * WIT_LANES) {
+      // few Poseidon2 rows: one 16-lane group each (latency; up to two rounds of groups: 2 x ~23 us against ~62 us one lane per
+      // row), the level's other instructions one lane each
+      for (u32 g = tid >> 4; g < p2_n; g += WIT_LANES / 16) exec_p2_coop(tape + sched[p2_lo + g] + 1, vals, wires, n, (int)(tid & 15));
       const u32 rest = (hi - lo) - p2_n;
       for (u32 i = tid; i < rest; i += WIT_LANES) {
         const u32 j = lo + i;
