@@ -4,19 +4,24 @@
     python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Default workload (`--workload table`, run_table below): BASELINE configs[3] sampled at `--rows` table rows per rank and step.
+Default workload (`--workload table`, run_table below): BASELINE configs[3] as ONE contiguous block of `--steps` x `--rows` table
+rows per rank (a step = `--rows` rows; the driver's `--steps 20` = a 20480-row block, row tree 15 levels deep, one work plan).
 Per row the reference proves 4 cells-tree nodes and 1 row-tree node, each a framework proof (witness generation, base prove(),
 wrap chain to 2^12 rows: recursion-framework/src/circuit_builder.rs:286-311, wrap_circuit.rs:122-148); here they are REAL
 circuits with the reference's tree logic (mapreduce-plonky2_amd/table.py), their witnesses replayed on the device
 (mp2g_witness_program_run_dev), the row tree scheduled by ryhope's batched work plan (mp2g_update_plan_*), the rows' multiset
-digests computed inside the timed region. value = framework proofs per second (5 per row); the line also extrapolates the
-2^20-row build and carries last round's headline (`--workload leaves`: prove() only, synthetic circuits, resident witnesses) as
-`leaves_prove_only`.
+digests computed inside the timed region. value = framework proofs per second (5 per row); the 2^20-row build is extrapolated
+from it (it does not fit one GPU in a bench run). At N = 1 the same JSON line carries BASELINE's other single-GPU configurations:
+`config2` = configs[2] at full size (1024 real leaf proofs aggregated 2-to-1: 2047 framework proofs), `by_base_degree` = the table
+rate with every base circuit padded to 2^k rows, k = 12..15, and carrying the reference's leaf gate set (the
+reference's real base degrees lie there), `leaves_prove_only` = round 2's headline (`--workload leaves`: prove() only, synthetic
+circuits, resident witnesses), `roofline` = configs[1].
 
-Self-check. After the timed loop: the block root's public inputs = the off-circuit tree hash / multiset digest / min / max; one
-framework proof of every circuit kind of the last step is re-proved from its captured witness by the CPU oracle -- caps, openings
-and FRI proof bit for bit, and accepted by its verifier (transcript, PLONK identity with the gate terms, FRI). "verified": k counts
-those prove() calls; any mismatch makes the run fail. The oracle proofs of that leg are the `cpu_baseline` sample at N=1.
+Self-check. After the timed region: the block root's public inputs = the off-circuit tree hash / multiset digest / min / max and the
+root passes the oracle's verifier; one framework proof of every circuit kind of the timed block is re-proved from its captured
+witness by the CPU oracle -- caps, openings and FRI proof bit for bit, and accepted by its verifier (transcript, PLONK identity with
+the gate terms, FRI). "verified": k counts those prove() calls; any mismatch makes the run fail. The oracle proofs of that leg are
+the `cpu_baseline` sample at N=1 (plus 1-thread / all-thread medians of 5 on one fixed prove() call, CPU model printed).
 
 Rows shard across ranks as blocks with no data-path collective ("scaling": "weak"); log2(N) join levels above the block roots
 move one final proof each, device to device over RCCL.
@@ -507,6 +512,33 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
                        "input": f"{n_hash} x {limbs} limbs of random field elements, hash_no_pad, resident"}}
 
 
+def visible_gpus():
+    """GPUs this process would see, counted WITHOUT the HIP / HSA runtime (the parent of the ranks must stay GPU-free: it starts
+    child processes): the KFD topology in sysfs -- nodes with SIMDs are GPUs -- narrowed by the *_VISIBLE_DEVICES lists. None when
+    sysfs does not tell (no amdgpu driver in this container): the ranks themselves then report a shortage."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = sorted(os.listdir(base), key=lambda x: int(x) if x.isdigit() else 1 << 30)
+    except OSError:
+        nodes = []
+    gpus = 0
+    for nd in nodes:
+        try:
+            with open(os.path.join(base, nd, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            gpus += 1
+    gpus = gpus or None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([x for x in v.split(",") if x.strip() != ""])
+            gpus = listed if gpus is None else min(gpus, listed)
+    return gpus
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher around it: start N ranks (one per GPU, `torch.distributed.run` on
     127.0.0.1) as a CHILD process, before this process has imported torch or made any GPU call (a process that has
@@ -514,9 +546,8 @@ def launch_ranks(n, argv):
     import socket
     import subprocess
     if os.environ.get("MP2G_BENCH_BACKEND", "nccl") == "nccl":
-        import torch  # device_count() reads the driver's device list without initialising a device
-        have = torch.cuda.device_count()
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             raise SystemExit(f"bench.py: --gpus {n} needs {n} visible GPUs for the RCCL backend, this node shows {have} "
                              "(MP2G_BENCH_BACKEND=gloo shares the devices among the ranks: a plumbing check, not a measurement)")
     with socket.socket() as s:
@@ -570,6 +601,13 @@ def main(argv=None):
     ap.add_argument("--lean", action="store_true", help="--workload table: keep only the frontier of the row tree in host memory (automatic above 16384 rows); the "
                     "self-check is then the root's public inputs and the oracle's verifier on the root, not the re-proving of sampled nodes")
     ap.add_argument("--no-leaves-leg", action="store_true", help="--workload table: skip the short prove()-only leg reported beside the headline")
+    ap.add_argument("--pad-base-bits", type=int, default=0, help="--workload table: pad every base circuit of both circuit sets to 2^k rows (no-op rows) and give it "
+                    "the reference's leaf gate set (SURVEY 8(d): base degrees k = 12..15); 0 = the circuits' natural degrees (the headline)")
+    ap.add_argument("--degree-sweep", default="12,13,14,15", help="--workload table at N = 1: after the headline, the table rate at these base degrees (one block of "
+                    "--sweep-rows rows each) in the same line as `by_base_degree`; '' = skip")
+    ap.add_argument("--sweep-rows", type=int, default=256, help="rows of the block timed at every base degree of --degree-sweep")
+    ap.add_argument("--config2-leaves", type=int, default=1024, help="--workload table at N = 1: leaves of the BASELINE configs[2] leg (2-to-1 aggregation of real leaf proofs, "
+                    "2 x leaves - 1 framework proofs) reported as `config2`; 0 = skip")
     ap.add_argument("--workload", choices=("table", "leaves", "tree", "recursion", "ntt"), default="table",
                     help="table (default, the headline): BASELINE configs[3] sampled -- per row 4 cells-tree + 1 row-tree REAL framework proofs, work-plan "
                          "scheduled, witness generation inside the timed region (run_table). leaves: prove() only on synthetic circuits with resident witnesses "
@@ -596,10 +634,14 @@ def main(argv=None):
         if backend != "nccl":
             local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
+        # a bounded wait on every collective and point-to-point transfer: a rank that died or never arrived makes its peers fail
+        # with the backend's error (non-zero exit) instead of waiting for ever. Longer than the longest stretch a rank proves alone.
+        import datetime
+        limit = datetime.timedelta(seconds=float(os.environ.get("MP2G_DIST_TIMEOUT_S", "1500")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
 
     VARIANT = 0 if args.hasher == "poseidon2" else 1
     if args.workload in ("tree", "recursion"):
@@ -614,24 +656,248 @@ def main(argv=None):
     return run_leaves(args, rank, local_rank, world, dist, torch, VARIANT, clocks)
 
 
+def cpu_model():
+    """the host CPU's model string (printed beside every CPU number)"""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_medians(unit, runs=5):
+    """medians of `runs` oracle runs of ONE fixed unit of work -- `unit` = a captured prove() call (label, circuit,
+    oracle params, circuit digest, wires, pi_hash, ...) -- with all hardware threads (one run after the other) and with one thread
+    (the `runs` single-thread runs side by side on otherwise idle cores, each timed by itself)."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import circuits as OC
+    label, ckt, ofp, cd, make_wires, ph = unit[:6]
+    wires = make_wires()
+    omp = ctypes.CDLL("libgomp.so.1")
+    cores = os.cpu_count() or 1
+
+    def one(threads, out, i):
+        omp.omp_set_num_threads(threads)
+        t0 = time.perf_counter()
+        OC.prove_witness(ckt, ofp, cd, wires, ph)
+        out[i] = time.perf_counter() - t0
+
+    warm = [0.0]
+    one(cores, warm, 0)
+    allt = [0.0] * runs
+    for i in range(runs):
+        one(cores, allt, i)
+    single = [0.0] * runs
+    ths = [threading.Thread(target=one, args=(1, single, i)) for i in range(runs)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    omp.omp_set_num_threads(cores)
+    return {"unit_of_work": f"one prove() of {label} (2^{ckt.log_n} rows) by oracle/ from the GPU run's captured witness", "runs": runs,
+            "all_threads": {"threads": cores, "median_s": float(np.median(allt)), "proofs_per_s": 1.0 / float(np.median(allt))},
+            "one_thread": {"threads": 1, "median_s": float(np.median(single)), "proofs_per_s": 1.0 / float(np.median(single)),
+                           "how": f"{runs} single-thread runs side by side on {cores} hardware threads, each timed by itself"}}
+
+
+class TableRig:
+    """what a table build runs on at one base degree: `workers` GPU contexts (= streams) with a prover set and a proof session each,
+    and the two circuit sets (table.TableParams) built for that degree. pad_bits = 0: the circuits at their natural degrees."""
+
+    def __init__(self, mods, local_rank, variant, workers, batch, subtree, host_witness, ranks_here, pad_bits=0):
+        mp2, R, FW, C, T, IX = mods
+        self.mods, self.variant, self.batch, self.subtree, self.pad_bits = mods, variant, batch, subtree, pad_bits
+        self.ctxs = [mp2.Context(local_rank) for _ in range(max(1, workers))]
+        self.ctx = self.ctxs[0]
+        self.provers = [FW.GpuProver(c, variant, witness_check=True, capacity=batch, device_witness=not host_witness) for c in self.ctxs]
+        self.sessions = [R.ProofSession(p) for p in self.provers]
+        t0 = time.perf_counter()
+        self.params = T.TableParams(self.provers[0], lambda ckt: FW.circuit_fri_params(ckt, variant), IX.empty_poseidon_hash(self.ctx, variant),
+                                    pad_base_bits=pad_bits, extra_gates=C.LEAF_KINDS if pad_bits else ())
+        self.setup_s = time.perf_counter() - t0
+        # host threads of one worker (host-witness replay only) and the device memory the provers will take, sized for every rank of
+        # the node being at work at once; a configuration that cannot fit one GPU is refused here, not by an allocation in mid-run
+        sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
+        free, total = self.ctx.mem_info()
+        self.plan = sharding.plan_rank_resources(self.params.shapes(), len(self.ctxs), batch, ranks_here, os.cpu_count() or 1, hbm_bytes=total)
+        if not self.plan["fits"] and not os.environ.get("MP2G_BENCH_BACKEND"):
+            raise SystemExit(f"bench.py: {len(self.ctxs)} workers x {batch} proofs in flight need ~{self.plan['device_bytes_per_rank'] / 1e9:.0f} GB of device memory at "
+                             f"these circuit shapes, the GPU has {total / 1e9:.0f} GB: lower --table-batch or --workers")
+        self.host_threads = self.plan["host_threads_per_worker"]
+        self.mem_total = total
+        self.n_proofs = 0
+
+    def build(self, n_rows, block, seed=0xC0FFEE04, n_cols=4, lean=False):
+        """one contiguous block of n_rows rows: off-circuit witness data, then every cells-tree and row-tree proof, work-plan scheduled"""
+        mp2, R, FW, C, T, IX = self.mods
+        table = T.SyntheticTable(n_rows, n_cols, seed=seed, block=block)
+        root, nodes, spans = T.balanced_bst(n_rows)
+        samples, keep = T.sample_nodes(nodes, spans)
+        tb = T.TableBuild(self.params, self.sessions, batch=self.batch, subtree_size=self.subtree, host_threads=self.host_threads,
+                          keep_proofs=not lean, keep_nodes=keep if lean else ())
+        wit = T.TableWitness(self.ctx, table, spans, self.variant)
+        proof, name = tb.run(table, wit, root, nodes)
+        self.n_proofs += tb.n_proofs
+        return {"table": table, "root": root, "nodes": nodes, "spans": spans, "samples": samples, "build": tb, "wit": wit, "proof": proof, "name": name,
+                "digest_w": wit.root_digest_w[root]}
+
+    def check_root(self, st, verify=True):
+        """the block root against the off-circuit side (tree hash, multiset digest = compute_table_row_digest of the block, min / max,
+        circuit-set digest) and, with `verify`, against the oracle's verifier (transcript, PLONK identity with the gate terms, FRI)"""
+        mp2, R, FW, C, T, IX = self.mods
+        table, pis = st["table"], st["proof"][3]
+        want = T.expected_root_public_inputs(self.ctx, table, st["wit"], st["root"], st["nodes"], st["spans"], self.variant)
+        assert np.array_equal(pis[:T.ROWS_IO], want), "the block root's public inputs differ from the off-circuit tree hash / digest / min / max"
+        assert np.array_equal(pis[T.ROWS_IO:], np.asarray(self.params.rows.set_digest, dtype=np.uint64)), "circuit-set digest"
+        w_all, wei_all = mp2.compute_table_row_digest(self.ctx, table.col_ids, table.values, table.values[:, 0:1])
+        assert np.array_equal(wei_all, pis[4:15]), "individual digest != compute_table_row_digest of the block"
+        if verify:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import circuits as OC
+            import oracle as O
+            wckt, _, wdig = self.params.rows.chains[st["name"]][-1]
+            rc = OC.verify(wckt, OC.oracle_params(wckt), np.asarray(wdig, dtype=np.uint64), O.hash_n_to_m_no_pad(pis, 4), *st["proof"][:3])
+            if rc:
+                raise SystemExit(f"bench.py self-check FAILED: the oracle's verifier rejects the block root (code {rc})")
+        return want, w_all
+
+    def capture_samples(self, st):
+        """one framework proof of every circuit kind of the block, re-proved WITH CAPTURE from the inputs the timed run used (row 0's
+        cells tree; row 0 and the widest node of every other kind of the row tree) and required to equal the timed run's proofs.
+        Returns the captured prove() calls grouped by framework proof: what the CPU oracle re-proves bit for bit."""
+        mp2, R, FW, C, T, IX = self.mods
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import circuits as OC
+        table, wit, nodes, build = st["table"], st["wit"], st["nodes"], st["build"]
+        cap, sess, row0, cells, Cn = [], self.sessions[0], 0, {}, table.n_cols
+        for k in sorted(range(1, Cn + 1), key=lambda k: ((k & -k).bit_length(), k)):
+            kids = [c for c in T.sbbst_children(Cn, k) if c is not None]
+            name = ("cells_leaf", "cells_partial", "cells_full")[len(kids)]
+            flat = T._u64cat([table.col_ids[k]], table.values[row0, k], [0], wit.cell_digest[row0, k - 1], T.NEUTRAL_FIELDS)
+            (pr,) = self.params.cells.generate_proofs_batch(name, [([cells[c][0] for c in kids], [cells[c][1] for c in kids], flat)], session=sess, capture=cap)
+            cells[k] = (pr, name)
+        root_cells = cells[T.sbbst_root(Cn)]
+        assert all(np.array_equal(a, b) for a, b in zip(root_cells[0], build.cells_roots[row0][0])), "re-proved cells root != the timed run's"
+        for k in st["samples"]:
+            name, job = build.row_job(table, wit, nodes, k, build.cells_roots[k], build.row_proofs)
+            (pr,) = self.params.rows.generate_proofs_batch(name, [job], session=sess, capture=cap)
+            assert all(np.array_equal(a, b) for a, b in zip(pr, build.row_proofs[k][0])), f"re-proved {name} != the timed run's"
+        samples, chain = [], []
+        for (name, stp, ckt, digest, wires, ph, caps, openings, proof) in cap:
+            if stp == 0 and chain:
+                samples.append(chain)
+                chain = []
+            chain.append((f"{name} step {stp}", ckt, OC.oracle_params(ckt), np.asarray(digest, dtype=np.uint64), (lambda w=wires: w), ph, caps, openings, proof, True))
+        samples.append(chain)
+        return samples
+
+    def close(self):
+        for p_ in self.provers:
+            p_.free()
+        for c in reversed(self.ctxs):
+            c.close()
+
+
+def config2_leg(rig, n_leaves, seed=0xC0FFEE03):
+    """BASELINE configs[2] at full size on this rig's workers: the 2-to-1 aggregation of `n_leaves` REAL leaf proofs of
+    recursion-framework/tests/integration.rs:138-261 -- n_leaves map proofs (base 2^6 + wrap 2^12 rows) and the n_leaves - 1 reduce
+    proofs above them (two universal verifiers: base 2^13 + wrap 2^12), ONE tree, level by level, the batches of a level dealt to the
+    workers. A 64-leaf tree first (untimed: creates the provers), then the timed tree. The root must expose (sum of the even elements,
+    hash tree of the chunks, circuit-set digest) and pass the oracle's verifier."""
+    from concurrent.futures import ThreadPoolExecutor
+    import queue
+    mp2, R, FW, C, T, IX = rig.mods
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import circuits as OC
+    import oracle as O
+    t0 = time.perf_counter()
+    fw = R.RecursiveCircuits([R.FrameworkCircuit("map", 0, R.map_logic, 5), R.FrameworkCircuit("reduce", 2, R.reduce_logic, 5)], rig.provers[0],
+                             lambda ckt: FW.circuit_fri_params(ckt, rig.variant))
+    for name in ("map", "reduce"):
+        fw.witness_programs(name)
+    setup_s = time.perf_counter() - t0
+    pool = queue.Queue()
+    for s_ in rig.sessions:
+        pool.put(s_)
+
+    def part(name, jobs):
+        sess = pool.get()
+        try:
+            sess.prover.ctx.make_current()
+            return fw.generate_proofs_batch(name, jobs, threads=rig.host_threads, session=sess)
+        finally:
+            pool.put(sess)
+
+    def level_of(ex, name, jobs):
+        # a level's jobs in batches of the provers' capacity, narrow levels in one batch per worker at most
+        per = max(1, min(rig.batch, -(-len(jobs) // len(rig.sessions))))
+        futs = [ex.submit(part, name, jobs[lo:lo + per]) for lo in range(0, len(jobs), per)]
+        return [pr for f in futs for pr in f.result()]
+
+    def tree(ex, n, data):
+        level, names, count = level_of(ex, "map", [([], [], data[4 * i:4 * i + 4]) for i in range(n)]), ["map"] * n, n
+        while len(level) > 1:
+            level = level_of(ex, "reduce", [([level[2 * i], level[2 * i + 1]], [names[2 * i], names[2 * i + 1]], None) for i in range(len(level) // 2)])
+            names = ["reduce"] * len(level)
+            count += len(level)
+        return level[0], names[0], count
+
+    data = C.rand_field(4 * n_leaves, seed)
+    with ThreadPoolExecutor(max_workers=len(rig.sessions)) as ex:
+        tree(ex, min(64, n_leaves), data)
+        for c in rig.ctxs:
+            c.sync()
+        t0 = time.perf_counter()
+        root, root_name, count = tree(ex, n_leaves, data)
+        for c in rig.ctxs:
+            c.sync()
+        dt = time.perf_counter() - t0
+    pis = root[3]
+    assert int(pis[0]) == sum(int(x) for x in data if int(x) % 2 == 0) % C.P, "configs[2] root: sum of the even elements"
+    hs = rig.ctx.hash_no_pad_batch(data.reshape(n_leaves, 4), 4, rig.variant)
+    while len(hs) > 1:
+        hs = rig.ctx.hash_no_pad_batch(hs.reshape(len(hs) // 2, 8), 4, rig.variant)
+    assert np.array_equal(pis[1:5], hs[0]) and np.array_equal(pis[5:], np.asarray(fw.set_digest, dtype=np.uint64)), "configs[2] root: hash tree / set digest"
+    wckt, _, wdig = fw.chains[root_name][-1]
+    rc = OC.verify(wckt, OC.oracle_params(wckt), np.asarray(wdig, dtype=np.uint64), O.hash_n_to_m_no_pad(pis, 4), *root[:3])
+    if rc:
+        raise SystemExit(f"bench.py self-check FAILED: the oracle's verifier rejects the configs[2] root (code {rc})")
+    return {"workload": f"configs[2] at full size: 2-to-1 aggregation of {n_leaves} real leaf proofs (integration.rs:138-261), one tree, {count} framework proofs "
+                        "(map: base 2^6 + wrap 2^12 rows; reduce: two universal verifiers, base 2^13 + wrap 2^12), witnesses on the device, witness check on",
+            "framework_proofs": count, "seconds": dt, "value": count / dt, "unit": "framework proofs/s", "leaf_proofs_per_s": n_leaves / dt,
+            "setup_s": round(setup_s, 1), "root_verified": True, "root_public_inputs": [int(x) for x in pis]}
+
+
 def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
-    """--workload table (the default, the headline): BASELINE configs[3] as a sample of `--rows` table rows per rank and step.
-    Per row the reference proves C = 4 cells-tree nodes (ryhope sbbst over the value columns: two leaves, a full node, a partial
+    """--workload table (the default, the headline): BASELINE configs[3] as ONE contiguous block of `--steps` x `--rows` table rows per
+    rank. Per row the reference proves C = 4 cells-tree nodes (ryhope sbbst over the value columns: two leaves, a full node, a partial
     node) and one row-tree node that verifies the cells root against the cells circuit set and its 0 / 1 / 2 row children
     (mapreduce-plonky2_amd/table.py; verifiable-db/src/cells_tree/api.rs, row_tree/api.rs; mp2-v1/tests/common/celltree.rs:54-189,
-    rowtree.rs:78-337). Every one of the 5 x rows framework proofs of a step is REAL: witness generation from its recorded witness
-    program (host threads), upload, base prove() with the device-side witness check, the wrap chain down to 2^12 rows (one wrap,
-    two for the three-verifier row full node: 2^14 -> 2^13 -> 2^12), download of what the parent verifies. The row tree of the rank's
-    block (a BST over the secondary index, every node a row) is scheduled by ryhope's batched work plan (mp2g_update_plan_*,
-    updatetree.rs:154-163,449-531): an item = a spun-off subtree = the unit one worker (GPU stream + provers + pinned wire
-    matrices) proves bottom-up, `--workers` of them concurrently. The off-circuit side of the same rows -- value digests, their
-    accumulation up both trees, row ids (mp2g_map_to_curve_batch, mp2g_row_digests, mp2g_curve_sum_ranges) -- is inside the timed
-    region too. With several ranks every rank builds its own block and log2(ranks) join levels follow: the owner of a parent
-    receives the other block's root proof (bincode bytes, point to point) and proves the separator row between the blocks.
-    value = framework proofs per second. After the timed region: the root's public inputs are compared with the off-circuit tree
-    hash / digest / min / max; sampled framework proofs of the last step (one of every circuit kind that occurred) are re-proved
-    from their captured witnesses by the CPU oracle -- bit-exact and verified; those oracle proofs are the cpu_baseline sample --
-    and the whole-table multiset digest of 2^20 rows is timed once for the extrapolation."""
+    rowtree.rs:78-337). Every one of the 5 x rows framework proofs is REAL: witness generation from its recorded witness program (on
+    the device), base prove() with the device-side witness check, the wrap chain down to 2^12 rows (one wrap, two for the
+    three-verifier row full node: 2^14 -> 2^13 -> 2^12). The row tree of the block (a BST over the secondary index, every node a row)
+    is scheduled by ryhope's batched work plan (mp2g_update_plan_*, updatetree.rs:154-163,449-531): an item = a spun-off subtree = the
+    unit one worker (GPU stream + provers) proves bottom-up, `--workers` of them concurrently. The off-circuit side of the same rows
+    -- value digests, their accumulation up both trees, row ids (mp2g_map_to_curve_batch, mp2g_row_digests, mp2g_curve_sum_ranges) --
+    is inside the timed region too.
+
+    A STEP is `--rows` rows (5 x rows framework proofs). The W warm-up steps are one contiguous block of W x rows rows (other rows than
+    the timed ones; it creates the provers), the K timed steps one contiguous block of K x rows rows -- one work plan, a row tree
+    log2(K x rows) deep -- not K rebuilds of the same rows. With several ranks every rank builds its own block and log2(ranks) join
+    levels follow inside the timed region: the owner of a parent receives the other block's root proof (device to device over RCCL)
+    and proves the separator row between the blocks. value = framework proofs per second.
+
+    After the timed region: the root's public inputs are compared with the off-circuit tree hash / digest / min / max and the root
+    passes the oracle's verifier; one framework proof of every circuit kind is re-proved from its captured witness by the CPU oracle
+    -- bit-exact and verified; those oracle proofs are the cpu_baseline sample. At N = 1 the same line then carries: BASELINE
+    configs[2] at full size (`config2`), the table rate at base degrees k = 12..15 (`by_base_degree`: every base circuit padded to
+    2^k rows with the reference's leaf gate set), the prove()-only loop of round 2 (`leaves_prove_only`), the kernel
+    legs (`roofline` = configs[1]'s 2^22-point NTT) and the whole-table multiset digest of 2^20 rows."""
     assert VARIANT == 0, "the recursive verifier circuit of recursion.py hashes with Poseidon2 gates (the reference's default config)"
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     R = importlib.import_module("mapreduce-plonky2_amd.recursion")
@@ -640,20 +906,13 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     T = importlib.import_module("mapreduce-plonky2_amd.table")
     IX = importlib.import_module("mapreduce-plonky2_amd.indexing")
     sharding = importlib.import_module("mapreduce-plonky2_amd.sharding")
-    n_workers, n_rows, n_cols = max(1, args.workers), args.rows, 4
-    ctxs = [mp2.Context(local_rank) for _ in range(n_workers)]
-    ctx = ctxs[0]
-    provers = [FW.GpuProver(c, VARIANT, witness_check=True, capacity=args.table_batch, device_witness=not args.host_witness) for c in ctxs]
-    sessions = [R.ProofSession(p) for p in provers]
-    t_setup = time.perf_counter()
-    params = T.TableParams(provers[0], lambda ckt: FW.circuit_fri_params(ckt, VARIANT), IX.empty_poseidon_hash(ctx, VARIANT))
-    t_setup = time.perf_counter() - t_setup
+    mods = (mp2, R, FW, C, T, IX)
+    n_cols, seed = 4, 0xC0FFEE04
     ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    host_threads = max(1, (os.cpu_count() or 1) // (n_workers * ranks_here))
-    lean = args.lean or n_rows > 16384  # a block this large keeps only the frontier of the tree in host memory (no per-node re-proving afterwards)
-    build = T.TableBuild(params, sessions, batch=args.table_batch, subtree_size=args.subtree, host_threads=host_threads, keep_proofs=not lean)
-    table = T.SyntheticTable(n_rows, n_cols, seed=0xC0FFEE04, block=2 * rank)
-    root, nodes, spans = T.balanced_bst(n_rows)
+    rig = TableRig(mods, local_rank, VARIANT, args.workers, args.table_batch, args.subtree, args.host_witness, ranks_here, pad_bits=args.pad_base_bits)
+    params, ctx = rig.params, rig.ctx
+    n_rows = max(1, args.steps) * args.rows           # the timed block of this rank
+    lean = args.lean or n_rows > 16384                # a block this large keeps the frontier of the tree + the sampled nodes only
     nccl = dist is not None and dist.get_backend() == "nccl"
     dev = torch.device("cuda", local_rank) if nccl else None
     final_ckt = params.rows.chains["row_leaf"][-1][0]  # every final proof of the row set has this shape (the shared common data)
@@ -661,14 +920,13 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     n_pis = T.ROWS_IO + 4
     proof_sizes = [n_pis, 3 * final_fp.cap_words, final_fp.n_openings * 2, final_fp.proof_words]
     names = list(params.rows.circuits)
-    last = {}
+    n_levels = world.bit_length() - 1
+    assert world & (world - 1) == 0, "ranks: a power of two (binary join levels)"
 
-    def step():
-        wit = T.TableWitness(ctx, table, spans, VARIANT)
-        proof, name = build.run(table, wit, root, nodes)
-        last["wit"], last["block_root"] = wit, (proof, name)
-        cur = (proof, name, wit.root_digest_w[root])
-        for lvl in range(world.bit_length() - 1):  # above the shard boundary: the separator rows between the ranks' blocks
+    def block(rows_, seed_, lean_):
+        st = rig.build(rows_, 2 * rank, seed_, n_cols, lean_)
+        cur = (st["proof"], st["name"], st["digest_w"])
+        for lvl in range(n_levels):  # above the shard boundary: the separator rows between the ranks' blocks
             bit = 1 << lvl
             if rank & (bit - 1):
                 break
@@ -676,33 +934,45 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                 # the root proof goes to the parent's rank from where the prover left it: device to device over RCCL
                 head = torch.from_numpy(np.concatenate([[names.index(cur[1])], np.asarray(cur[2], dtype=np.uint64).view(np.int64)]).astype(np.int64))
                 dist.send(head.to(dev) if nccl else head, rank - bit)
-                sess = build.last_session
-                sharding.send_device_proof(dist, sess.prover.ctx, sess.prover.last_device_proof(0), rank - bit, dev)
+                pv = st["build"].last_session.prover
+                ch = getattr(pv, "last_chain", None)
+                if ch is not None and not args.host_witness:
+                    assert ch.last_batch == 1, "the chain's last run was the root alone: its proof 0 is the root"
+                    out = pv.last_device_proof(0)
+                else:
+                    out = cur[0]  # the host-witness back end leaves no chain outputs on the device: the host proof goes (uploaded for RCCL)
+                sharding.send_device_proof(dist, pv.ctx, out, rank - bit, dev)
                 break
             head = torch.zeros(6, dtype=torch.int64, device=dev)
             dist.recv(head, rank + bit)
             head = head.cpu().numpy()
             other = sharding.recv_device_proof(dist, proof_sizes, rank + bit, dev)
-            cur = T.join_blocks(build, ctx, cur, (other, names[int(head[0])], head[1:6].view(np.uint64)), 2 * (rank + bit) - 1, n_cols, 0xC0FFEE04, VARIANT)
-        return cur
+            cur = T.join_blocks(st["build"], ctx, cur, (other, names[int(head[0])], head[1:6].view(np.uint64)), 2 * (rank + bit) - 1, n_cols, seed_, VARIANT)
+            rig.n_proofs += 5
+        return st, cur
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-        for c in ctxs:
+        for c in rig.ctxs:
             c.sync()
 
-    for _ in range(args.warmup):  # the first pass creates the provers of every circuit (with --warmup 0 that falls into the timed region)
-        cur = step()
+    rccl_ranks = None
+    if dist is not None:  # every rank is there and the backend's collective works before anything is timed
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
+        assert rccl_ranks == world, f"{rccl_ranks} of {world} ranks answered"
+    if args.warmup > 0:  # the warm-up block creates the provers of every circuit (with --warmup 0 that falls into the timed region)
+        block(args.warmup * args.rows, seed ^ 0x5A5A5A, args.lean or args.warmup * args.rows > 16384)
     barrier()
-    n0 = build.n_proofs
+    n0 = rig.n_proofs
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cur = step()
+    st, cur = block(n_rows, seed, lean)
     barrier()
     dt = time.perf_counter() - t0
-    n_local = build.n_proofs - n0
+    n_local = rig.n_proofs - n0
     if dist is not None:
         t = torch.tensor([dt, float(n_local)], device="cuda" if nccl else "cpu", dtype=torch.float64)
         dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
@@ -712,78 +982,35 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         n_total = n_local
 
     # ---- checks (outside the timed region) ---------------------------------------------------------------------------------
-    # every rank: its block's root exposes the off-circuit tree hash, multiset digest, min / max of the block
-    wit = last["wit"]
-    block_pis = last["block_root"][0][3]
-    want = T.expected_root_public_inputs(ctx, table, wit, root, nodes, spans, VARIANT)
-    assert np.array_equal(block_pis[:T.ROWS_IO], want), "the block root's public inputs differ from the off-circuit tree hash / digest / min / max"
-    assert np.array_equal(block_pis[T.ROWS_IO:], np.asarray(params.rows.set_digest, dtype=np.uint64)), "circuit-set digest"
-    w_all, wei_all = mp2.compute_table_row_digest(ctx, table.col_ids, table.values, table.values[:, 0:1])
-    assert np.array_equal(wei_all, block_pis[4:15]), "individual digest != compute_table_row_digest of the block"
-    verified, cpu_base, sample_desc = 0, None, ""
-    if rank == 0:
+    # every rank: its block's root exposes the off-circuit tree hash, multiset digest, min / max of the block; the oracle verifies it
+    want, w_all = rig.check_root(st, verify=not args.no_verify)
+    verified, cpu_base, medians = (0 if args.no_verify else 1), None, None
+    if rank == 0 and world > 1:  # the joined tree: digest = the whole table's (blocks and separators), min of block 0
         root_pis = cur[0][3]
-        if world > 1:  # the joined tree: digest = the whole table's (blocks and separators), min of block 0, max of the last block
-            ws = [w_all]
-            for r in range(1, world):
-                tb = T.SyntheticTable(n_rows, n_cols, 0xC0FFEE04, 2 * r)
-                ws.append(mp2.compute_table_row_digest(ctx, tb.col_ids, tb.values, tb.values[:, 0:1])[0])
-            for s_ in range(world - 1):
-                tb = T.SyntheticTable(1, n_cols, 0xC0FFEE04, 2 * s_ + 1)
-                ws.append(mp2.compute_table_row_digest(ctx, tb.col_ids, tb.values, tb.values[:, 0:1])[0])
-            assert np.array_equal(mp2.curve_sum(ctx, np.stack(ws), weierstrass=True)[1], root_pis[4:15]), "root digest != digest of the whole table"
-            assert np.array_equal(root_pis[26:34], want[26:34]), "root min != min of block 0"
-    if lean and not args.no_verify:  # the oracle's verifier on the block root (transcript, PLONK identity with the gate terms, FRI)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import circuits as OC
-        import oracle as O
-        wckt, _, wdig = params.rows.chains[last["block_root"][1]][-1]
-        rc = OC.verify(wckt, OC.oracle_params(wckt), np.asarray(wdig, dtype=np.uint64), O.hash_n_to_m_no_pad(block_pis, 4), *last["block_root"][0][:3])
-        if rc:
-            raise SystemExit(f"bench.py self-check FAILED: the oracle's verifier rejects the block root (code {rc})")
-        verified = 1
-    elif not args.no_verify:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import circuits as OC
-        # one framework proof of every circuit kind of the last step, re-proved with capture from the inputs the timed run used
-        cap = []
-        sess = sessions[0]
-        row0 = 0
-        cells = {}
-        Cn = table.n_cols
-        for k in sorted(range(1, Cn + 1), key=lambda k: ((k & -k).bit_length(), k)):
-            kids = [c for c in T.sbbst_children(Cn, k) if c is not None]
-            name = ("cells_leaf", "cells_partial", "cells_full")[len(kids)]
-            flat = T._u64cat([table.col_ids[k]], table.values[row0, k], [0], wit.cell_digest[row0, k - 1], T.NEUTRAL_FIELDS)
-            (pr,) = params.cells.generate_proofs_batch(name, [([cells[c][0] for c in kids], [cells[c][1] for c in kids], flat)], session=sess, capture=cap)
-            cells[k] = (pr, name)
-        root_cells = cells[T.sbbst_root(Cn)]
-        assert all(np.array_equal(a, b) for a, b in zip(root_cells[0], build.cells_roots[row0][0])), "re-proved cells root != the timed run's"
-        seen = set()
-        for k in [row0] + sorted(nodes, key=lambda k: -(spans[k][1] - spans[k][0])):
-            kind = sum(c is not None for c in nodes[k])
-            if kind in seen:
-                continue
-            seen.add(kind)
-            name, job = build.row_job(table, wit, nodes, k, build.cells_roots[k], build.row_proofs)
-            (pr,) = params.rows.generate_proofs_batch(name, [job], session=sess, capture=cap)
-            assert all(np.array_equal(a, b) for a, b in zip(pr, build.row_proofs[k][0])), f"re-proved {name} != the timed run's"
-        # group the captured prove() calls by framework proof (a chain of steps), all mandatory
-        samples, chain = [], []
-        for (name, stp, ckt, digest, wires, ph, caps, openings, proof) in cap:
-            if stp == 0 and chain:
-                samples.append(chain)
-                chain = []
-            chain.append((f"{name} step {stp}", ckt, OC.oracle_params(ckt), np.asarray(digest, dtype=np.uint64), (lambda w=wires: w), ph, caps, openings, proof, True))
-        samples.append(chain)
+        ws = [w_all]
+        for r in range(1, world):
+            tb = T.SyntheticTable(n_rows, n_cols, seed, 2 * r)
+            ws.append(mp2.compute_table_row_digest(ctx, tb.col_ids, tb.values, tb.values[:, 0:1])[0])
+        for s_ in range(world - 1):
+            tb = T.SyntheticTable(1, n_cols, seed, 2 * s_ + 1)
+            ws.append(mp2.compute_table_row_digest(ctx, tb.col_ids, tb.values, tb.values[:, 0:1])[0])
+        assert np.array_equal(mp2.curve_sum(ctx, np.stack(ws), weierstrass=True)[1], root_pis[4:15]), "root digest != digest of the whole table"
+        assert np.array_equal(root_pis[26:34], want[26:34]), "root min != min of block 0"
+    if not args.no_verify:
+        samples = rig.capture_samples(st)
         timed = world == 1 and not args.no_cpu_baseline
-        verified, cpu_base = check_against_oracle(samples, args.cpu_budget, timed, ranks_here)
+        v, cpu_base = check_against_oracle(samples, args.cpu_budget, timed, ranks_here)
+        verified += v
         if cpu_base is not None:
             kinds = [c[0][0].rsplit(" step", 1)[0] for c in samples]
             cpu_base["unit"] = "proofs/s"
             cpu_base["sample_wall_s"] = cpu_base.pop("single_leaf_latency_s")
-            cpu_base["sample"] = (f"{len(samples)} framework proofs of the last step ({', '.join(kinds)}: {sum(len(c) for c in samples)} prove() calls of 2^6..2^14 rows) re-proved "
-                                  "from their captured witnesses by oracle/ (our C restatement, not the Rust prover); every one compared bit for bit with the GPU's and verified")
+            cpu_base["cpu_model"] = cpu_model()
+            cpu_base["sample"] = (f"{len(samples)} framework proofs of the timed block ({', '.join(kinds)}: {sum(len(c) for c in samples)} prove() calls of 2^6..2^14 rows) re-proved "
+                                  "from their captured witnesses by oracle/ (our C restatement, not the Rust prover), all hardware threads; every one compared bit for bit with "
+                                  "the GPU's and verified. `medians`: the same oracle on one fixed prove() call, 5 runs with all threads and 5 with one thread")
+            # the fixed unit of the medians: the final wrap step of the first sampled proof (2^12 rows: the shape every framework proof ends with)
+            cpu_base["medians"] = cpu_medians(samples[0][-1])
     if dist is not None:
         v = torch.tensor([verified], device="cuda" if nccl else "cpu", dtype=torch.int64)
         dist.all_reduce(v)
@@ -793,8 +1020,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     digest_ms = None
     if rank == 0:
         big = 1 << 20
-        rng = np.random.default_rng(0xC0FFEE04)
-        d_ids = ctx.to_device(table.col_ids)
+        rng = np.random.default_rng(seed)
+        d_ids = ctx.to_device(st["table"].col_ids)
         d_values = ctx.to_device(rng.integers(0, 1 << 32, size=(big, n_cols + 1, 8), dtype=np.uint32))
         d_unique = ctx.to_device(rng.integers(0, 1 << 32, size=(big, 1, 8), dtype=np.uint32))
         mp2.compute_table_row_digest_dev(ctx, d_ids, n_cols + 1, d_values, d_unique, 1, 1 << 12)
@@ -804,48 +1031,84 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         for b_ in (d_ids, d_values, d_unique):
             b_.free()
 
+    side = world == 1  # the side legs run at N = 1 only (like cpu_baseline): the scaling runs time the table build and nothing else
+    config2 = config2_leg(rig, args.config2_leaves) if side and args.config2_leaves > 0 else None
     legs = kernel_legs(ctx, mp2, C, VARIANT, args.hasher, rank) if rank == 0 else None
     shapes = params.shapes()
-    for p_ in provers:
-        p_.free()
-    for c in reversed(ctxs):
-        c.close()
-    # the prove()-only loop on synthetic circuits (last round's headline) beside it, briefly
+    mem_free, mem_total = ctx.mem_info()  # with every prover of the run still alive: what the planner's estimate is calibrated on
+    setup_s, workers, host_threads, plan = rig.setup_s, len(rig.ctxs), rig.host_threads, rig.plan
+    root_pis_out = [int(x) for x in cur[0][3]]
+    del st
+    rig.close()
+
+    # the table rate bracketed by base degree: every base circuit padded to 2^k rows + the reference's leaf gate set
+    by_degree = None
+    if side and args.degree_sweep:
+        by_degree = {}
+        for k in [int(x) for x in args.degree_sweep.split(",") if x]:
+            bk = max(4, args.table_batch >> max(0, k - 12))  # proofs in flight per worker shrink with the degree: the same device memory at every k
+            rk = TableRig(mods, local_rank, VARIANT, args.workers, bk, args.subtree, args.host_witness, ranks_here, pad_bits=k)
+            rk.build(min(64, args.sweep_rows), 0, seed ^ 0x5A5A5A, n_cols, False)
+            for c in rk.ctxs:
+                c.sync()
+            n0k = rk.n_proofs
+            t1 = time.perf_counter()
+            stk = rk.build(args.sweep_rows, 0, seed, n_cols, False)
+            for c in rk.ctxs:
+                c.sync()
+            dtk = time.perf_counter() - t1
+            rk.check_root(stk, verify=not args.no_verify)
+            by_degree[str(k)] = {"value": (rk.n_proofs - n0k) / dtk, "unit": "proofs/s", "rows": args.sweep_rows, "seconds": dtk, "batch": bk,
+                                 "shapes": rk.params.shapes(), "setup_s": round(rk.setup_s, 1), "root_verified": not args.no_verify}
+            del stk
+            rk.close()
+
+    # the prove()-only loop on synthetic circuits (round 2's headline) beside it, briefly
     leaves = None
-    if not args.no_leaves_leg:
+    if side and not args.no_leaves_leg:
         import copy
         a2 = copy.copy(args)
         a2.steps, a2.warmup, a2.batch = 3, 1, 128
         leaves = run_leaves(a2, rank, local_rank, world, dist, torch, VARIANT, clocks, brief=True)
     out = None
     if rank == 0:
-        rows_per_s = world * n_rows * args.steps / dt
+        rows_per_s = world * n_rows / dt
+        depth = max(1, (n_rows - 1).bit_length())
         out = {"metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build, 1/2/4/8 GPU",
                "value": n_total / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": dt / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u64 (Goldilocks field)", "data": "synthetic", "verified": verified,
                "rows_per_s": rows_per_s,
                "table_2p20_rows_extrapolated_s": (1 << 20) / rows_per_s + (digest_ms or 0) / 1e3,
                "table_digest_2p20_rows_ms": digest_ms,
-               "config": {"workload": f"table: configs[3] sampled at {n_rows} rows per rank and step -- per row {n_cols} cells-tree proofs (2 leaves, 1 full, 1 partial) + 1 "
-                                      "row-tree proof (leaf / partial / full + the cells root through the cells-set verifier gadget), all REAL framework proofs = witness "
-                                      "program + base prove() + wrap chain to 2^12 rows, witness check on; row tree scheduled by the batched UpdateTree work plan; the rows' "
-                                      "multiset digests (map-to-curve, row ids, accumulation up both trees) inside the timed region; value = framework proofs/s "
-                                      "(5 per row); roofline leg = configs[1] 2^22-point NTT",
-                          "rows_per_rank_and_step": n_rows, "value_columns": n_cols, "workers": n_workers, "batch": args.table_batch, "subtree_size": args.subtree,
+               "config": {"workload": f"table: configs[3], ONE contiguous block of {n_rows} rows per rank (= {args.steps} steps x {args.rows} rows; row tree {depth} levels deep, one work plan) "
+                                      f"-- per row {n_cols} cells-tree proofs (2 leaves, 1 full, 1 partial) + 1 row-tree proof (leaf / partial / full + the cells root through the "
+                                      "cells-set verifier gadget), all REAL framework proofs = witness program + base prove() + wrap chain to 2^12 rows, witness check on; row tree "
+                                      "scheduled by the batched UpdateTree work plan; the rows' multiset digests (map-to-curve, row ids, accumulation up both trees) inside the timed "
+                                      "region; value = framework proofs/s (5 per row). The full 2^20-row build does not fit one GPU in a bench run (extrapolated below); configs[2] at "
+                                      "full size = `config2`; base degrees 12..15 = `by_base_degree`; roofline leg = configs[1] 2^22-point NTT",
+                          "rows_per_rank": n_rows, "rows_per_step": args.rows, "row_tree_depth": depth, "warmup_rows_per_rank": args.warmup * args.rows,
+                          "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "pad_base_bits": args.pad_base_bits,
+                          "lean": bool(lean),
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
-                          "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "shapes": shapes,
-                          "setup_s": round(t_setup, 1), "hasher": "Poseidon2",
-                          "sharding": f"{world} rank(s): one block of rows each, no collective below the block roots; {world.bit_length() - 1} join level(s) move a root proof point to point "
+                          "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "ranks_on_host": ranks_here, "shapes": shapes,
+                          "device_memory_used_bytes": mem_total - mem_free, "device_memory_planned_bytes": plan["device_bytes_per_rank"],
+                          "setup_s": round(setup_s, 1), "hasher": "Poseidon2", "backend": (dist.get_backend() if dist is not None else None), "rccl_ranks": rccl_ranks,
+                          "join_levels": n_levels,
+                          "sharding": f"{world} rank(s): one block of rows each, no collective below the block roots; {n_levels} join level(s) move a root proof point to point "
                                       f"({sum(proof_sizes) * 8} B" + (")" if world == 1 else ", device to device over RCCL into the parent's device-side witness inputs)" if nccl else ", host tensors over gloo)"),
-                          "root_public_inputs": [int(x) for x in cur[0][3]],
-                          "verified": f"{verified} prove() calls of sampled framework proofs (one of every circuit kind of the last step, on every rank) equal the CPU "
-                                      "oracle's proofs of the same witnesses bit for bit and pass its verifier; the block roots expose the off-circuit tree hash, "
-                                      "digest (= compute_table_row_digest of the block), min, max and the circuit-set digest"},
+                          "root_public_inputs": root_pis_out,
+                          "verified": f"{verified} prove() calls: on every rank the block root passes the oracle's verifier and one framework proof of every circuit kind of the timed "
+                                      "block equals the CPU oracle's proofs of the same witnesses bit for bit and passes its verifier; the block roots expose the off-circuit "
+                                      "tree hash, digest (= compute_table_row_digest of the block), min, max and the circuit-set digest"},
                "clocks": clocks.read(local_rank)}
+        if config2 is not None:
+            out["config2"] = config2
+        if by_degree is not None:
+            out["by_base_degree"] = by_degree
         if leaves is not None:
             out["leaves_prove_only"] = {"value": leaves["value"], "unit": "leaf proofs/s (base 2^13 + wrap 2^12 prove() on synthetic circuits, resident witnesses: "
-                                        "`--workload leaves`, last round's headline)", "ms_per_step": leaves["ms_per_step"], "batch": 128}
+                                        "`--workload leaves`, round 2's headline)", "ms_per_step": leaves["ms_per_step"], "batch": 128}
         out.update(legs)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base

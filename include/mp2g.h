@@ -43,6 +43,8 @@ int mp2g_ctx_sync(mp2g_ctx* ctx);
  * that drives a context of another device (one process per GPU with several proving threads, rank > 0 of a node) calls this once before
  * its first call: allocations and launches follow the thread's current device. */
 int mp2g_ctx_make_current(mp2g_ctx* ctx);
+/* free / total bytes of the context's device (hipMemGetInfo): what a host sizes its provers' capacities against */
+int mp2g_ctx_mem_info(mp2g_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 void* mp2g_ctx_stream(mp2g_ctx* ctx);                 /* hipStream_t the context launches on */
 int mp2g_ctx_set_stream(mp2g_ctx* ctx, void* stream); /* adopt a caller-owned hipStream_t     */
 int mp2g_dev_alloc(mp2g_ctx* ctx, size_t bytes, void** d_ptr);

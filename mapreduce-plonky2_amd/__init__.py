@@ -126,6 +126,12 @@ class Context:
         """select this context's device for the calling thread (HIP's current device is per thread; call at the start of a worker thread)"""
         _ck(load().mp2g_ctx_make_current(self.h))
 
+    def mem_info(self):
+        """(free, total) bytes of the context's device"""
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        _ck(load().mp2g_ctx_mem_info(self.h, ctypes.byref(free), ctypes.byref(total)))
+        return int(free.value), int(total.value)
+
     def sync(self):
         _ck(load().mp2g_ctx_sync(self.h))
 
@@ -702,13 +708,15 @@ def curve_sum_ranges(ctx, pts_w, ranges):
     return w, wei
 
 
-def scalar_mul_batch(ctx, pts_w, scalars):
-    """scalars: python ints < 2^128 (hash_to_int_value range)."""
+def scalar_mul_batch(ctx, pts_w, scalars, weierstrass=False):
+    """scalars: python ints < 2^128 (hash_to_int_value range). Returns the encodings [count][5] (and the 11-limb Weierstrass
+    forms = Point::to_fields when asked)."""
     a = _arr(pts_w).reshape(-1, 5)
-    k = _arr([[(int(s) >> (32 * i)) & 0xFFFFFFFF for i in range(4)] for s in scalars], np.uint32)
+    k = _arr([[(int(s) >> (32 * i)) & 0xFFFFFFFF for i in range(4)] for s in scalars], np.uint32).reshape(-1, 4)
     out = np.empty((a.shape[0], 5), dtype=np.uint64)
-    _ck(load().mp2g_scalar_mul_batch(ctx.h, _p(a), _p(k), a.shape[0], _p(out), None))
-    return out
+    wei = np.empty((a.shape[0], 11), dtype=np.uint64) if weierstrass else None
+    _ck(load().mp2g_scalar_mul_batch(ctx.h, _p(a), _p(k), a.shape[0], _p(out), _p(wei) if weierstrass else None))
+    return (out, wei) if weierstrass else out
 
 
 def field_hashed_scalar_mul(ctx, inputs, base_w, variant=POSEIDON2):

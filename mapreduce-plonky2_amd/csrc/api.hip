@@ -96,6 +96,12 @@ int mp2g_ctx_make_current(mp2g_ctx* c) {
   CK(hipSetDevice(c->device));
   return 0;
 }
+int mp2g_ctx_mem_info(mp2g_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+  NEED(c && free_bytes && total_bytes, "ctx / outputs");
+  CK(hipSetDevice(c->device));
+  CK(hipMemGetInfo(free_bytes, total_bytes));
+  return 0;
+}
 int mp2g_h2d(mp2g_ctx* c, void* d_dst, const void* src, size_t bytes) {
   NEED(c, "ctx");
   CK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));

@@ -18,8 +18,11 @@ struct DevBuf {
   ~DevBuf() { if (p) (void)hipFree(p); }
   hipError_t alloc(size_t b) {
     if (p) { (void)hipFree(p); p = nullptr; }
+    bytes = 0;
+    hipError_t e = hipMalloc((void**)&p, b ? b : 8);
+    if (e != hipSuccess) { p = nullptr; return e; }  // bytes stays 0: the next caller that needs the buffer retries the allocation
     bytes = b;
-    return hipMalloc((void**)&p, b ? b : 8);
+    return hipSuccess;
   }
 };
 }  // namespace mp2g

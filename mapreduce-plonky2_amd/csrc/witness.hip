@@ -400,7 +400,7 @@ static int witness_program_create(const uint64_t* tape, size_t tape_len, uint32_
     struct Ins { u32 off, lvl, op; };
     std::vector<Ins> ins;
     std::vector<u32> lvl(n_slots, 0);
-    std::vector<uint8_t> written(n_slots, 0);
+    std::vector<uint8_t> written(n_slots, 0), was_read(n_slots, 0);
     for (uint32_t i = 0; i < n_inputs; i++) written[input_sids[i]] = 1;
     for (uint32_t i = 0; i < n_consts; i++) written[const_slots[2 * i]] = 1;
     const u64* base = P->tape.data();
@@ -427,11 +427,13 @@ static int witness_program_create(const uint64_t* tape, size_t tape_len, uint32_
         default: break;
       }
       u32 l = 0;
-      for (u32 i = 0; i < nr; i++) { const u32 sl = (u32)a[r0 + i]; if (lvl[sl] > l) l = lvl[sl]; }
+      for (u32 i = 0; i < nr; i++) { const u32 sl = (u32)a[r0 + i]; if (lvl[sl] > l) l = lvl[sl]; was_read[sl] = 1; }
       l += 1;
       for (u32 i = 0; i < nw; i++) {
         const u32 sl = (u32)a[w0 + i];
-        if (written[sl]) P->ssa = false;  // a slot written twice: the level schedule would reorder the writes
+        // a slot written twice, or written after an earlier instruction read it (the host replay saw 0 there): the level
+        // schedule would reorder the accesses, so the device replay refuses the program
+        if (written[sl] || was_read[sl]) P->ssa = false;
         written[sl] = 1;
         lvl[sl] = l;
       }
@@ -515,7 +517,7 @@ int mp2g_witness_program_run_dev(mp2g_witness_program* P, mp2g_ctx* c, const uin
                                  uint64_t* d_probe_out) {
   NEED(P && c && d_inputs && d_wires && batch >= 1, "program / ctx / inputs / wires");
   NEED(P->probe.empty() || d_probe_out, "probe output");
-  if (!P->ssa) return fail("the witness program writes a slot twice: it cannot be level-scheduled for the device");
+  if (!P->ssa) return fail("the witness program writes a slot twice, or writes a slot an earlier instruction read: it cannot be level-scheduled for the device");
   WitnessDev* d = nullptr;
   int rc = witness_dev_data(P, c, &d);
   if (rc) return rc;

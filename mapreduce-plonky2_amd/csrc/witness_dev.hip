@@ -273,6 +273,9 @@ GLD void exec_one(const u64* t, u64* vals, u64* wires, u64 n, const u64* domtab)
 #define WIT_BOUNDS WIT_LANES_N
 #endif
 constexpr int WIT_LANES = WIT_LANES_N;
+#ifdef WIT_PROF
+__device__ u64 g_wit_prof[8];
+#endif
 __global__ void __launch_bounds__(WIT_BOUNDS) witness_exec_kernel(const u64* __restrict__ tape, const u32* __restrict__ sched,
                                                                 const u32* __restrict__ level_off, const u32* __restrict__ level_p2, u32 n_levels, u32 n_slots, u32 log_n,
                                                                 const u32* __restrict__ input_sids, u32 n_inputs, const u64* __restrict__ consts,
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(WIT_BOUNDS) witness_exec_kernel(const u64* __r
   __syncthreads();
 #ifdef WIT_PROF
   // tools/dbg/witness_prof.sh: shader cycles of block 0 per class of level (0 narrow Poseidon2, 1 wide Poseidon2, 2 reducing / interpolation /
-  // inverse, 3 the rest), accumulated in the last 8 words of proof 0's probe row... of a side buffer: probe_out[n_probe * gridDim.x ..]
+  // inverse, 3 the rest), left in the side buffer g_wit_prof (read back with mp2g_dbg_witness_prof; nothing of the caller's is touched)
   u64 prof[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};
 #endif
   for (u32 l = 0; l < n_levels; l++) {
@@ -320,7 +323,7 @@ __global__ void __launch_bounds__(WIT_BOUNDS) witness_exec_kernel(const u64* __r
   for (u32 i = tid; i < n_probe; i += WIT_LANES) probe_out[(u64)b * n_probe + i] = vals[probe[i]];
 #ifdef WIT_PROF
   if (b == 0 && tid == 0)
-    for (int k = 0; k < 4; k++) { probe_out[(u64)gridDim.x * n_probe + 2 * k] = prof[k]; probe_out[(u64)gridDim.x * n_probe + 2 * k + 1] = cnt[k]; }
+    for (int k = 0; k < 4; k++) { g_wit_prof[2 * k] = prof[k]; g_wit_prof[2 * k + 1] = cnt[k]; }
 #endif
 }
 }  // namespace
@@ -333,3 +336,9 @@ hipError_t witness_exec_launch(hipStream_t s, const WitnessDev& d, u32 n_levels,
   return hipGetLastError();
 }
 }  // namespace mp2g
+#ifdef WIT_PROF
+// debug builds only (tools/dbg/witness_prof.sh): (cycles, levels) per class of level of block 0 of the last witness launch
+extern "C" int mp2g_dbg_witness_prof(uint64_t* out8) {
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(mp2g::g_wit_prof), 8 * sizeof(uint64_t)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -6,6 +6,9 @@
 // as single-node subtrees of size 1 only if their parent link still exists (it never does after
 // `done`), and subtree_size 0 degenerates to single-node subtrees.
 #include <algorithm>
+#include <exception>
+#include <memory>
+#include <new>
 #include <set>
 #include <unordered_map>
 #include <utility>
@@ -13,6 +16,21 @@
 #include "ctx.h"
 
 using namespace mp2g;
+
+// No exception crosses the C ABI: every entry point that allocates (plain `new`, std::set / unordered_map / vector growth) runs
+// inside guarded(), which turns bad_alloc and anything else into the library's error code + mp2g_last_error().
+template <class F> static int guarded(int on_error, F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    fail("out of memory");
+  } catch (const std::exception& e) {
+    fail("internal error: %s", e.what());
+  } catch (...) {
+    fail("internal error");
+  }
+  return on_error;
+}
 
 struct UtNode {
   int32_t parent;            // -1: none
@@ -64,8 +82,8 @@ struct mp2g_update_tree {
     }
     return descend(0, path + 1, len - 1);
   }
-  mp2g_update_tree* spin_off(uint32_t new_root) const {  // :184-228
-    auto* t = new mp2g_update_tree;
+  std::unique_ptr<mp2g_update_tree> spin_off(uint32_t new_root) const {  // :184-228
+    std::unique_ptr<mp2g_update_tree> t(new mp2g_update_tree);
     t->epoch = epoch;
     std::vector<uint32_t> d;
     descendants(new_root, d);
@@ -91,49 +109,52 @@ extern "C" {
 int mp2g_update_tree_from_paths(const uint64_t* keys, const uint32_t* path_lens, uint32_t n_paths, int64_t epoch,
                                 mp2g_update_tree** out) {
   if (!out || (n_paths && (!keys || !path_lens))) return fail("invalid argument: null pointer");
-  auto* t = new (std::nothrow) mp2g_update_tree;
-  if (!t) return fail("out of memory");
-  t->epoch = epoch;
-  const uint64_t* p = keys;
-  for (uint32_t i = 0; i < n_paths; i++) {
-    if (i == 0 && path_lens[0] == 0) { delete t; return fail("empty path"); }
-    if (t->extend(p, path_lens[i])) { delete t; return 1; }
-    p += path_lens[i];
-  }
-  *out = t;
-  return 0;
+  return guarded(1, [&]() -> int {
+    std::unique_ptr<mp2g_update_tree> t(new mp2g_update_tree);
+    t->epoch = epoch;
+    const uint64_t* p = keys;
+    for (uint32_t i = 0; i < n_paths; i++) {
+      if (i == 0 && path_lens[0] == 0) return fail("empty path");
+      if (t->extend(p, path_lens[i])) return 1;
+      p += path_lens[i];
+    }
+    *out = t.release();
+    return 0;
+  });
 }
 // UpdateTree::from_map (:296-331): pre-order walk from `root` over a map key -> (left, right); a child key that
 // is not in the map is skipped; is_path_end = the node's context has no children at all (NodeContext::is_leaf)
 int mp2g_update_tree_from_map(const uint64_t* keys, const uint64_t* left, const uint64_t* right, const uint8_t* has_left,
                               const uint8_t* has_right, uint32_t n, uint64_t root, int64_t epoch, mp2g_update_tree** out) {
   if (!out || (n && (!keys || !left || !right || !has_left || !has_right))) return fail("invalid argument: null pointer");
-  std::unordered_map<uint64_t, uint32_t> ctx;
-  for (uint32_t i = 0; i < n; i++) ctx.emplace(keys[i], i);
-  auto* t = new (std::nothrow) mp2g_update_tree;
-  if (!t) return fail("out of memory");
-  t->epoch = epoch;
-  // explicit stack: (key, parent arena index); children pushed right first so that left is visited first
-  std::vector<std::pair<uint64_t, int32_t>> stack{{root, -1}};
-  while (!stack.empty()) {
-    auto [k, parent] = stack.back();
-    stack.pop_back();
-    auto it = ctx.find(k);
-    if (it == ctx.end()) continue;
-    const uint32_t c = it->second, cur = (uint32_t)t->nodes.size();
-    if (!t->idx.emplace(k, cur).second) { delete t; return fail("duplicated key found"); }
-    t->nodes.push_back(UtNode{parent, {}, k, !has_left[c] && !has_right[c]});
-    if (parent >= 0) t->nodes[parent].children.insert(cur);
-    if (has_right[c]) stack.push_back({right[c], (int32_t)cur});
-    if (has_left[c]) stack.push_back({left[c], (int32_t)cur});
-  }
-  *out = t;
-  return 0;
+  return guarded(1, [&]() -> int {
+    std::unordered_map<uint64_t, uint32_t> ctx;
+    for (uint32_t i = 0; i < n; i++) ctx.emplace(keys[i], i);
+    std::unique_ptr<mp2g_update_tree> t(new mp2g_update_tree);
+    t->epoch = epoch;
+    // explicit stack: (key, parent arena index); children pushed right first so that left is visited first
+    std::vector<std::pair<uint64_t, int32_t>> stack{{root, -1}};
+    while (!stack.empty()) {
+      auto [k, parent] = stack.back();
+      stack.pop_back();
+      auto it = ctx.find(k);
+      if (it == ctx.end()) continue;
+      const uint32_t c = it->second, cur = (uint32_t)t->nodes.size();
+      if (!t->idx.emplace(k, cur).second) return fail("duplicated key found");
+      t->nodes.push_back(UtNode{parent, {}, k, !has_left[c] && !has_right[c]});
+      if (parent >= 0) t->nodes[parent].children.insert(cur);
+      if (has_right[c]) stack.push_back({right[c], (int32_t)cur});
+      if (has_left[c]) stack.push_back({left[c], (int32_t)cur});
+    }
+    *out = t.release();
+    return 0;
+  });
 }
 int mp2g_update_tree_extend_with_path(mp2g_update_tree* t, const uint64_t* path, uint32_t len) {
   if (!t || (len && !path)) return fail("invalid argument: null pointer");
   if (t->nodes.empty() && len) return fail("extend_with_path on an empty update tree");
-  return t->extend(path, len);
+  // (a failure half way leaves the nodes inserted so far in place: they form a valid prefix of the path)
+  return guarded(1, [&]() -> int { return t->extend(path, len); });
 }
 uint32_t mp2g_update_tree_size(const mp2g_update_tree* t) { return t ? (uint32_t)t->nodes.size() : 0; }
 int64_t mp2g_update_tree_epoch(const mp2g_update_tree* t) { return t ? t->epoch : 0; }
@@ -158,14 +179,15 @@ void mp2g_update_tree_free(mp2g_update_tree* t) { delete t; }
 
 int mp2g_update_plan_create(mp2g_update_tree* t, uint32_t subtree_size, mp2g_update_plan** out) {
   if (!t || !out) return fail("invalid argument: null pointer");
-  auto* p = new (std::nothrow) mp2g_update_plan;
-  if (!p) return fail("out of memory");
-  p->t = t;
-  p->batch_size = subtree_size;
-  for (const UtNode& n : t->nodes)  // every leaf is ready (:428-441)
-    if (n.children.empty()) p->anchors.push_back(n.k);
-  *out = p;
-  return 0;
+  return guarded(1, [&]() -> int {
+    std::unique_ptr<mp2g_update_plan> p(new mp2g_update_plan);
+    p->t = t;
+    p->batch_size = subtree_size;
+    for (const UtNode& n : t->nodes)  // every leaf is ready (:428-441)
+      if (n.children.empty()) p->anchors.push_back(n.k);
+    *out = p.release();
+    return 0;
+  });
 }
 int mp2g_update_plan_next(mp2g_update_plan* p, uint64_t* k, int* is_path_end, mp2g_update_tree** subtree) {
   if (!p || !k) { fail("invalid argument: null pointer"); return -1; }
@@ -174,24 +196,33 @@ int mp2g_update_plan_next(mp2g_update_plan* p, uint64_t* k, int* is_path_end, mp
   if (t.nodes.empty()) return MP2G_PLAN_FINISHED;
   if (p->anchors.empty()) return MP2G_PLAN_NOT_YET;
   const uint64_t anchor = p->anchors.back();
-  p->anchors.pop_back();
   if (p->batch_size == 1) {
+    auto it = t.idx.find(anchor);
+    if (it == t.idx.end()) { fail("internal error: anchor not in the tree"); return -1; }
+    p->anchors.pop_back();
     *k = anchor;
-    if (is_path_end) *is_path_end = t.nodes[t.idx[anchor]].is_path_end ? 1 : 0;
+    if (is_path_end) *is_path_end = t.nodes[it->second].is_path_end ? 1 : 0;
     return MP2G_PLAN_READY;
   }
-  if (!subtree) { p->anchors.push_back(anchor); fail("invalid argument: a batched plan needs the subtree out-pointer"); return -1; }
-  // furthest ancestor whose subtree still fits the batch size (:481-515)
-  uint32_t root = t.idx[anchor];
-  while (t.nodes[root].parent >= 0) {
-    const uint32_t parent = (uint32_t)t.nodes[root].parent;
-    if (t.subtree_size_i(parent) > p->batch_size) break;
-    root = parent;
-  }
-  *k = t.nodes[root].k;
-  if (is_path_end) *is_path_end = t.nodes[root].is_path_end ? 1 : 0;
-  *subtree = t.spin_off(root);
-  return MP2G_PLAN_READY;
+  if (!subtree) { fail("invalid argument: a batched plan needs the subtree out-pointer"); return -1; }
+  // furthest ancestor whose subtree still fits the batch size (:481-515). The anchor leaves the list only once the subtree
+  // exists: an allocation failure inside spin_off returns -1 with the plan unchanged.
+  return guarded(-1, [&]() -> int {
+    auto it = t.idx.find(anchor);
+    if (it == t.idx.end()) { fail("internal error: anchor not in the tree"); return -1; }
+    uint32_t root = it->second;
+    while (t.nodes[root].parent >= 0) {
+      const uint32_t parent = (uint32_t)t.nodes[root].parent;
+      if (t.subtree_size_i(parent) > p->batch_size) break;
+      root = parent;
+    }
+    std::unique_ptr<mp2g_update_tree> sub = t.spin_off(root);
+    p->anchors.pop_back();
+    *k = t.nodes[root].k;
+    if (is_path_end) *is_path_end = t.nodes[root].is_path_end ? 1 : 0;
+    *subtree = sub.release();
+    return MP2G_PLAN_READY;
+  });
 }
 int mp2g_update_plan_done(mp2g_update_plan* p, uint64_t k) {
   if (!p) return fail("invalid argument: null plan");
@@ -199,16 +230,23 @@ int mp2g_update_plan_done(mp2g_update_plan* p, uint64_t k) {
   auto it = t.idx.find(k);
   if (it == t.idx.end()) return fail("key not found");
   const uint32_t i = it->second;
-  p->anchors.erase(std::remove(p->anchors.begin(), p->anchors.end(), k), p->anchors.end());
-  if (i == 0) {
-    t.nodes.clear();
-  } else {
-    if (i >= t.nodes.size()) return fail("key not found");  // plan already finished
-    const uint32_t parent = (uint32_t)t.nodes[i].parent;
-    t.nodes[parent].children.erase(i);
-    if (t.nodes[parent].children.empty()) p->anchors.push_back(t.nodes[parent].k);
-  }
-  return 0;
+  return guarded(1, [&]() -> int {
+    if (i != 0) {
+      if (i >= t.nodes.size()) return fail("key not found");  // plan already finished
+      const uint32_t parent = (uint32_t)t.nodes[i].parent;
+      if (t.nodes[parent].children.size() == 1 && t.nodes[parent].children.count(i))
+        p->anchors.reserve(p->anchors.size() + 1);  // the one step that can allocate comes first: a failure leaves the plan unchanged
+    }
+    p->anchors.erase(std::remove(p->anchors.begin(), p->anchors.end(), k), p->anchors.end());
+    if (i == 0) {
+      t.nodes.clear();
+    } else {
+      const uint32_t parent = (uint32_t)t.nodes[i].parent;
+      t.nodes[parent].children.erase(i);
+      if (t.nodes[parent].children.empty()) p->anchors.push_back(t.nodes[parent].k);
+    }
+    return 0;
+  });
 }
 int mp2g_update_plan_completed(const mp2g_update_plan* p) { return p && p->t->nodes.empty() ? 1 : 0; }
 void mp2g_update_plan_free(mp2g_update_plan* p) {

@@ -779,6 +779,35 @@ class Builder:
         self.tape += [OP_COSET, row, bits, shift.sid] + [x for v in values for x in (v.a.sid, v.b.sid)] + [point.a.sid, point.b.sid, out.a.sid, out.b.sid]
         return out
 
+    # ---- gate set ------------------------------------------------------------------------------------------------------------------
+    def add_gate_rows(self, kinds, seed=0xC0FFEE06):
+        """one satisfied row of every gate (kind, p0, p1, p2) of `kinds` the circuit does not contain yet. plonky2 evaluates every
+        gate of a circuit at every point of the LDE domain, so a circuit's proving cost depends on its gate SET and its degree, not
+        on how many rows each gate has: this is how a circuit whose own logic is light is given the gate set (and with
+        build(min_log_n) the degree) of the reference's heavier circuit of the same role (base degrees k = 12..15).
+        The rows' wires are fixed values (circuits.fill_row: a satisfying assignment), written by OP_WIRE from constant slots, so the
+        witness program reproduces them on host and device; no copy constraint touches them."""
+        present = {(r.kind, r.p0, r.p1, r.p2) for r in self.rows}
+        for kind, p0, p1, p2 in kinds:
+            if kind in (C.NOOP, C.PUBLIC_INPUT, C.CONSTANT) or (kind, p0, p1, p2) in present:
+                continue
+            present.add((kind, p0, p1, p2))
+            rng = np.random.default_rng([seed, kind, p0, p1, p2])
+            w = [None] * NUM_WIRES
+            # gate constants (0, 0): a RandomAccessGate row's two extra-constant cells stay free for _place_constants
+            C.fill_row(Gate(kind, p0, p1, p2, 0, 0, 0), w, (0, 0), lambda col: int(rng.integers(0, P, dtype=np.uint64)), rng, (0, 0, 0, 0))
+            row = self._new_row(kind, p0, p1, p2, consts=(0, 0))
+            if kind == C.RANDOM_ACCESS:
+                for i in range(p2):
+                    w[(2 + (1 << p0)) * p1 + i] = 0
+            for col, v in enumerate(w):
+                v = int(v) % P
+                if v:
+                    self.rows[row].wires[col] = v
+                    sid = self._sid()
+                    self.const_slots.append((sid, v))
+                    self.tape += [OP_WIRE, row, col, sid]
+
     # ---- public inputs -------------------------------------------------------------------------------------------------------------
     def register_public_inputs(self, targets):
         self.public_inputs += list(targets)
@@ -1387,8 +1416,12 @@ class FrameworkCircuit:
     own logic, the circuit-set digest as the last public inputs; then the wrap chain down to the threshold shape.
     `logic(b, child_public_inputs, inputs)` returns the circuit's own public-input targets (CircuitLogicWires)."""
 
-    def __init__(self, name, num_verifiers, logic, num_public_inputs):
+    def __init__(self, name, num_verifiers, logic, num_public_inputs, min_log_n=6, extra_gates=()):
+        """min_log_n / extra_gates: pad the base circuit with no-op rows to 2^min_log_n rows and give it one row of every gate of
+        `extra_gates` it lacks (Builder.add_gate_rows) -- the knobs of the base-degree sweep (the reference's real base
+        degrees come from CircuitWithUniversalVerifier::wrapped_circuit_size, circuit_builder.rs:323-325, and are 12..15)"""
         self.name, self.num_verifiers, self.logic, self.num_public_inputs = name, num_verifiers, logic, num_public_inputs
+        self.min_log_n, self.extra_gates = max(6, int(min_log_n)), tuple(extra_gates)
 
     def build_base(self, fw, child_proofs, child_vds, memberships, inputs, set_digest, strict=True):
         if self.num_verifiers and fw.rec.fp.num_lookup_polys:
@@ -1404,7 +1437,9 @@ class FrameworkCircuit:
         own = self.logic(b, child_pis, inputs)
         assert len(own) == self.num_public_inputs
         b.register_public_inputs(list(own) + set_t)
-        return b.build(min_log_n=6)
+        if self.extra_gates:
+            b.add_gate_rows(self.extra_gates)
+        return b.build(min_log_n=self.min_log_n)
 
 
 def build_wrap_chain(prover, fri_params, base_vd):

@@ -18,6 +18,27 @@ CPU tests); no arithmetic happens in this module.
 import numpy as np
 
 
+# device bytes a prover holds per proof in flight and per row of its circuit: the x8 LDEs of the 135 wire, 20 Z / partial-product
+# and 16 quotient polynomials with their coefficients, the Merkle levels of the four oracles, FRI layers, witness slots
+# (calibrated on the bench's table build: `device_memory_used_bytes` in its JSON)
+PROOF_BYTES_PER_ROW = 14 * 1024
+HBM_BYTES = 288 * 10**9
+
+
+def plan_rank_resources(shapes, workers, batch, ranks_on_host, host_cpus, hbm_bytes=HBM_BYTES):
+    """What ONE rank of a node takes for a table / recursion build: `shapes` = {circuit: [log2 rows of the base circuit and of every
+    wrap step]} (TableParams.shapes()), `workers` proving threads (GPU streams with a prover set each) holding `batch` proofs in
+    flight per circuit chain. Returns the host threads per worker (the node's hardware threads over the workers of all ranks on the
+    host: never more threads than the host has), their total over the node, and the device bytes the rank's provers need -- each
+    rank has a GPU of its own, so this is compared with ONE GPU's memory. `fits` false = shrink `batch` or `workers`."""
+    rows = sum(1 << int(k) for chain in shapes.values() for k in chain)
+    device_bytes = int(workers) * int(batch) * rows * PROOF_BYTES_PER_ROW
+    workers_on_host = max(1, int(workers) * max(1, int(ranks_on_host)))
+    host_threads = max(1, int(host_cpus) // workers_on_host)
+    return {"host_threads_per_worker": host_threads, "host_threads_on_node": host_threads * workers_on_host, "worker_threads_on_node": workers_on_host,
+            "device_bytes_per_rank": device_bytes, "fits": device_bytes <= 0.9 * hbm_bytes}
+
+
 def shard_range(n_items, rank, world):
     """Contiguous block partition: rank r owns [lo, hi). Sizes differ by at most one."""
     base, rem = divmod(n_items, world)
@@ -151,16 +172,24 @@ def send_device_proof(dist, ctx, dp, dst, device=None):
     prover's output buffers are sent as they are, device to device; gloo: through host tensors. The context's stream is drained
     first: the collective runs on torch's stream."""
     import torch
+    from .recursion import DeviceProof
     ctx.sync()
-    if device is not None:
+    if isinstance(dp, DeviceProof) and device is not None:
         parts = [torch.as_tensor(_RawView(ptr, n, dp.keep), device=device) for ptr, n in dp.parts]
     else:
-        caps, openings, fri, pis = dp.to_host(ctx)
-        parts = [torch.from_numpy(np.ascontiguousarray(a).view(np.int64).ravel().copy()) for a in (pis, caps[1:4], openings, fri)]
-    for t in parts:
-        dist.send(t, dst)
-    if device is not None:
-        torch.cuda.synchronize()
+        # a host proof tuple (the host-witness back end keeps no chain outputs on the device), or gloo: host tensors; with RCCL they
+        # go up first -- the receiver sees device tensors either way
+        caps, openings, fri, pis = dp.to_host(ctx) if isinstance(dp, DeviceProof) else dp
+        parts = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64).ravel().copy()) for a in (pis, np.asarray(caps)[1:4], openings, fri)]
+        if device is not None:
+            parts = [t.to(device) for t in parts]
+    try:
+        for t in parts:
+            dist.send(t, dst)
+        if device is not None:
+            torch.cuda.synchronize()
+    except Exception as e:  # a failed point-to-point transfer must end the job with the reason, not leave the peers waiting
+        raise RuntimeError(f"rank {dist.get_rank()}: sending a root proof to rank {dst} failed ({dist.get_backend()}): {e}") from e
 
 
 def recv_device_proof(dist, sizes, src, device=None):
@@ -168,9 +197,13 @@ def recv_device_proof(dist, sizes, src, device=None):
     the received device tensors (RCCL) or the host proof tuple (gloo)."""
     import torch
     from .recursion import DeviceProof
-    ts = recv_proof_words(dist, sizes, src, device)
+    try:
+        ts = recv_proof_words(dist, sizes, src, device)
+        if device is not None:
+            torch.cuda.synchronize()
+    except Exception as e:
+        raise RuntimeError(f"rank {dist.get_rank()}: receiving a root proof from rank {src} failed ({dist.get_backend()}): {e}") from e
     if device is not None:
-        torch.cuda.synchronize()
         return DeviceProof([(t.data_ptr(), t.numel()) for t in ts], keep=ts)
     pis, caps3, openings, fri = [t.numpy().view(np.uint64) for t in ts]
     caps = np.concatenate([np.zeros(caps3.size // 3, dtype=np.uint64), caps3]).reshape(4, -1)

@@ -200,12 +200,18 @@ class TableParams:
     CELL_KINDS = (("cells_leaf", 0, "leaf"), ("cells_full", 2, "full"), ("cells_partial", 1, "partial"), ("cells_empty", 0, "empty"))
     ROW_KINDS = (("row_leaf", 0, "leaf"), ("row_full", 2, "full"), ("row_partial", 1, "partial"))
 
-    def __init__(self, prover, fri_params, empty_hash):
+    def __init__(self, prover, fri_params, empty_hash, pad_base_bits=0, extra_gates=()):
+        """pad_base_bits = k > 0: every base circuit of both sets is padded with no-op rows to at least 2^k rows and carries one row
+        of every gate of `extra_gates` it lacks (FrameworkCircuit(min_log_n, extra_gates)): the base-degree sweep of SURVEY 8(d). The
+        reference's cells / rows circuits hold curve and u256 gadgets on top of the tree logic built here, so their base degrees lie
+        in 12..15 (circuit_builder.rs:323-325 is where the real number would come from); k brackets them."""
         self.empty_hash = [int(x) for x in empty_hash]
-        self.cells = R.RecursiveCircuits([R.FrameworkCircuit(n, k, cells_logic(kind, self.empty_hash), CELLS_IO) for n, k, kind in self.CELL_KINDS],
+        self.pad_base_bits = int(pad_base_bits)
+        kw = dict(min_log_n=max(6, self.pad_base_bits), extra_gates=tuple(extra_gates))
+        self.cells = R.RecursiveCircuits([R.FrameworkCircuit(n, k, cells_logic(kind, self.empty_hash), CELLS_IO, **kw) for n, k, kind in self.CELL_KINDS],
                                          prover, fri_params)
         self.gadget = R.RecursiveCircuitsVerifierGadget(self.cells)
-        self.rows = R.RecursiveCircuits([R.FrameworkCircuit(n, k, rows_logic(kind, self.gadget, self.empty_hash), ROWS_IO) for n, k, kind in self.ROW_KINDS],
+        self.rows = R.RecursiveCircuits([R.FrameworkCircuit(n, k, rows_logic(kind, self.gadget, self.empty_hash), ROWS_IO, **kw) for n, k, kind in self.ROW_KINDS],
                                         prover, fri_params)
         for fw in (self.cells, self.rows):
             for name in fw.circuits:
@@ -274,11 +280,13 @@ class TableBuild:
     subtree's row nodes bottom-up, level by level in batches, and returns. Workers run concurrently; the plan hands out an item once
     the subtrees below it are done."""
 
-    def __init__(self, params, sessions, batch=32, subtree_size=64, host_threads=0, keep_proofs=True):
+    def __init__(self, params, sessions, batch=32, subtree_size=64, host_threads=0, keep_proofs=True, keep_nodes=()):
         """keep_proofs: retain every row proof and cells-tree root after the run (what a checker re-proves sampled nodes from: ~130 KB
         per row); off, a proof is dropped as soon as its parent is proved -- the live set is the frontier of the tree, which is
-        what a 2^17-row block needs"""
+        what a 2^17-row block needs -- except for the row-tree nodes listed in keep_nodes (their row proofs and cells roots stay:
+        the nodes a checker samples from a large block, and their children)"""
         self.p, self.sessions, self.batch, self.subtree_size, self.keep_proofs = params, sessions, batch, subtree_size, keep_proofs
+        self.keep_nodes = set(keep_nodes)
         self.host_threads = host_threads
         self.pool = queue.Queue()
         for s in sessions:
@@ -339,6 +347,8 @@ class TableBuild:
             cells = self.cells_proofs(table, wit, sorted(keys), sess)
             if self.keep_proofs:
                 self.cells_roots.update(cells)
+            else:
+                self.cells_roots.update({k: v for k, v in cells.items() if k in self.keep_nodes})
             height = {}
 
             def h(k):
@@ -360,7 +370,7 @@ class TableBuild:
                         if height[k] == lvl:
                             cells.pop(k, None)
                             for c in nodes[k]:
-                                if c is not None:
+                                if c is not None and c not in self.keep_nodes:
                                     row_proofs.pop(c, None)
         finally:
             self.pool.put(sess)
@@ -394,6 +404,22 @@ class TableBuild:
         assert plan.completed()
         plan.free()
         return row_proofs[root]
+
+
+def sample_nodes(nodes, spans, row0=0):
+    """the row-tree nodes a checker re-proves after a build: row0, then the node with the widest span of every kind (leaf / partial /
+    full) not seen yet. Returns (samples in that order, the set to keep in a lean build = the samples and their children)."""
+    seen, samples = set(), []
+    for k in [row0] + sorted(nodes, key=lambda k: (-(spans[k][1] - spans[k][0]), k)):
+        kind = sum(c is not None for c in nodes[k])
+        if kind in seen:
+            continue
+        seen.add(kind)
+        samples.append(k)
+    keep = set(samples)
+    for k in samples:
+        keep.update(c for c in nodes[k] if c is not None)
+    return samples, keep
 
 
 def join_blocks(build, ctx, left, right, sep_block, n_cols=4, seed=0xC0FFEE04, variant=0):

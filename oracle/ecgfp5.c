@@ -257,3 +257,65 @@ void orc_row_digest_batch(int variant, const gl_t* col_ids, size_t n_cols, const
   }
   emit(total, w, wei);
 }
+
+// ---- off-chain table commitment, mp2-v1/src/api.rs:553-603 -----------------------------------------
+// add_primary_index_to_digest, verifiable-db/src/block_tree/mod.rs:37-53:
+//   HashToInt(H(primary_index_id || index_value.to_fields())) * digest
+int orc_add_primary_index_to_digest(int variant, gl_t primary_id, const uint32_t index_value_be[8], const gl_t digest_w[5], gl_t w[5], gl_t wei[11]) {
+  gl_t in[9];
+  in[0] = primary_id;
+  for (int j = 0; j < 8; j++) in[1 + j] = index_value_be[j];
+  return orc_field_hashed_scalar_mul(variant, in, 9, digest_w, w, wei);
+}
+// flatten_poseidon_hash_value, mp2-common/src/poseidon.rs:92-103: per limb [high 32 bits, low 32 bits]
+static void flatten_hash(const gl_t h[4], gl_t out[8]) {
+  for (int i = 0; i < 4; i++) { out[2 * i] = h[i] >> 32; out[2 * i + 1] = h[i] & 0xFFFFFFFFULL; }
+}
+static const uint32_t* g_sort_keys;  // qsort context (single-threaded test helper)
+static int cmp_u256_be(const void* a, const void* b) {
+  const uint32_t* x = g_sort_keys + 8 * *(const size_t*)a;
+  const uint32_t* y = g_sort_keys + 8 * *(const size_t*)b;
+  for (int j = 0; j < 8; j++) if (x[j] != y[j]) return x[j] < y[j] ? -1 : 1;
+  return *(const size_t*)a < *(const size_t*)b ? -1 : (*(const size_t*)a > *(const size_t*)b);
+}
+// update_off_chain_data_commitment (api.rs:556-596). Rows: primary[rows][8] = the primary-index value of each row, values
+// [rows][n_cols][8] = its other columns (ids col_ids), unique[rows][n_unique][8] = the values of its row-unique columns, every
+// U256 as 8 big-endian u32 words. old_commitment: 32 bytes or NULL (HashOutput::default() = zeros). Groups the rows by
+// increasing primary value (the BTreeMap of :562-570) and, group by group,
+//   commitment <- flatten(H(commitment[8] || add_primary_index_to_digest(primary_id, primary, compute_table_row_digest(group)).to_fields()))
+// starting from the old commitment packed as 8 little-endian u32 (:572-580); out = the 8 limbs as little-endian u32 bytes (:599-603).
+void orc_update_off_chain_data_commitment(int variant, gl_t primary_id, const uint32_t* primary, const gl_t* col_ids, size_t n_cols,
+                                          const uint32_t* values, const uint32_t* unique, size_t n_unique, size_t rows,
+                                          const uint8_t* old_commitment, uint8_t out[32]) {
+  gl_t com[8];
+  for (int i = 0; i < 8; i++) {
+    com[i] = 0;
+    if (old_commitment)
+      for (int b = 0; b < 4; b++) com[i] |= (gl_t)old_commitment[4 * i + b] << (8 * b);
+  }
+  size_t* order = malloc((rows ? rows : 1) * sizeof(size_t));
+  for (size_t r = 0; r < rows; r++) order[r] = r;
+  g_sort_keys = primary;
+  qsort(order, rows, sizeof(size_t), cmp_u256_be);
+  uint32_t* gv = malloc((rows * n_cols * 8 + 1) * sizeof(uint32_t));
+  uint32_t* gu = malloc((rows * n_unique * 8 + 1) * sizeof(uint32_t));
+  for (size_t lo = 0; lo < rows;) {
+    size_t hi = lo + 1;
+    while (hi < rows && memcmp(primary + 8 * order[hi], primary + 8 * order[lo], 32) == 0) hi++;
+    for (size_t i = lo; i < hi; i++) {
+      memcpy(gv + (i - lo) * n_cols * 8, values + order[i] * n_cols * 8, n_cols * 32);
+      memcpy(gu + (i - lo) * n_unique * 8, unique + order[i] * n_unique * 8, n_unique * 32);
+    }
+    gl_t dw[5], pw[5], fields[11], payload[19], h[4];
+    orc_row_digest_batch(variant, col_ids, n_cols, gv, gu, n_unique, hi - lo, dw, NULL);
+    if (!orc_add_primary_index_to_digest(variant, primary_id, primary + 8 * order[lo], dw, pw, fields)) abort();
+    memcpy(payload, com, sizeof(com));
+    memcpy(payload + 8, fields, sizeof(fields));
+    orc_hash_n_to_m_no_pad(variant, payload, 19, h, 4);
+    flatten_hash(h, com);
+    lo = hi;
+  }
+  free(order); free(gv); free(gu);
+  for (int i = 0; i < 8; i++)
+    for (int b = 0; b < 4; b++) out[4 * i + b] = (uint8_t)(com[i] >> (8 * b));
+}

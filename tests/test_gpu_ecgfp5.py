@@ -191,3 +191,55 @@ def test_row_id_helpers_agree_with_the_fused_digest(ctx, mp2):
     w = np.zeros(5, dtype=np.uint64)
     assert O.lib().orc_field_hashed_scalar_mul(0, O.p(O.arr(inputs)), O.sz(inputs.size), O.p(O.arr(fused)), O.p(w), None)
     assert np.array_equal(dg.add_primary_index_to_digest(ctx, 77, values[0, 0], fused), w)
+
+
+def _o_commitment(primary_id, primary, col_ids, values, unique, old, variant=0):
+    out = np.zeros(32, dtype=np.uint8)
+    oldb = np.frombuffer(old, dtype=np.uint8).copy() if old is not None else None
+    O.lib().orc_update_off_chain_data_commitment(variant, ctypes.c_uint64(primary_id), O.p(O.arr(primary, np.uint32)), O.p(O.arr(col_ids)), O.sz(len(col_ids)),
+                                                 O.p(O.arr(values, np.uint32)), O.p(O.arr(unique, np.uint32)), O.sz(unique.shape[1]), O.sz(values.shape[0]),
+                                                 O.p(oldb) if oldb is not None else None, O.p(out))
+    return out.tobytes()
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("rows,n_groups,n_cols,uniq", [(1, 1, 1, (0,)), (12, 3, 4, (1,)), (200, 17, 5, (0, 2)), (9, 9, 2, ()), (0, 0, 3, (0,))])
+def test_update_off_chain_data_commitment(ctx, mp2, variant, rows, n_groups, n_cols, uniq):
+    """mp2-v1/src/api.rs:556-603 over the batched kernels (digest.update_off_chain_data_commitment) against the oracle's restatement
+    (orc_update_off_chain_data_commitment: group by group, one compute_table_row_digest each): rows scattered over n_groups primary
+    values in shuffled order, with and without an old commitment; the update is incremental (committing groups below a cut, then
+    the rest, equals committing everything) and does not depend on the order the rows are given in."""
+    import importlib
+    dg = importlib.import_module("mapreduce-plonky2_amd.digest")
+    rng = np.random.default_rng(1000 * rows + n_groups)
+    col_ids = O.rand_field(n_cols, 0xC0FFEE04 + n_cols)
+    primary_id = int(O.rand_field(1, 7)[0])
+    values = rng.integers(0, 1 << 32, size=(rows, n_cols, 8), dtype=np.uint32)
+    gvals = rng.integers(0, 1 << 32, size=(max(1, n_groups), 8), dtype=np.uint32)
+    if n_groups > 2:
+        gvals[1, :7] = gvals[0, :7]  # two primaries that differ in the least significant word only
+    which = np.concatenate([np.arange(n_groups), rng.integers(0, max(1, n_groups), size=max(0, rows - n_groups))])[:rows].astype(np.int64)
+    rng.shuffle(which)
+    primary = gvals[which].reshape(rows, 8)
+    ucols = [col_ids[i] for i in uniq]
+    unique = np.ascontiguousarray(values[:, list(uniq), :]) if uniq else np.zeros((rows, 0, 8), dtype=np.uint32)
+    old = bytes(rng.integers(0, 256, size=32, dtype=np.uint8))
+    for oc in (None, old):
+        got = dg.update_off_chain_data_commitment(ctx, primary_id, primary, col_ids, values, ucols, oc, variant)
+        assert len(got) == 32 and got == _o_commitment(primary_id, primary, col_ids, values, unique, oc, variant)
+    if rows == 0:
+        assert dg.update_off_chain_data_commitment(ctx, primary_id, primary, col_ids, values, ucols, old, variant) == old
+        return
+    assert dg.off_chain_data_commitment(ctx, primary_id, primary, col_ids, values, ucols, variant) == _o_commitment(primary_id, primary, col_ids, values, unique, None, variant)
+    # row order does not matter
+    perm = rng.permutation(rows)
+    assert dg.update_off_chain_data_commitment(ctx, primary_id, primary[perm], col_ids, values[perm], ucols, old, variant) == got
+    # incremental: the groups below a cut first, then the others on top of that commitment
+    ints = [sum(int(x) << (32 * (7 - j)) for j, x in enumerate(pv)) for pv in primary]
+    cut = sorted(set(ints))[len(set(ints)) // 2]
+    lo = np.array([v < cut for v in ints])
+    if lo.any() and (~lo).any():
+        first = dg.update_off_chain_data_commitment(ctx, primary_id, primary[lo], col_ids, values[lo], ucols, old, variant)
+        assert dg.update_off_chain_data_commitment(ctx, primary_id, primary[~lo], col_ids, values[~lo], ucols, first, variant) == got
+    with pytest.raises(ValueError):
+        dg.update_off_chain_data_commitment(ctx, primary_id, primary, col_ids, values, [int(col_ids[0]) ^ 1], None, variant)

@@ -160,12 +160,23 @@ def _bench(args, env=None, timeout=2400):
 
 
 def test_bench_default_workload_is_the_table_build():
-    """python bench.py (no --workload): the table build, self-verifying, with roofline and cpu_baseline objects"""
-    line = _bench(["--rows", "16", "--steps", "1", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "8", "--cpu-budget", "1"])
+    """python bench.py (no --workload): the table build as ONE contiguous block of steps x rows rows, self-verifying, with roofline and
+    cpu_baseline objects (all-thread / one-thread medians, CPU model), and the side legs of the driver's line at small sizes: BASELINE
+    configs[2] (a 64-leaf tree of real proofs here), the table rate at a padded base degree, the prove()-only loop"""
+    line = _bench(["--rows", "8", "--steps", "2", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "8", "--cpu-budget", "1",
+                   "--config2-leaves", "64", "--degree-sweep", "12", "--sweep-rows", "8"])
     assert line["config"]["workload"].startswith("table:") and line["unit"] == "proofs/s" and line["n_gpus"] == 1
+    assert line["config"]["rows_per_rank"] == 16 and line["config"]["row_tree_depth"] == 4 and line["steps"] == 2
+    assert abs(line["value"] * line["ms_per_step"] * 2 / 1e3 - 5 * 16) < 1e-6  # one 16-row block, 5 framework proofs per row
     assert line["config"]["shapes"]["row_full"] == [14, 13, 12]
-    assert line["value"] > 0 and line["verified"] >= 15 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+    assert line["value"] > 0 and line["verified"] >= 16 and line["roofline"]["frac"] > 0 and line["cpu_baseline"]["value"] > 0
+    med = line["cpu_baseline"]["medians"]
+    assert med["runs"] == 5 and med["one_thread"]["median_s"] >= med["all_threads"]["median_s"] > 0 and line["cpu_baseline"]["cpu_model"]
     assert line["leaves_prove_only"]["value"] > 0 and len(line["config"]["root_public_inputs"]) == T.ROWS_IO + 4
+    assert line["config2"]["framework_proofs"] == 127 and line["config2"]["value"] > 0 and line["config2"]["root_verified"]
+    k12 = line["by_base_degree"]["12"]
+    assert k12["value"] > 0 and k12["root_verified"] and all(ch[0] >= 12 for ch in k12["shapes"].values()) and k12["shapes"]["cells_leaf"] == [12, 12]
+    assert line["config"]["device_memory_used_bytes"] > 0
 
 
 def test_bench_gpus_2_starts_its_own_ranks():
@@ -237,3 +248,15 @@ def test_bench_gpus_4_two_join_levels():
                    "--no-cpu-baseline"], env={"MP2G_BENCH_BACKEND": "gloo"})
     assert line["n_gpus"] == 4 and "2 join level" in line["config"]["sharding"]
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * (4 * 6 + 3)) < 1e-6 and line["verified"] >= 4 * 13
+
+
+def test_bench_gpus_8_three_join_levels():
+    """eight ranks (gloo, sharing this box's GPU) -- the shape of the driver's 8-GPU scaling run: eight blocks, seven separator rows,
+    three join levels (1 -> 0, 3 -> 2, 5 -> 4, 7 -> 6; 2 -> 0, 6 -> 4; 4 -> 0). The run asserts the root's digest = the digest of all
+    8 x 2 + 7 rows and its min = block 0's; every rank checks its block root and its sampled proofs; all eight ranks answer the
+    backend's all_reduce before anything is timed."""
+    line = _bench(["--gpus", "8", "--rows", "2", "--steps", "1", "--warmup", "1", "--workers", "1", "--table-batch", "4", "--subtree", "4", "--no-leaves-leg",
+                   "--no-cpu-baseline"], env={"MP2G_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 8 and line["config"]["join_levels"] == 3 and "3 join level" in line["config"]["sharding"]
+    assert line["config"]["rccl_ranks"] == 8 and line["config"]["ranks_on_host"] == 8 and line["config"]["backend"] == "gloo"
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * (8 * 2 + 7)) < 1e-6 and line["verified"] >= 8 * 10

@@ -146,3 +146,44 @@ def test_curve_group_laws():
     s = np.zeros(5, dtype=np.uint64)
     assert L.orc_curve_sum(O.p(both), O.sz(2), O.p(s), None)
     assert np.array_equal(s, mul(a + b))
+
+
+def test_off_chain_commitment_restatement_composes_its_parts():
+    """orc_update_off_chain_data_commitment (mp2-v1/src/api.rs:556-603) against its own parts composed here in Python: per group of
+    equal primary values (increasing U256 order) compute_table_row_digest, add_primary_index_to_digest
+    (verifiable-db/src/block_tree/mod.rs:37-53), H(commitment || to_fields), flatten_poseidon_hash_value
+    (mp2-common/src/poseidon.rs:92-103: [high, low] per limb); the old commitment enters as 8 little-endian u32 and the result
+    leaves the same way; no rows = the old commitment unchanged."""
+    import ctypes
+    rng = np.random.default_rng(11)
+    rows, n_cols = 7, 3
+    col_ids = O.rand_field(n_cols, 5)
+    values = rng.integers(0, 1 << 32, size=(rows, n_cols, 8), dtype=np.uint32)
+    unique = np.ascontiguousarray(values[:, :1, :])
+    gv = rng.integers(0, 1 << 32, size=(3, 8), dtype=np.uint32)
+    gv[1] = gv[0]
+    gv[1, 7] ^= 1
+    which = np.array([2, 0, 1, 0, 2, 2, 1])
+    primary = gv[which]
+    old = bytes(range(32))
+    out = np.zeros(32, dtype=np.uint8)
+    oldb = np.frombuffer(old, dtype=np.uint8).copy()
+
+    def run(n, oldp):
+        O.lib().orc_update_off_chain_data_commitment(0, ctypes.c_uint64(99), O.p(O.arr(primary[:n], np.uint32)), O.p(col_ids), O.sz(n_cols),
+                                                     O.p(O.arr(values[:n], np.uint32)), O.p(O.arr(unique[:n], np.uint32)), O.sz(1), O.sz(n), oldp, O.p(out))
+        return out.tobytes()
+
+    assert run(0, O.p(oldb)) == old and run(0, None) == bytes(32)
+    got = run(rows, O.p(oldb))
+    com = [int.from_bytes(old[4 * i:4 * i + 4], "little") for i in range(8)]
+    ints = [sum(int(x) << (32 * (7 - j)) for j, x in enumerate(p)) for p in primary]
+    for g in sorted(set(ints)):
+        idx = [i for i, v in enumerate(ints) if v == g]
+        dw, pw, fields = np.zeros(5, dtype=np.uint64), np.zeros(5, dtype=np.uint64), np.zeros(11, dtype=np.uint64)
+        O.lib().orc_row_digest_batch(0, O.p(col_ids), O.sz(n_cols), O.p(O.arr(values[idx], np.uint32)), O.p(O.arr(unique[idx], np.uint32)), O.sz(1), O.sz(len(idx)), O.p(dw), None)
+        inputs = np.concatenate([[np.uint64(99)], primary[idx[0]].astype(np.uint64)])
+        assert O.lib().orc_field_hashed_scalar_mul(0, O.p(O.arr(inputs)), O.sz(9), O.p(dw), O.p(pw), O.p(fields))
+        h = O.hash_n_to_m_no_pad(np.concatenate([np.asarray(com, dtype=np.uint64), fields]), 4)
+        com = [x for limb in h for x in (int(limb) >> 32, int(limb) & 0xFFFFFFFF)]
+    assert got == b"".join(int(x).to_bytes(4, "little") for x in com)

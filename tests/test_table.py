@@ -96,3 +96,41 @@ def test_one_row_table_on_the_oracle_prover(params):
     assert np.array_equal(pis[4:15], owei)
     wckt, wcap, wdig = params.rows.chains["row_leaf"][-1]
     assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *proof[:3]) == 0
+
+
+def test_base_degree_padding_and_reference_gate_set():
+    """the base-degree sweep's knobs (FrameworkCircuit(min_log_n, extra_gates)): a cells-tree leaf padded from its
+    natural 2^6 rows to 2^8 rows with one row of every gate of the reference's leaf set it lacks -- the recorded witness program
+    reproduces the builder's wires (extra rows included), the oracle proves the circuit and its verifier accepts (every gate's
+    constraints vanish on H, the extra gates' too), and the unpadded circuit is untouched by the knobs' defaults"""
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    PC = importlib.import_module("mapreduce-plonky2_amd.circuits")
+    from test_recursion import verifier_data
+    empty = [int(x) for x in O.hash_n_to_m_no_pad(np.zeros(0, dtype=np.uint64), 4)]
+    logic = T.cells_logic("leaf", empty)
+    inputs = [int(x) for x in O.rand_field(T.CELL_LEN + 22, 5)]
+    inputs[1:9] = [x & 0xFFFFFFFF for x in inputs[1:9]]
+    inputs[9] = 0
+    plain = R.FrameworkCircuit("cells_leaf", 0, logic, T.CELLS_IO).build_base(None, [], [], [], inputs, [1, 2, 3, 4])
+    padded = R.FrameworkCircuit("cells_leaf", 0, logic, T.CELLS_IO, min_log_n=8, extra_gates=PC.LEAF_KINDS).build_base(None, [], [], [], inputs, [1, 2, 3, 4])
+    assert plain.log_n == 6 and padded.log_n == 8
+    have = {(g.kind, g.p0, g.p1, g.p2) for g in padded.gates}
+    assert all(k in have for k in PC.LEAF_KINDS if k[0] != PC.CONSTANT), "the padded circuit carries the whole leaf gate set (constants ride in the RandomAccess row)"
+    assert len(padded.gates) > len(plain.gates)
+    assert np.array_equal(padded.public_inputs, plain.public_inputs)
+    prog = mp2.WitnessProgram(padded)
+    other = list(inputs)
+    other[0] = 12345
+    wires, pi_hash, pis = prog.run(np.array([[1, 2, 3, 4] + inputs, [1, 2, 3, 4] + other], dtype=np.uint64))  # inputs: the set digest, then the circuit's own
+    assert np.array_equal(wires[0], padded.wires), "witness program != builder (the extra gate rows are part of the witness)"
+    again = R.FrameworkCircuit("cells_leaf", 0, logic, T.CELLS_IO, min_log_n=8, extra_gates=PC.LEAF_KINDS).build_base(None, [], [], [], other, [1, 2, 3, 4])
+    assert np.array_equal(again.pre, padded.pre) and np.array_equal(wires[1], again.wires)
+    fp = C.oracle_params(padded, pow_bits=8, num_queries=4)
+    cap, cd = verifier_data(padded)
+    caps, openings, proof, _ = C.prove(padded, fp, cd)
+    assert C.verify(padded, fp, cd, padded.pi_hash, caps, openings, proof) == 0
+    bad = padded.wires.copy()
+    row = next(i for i, g in enumerate(padded.instances) if padded.gates[g].kind == PC.COMPARISON)
+    bad[2, row] ^= 1  # the comparison gate's result bit
+    c2, o2, p2, _ = C.prove_witness(padded, fp, cd, bad, padded.pi_hash)
+    assert C.verify(padded, fp, cd, padded.pi_hash, c2, o2, p2) != 0, "a violated extra gate row must not verify"

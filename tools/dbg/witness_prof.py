@@ -1,5 +1,5 @@
 """where the device witness replay spends its time, per class of level (needs a library built with -DWIT_PROF: tools/dbg/witness_prof.sh)"""
-import importlib, os, sys
+import ctypes, importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -19,10 +19,11 @@ n = 1 << prog.log_n
 names = ["narrow Poseidon2 levels (lane-cooperative)", "wide Poseidon2 levels (one lane per row)", "reducing / interpolation / inverse levels", "other levels"]
 for B in (1, 32, 128):
     inp = np.tile(row, (B, 1))
-    d_in, d_w, d_pr = ctx.to_device(inp), ctx.alloc(B * 135 * n * 8), ctx.alloc((B * prog.probe.size + 8) * 8)
+    d_in, d_w, d_pr = ctx.to_device(inp), ctx.alloc(B * 135 * n * 8), ctx.alloc(B * prog.probe.size * 8)
     prog.run_dev(ctx, d_in, B, d_w, d_pr); ctx.sync()
     ctx.timer_start(); prog.run_dev(ctx, d_in, B, d_w, d_pr); ms = ctx.timer_stop()
-    prof = d_pr.download((B * prog.probe.size + 8,))[-8:]
+    prof = (ctypes.c_uint64 * 8)()
+    assert mp2.load().mp2g_dbg_witness_prof(prof) == 0
     tot = sum(int(prof[2 * k]) for k in range(4))
     print(f"B={B}: {ms:.2f} ms; block 0: {tot} shader cycles in levels")
     for k in range(4):

@@ -1,7 +1,6 @@
 #!/bin/bash
-# per-class timing of the witness kernel's levels: a library with -DWIT_PROF built on the box, then tools/dbg/witness_prof.py
+# per-class timing of the witness kernel's levels: a -DWIT_PROF variant of the library built beside the product
+# (build_dbg/witprof/libmp2gpu.so, selected with MP2G_LIB; the product library is not touched), then tools/dbg/witness_prof.py
 R=$GRAFT_REPO_ROOT
-cd $R/mapreduce-plonky2_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -I../../include -DWIT_PROF -c witness_dev.hip -o witness_dev.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../libmp2gpu.so *.o
-cd $R && python tools/dbg/witness_prof.py
+bash $R/tools/dbg/build_variant.sh witprof "-DWIT_PROF" witness_dev.hip > /dev/null
+cd $R && MP2G_LIB=$R/build_dbg/witprof/libmp2gpu.so python tools/dbg/witness_prof.py
