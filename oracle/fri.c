@@ -158,8 +158,12 @@ static void batch_poly(const orc_fri_params* P, int batch, size_t j, uint32_t* o
 
 // prove_openings + fri_proof. coeffs[o] = [w_o][n] base coefficients; leaves[o] = [8n][w_o];
 // levels[o] = Merkle levels. Challenger state continues the caller's transcript.
-// `pow_witness_in`: if not NULL, use this witness instead of searching (the reference's search
+// The proof-of-work witness is the smallest one, or the one armed with orc_set_pow_witness (the reference's search
 // is a non-deterministic find_any; parity is defined given the witness).
+static gl_t g_pow_override;
+static int g_pow_override_armed;
+// the NEXT proof made by this library (one proof, then the search is back) takes `witness` as its proof-of-work witness
+void orc_set_pow_witness(gl_t witness) { g_pow_override = witness; g_pow_override_armed = 1; }
 void orc_fri_prove(const orc_fri_params* P, gl_t* const* coeffs, gl_t* const* leaves, gl_t* const* levels,
                    gl2_t zeta, orc_challenger* ch, gl_t* proof) {
   unsigned k = P->log_n, lg = k + P->rate_bits;
@@ -251,8 +255,17 @@ void orc_fri_prove(const orc_fri_params* P, gl_t* const* coeffs, gl_t* const* le
   for (size_t i = 0; i < final_len; i++) { out_final[2 * i] = cf[i].c[0]; out_final[2 * i + 1] = cf[i].c[1]; }
   orc_ch_observe(ch, out_final, 2 * final_len);
 
-  // ---- proof of work: smallest witness whose response has >= pow_bits leading zeros
-  {
+  // ---- proof of work: smallest witness whose response has >= pow_bits leading zeros -- unless orc_set_pow_witness() armed another
+  // one: the reference searches with rayon's find_any, so ITS proof holds any valid witness, and everything after the PoW (the
+  // query indices) follows from it; a proof of the reference is reproduced bit for bit given its witness (tests/test_reference_vectors.py)
+  if (g_pow_override_armed) {
+    gl_t wit = g_pow_override;
+    g_pow_override_armed = 0;
+    out_final[2 * final_len] = wit;
+    orc_ch_observe(ch, &wit, 1);
+    gl_t resp = orc_ch_get(ch);
+    if (P->pow_bits && (resp >> (64 - P->pow_bits)) != 0) { fprintf(stderr, "oracle: the given pow witness does not satisfy the transcript\n"); abort(); }
+  } else {
     gl_t st[12];
     memcpy(st, ch->state, sizeof st);
     memcpy(st, ch->in, ch->n_in * sizeof(gl_t));

@@ -1,0 +1,279 @@
+//! Writes `reference_vectors.json`: outputs of the REFERENCE's own dependencies (plonky2 0.2.2 @ Lagrange-Labs/plonky2#upstream,
+//! poseidon2_plonky2, plonky2_ecgfp5) and of mp2-common / mp2-v1 on fixed inputs, in the schema documented in the builder
+//! repository's DESIGN.md section 2 and consumed by its `tests/test_reference_vectors.py` (CPU: the C oracle; `-m gpu`: the HIP
+//! library). Every section states the reference call it records. Inputs are either small literal sequences or the SplitMix64
+//! stream the builder's workload generator uses (`splitmix_field`), so both sides can regenerate them.
+//!
+//! NOT compiled in the builder's image (no Rust toolchain there): written against the plonky2 0.2.2 API as the reference uses it
+//! (call sites cited inline); a maintainer with the reference checked out runs `tools/ref_vectors/run.sh <reference dir>`.
+#![allow(incomplete_features)]
+#![feature(generic_const_exprs)]
+
+use std::{env, fs::File, io::Write};
+
+use anyhow::Result;
+use itertools::Itertools;
+use mp2_common::{
+    group_hashing::map_to_curve_point,
+    poseidon::{flatten_poseidon_hash_value, hash_to_int_value},
+    proof::serialize_proof,
+    utils::ToFields,
+    C, D, F,
+};
+use plonky2::{
+    field::{
+        extension::Extendable,
+        polynomial::{PolynomialCoeffs, PolynomialValues},
+        types::{Field, PrimeField64},
+    },
+    fri::oracle::PolynomialBatch,
+    gates::noop::NoopGate,
+    hash::{
+        hash_types::HashOut,
+        hashing::PlonkyPermutation,
+        merkle_tree::MerkleTree,
+    },
+    iop::{
+        challenger::Challenger,
+        generator::generate_partial_witness,
+        witness::{PartialWitness, WitnessWrite},
+    },
+    plonk::{
+        circuit_builder::CircuitBuilder,
+        circuit_data::CircuitConfig,
+        config::{GenericConfig, Hasher, PoseidonGoldilocksConfig},
+    },
+    util::timing::TimingTree,
+};
+use plonky2_ecgfp5::curve::{curve::Point, scalar_field::Scalar};
+use poseidon2_plonky2::poseidon2_goldilock::Poseidon2GoldilocksConfig;
+use serde_json::{json, Map, Value};
+
+type P2 = <Poseidon2GoldilocksConfig as GenericConfig<D>>::Hasher;
+type P1 = <PoseidonGoldilocksConfig as GenericConfig<D>>::Hasher;
+type H = <C as GenericConfig<D>>::Hasher; // the configuration the reference was compiled with (mp2-common/src/lib.rs:37-42)
+
+fn u(x: F) -> u64 {
+    x.to_canonical_u64()
+}
+fn us(v: &[F]) -> Vec<u64> {
+    v.iter().map(|x| u(*x)).collect()
+}
+fn f(x: u64) -> F {
+    F::from_canonical_u64(x)
+}
+fn hash_limbs(h: HashOut<F>) -> Vec<u64> {
+    us(&h.elements)
+}
+
+/// the builder's `rand_field(shape, seed)` (mapreduce-plonky2_amd/circuits.py): SplitMix64 of seed + i * gamma for i = 1.., values
+/// >= p are re-drawn from the continuation of the stream (index n + 1, n + 2, ...) in order of appearance
+fn splitmix_field(n: usize, seed: u64) -> Vec<F> {
+    const P: u64 = 0xFFFF_FFFF_0000_0001;
+    let draw = |i: u64| {
+        let mut z = seed.wrapping_add(i.wrapping_mul(0x9E37_79B9_7F4A_7C15));
+        z = (z ^ (z >> 30)).wrapping_mul(0xBF58_476D_1CE4_E5B9);
+        z = (z ^ (z >> 27)).wrapping_mul(0x94D0_49BB_1331_11EB);
+        z ^ (z >> 31)
+    };
+    let mut z: Vec<u64> = (1..=n as u64).map(draw).collect();
+    let mut next = n as u64 + 1;
+    let mut bad: Vec<usize> = (0..n).filter(|&i| z[i] >= P).collect();
+    while !bad.is_empty() {
+        for &i in &bad {
+            z[i] = draw(next);
+            next += 1;
+        }
+        bad.retain(|&i| z[i] >= P);
+    }
+    z.into_iter().map(f).collect()
+}
+
+/// permute([0, 1, .., 11]) and the sponge / Merkle helpers of one hasher (plonky2 hash/hashing.rs, hash/merkle_tree.rs)
+fn hasher_section<Hs: Hasher<F, Hash = HashOut<F>>>() -> Value {
+    let mut perm = Hs::Permutation::new((0..12u64).map(f));
+    perm.permute();
+    let state: Vec<u64> = us(perm.as_ref());
+    let mut no_pad = Map::new();
+    for len in [0usize, 1, 4, 7, 8, 9, 17, 135] {
+        let input: Vec<F> = (0..len as u64).map(f).collect();
+        no_pad.insert(len.to_string(), json!(hash_limbs(Hs::hash_no_pad(&input))));
+    }
+    let mut pad = Map::new();
+    for len in [0usize, 3, 8] {
+        let input: Vec<F> = (0..len as u64).map(f).collect();
+        pad.insert(len.to_string(), json!(hash_limbs(Hs::hash_pad(&input))));
+    }
+    let mut noop = Map::new();
+    for len in [3usize, 4, 5] {
+        let input: Vec<F> = (1..=len as u64).map(f).collect();
+        noop.insert(len.to_string(), json!(hash_limbs(Hs::hash_or_noop(&input))));
+    }
+    let l = HashOut { elements: [f(1), f(2), f(3), f(4)] };
+    let r = HashOut { elements: [f(5), f(6), f(7), f(8)] };
+    json!({
+        "permute_0_to_11": state,
+        "hash_no_pad": no_pad,   // input = [0, 1, .., len - 1]
+        "hash_pad": pad,         // same inputs
+        "hash_or_noop": noop,    // input = [1, .., len]
+        "two_to_one_1234_5678": hash_limbs(Hs::two_to_one(l, r)),
+    })
+}
+
+/// plonky2_field fft.rs / polynomial.rs on the first 2^log_n values of the SplitMix64 stream with seed 0xC0FFEE02
+fn fft_section(log_n: usize) -> Value {
+    let n = 1usize << log_n;
+    let input = splitmix_field(n, 0xC0FFEE02);
+    let shift = F::coset_shift();
+    let as_coeffs = PolynomialCoeffs::new(input.clone());
+    let as_values = PolynomialValues::new(input.clone());
+    json!({
+        "input": us(&input),
+        "fft": us(&as_coeffs.clone().fft().values),                 // v[i] = P(w^i), natural order
+        "ifft": us(&as_values.ifft().coeffs),
+        "coset_fft": us(&as_coeffs.coset_fft(shift).values),        // v[i] = P(g w^i)
+        "lde1_coset_fft": us(&as_coeffs.lde(1).coset_fft(shift).values), // zero-padded to 2n, then the coset transform
+    })
+}
+
+/// PolynomialBatch::from_values (fri/oracle.rs) as prove() calls it: 3 polynomials of 2^4 values, rate_bits 3, no blinding, cap
+/// height 4 -> 2^7 leaves of 3 limbs (hash_or_noop: used as they are), 16 cap entries, Merkle proofs of 3 siblings
+fn batch_section() -> Value {
+    let (log_n, w, rate_bits, cap_height) = (4usize, 3usize, 3usize, 4usize);
+    let n = 1 << log_n;
+    let all = splitmix_field(w * n, 0xC0FFEE02);
+    let values: Vec<PolynomialValues<F>> = (0..w).map(|i| PolynomialValues::new(all[i * n..(i + 1) * n].to_vec())).collect();
+    let mut timing = TimingTree::default();
+    let batch = PolynomialBatch::<F, C, D>::from_values(values.clone(), rate_bits, false, cap_height, &mut timing, None);
+    let tree: &MerkleTree<F, H> = &batch.merkle_tree;
+    let idx = 77usize;
+    let proof = tree.prove(idx);
+    json!({
+        "log_n": log_n, "polys": w, "rate_bits": rate_bits, "cap_height": cap_height,
+        "values": values.iter().map(|p| us(&p.values)).collect_vec(),
+        "coeffs": batch.polynomials.iter().map(|p| us(&p.coeffs)).collect_vec(),
+        "leaves": [us(&tree.leaves[0]), us(&tree.leaves[1]), us(&tree.leaves[idx])],  // leaf i = evaluations at g w_{8n}^bitrev(i)
+        "leaf_indices": [0, 1, idx],
+        "cap": tree.cap.0.iter().map(|h| hash_limbs(*h)).collect_vec(),
+        "proof_index": idx,
+        "proof_siblings": proof.siblings.iter().map(|h| hash_limbs(*h)).collect_vec(),
+    })
+}
+
+/// iop/challenger.rs with the configured hasher: a fixed observe / squeeze script
+fn challenger_section() -> Value {
+    let mut ch = Challenger::<F, H>::new();
+    ch.observe_elements(&[f(1), f(2), f(3)]);
+    let a = ch.get_n_challenges(2);
+    ch.observe_hash::<H>(HashOut { elements: [f(7), f(8), f(9), f(10)] });
+    let e = ch.get_extension_challenge::<D>();
+    let e: [F; D] = <<F as Extendable<D>>::Extension as plonky2::field::extension::FieldExtension<D>>::to_basefield_array(&e);
+    ch.observe_elements(&(11..=22u64).map(f).collect_vec()); // 12 elements: one full duplexing and 4 buffered
+    let b = ch.get_n_challenges(9);                          // empties the output buffer (8) and duplexes again
+    json!({
+        "script": "observe [1,2,3]; get 2; observe_hash [7,8,9,10]; get_extension; observe [11..=22]; get 9",
+        "first_two": us(&a), "extension": us(&e), "next_nine": us(&b),
+    })
+}
+
+fn point_json(p: Point) -> Value {
+    json!({ "encode": us(&p.encode().0), "fields": us(&p.to_fields()) }) // 5-limb w = y/x; 11-limb Weierstrass form (group_hashing/mod.rs:163-180)
+}
+
+/// plonky2_ecgfp5 through mp2-common/src/group_hashing: map_to_curve_point (field_to_curve.rs:36-48), point addition
+/// (curve_add.rs:17-22), doubling, scalar multiplication by a hash_to_int_value-sized scalar (mod.rs:220-225), to_weierstrass
+fn ecgfp5_section() -> Value {
+    let inputs: Vec<Vec<F>> = vec![vec![f(1), f(2), f(3)], (0..9u64).map(f).collect(), splitmix_field(17, 0xC0FFEE04)];
+    let pts: Vec<Point> = inputs.iter().map(|i| map_to_curve_point(i)).collect();
+    let h = HashOut { elements: [f(0x0123_4567_89AB_CDEF), f(0xFFFF_FFFF_0000_0000), f(3), f(4)] };
+    let int = hash_to_int_value(h);
+    let scalar = Scalar::from_noncanonical_biguint(int.clone());
+    json!({
+        "map_to_curve": inputs.iter().zip(&pts).map(|(i, p)| json!({"input": us(i), "point": point_json(*p)})).collect_vec(),
+        "add_0_1": point_json(pts[0] + pts[1]),
+        "sum_all": point_json(pts.iter().fold(Point::NEUTRAL, |acc, p| acc + *p)),
+        "double_0": point_json(pts[0] + pts[0]),
+        "neutral": point_json(Point::NEUTRAL),
+        "hash_to_int": { "hash": hash_limbs(h), "value": int.to_string(), "flatten": us(&flatten_poseidon_hash_value(h)) },
+        "scalar_mul_0": point_json(scalar * pts[0]),
+    })
+}
+
+/// One complete proof of a 2^5-row circuit under standard_recursion_config and everything a foreign prover needs to redo it:
+/// the gate list with selectors, the preprocessed polynomials' values on H, the full wire matrix, the verifier data and the
+/// proof as mp2-common/src/proof.rs:84-88 serialises it (bincode). The PoW witness is whatever rayon's find_any returned:
+/// compare everything before it bit for bit, then verify the whole proof.
+fn proof_section() -> Result<Value> {
+    let config = CircuitConfig::standard_recursion_config();
+    let mut b = CircuitBuilder::<F, D>::new(config);
+    let x = b.add_virtual_target();
+    let y = b.add_virtual_target();
+    let xy = b.mul(x, y);
+    let s = b.add(xy, x);
+    let c = b.constant(f(0xC0FFEE));
+    let t = b.mul_add(s, c, y);
+    b.register_public_input(x);
+    b.register_public_input(t);
+    while b.num_gates() < 20 {
+        b.add_gate(NoopGate, vec![]);
+    }
+    let data = b.build::<C>();
+    let mut pw = PartialWitness::new();
+    pw.set_target(x, f(3));
+    pw.set_target(y, f(0x1234_5678_9ABC_DEF0));
+    let n = data.common.degree();
+    let witness = generate_partial_witness(pw.clone(), &data.prover_only, &data.common).full_witness();
+    let wires: Vec<Vec<u64>> = (0..data.common.config.num_wires).map(|c| (0..n).map(|r| u(witness.get_wire(r, c))).collect()).collect();
+    let proof = data.prove(pw)?;
+    data.verify(proof.clone())?;
+    let pre = &data.prover_only.constants_sigmas_commitment;
+    let pre_values: Vec<Vec<u64>> = pre.polynomials.iter().map(|p| us(&p.clone().fft().values)).collect();
+    let sel = &data.common.selectors_info;
+    Ok(json!({
+        "degree_bits": data.common.degree_bits(),
+        "config": "CircuitConfig::standard_recursion_config()",
+        "gates": data.common.gates.iter().map(|g| g.0.id()).collect_vec(),
+        "selector_indices": sel.selector_indices,
+        "selector_groups": sel.groups.iter().map(|r| vec![r.start, r.end]).collect_vec(),
+        "num_constants": data.common.num_constants,
+        "k_is": us(&data.common.k_is),
+        "constants_sigmas": pre_values,   // selectors, then gate constants, then the 80 sigmas; values on H in natural order
+        "wires": wires,                   // [135][n]
+        "public_inputs": us(&proof.public_inputs),
+        "circuit_digest": hash_limbs(data.verifier_only.circuit_digest),
+        "constants_sigmas_cap": data.verifier_only.constants_sigmas_cap.0.iter().map(|h| hash_limbs(*h)).collect_vec(),
+        "proof_bincode_hex": hex::encode(serialize_proof(&proof)?),
+        "pow_witness": u(proof.proof.opening_proof.pow_witness),
+    }))
+}
+
+fn main() -> Result<()> {
+    let out = env::args().nth(1).unwrap_or_else(|| "reference_vectors.json".to_string());
+    let default_hasher = if cfg!(feature = "original_poseidon") { "poseidon" } else { "poseidon2" };
+    let doc = json!({
+        "schema": 1,
+        "source": "reference (Lagrange-Labs/mapreduce-plonky2 v3.0.0 workspace, its Cargo.lock)",
+        "default_hasher": default_hasher,
+        "field": {
+            "order": F::ORDER,
+            "multiplicative_group_generator": u(F::MULTIPLICATIVE_GROUP_GENERATOR),
+            "power_of_two_generator": u(F::POWER_OF_TWO_GENERATOR),
+            "two_adicity": F::TWO_ADICITY,
+            "coset_shift": u(F::coset_shift()),
+            "root_of_unity_log3": u(F::primitive_root_of_unity(3)),
+            "root_of_unity_log6": u(F::primitive_root_of_unity(6)),
+        },
+        "hashers": { "poseidon2": hasher_section::<P2>(), "poseidon": hasher_section::<P1>() },
+        // mp2-v1/src/values_extraction/mod.rs:157-160 under the compiled configuration
+        "identifier_block_column": mp2_v1::values_extraction::identifier_block_column(),
+        "fft": { "3": fft_section(3), "10": fft_section(10) },
+        "polynomial_batch": batch_section(),
+        "challenger": challenger_section(),
+        "ecgfp5": ecgfp5_section(),
+        "proof": proof_section()?,
+    });
+    let mut file = File::create(&out)?;
+    file.write_all(serde_json::to_string(&doc)?.as_bytes())?;
+    eprintln!("wrote {out}");
+    Ok(())
+}
