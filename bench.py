@@ -1032,7 +1032,19 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
             b_.free()
 
     side = world == 1  # the side legs run at N = 1 only (like cpu_baseline): the scaling runs time the table build and nothing else
-    config2 = config2_leg(rig, args.config2_leaves) if side and args.config2_leaves > 0 else None
+    # a side leg that fails must not take the headline with it: its field then carries the error, `side_leg_errors` names it
+    side_errors = []
+
+    def guarded(name, fn):
+        try:
+            return fn()
+        except BaseException as e:  # SystemExit of a failed self-check included
+            import traceback
+            traceback.print_exc()
+            side_errors.append(name)
+            return {"error": f"{type(e).__name__}: {e}"[:400]}
+
+    config2 = guarded("config2", lambda: config2_leg(rig, args.config2_leaves)) if side and args.config2_leaves > 0 else None
     legs = kernel_legs(ctx, mp2, C, VARIANT, args.hasher, rank) if rank == 0 else None
     shapes = params.shapes()
     mem_free, mem_total = ctx.mem_info()  # with every prover of the run still alive: what the planner's estimate is calibrated on
@@ -1045,23 +1057,27 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     by_degree = None
     if side and args.degree_sweep:
         by_degree = {}
-        for k in [int(x) for x in args.degree_sweep.split(",") if x]:
+        def at_degree(k):
             bk = max(4, args.table_batch >> max(0, k - 12))  # proofs in flight per worker shrink with the degree: the same device memory at every k
             rk = TableRig(mods, local_rank, VARIANT, args.workers, bk, args.subtree, args.host_witness, ranks_here, pad_bits=k)
-            rk.build(min(64, args.sweep_rows), 0, seed ^ 0x5A5A5A, n_cols, False)
-            for c in rk.ctxs:
-                c.sync()
-            n0k = rk.n_proofs
-            t1 = time.perf_counter()
-            stk = rk.build(args.sweep_rows, 0, seed, n_cols, False)
-            for c in rk.ctxs:
-                c.sync()
-            dtk = time.perf_counter() - t1
-            rk.check_root(stk, verify=not args.no_verify)
-            by_degree[str(k)] = {"value": (rk.n_proofs - n0k) / dtk, "unit": "proofs/s", "rows": args.sweep_rows, "seconds": dtk, "batch": bk,
-                                 "shapes": rk.params.shapes(), "setup_s": round(rk.setup_s, 1), "root_verified": not args.no_verify}
-            del stk
-            rk.close()
+            try:
+                rk.build(min(64, args.sweep_rows), 0, seed ^ 0x5A5A5A, n_cols, False)
+                for c in rk.ctxs:
+                    c.sync()
+                n0k = rk.n_proofs
+                t1 = time.perf_counter()
+                stk = rk.build(args.sweep_rows, 0, seed, n_cols, False)
+                for c in rk.ctxs:
+                    c.sync()
+                dtk = time.perf_counter() - t1
+                rk.check_root(stk, verify=not args.no_verify)
+                return {"value": (rk.n_proofs - n0k) / dtk, "unit": "proofs/s", "rows": args.sweep_rows, "seconds": dtk, "batch": bk,
+                        "shapes": rk.params.shapes(), "setup_s": round(rk.setup_s, 1), "root_verified": not args.no_verify}
+            finally:
+                rk.close()
+
+        for k in [int(x) for x in args.degree_sweep.split(",") if x]:
+            by_degree[str(k)] = guarded(f"by_base_degree[{k}]", lambda k=k: at_degree(k))
 
     # the prove()-only loop on synthetic circuits (round 2's headline) beside it, briefly
     leaves = None
@@ -1069,7 +1085,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         import copy
         a2 = copy.copy(args)
         a2.steps, a2.warmup, a2.batch = 3, 1, 128
-        leaves = run_leaves(a2, rank, local_rank, world, dist, torch, VARIANT, clocks, brief=True)
+        leaves = guarded("leaves_prove_only", lambda: run_leaves(a2, rank, local_rank, world, dist, torch, VARIANT, clocks, brief=True))
     out = None
     if rank == 0:
         rows_per_s = world * n_rows / dt
@@ -1107,8 +1123,11 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         if by_degree is not None:
             out["by_base_degree"] = by_degree
         if leaves is not None:
-            out["leaves_prove_only"] = {"value": leaves["value"], "unit": "leaf proofs/s (base 2^13 + wrap 2^12 prove() on synthetic circuits, resident witnesses: "
-                                        "`--workload leaves`, round 2's headline)", "ms_per_step": leaves["ms_per_step"], "batch": 128}
+            out["leaves_prove_only"] = leaves if "error" in leaves else {
+                "value": leaves["value"], "unit": "leaf proofs/s (base 2^13 + wrap 2^12 prove() on synthetic circuits, resident witnesses: "
+                "`--workload leaves`, round 2's headline)", "ms_per_step": leaves["ms_per_step"], "batch": 128}
+        if side_errors:
+            out["side_leg_errors"] = side_errors
         out.update(legs)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
@@ -1116,6 +1135,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     clocks.close()
     if dist is not None:
         dist.destroy_process_group()
+    if side_errors:  # the headline stands (exit code 0); the line names the failed legs in `side_leg_errors` and in their own fields
+        print(f"bench.py: side leg(s) failed: {', '.join(side_errors)}", file=sys.stderr)
     return out
 
 

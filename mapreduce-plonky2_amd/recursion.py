@@ -1081,7 +1081,117 @@ def eval_gate_circuit(b, g, consts, wires, pih):
         val = at(w_val)
         out += [b.sub_ext(val[0], ev[0]), b.sub_ext(val[1], ev[1])]
         return out
+    if k == C.MUL_EXT:  # gates/multiplication_extension.rs: 3 D wires per operation
+        for i in range(g.p0):
+            m0, m1, o = [(wires[6 * i + 2 * j], wires[6 * i + 2 * j + 1]) for j in range(3)]
+            pr = alg_mul(b, m0, m1)
+            out += [b.sub_ext(o[j], b.mul_ext(pr[j], consts[0])) for j in range(2)]
+        return out
+    if k == C.EXPONENTIATION:  # gates/exponentiation.rs: base 0, bits 1..nb (most significant first in the loop), output nb+1, intermediates
+        nb = g.p0
+        base, one = wires[0], b.one_ext()
+        for i in range(nb):
+            prev = one if i == 0 else b.mul_ext(wires[nb + 2 + i - 1], wires[nb + 2 + i - 1])
+            bit = wires[1 + (nb - 1 - i)]
+            mulby = b.add_ext(b.mul_ext(bit, base), b.sub_ext(one, bit))
+            out.append(b.mul_sub_ext(prev, mulby, wires[nb + 2 + i]))
+        out.append(b.sub_ext(wires[nb + 1], wires[nb + 2 + nb - 1]))
+        return out
+    if k in (C.U32_ARITHMETIC, C.U32_RANGE_CHECK, C.U32_SUBTRACTION, C.U32_ADD_MANY, C.COMPARISON):
+        return eval_u32_gate_circuit(b, g, wires)
     raise NotImplementedError(f"no in-circuit evaluator for gate kind {k}")
+
+
+def _limb_range(b, limb, base):
+    """limb (limb - 1) ... (limb - (base - 1))"""
+    pr = limb
+    for x in range(1, base):
+        pr = b.mul_ext(pr, b.add_const_ext(limb, P - x))
+    return pr
+
+
+def _limb_sum(b, limbs, base):
+    """sum_j limbs[j] base^j by Horner from the most significant limb"""
+    acc = b.zero_ext()
+    for x in reversed(limbs):
+        acc = b.mul_const_add_ext(base, acc, x)
+    return acc
+
+
+def eval_u32_gate_circuit(b, g, wires):
+    """the plonky2-u32 / plonky2_crypto gates a leaf circuit of the reference carries (mp2-common/src/serialization/
+    circuit_data_serialization.rs:254-262), constraint by constraint in the order of oracle/gates_body.inc (the prover's evaluators)"""
+    k, out = g.kind, []
+    one, two32 = b.one_ext(), 1 << 32
+    if k == C.U32_ARITHMETIC:  # per op m0, m1, addend, output_low, output_high, inverse; 32 two-bit limbs of the 64-bit output
+        ops = g.p0
+        for i in range(ops):
+            m0, m1, ad, lo, hi, inv_w = wires[6 * i:6 * i + 6]
+            computed = b.mul_add_ext(m0, m1, ad)
+            diff = b.sub_ext(b.constant_ext((0xFFFFFFFF, 0)), hi)
+            hi_not_max = b.mul_sub_ext(inv_w, diff, one)
+            out.append(b.mul_ext(hi_not_max, lo))
+            out.append(b.sub_ext(b.mul_const_add_ext(two32, hi, lo), computed))
+            limbs = [wires[6 * ops + 32 * i + j] for j in range(32)]
+            out += [_limb_range(b, limbs[j], 4) for j in reversed(range(32))]
+            out.append(b.sub_ext(_limb_sum(b, limbs[:16], 4), lo))
+            out.append(b.sub_ext(_limb_sum(b, limbs[16:], 4), hi))
+        return out
+    if k == C.U32_RANGE_CHECK:  # inputs 0..k, 16 two-bit limbs per input after them
+        n_in = g.p0
+        for i in range(n_in):
+            limbs = [wires[n_in + 16 * i + j] for j in range(16)]
+            out.append(b.sub_ext(_limb_sum(b, limbs, 4), wires[i]))
+            out += [_limb_range(b, x, 4) for x in limbs]
+        return out
+    if k == C.U32_SUBTRACTION:  # per op x, y, borrow_in, result, borrow_out; 16 two-bit limbs of the result
+        ops = g.p0
+        for i in range(ops):
+            x, y, bi, res, bo = wires[5 * i:5 * i + 5]
+            initial = b.sub_ext(b.sub_ext(x, y), bi)
+            out.append(b.sub_ext(res, b.mul_const_add_ext(two32, bo, initial)))
+            limbs = [wires[5 * ops + 16 * i + j] for j in range(16)]
+            out += [_limb_range(b, limbs[j], 4) for j in reversed(range(16))]
+            out.append(b.sub_ext(_limb_sum(b, limbs, 4), res))
+            out.append(b.mul_ext(bo, b.sub_ext(one, bo)))
+        return out
+    if k == C.U32_ADD_MANY:  # per op p0 addends, carry_in, result, carry_out; 16 result + 2 carry limbs
+        na, ops, per = g.p0, g.p1, g.p0 + 3
+        for i in range(ops):
+            w = wires[per * i:per * i + per]
+            computed = w[na]
+            for j in range(na):
+                computed = b.add_ext(computed, w[j])
+            res, co = w[na + 1], w[na + 2]
+            out.append(b.sub_ext(b.mul_const_add_ext(two32, co, res), computed))
+            limbs = [wires[per * ops + 18 * i + j] for j in range(18)]
+            out += [_limb_range(b, limbs[j], 4) for j in reversed(range(18))]
+            out.append(b.sub_ext(_limb_sum(b, limbs[:16], 4), res))
+            out.append(b.sub_ext(_limb_sum(b, limbs[16:], 4), co))
+        return out
+    # ComparisonGate: first <= second over p0 bits in p1 chunks
+    nc = g.p1
+    cb = (g.p0 + nc - 1) // nc
+    cs = 1 << cb
+    fc, sc, ed, ce, iv = [[wires[4 + q * nc + i] for i in range(nc)] for q in range(5)]
+    bits = [wires[4 + 5 * nc + i] for i in range(cb + 1)]
+    out.append(b.sub_ext(_limb_sum(b, fc, cs), wires[0]))
+    out.append(b.sub_ext(_limb_sum(b, sc, cs), wires[1]))
+    msd = b.zero_ext()
+    for i in range(nc):
+        out.append(_limb_range(b, fc[i], cs))
+        out.append(_limb_range(b, sc[i], cs))
+        diff = b.sub_ext(sc[i], fc[i])
+        out.append(b.sub_ext(b.mul_ext(diff, ed[i]), b.sub_ext(one, ce[i])))
+        out.append(b.mul_ext(ce[i], diff))
+        out.append(b.sub_ext(iv[i], b.mul_ext(ce[i], msd)))
+        msd = b.mul_add_ext(b.sub_ext(one, ce[i]), diff, iv[i])
+    out.append(b.sub_ext(wires[3], msd))
+    bc = _limb_sum(b, bits, 2)
+    out += [b.mul_ext(x, b.sub_ext(one, x)) for x in bits]
+    out.append(b.sub_ext(b.add_const_ext(wires[3], cs), bc))
+    out.append(b.sub_ext(wires[2], bits[cb]))
+    return out
 
 
 def alg_mul(b, x, y):

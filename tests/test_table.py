@@ -129,6 +129,19 @@ def test_base_degree_padding_and_reference_gate_set():
     cap, cd = verifier_data(padded)
     caps, openings, proof, _ = C.prove(padded, fp, cd)
     assert C.verify(padded, fp, cd, padded.pi_hash, caps, openings, proof) == 0
+    # the wrap step over it: plonky2's recursive verifier evaluates EVERY gate of the inner circuit in-circuit, the u32 / comparison /
+    # exponentiation / MulExtension gates of the leaf set included (recursion.eval_gate_circuit); the strict builder stops at the first
+    # constraint that does not match the opened values, and the wrap circuit's own witness satisfies all of its gates
+    sfp = C.oracle_params(padded)
+    sc, so, sp, _ = C.prove(padded, sfp, cd)
+    inner = R.InnerCircuit(padded, sfp, cap, cd, len(padded.public_inputs))
+    wrap = R.wrap_circuit(inner, sc, so, sp, padded.public_inputs)
+    assert wrap.log_n in (12, 13) and np.array_equal(wrap.public_inputs, padded.public_inputs)
+    assert not C.eval_on_points(wrap, wrap.pre[:wrap.num_constants], wrap.wires).any()
+    tampered = so.copy()
+    tampered[padded.num_constants + PC.NUM_ROUTED + 3, 0] ^= np.uint64(1)  # one opened wire value
+    with pytest.raises(AssertionError):
+        R.wrap_circuit(inner, sc, tampered, sp, padded.public_inputs)
     bad = padded.wires.copy()
     row = next(i for i, g in enumerate(padded.instances) if padded.gates[g].kind == PC.COMPARISON)
     bad[2, row] ^= 1  # the comparison gate's result bit
