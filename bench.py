@@ -1050,6 +1050,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     mem_free, mem_total = ctx.mem_info()  # with every prover of the run still alive: what the planner's estimate is calibrated on
     setup_s, workers, host_threads, plan = rig.setup_s, len(rig.ctxs), rig.host_threads, rig.plan
     root_pis_out = [int(x) for x in cur[0][3]]
+    waves = [[n_items, n_pr, round(sec, 2)] for n_items, n_pr, sec in st["build"].wave_log]
     del st
     rig.close()
 
@@ -1105,7 +1106,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                                       "full size = `config2`; base degrees 12..15 = `by_base_degree`; roofline leg = configs[1] 2^22-point NTT",
                           "rows_per_rank": n_rows, "rows_per_step": args.rows, "row_tree_depth": depth, "warmup_rows_per_rank": args.warmup * args.rows,
                           "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "pad_base_bits": args.pad_base_bits,
-                          "lean": bool(lean),
+                          "lean": bool(lean), "work_plan_waves": waves,  # per wave of the work plan: [items, framework proofs, seconds]
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "ranks_on_host": ranks_here, "shapes": shapes,
                           "device_memory_used_bytes": mem_total - mem_free, "device_memory_planned_bytes": plan["device_bytes_per_rank"],

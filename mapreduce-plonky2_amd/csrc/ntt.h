@@ -10,6 +10,7 @@ namespace mp2g {
 struct NttPlan {
   u32 log_n = 0, log_n1 = 0, log_n2 = 0;
   u64 *tw_a = nullptr, *tw_b = nullptr, *tw4_lo = nullptr, *tw4_hi = nullptr, *tw4_full = nullptr;
+  u64 *tc_a = nullptr, *tc_b = nullptr;  // merged twiddles of the shift-twiddle scheme (pass A / pass B), null where the pass size does not run it
   u64 n_inv = 0;
   ~NttPlan();
 };

@@ -48,6 +48,7 @@ struct NttArgs {
   u64 post;              // scalar multiplied on the final store (n^-1 for inverse), 0 = none
   u32 bitrev_out;
   u32 inverse;           // tables hold powers of the inverse root: the w_8 constants inside a butterfly follow
+  const u64* tc;         // shift-twiddle scheme (ShiftGeom): [64][2^(LT-6)] merged twiddles w_T^(b (r + 8 r')) of this pass; null = classic tables
 };
 
 // lanes per block: one radix-2^NTT_RMAX item per lane and round
@@ -119,9 +120,60 @@ template <int K> __device__ __forceinline__ u64 gl_sub_mul_w8(u64 u, u64 v) {  /
 template <int K> __device__ __forceinline__ u64 bfly_lo(u64 u, u64 v, bool inverse) {
   return inverse ? gl_sub_mul_w8<4 - K>(v, u) : gl_sub_mul_w8<K>(u, v);
 }
+// x * 2^S (mod p) for a compile-time S in [0, 192), canonical in and out: 2^96 = -1, 2^64 = 2^32 - 1. POWER_OF_TWO_GENERATOR gives
+// w_64 = 2^3, so every twiddle of a sub-transform of at most 64 points is such a shift (12-18 issue slots against 29 for a general
+// multiplication with a table load in front of it)
+template <int S> __device__ __forceinline__ u64 gl_mul_2pow(u64 x) {
+  static_assert(S >= 0 && S < 192, "exponent mod 192");
+  if constexpr (S == 0) return x;
+  else if constexpr (S >= 96) return gl_neg(gl_mul_2pow<S - 96>(x));
+  else if constexpr (S <= 32) return gl_canon(gl_reduce96w(x << S, x >> (64 - S)));
+  else if constexpr (S < 64) return gl_reduce128(x << S, x >> (64 - S));
+  else if constexpr (S == 64) return gl_reduce128(0, x);
+  else {  // x 2^S = (x << K) 2^64 with x << K = h 2^64 + t, and 2^128 = -2^32: h < 2^31, so h 2^32 is canonical
+    constexpr int K = S - 64;
+    return gl_sub(gl_reduce128(0, x << K), (x >> (64 - K)) << 32);
+  }
+}
+// Shift-twiddle scheme (one-barrier kernels, ShiftGeom below). The twiddle after the first radix-8 round is w_T^(j r) with j the
+// L0 = LT - 3 index bits still to transform and r the round's output frequency. Split j = a 2^(L0-3) + b (a = its top three bits):
+//   w_T^(j r) = w_64^(a r) * w_T^(b r).
+// The first factor is a power of two -- and `a` is the SAME for all lanes of a wave in these tile shapes, so a scalar switch picks
+// code with compile-time shift amounts; the second factor does not depend on the bits the NEXT round transforms (a), so it moves
+// behind that round and merges with its own twiddle w_{T/8}^(b r') into ONE table entry w_T^(b (r + 8 r')) (args.tc, [64][2^(L0-3)],
+// row r + 8 r'; r is wave-uniform in the second round: a wave owns one output block of the first). Two table multiplications
+// per point become one shift and one table multiplication.
+template <int A, bool INV, int M> __device__ __forceinline__ u64 shift_tw1(u64 x) {
+  constexpr int R = ((M & 1) << 2) | (M & 2) | (M >> 2);
+  constexpr int E = (A * R) & 63;
+  return gl_mul_2pow<3 * (INV ? (64 - E) & 63 : E)>(x);
+}
+template <int A, bool INV> __device__ __forceinline__ void shift_tw(u64* x) {
+  x[1] = shift_tw1<A, INV, 1>(x[1]); x[2] = shift_tw1<A, INV, 2>(x[2]); x[3] = shift_tw1<A, INV, 3>(x[3]); x[4] = shift_tw1<A, INV, 4>(x[4]);
+  x[5] = shift_tw1<A, INV, 5>(x[5]); x[6] = shift_tw1<A, INV, 6>(x[6]); x[7] = shift_tw1<A, INV, 7>(x[7]);
+}
+// a: wave-uniform (the caller passes it through readfirstlane, so this is a scalar branch, not eight masked passes)
+template <bool INV> __device__ __forceinline__ void shift_twiddles_dir(u64* x, int a) {
+  switch (a) {
+    case 1: shift_tw<1, INV>(x); break;
+    case 2: shift_tw<2, INV>(x); break;
+    case 3: shift_tw<3, INV>(x); break;
+    case 4: shift_tw<4, INV>(x); break;
+    case 5: shift_tw<5, INV>(x); break;
+    case 6: shift_tw<6, INV>(x); break;
+    case 7: shift_tw<7, INV>(x); break;
+    default: break;
+  }
+}
+__device__ __forceinline__ void shift_twiddles(u64* x, int a, bool inverse) {
+  if (inverse) shift_twiddles_dir<true>(x, a); else shift_twiddles_dir<false>(x, a);
+}
+
 // the 2^R-point DIF butterfly of one lane (R = 3: true radix-8 with the w_8 shifts; R < 3: the last, partial round) followed by
 // the round's general twiddles w_T^(E r), r = bitrev3(m), looked up at [r-1][below]
-template <int LT, int HI, int R, bool TWG = false>
+// MERGED: the second round of the shift-twiddle scheme -- twg = the wave's rows of args.tc (row r of the first round's output
+// block), every output m (0 included) is multiplied by twg[(8 r'(m)) << LO | below]
+template <int LT, int HI, int R, bool TWG = false, bool MERGED = false>
 __device__ __forceinline__ void butterfly(u64* x, int below, const u64* tw, const u64* __restrict__ twg, bool inverse) {
   constexpr int LO = HI - R + 1;
   constexpr int RHO = (LT - 1 - HI) / 3;
@@ -143,10 +195,27 @@ __device__ __forceinline__ void butterfly(u64* x, int below, const u64* tw, cons
 #pragma unroll
     for (int m = 0; m < 8; m += 2) {
       u64 u = x[m], v = x[m + 1];
-      x[m] = (LO > 0 && m > 0) ? gl_addw(u, v) : gl_add(u, v);
+      x[m] = (MERGED || (LO > 1 && m > 0)) ? gl_addw(u, v) : gl_add(u, v);  // weak only where a table multiplication follows
       x[m + 1] = gl_sub(u, v);
     }
-    if constexpr (LO > 0) {
+    if constexpr (MERGED) {
+#pragma unroll
+      for (int m = 0; m < 8; m++) {
+        const int r = ((m & 1) << 2) | (m & 2) | (m >> 2);
+        x[m] = gl_mul(x[m], twg[((8 * r) << LO) + below]);
+      }
+    } else if constexpr (LO == 1) {
+      // sub-transforms of 16 points: w_16 = 2^12, the twiddle of output m is 2^(12 r) for the odd `below`, 1 for the even one
+      if (inverse) {
+        x[1] = below ? gl_mul_2pow<192 - 48>(x[1]) : x[1]; x[2] = below ? gl_mul_2pow<192 - 24>(x[2]) : x[2]; x[3] = below ? gl_mul_2pow<192 - 72>(x[3]) : x[3];
+        x[4] = below ? gl_mul_2pow<192 - 12>(x[4]) : x[4]; x[5] = below ? gl_mul_2pow<192 - 60>(x[5]) : x[5]; x[6] = below ? gl_mul_2pow<192 - 36>(x[6]) : x[6];
+        x[7] = below ? gl_mul_2pow<192 - 84>(x[7]) : x[7];
+      } else {
+        x[1] = below ? gl_mul_2pow<48>(x[1]) : x[1]; x[2] = below ? gl_mul_2pow<24>(x[2]) : x[2]; x[3] = below ? gl_mul_2pow<72>(x[3]) : x[3];
+        x[4] = below ? gl_mul_2pow<12>(x[4]) : x[4]; x[5] = below ? gl_mul_2pow<60>(x[5]) : x[5]; x[6] = below ? gl_mul_2pow<36>(x[6]) : x[6];
+        x[7] = below ? gl_mul_2pow<84>(x[7]) : x[7];
+      }
+    } else if constexpr (LO > 0) {
       const u64* tab = (TWG || RHO < R8Tw<LT>::GLOBAL_ROUNDS) ? twg + R8Tw<LT>::off(RHO) : tw + (R8Tw<LT>::off(RHO) - R8Tw<LT>::LDS_OFF);
 #pragma unroll
       for (int m = 1; m < 8; m++) {
@@ -370,14 +439,23 @@ template <int LT, int LW, bool COLS> struct WaveGeom {
   static constexpr int LWL = 9 - LTS;          // log2 of the sub-transforms (rows) / columns of a wave's 512 points
   static constexpr bool OK = LT >= 3 && LT <= 13 && (!COLS || LT <= 12) && ((1 << LT) << LW) == 8 * NttGeom<LT, LW>::NT && (!COLS || LW >= LWL);
 };
+// tile shapes that run the shift-twiddle scheme: the three index bits `a` below the first round's are wave-uniform in the first round
+// (rows: lane = position, so 2^(L0-3) >= 64; columns: lane = (row bits, column), so 2^(LW + L0 - 3) >= 64) and the first wave-local
+// round is a full radix-8 one whose block (the first round's output index) is wave-uniform
+template <int LT, int LW, bool COLS> struct ShiftGeom {
+  using G = WaveGeom<LT, LW, COLS>;
+  static constexpr int L0 = LT - 3;
+  static constexpr bool OK = G::OK && G::NBR == 1 && G::LTS >= 6 && (COLS ? (LW + L0 - 3 >= 6) : (LW == 0 && L0 - 3 >= 6));
+  static constexpr int TC_WORDS = 64 << (L0 - 3);
+};
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // one round of the sub-transforms of length 2^LTS inside the 512 points at `base`; LWS = log2 of the tile's row stride (COLS)
-template <int LT, int LTS, int HI, int R, bool COLS, int LWL, int LWS>
-__device__ __forceinline__ void wave_round(u64* s, int base, const u64* tw, int lane, bool inverse) {
+template <int LT, int LTS, int HI, int R, bool COLS, int LWL, int LWS, bool MERGED = false>
+__device__ __forceinline__ void wave_round(u64* s, int base, const u64* tw, int lane, bool inverse, const u64* __restrict__ tcw = nullptr) {
   constexpr int LO = HI - R + 1, WL = 1 << LWL;
   constexpr int ITEMS = 512 >> R;
 #pragma unroll
@@ -394,7 +472,7 @@ __device__ __forceinline__ void wave_round(u64* s, int base, const u64* tw, int 
       int j = j0 + (m << LO);
       x[m] = s[lds_pad(base + (COLS ? (j << LWS) + c : (c << LTS) + j))];
     }
-    butterfly<LT, HI, R>(x, below, tw, nullptr, inverse);
+    butterfly<LT, HI, R, false, MERGED>(x, below, tw, tcw, inverse);
 #pragma unroll
     for (int m = 0; m < (1 << R); m++) {
       int j = j0 + (m << LO);
@@ -402,19 +480,21 @@ __device__ __forceinline__ void wave_round(u64* s, int base, const u64* tw, int 
     }
   }
 }
-template <int LT, int LTS, int HI, bool COLS, int LWL, int LWS>
-__device__ __forceinline__ void wave_rounds(u64* s, int base, const u64* tw, int lane, bool inverse) {
+// tcw != nullptr only in the instantiations with SHIFT: the first of these rounds then takes the merged table
+template <int LT, int LTS, int HI, bool COLS, int LWL, int LWS, bool SHIFT = false>
+__device__ __forceinline__ void wave_rounds(u64* s, int base, const u64* tw, int lane, bool inverse, const u64* __restrict__ tcw = nullptr) {
   if constexpr (HI >= 0) {
     constexpr int R = (HI + 1 >= 3) ? 3 : HI + 1;
     wave_sync();
-    wave_round<LT, LTS, HI, R, COLS, LWL, LWS>(s, base, tw, lane, inverse);
-    wave_rounds<LT, LTS, HI - R, COLS, LWL, LWS>(s, base, tw, lane, inverse);
+    wave_round<LT, LTS, HI, R, COLS, LWL, LWS, SHIFT>(s, base, tw, lane, inverse, tcw);
+    wave_rounds<LT, LTS, HI - R, COLS, LWL, LWS, false>(s, base, tw, lane, inverse);
   }
 }
 
-template <int LT, int LW>
+template <int LT, int LW, bool SHIFT = false>
 __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_rows_v2_kernel(NttArgs a) {
   using G = WaveGeom<LT, LW, false>;
+  static_assert(!SHIFT || ShiftGeom<LT, LW, false>::OK, "tile shape without wave-uniform shift twiddles");
   constexpr int T = 1 << LT, E = T << LW, NT = NttGeom<LT, LW>::NT, LTS = G::LTS, L0 = LT - 3;
   extern __shared__ __align__(16) u64 smem[];
   u64* s = smem;
@@ -454,7 +534,12 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_rows
       for (int m = 0; m < 8; m++) x[m] = 0;
     }
 #if NTT_DBG != 1
-    butterfly<LT, LT - 1, 3, true>(x, below, tw, a.tw, inverse);
+    if constexpr (SHIFT) {
+      butterfly<LT, 2, 3>(x, 0, nullptr, nullptr, inverse);  // the radix-8 butterfly alone (HI = 2: no table)
+      shift_twiddles(x, __builtin_amdgcn_readfirstlane(below >> (L0 - 3)), inverse);
+    } else {
+      butterfly<LT, LT - 1, 3, true>(x, below, tw, a.tw, inverse);
+    }
 #endif
 #pragma unroll
     for (int m = 0; m < 8; m++) s[lds_pad((c << LT) + below + (m << L0))] = x[m];
@@ -465,7 +550,13 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_rows
     dif_round<LT, LT - 4, 3, false, LW, NT>(s, tw, a.tw, tid, inverse);
     __syncthreads();
   }
-  wave_rounds<LT, LTS, LTS - 1, false, G::LWL, 0>(s, wave << 9, tw, lane, inverse);
+  if constexpr (SHIFT) {
+    // wave m owns the first round's output block m, whose frequency is r = bitrev3(m): rows r + 8 r' of the merged table
+    const int r = __builtin_amdgcn_readfirstlane((int)bitrev32((u32)(wave & 7), 3));
+    wave_rounds<LT, LTS, LTS - 1, false, G::LWL, 0, true>(s, wave << 9, tw, lane, inverse, a.tc + (r << (L0 - 3)));
+  } else {
+    wave_rounds<LT, LTS, LTS - 1, false, G::LWL, 0>(s, wave << 9, tw, lane, inverse);
+  }
 #endif
   if (a.bitrev_out) {
     wave_sync();
@@ -502,9 +593,10 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_rows
   }
 }
 
-template <int LT, int LW>
+template <int LT, int LW, bool SHIFT = false>
 __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_cols_v2_kernel(NttArgs a, u64* dst_dense) {
   using G = WaveGeom<LT, LW, true>;
+  static_assert(!SHIFT || ShiftGeom<LT, LW, true>::OK, "tile shape without wave-uniform shift twiddles");
   constexpr int W = 1 << LW, E = (1 << LT) << LW, NT = NttGeom<LT, LW>::NT, LTS = G::LTS, LWL = G::LWL;
   extern __shared__ __align__(16) u64 smem[];
   u64* s = smem;
@@ -537,7 +629,12 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_cols
       for (int m = 0; m < 8; m++) x[m] = gl_mul(gl_mul(x[m], pl), a.pre_hi[((u64)coset << LT) + below + (m << LTS)]);
     }
 #if NTT_DBG != 1
-    butterfly<LT, LT - 1, 3, true>(x, below, tw, a.tw, inverse);
+    if constexpr (SHIFT) {
+      butterfly<LT, 2, 3>(x, 0, nullptr, nullptr, inverse);
+      shift_twiddles(x, __builtin_amdgcn_readfirstlane(below >> (LTS - 3)), inverse);
+    } else {
+      butterfly<LT, LT - 1, 3, true>(x, below, tw, a.tw, inverse);
+    }
 #endif
 #pragma unroll
     for (int m = 0; m < 8; m++) s[lds_pad(((below + (m << LTS)) << LW) + c)] = x[m];
@@ -547,7 +644,12 @@ __global__ void __launch_bounds__((NttGeom<LT, LW>::NT)) NTT_WAVES_ATTR ntt_cols
   {
     constexpr int GW = W >> LWL;  // column groups of a tile; wave = (top three row bits, column group)
     const int cg = wave & (GW - 1), jh = wave / GW;
-    wave_rounds<LT, LTS, LTS - 1, true, LWL, LW>(s, ((jh << LTS) << LW) + (cg << LWL), tw, lane, inverse);
+    if constexpr (SHIFT) {
+      const int r = __builtin_amdgcn_readfirstlane((int)bitrev32((u32)jh, 3));
+      wave_rounds<LT, LTS, LTS - 1, true, LWL, LW, true>(s, ((jh << LTS) << LW) + (cg << LWL), tw, lane, inverse, a.tc + (r << (LTS - 3)));
+    } else {
+      wave_rounds<LT, LTS, LTS - 1, true, LWL, LW>(s, ((jh << LTS) << LW) + (cg << LWL), tw, lane, inverse);
+    }
   }
 #endif
   __syncthreads();
@@ -589,6 +691,12 @@ __global__ void r8_round_twiddles_kernel(u64* out, u64 w, u32 lo, u32 shift) {
   if (i >= (7u << lo)) return;
   u32 r = (i >> lo) + 1, below = i & ((1u << lo) - 1);
   out[i] = gl_pow(w, ((u64)below << shift) * r);
+}
+// merged table of the shift-twiddle scheme: out[q << lb | b] = w^(b q), q < 64, b < 2^lb
+__global__ void merged_twiddles_kernel(u64* out, u64 w, u32 lb) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (64u << lb)) return;
+  out[i] = gl_pow(w, (u64)(i & ((1u << lb) - 1)) * (i >> lb));
 }
 __global__ void powers_kernel(u64* out, u64 base, u64 first, u64 stride_exp, u32 count) {
   // out[i] = first * base^(i * stride_exp)
@@ -636,6 +744,7 @@ static hipError_t dev_alloc(u64** p, size_t words) { return hipMalloc((void**)p,
 
 NttPlan::~NttPlan() {
   (void)hipFree(tw_a); (void)hipFree(tw_b); (void)hipFree(tw4_lo); (void)hipFree(tw4_hi); (void)hipFree(tw4_full);
+  (void)hipFree(tc_a); (void)hipFree(tc_b);
 }
 CosetTables::~CosetTables() { (void)hipFree(lo); (void)hipFree(hi); (void)hipFree(full); }
 
@@ -649,6 +758,26 @@ static u32 split_log_n1(u32 log_n) {
     if (v >= 7 && v <= 12 && (int)log_n - v >= 1 && (int)log_n - v <= 12) l1 = (u32)v;
   }
   return l1;
+}
+// points per block (measured on MI355X, tools/dbg/ntt_only.py): 4096 (256 lanes) for T <= 2^10 and
+// T = 2^12, 8192 (512 lanes, two blocks per CU) for T = 2^11 where the twiddle table is amortised
+template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : (LT == 11 ? 2 : 12 - LT); }  // 2^13: one row of 8192 points
+template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : (LT == 10 ? 3 : 12 - LT); }  // 2^10 x 8 columns: +4 % at 2^22 (ntt22.py)
+// pass sizes whose default tile shape runs the shift-twiddle scheme (ShiftGeom); MP2G_NTT_NOSHIFT=1 keeps the classic tables (A/B)
+static bool shift_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MP2G_NTT_NOSHIFT"); v = (e && atoi(e)) ? 0 : 1; }
+  return v != 0;
+}
+template <int LT> static constexpr bool shift_rows_lt() { return ShiftGeom<LT, rows_lw<LT>(), false>::OK; }
+template <int LT> static constexpr bool shift_cols_lt() { return ShiftGeom<LT, cols_lw<LT>(), true>::OK; }
+static bool shift_rows_ok(u32 lt) {
+  if (!shift_enabled()) return false;
+  switch (lt) { case 12: return shift_rows_lt<12>(); case 13: return shift_rows_lt<13>(); default: return false; }
+}
+static bool shift_cols_ok(u32 lt) {
+  if (!shift_enabled()) return false;
+  switch (lt) { case 9: return shift_cols_lt<9>(); case 10: return shift_cols_lt<10>(); case 11: return shift_cols_lt<11>(); case 12: return shift_cols_lt<12>(); default: return false; }
 }
 hipError_t NttEngine::plan(u32 log_n, bool inverse, NttPlan** out) {
   u32 key = log_n * 2 + (inverse ? 1 : 0);
@@ -679,9 +808,18 @@ hipError_t NttEngine::plan(u32 log_n, bool inverse, NttPlan** out) {
     }
     return hipSuccess;
   };
+  // merged tables of the shift-twiddle scheme for the pass sizes that run it (shift_rows_ok / shift_cols_ok)
+  auto merged_tw = [&](u64** dst, u64 base, u32 lt) -> hipError_t {
+    const u32 lb = lt - 6, count = 64u << lb;
+    HIPCHK(dev_alloc(dst, count));
+    hipLaunchKernelGGL(merged_twiddles_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, *dst, base, lb);
+    return hipGetLastError();
+  };
   HIPCHK(stage_tw(&p->tw_b, w2, p->log_n2));
+  if (shift_rows_ok(p->log_n2)) HIPCHK(merged_tw(&p->tc_b, w2, p->log_n2));
   if (p->log_n1) {
     HIPCHK(stage_tw(&p->tw_a, w1, p->log_n1));
+    if (shift_cols_ok(p->log_n1)) HIPCHK(merged_tw(&p->tc_a, w1, p->log_n1));
     HIPCHK(powers(&p->tw4_lo, wn, 4096));
     HIPCHK(powers(&p->tw4_hi, gl_pow(wn, 4096), log_n > 12 ? (1u << (log_n - 12)) : 1));
     if (log_n <= 22 && !getenv("MP2G_NTT_NOFULL")) {  // full 4-step table (<= 32 MB): one multiply per point instead of two
@@ -735,10 +873,6 @@ hipError_t NttEngine::ensure_scratch(size_t words) {
   return hipSuccess;
 }
 
-// points per block (measured on MI355X, tools/dbg/ntt_only.py): 4096 (256 lanes) for T <= 2^10 and
-// T = 2^12, 8192 (512 lanes, two blocks per CU) for T = 2^11 where the twiddle table is amortised
-template <int LT> static constexpr int rows_lw() { return LT >= 12 ? 0 : (LT == 11 ? 2 : 12 - LT); }  // 2^13: one row of 8192 points
-template <int LT> static constexpr int cols_lw() { return LT >= 11 ? 2 : (LT == 10 ? 3 : 12 - LT); }  // 2^10 x 8 columns: +4 % at 2^22 (ntt22.py)
 template <int LT, int LW> static size_t lds_bytes() {
   int e = (1 << LT) << LW;
   return (size_t)(e + (e >> 4) + 1 + R8Tw<LT>::LDS_WORDS + 1) * sizeof(u64);
@@ -769,6 +903,15 @@ static hipError_t launch_rows_lw(const NttArgs& a, bool nat_two_pass, hipStream_
   constexpr int NT = NttGeom<LT, LW>::NT;
   size_t lds = lds_bytes<LT, LW>();
   u64 total_rows = (u64)a.batch << a.log_n1;
+  if constexpr (ShiftGeom<LT, LW, false>::OK) {
+    if (!nat_two_pass && !use_v1() && a.tc) {
+      static bool flags[MP2G_MAX_DEVICES];
+      bool* attr = attr_flag(flags);
+      if (!*attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_rows_v2_kernel<LT, LW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); *attr = true; }
+      hipLaunchKernelGGL((ntt_rows_v2_kernel<LT, LW, true>), dim3((u32)((total_rows + (1u << LW) - 1) >> LW)), dim3(NT), lds, st, a);
+      return hipGetLastError();
+    }
+  }
   if constexpr (WaveGeom<LT, LW, false>::OK) {
     if (!nat_two_pass && !use_v1()) {
       static bool flags[MP2G_MAX_DEVICES];
@@ -803,6 +946,15 @@ template <int LT, int LW>
 static hipError_t launch_cols_lw(const NttArgs& a, u64* dst_dense, hipStream_t st) {
   constexpr int NT = NttGeom<LT, LW>::NT;
   size_t lds = lds_bytes<LT, LW>();
+  if constexpr (ShiftGeom<LT, LW, true>::OK) {
+    if (!use_v1() && a.tc) {
+      static bool flags[MP2G_MAX_DEVICES];
+      bool* attr = attr_flag(flags);
+      if (!*attr) { HIPCHK(hipFuncSetAttribute((const void*)ntt_cols_v2_kernel<LT, LW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); *attr = true; }
+      hipLaunchKernelGGL((ntt_cols_v2_kernel<LT, LW, true>), dim3(a.batch << (a.log_n2 - LW)), dim3(NT), lds, st, a, dst_dense);
+      return hipGetLastError();
+    }
+  }
   if constexpr (WaveGeom<LT, LW, true>::OK) {
     if (!use_v1()) {
       static bool flags[MP2G_MAX_DEVICES];
@@ -865,7 +1017,7 @@ hipError_t NttEngine::run(const u64* in, u64* out, u32 log_n, u32 polys, u32 log
   a.bitrev_out = bitrev_out ? 1 : 0;
   a.inverse = inverse ? 1 : 0;
   if (p->log_n1 == 0) {
-    a.tw = p->tw_b;
+    a.tw = p->tw_b; a.tc = p->tc_b;
     return dispatch_rows(p->log_n2, a, false, stream);
   }
   u64* dense = nullptr;
@@ -873,9 +1025,9 @@ hipError_t NttEngine::run(const u64* in, u64* out, u32 log_n, u32 polys, u32 log
     HIPCHK(ensure_scratch((size_t)a.batch << log_n));
     dense = scratch;
   }
-  a.tw = p->tw_a;
+  a.tw = p->tw_a; a.tc = p->tc_a;
   HIPCHK(dispatch_cols(p->log_n1, a, dense, stream));
-  a.tw = p->tw_b;
+  a.tw = p->tw_b; a.tc = p->tc_b;
   a.pre_lo = a.pre_hi = a.pre_full = nullptr;
   if (!bitrev_out) a.in = dense;
   return dispatch_rows(p->log_n2, a, !bitrev_out, stream);

@@ -29,6 +29,7 @@ curve gadgets on top).
 """
 import queue
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -381,15 +382,17 @@ class TableBuild:
         plan = ut.into_batched_workplan(self.subtree_size) if self.subtree_size > 1 else ut.into_workplan()
         row_proofs = {}
         self.row_proofs, self.cells_roots = row_proofs, {}  # kept after the run: what a checker re-proves sampled nodes from
+        self.wave_log = []
         with ThreadPoolExecutor(max_workers=len(self.sessions)) as ex:
             while True:
                 # one wave = every item that is Ready now; its items are disjoint subtrees and run concurrently. The plan is only
                 # polled again once the whole wave is done: polled with items outstanding it re-cuts the subtrees around them
                 # and hands out nodes a second time (updatetree.rs:479-515 builds an item from whatever is ready at the moment)
+                t_wave = time.perf_counter()
                 wave = W.drain_wave(plan)
                 if not wave:
                     break
-                futures = []
+                futures, n_before = [], self.n_proofs
                 for it in wave:
                     if it.subtree is not None:
                         keys = [int(k) for k in it.subtree.nodes()]
@@ -401,6 +404,7 @@ class TableBuild:
                     f.result()  # re-raises a worker's failure (an unsatisfied witness makes prove() refuse, as the reference panics)
                 for it in wave:
                     plan.done(it.k)
+                self.wave_log.append((len(wave), self.n_proofs - n_before, time.perf_counter() - t_wave))  # (items, proofs, seconds)
         assert plan.completed()
         plan.free()
         return row_proofs[root]

@@ -175,7 +175,7 @@ def test_bench_default_workload_is_the_table_build():
     assert line["leaves_prove_only"]["value"] > 0 and len(line["config"]["root_public_inputs"]) == T.ROWS_IO + 4
     assert line["config2"]["framework_proofs"] == 127 and line["config2"]["value"] > 0 and line["config2"]["root_verified"]
     k12 = line["by_base_degree"]["12"]
-    assert k12["value"] > 0 and k12["root_verified"] and all(ch[0] >= 12 for ch in k12["shapes"].values()) and k12["shapes"]["cells_leaf"] == [12, 12]
+    assert k12["value"] > 0 and k12["root_verified"] and all(ch[0] >= 12 for ch in k12["shapes"].values()) and k12["shapes"]["cells_leaf"][0] == 12 and k12["shapes"]["cells_leaf"][-1] == 12
     assert line["config"]["device_memory_used_bytes"] > 0
 
 
