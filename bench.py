@@ -596,6 +596,8 @@ def main(argv=None):
     ap.add_argument("--workers", type=int, default=4, help="--workload table: concurrent work-plan items per rank, one host thread + GPU stream + prover set each")
     ap.add_argument("--table-batch", type=int, default=32, help="--workload table: proofs per prove() launch sequence of a worker")
     ap.add_argument("--subtree", type=int, default=64, help="--workload table: into_batched_workplan(subtree_size), the rows of one work-plan item")
+    ap.add_argument("--group-rows", type=int, default=None, help="--workload table: rows a worker takes at a time = several work-plan items of one wave proved as one unit "
+                    "(cells trees in full batches, row-tree levels merged across the items); default 4 x --table-batch, 1 = one item at a time")
     ap.add_argument("--host-witness", action="store_true", help="--workload table / recursion: replay the witness programs on host threads (mp2g_witness_program_run_rows) "
                     "instead of on the device (mp2g_witness_program_run_dev, the default): the A/B switch")
     ap.add_argument("--lean", action="store_true", help="--workload table: keep only the frontier of the row tree in host memory (automatic above 16384 rows); the "
@@ -709,9 +711,9 @@ class TableRig:
     """what a table build runs on at one base degree: `workers` GPU contexts (= streams) with a prover set and a proof session each,
     and the two circuit sets (table.TableParams) built for that degree. pad_bits = 0: the circuits at their natural degrees."""
 
-    def __init__(self, mods, local_rank, variant, workers, batch, subtree, host_witness, ranks_here, pad_bits=0):
+    def __init__(self, mods, local_rank, variant, workers, batch, subtree, host_witness, ranks_here, pad_bits=0, group_rows=None):
         mp2, R, FW, C, T, IX = mods
-        self.mods, self.variant, self.batch, self.subtree, self.pad_bits = mods, variant, batch, subtree, pad_bits
+        self.mods, self.variant, self.batch, self.subtree, self.pad_bits, self.group_rows = mods, variant, batch, subtree, pad_bits, group_rows
         self.ctxs = [mp2.Context(local_rank) for _ in range(max(1, workers))]
         self.ctx = self.ctxs[0]
         self.provers = [FW.GpuProver(c, variant, witness_check=True, capacity=batch, device_witness=not host_witness) for c in self.ctxs]
@@ -739,7 +741,7 @@ class TableRig:
         root, nodes, spans = T.balanced_bst(n_rows)
         samples, keep = T.sample_nodes(nodes, spans)
         tb = T.TableBuild(self.params, self.sessions, batch=self.batch, subtree_size=self.subtree, host_threads=self.host_threads,
-                          keep_proofs=not lean, keep_nodes=keep if lean else ())
+                          keep_proofs=not lean, keep_nodes=keep if lean else (), group_rows=self.group_rows)
         wit = T.TableWitness(self.ctx, table, spans, self.variant)
         proof, name = tb.run(table, wit, root, nodes)
         self.n_proofs += tb.n_proofs
@@ -909,7 +911,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     mods = (mp2, R, FW, C, T, IX)
     n_cols, seed = 4, 0xC0FFEE04
     ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-    rig = TableRig(mods, local_rank, VARIANT, args.workers, args.table_batch, args.subtree, args.host_witness, ranks_here, pad_bits=args.pad_base_bits)
+    rig = TableRig(mods, local_rank, VARIANT, args.workers, args.table_batch, args.subtree, args.host_witness, ranks_here, pad_bits=args.pad_base_bits,
+                   group_rows=args.group_rows)
     params, ctx = rig.params, rig.ctx
     n_rows = max(1, args.steps) * args.rows           # the timed block of this rank
     lean = args.lean or n_rows > 16384                # a block this large keeps the frontier of the tree + the sampled nodes only
@@ -1060,7 +1063,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         by_degree = {}
         def at_degree(k):
             bk = max(4, args.table_batch >> max(0, k - 12))  # proofs in flight per worker shrink with the degree: the same device memory at every k
-            rk = TableRig(mods, local_rank, VARIANT, args.workers, bk, args.subtree, args.host_witness, ranks_here, pad_bits=k)
+            rk = TableRig(mods, local_rank, VARIANT, args.workers, bk, args.subtree, args.host_witness, ranks_here, pad_bits=k, group_rows=args.group_rows)
             try:
                 rk.build(min(64, args.sweep_rows), 0, seed ^ 0x5A5A5A, n_cols, False)
                 for c in rk.ctxs:
@@ -1105,7 +1108,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                                       "region; value = framework proofs/s (5 per row). The full 2^20-row build does not fit one GPU in a bench run (extrapolated below); configs[2] at "
                                       "full size = `config2`; base degrees 12..15 = `by_base_degree`; roofline leg = configs[1] 2^22-point NTT",
                           "rows_per_rank": n_rows, "rows_per_step": args.rows, "row_tree_depth": depth, "warmup_rows_per_rank": args.warmup * args.rows,
-                          "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "pad_base_bits": args.pad_base_bits,
+                          "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "group_rows": args.group_rows or 4 * args.table_batch, "pad_base_bits": args.pad_base_bits,
                           "lean": bool(lean), "work_plan_waves": waves,  # per wave of the work plan: [items, framework proofs, seconds]
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "ranks_on_host": ranks_here, "shapes": shapes,

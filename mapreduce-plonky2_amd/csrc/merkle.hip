@@ -11,6 +11,7 @@
 // polynomial-major in HBM so that lane i reading limb p of leaf i is a perfectly coalesced
 // 8 B/lane stream (no transposed copy of the 8n x w matrix is ever materialised).
 #include "merkle.h"
+#include <cstdlib>
 #include "poseidon_wave.cuh"
 
 namespace mp2g {
@@ -46,6 +47,40 @@ __global__ void __launch_bounds__(256) leaf_hash_poly_major_kernel(const u64* __
   d[0] = make_ulonglong2(s[0], s[1]);
   d[1] = make_ulonglong2(s[2], s[3]);
 }
+// Two sponges per lane (leaves i and i + n/2: both loads stay coalesced streams): the experiment the round-3 review asked for
+// (MP2G_LEAF_ILP2=1; tools/dbg/sponge_ilp2.sh holds the numbers). Poseidon2 only, n even, w > 4.
+// the body shared by the two builds below
+#define LEAF_ILP2_BODY                                                                                      \
+  const u64 half = n >> 1;                                                                                  \
+  u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;                                                       \
+  if (i >= half) return;                                                                                    \
+  values += blockIdx.y * in_bstride;                                                                        \
+  digests += blockIdx.y * out_bstride;                                                                      \
+  u64 s[12], t[12];                                                                                         \
+  _Pragma("unroll") for (int k = 0; k < 12; k++) s[k] = t[k] = 0;                                           \
+  const u64* v = values + i;                                                                                \
+  u32 p = 0;                                                                                                \
+  for (; p + 8 <= w; p += 8) {                                                                              \
+    _Pragma("unroll") for (int k = 0; k < 8; k++) { s[k] = v[(u64)(p + k) * stride]; t[k] = v[(u64)(p + k) * stride + half]; } \
+    poseidon2_perm2(s, t);                                                                                  \
+  }                                                                                                         \
+  if (p < w) {                                                                                              \
+    _Pragma("unroll") for (int k = 0; k < 8; k++)                                                           \
+      if (p + k < w) { s[k] = v[(u64)(p + k) * stride]; t[k] = v[(u64)(p + k) * stride + half]; }           \
+    poseidon2_perm2(s, t);                                                                                  \
+  }                                                                                                         \
+  ulonglong2* d = reinterpret_cast<ulonglong2*>(digests + 4 * i);                                           \
+  d[0] = make_ulonglong2(s[0], s[1]);                                                                       \
+  d[1] = make_ulonglong2(s[2], s[3]);                                                                       \
+  d = reinterpret_cast<ulonglong2*>(digests + 4 * (i + half));                                              \
+  d[0] = make_ulonglong2(t[0], t[1]);                                                                       \
+  d[1] = make_ulonglong2(t[2], t[3]);
+// as the register allocator likes it (194 VGPRs: two waves per SIMD) ...
+__global__ void __launch_bounds__(256) leaf_hash_poly_major_ilp2_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ digests,
+                                                                        u64 in_bstride, u64 out_bstride) { LEAF_ILP2_BODY }
+// ... and held to the three waves per SIMD of the single-sponge kernel (168 VGPRs, the rest spilled)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+leaf_hash_poly_major_ilp2_w3_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ digests, u64 in_bstride, u64 out_bstride) { LEAF_ILP2_BODY }
 template <int V>
 __global__ void __launch_bounds__(256) leaf_hash_row_major_kernel(const u64* __restrict__ leaves, u32 len, u64 n, u64* __restrict__ digests) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,6 +236,13 @@ static inline dim3 grid1(u64 n, u32 block, u32 batch = 1) { return dim3((u32)((n
 hipError_t leaf_hash_poly_major(hipStream_t st, int variant, const u64* values, u32 w, u64 stride, u64 n, u64* digests,
                                 u32 batch, u64 in_bstride, u64 out_bstride) {
   if (!n || !batch) return hipSuccess;
+  static int ilp2 = -1;  // A/B switch of the two-sponges-per-lane kernel
+  if (ilp2 < 0) { const char* e = getenv("MP2G_LEAF_ILP2"); ilp2 = e ? atoi(e) : 0; }
+  if (ilp2 && variant == MP2G_POSEIDON2 && w > 4 && (n & 1) == 0) {
+    if (ilp2 == 2) hipLaunchKernelGGL(leaf_hash_poly_major_ilp2_w3_kernel, grid1(n >> 1, 256, batch), dim3(256), 0, st, values, w, stride, n, digests, in_bstride, out_bstride);
+    else hipLaunchKernelGGL(leaf_hash_poly_major_ilp2_kernel, grid1(n >> 1, 256, batch), dim3(256), 0, st, values, w, stride, n, digests, in_bstride, out_bstride);
+    return hipGetLastError();
+  }
   LAUNCH_V(leaf_hash_poly_major_kernel, grid1(n, 256, batch), dim3(256), st, values, w, stride, n, digests, in_bstride, out_bstride);
   return hipGetLastError();
 }

@@ -164,6 +164,38 @@ P2_UNROLL(P2_UNROLL_EXT)
   for (int i = 0; i < 12; i++) s[i] = gl_canon(s[i]);
 }
 
+// Two independent states through the permutation side by side (the two-sponges-per-lane experiment of merkle.hip: the 22 partial
+// rounds are a chain of four dependent multiplications on one limb, and a second state gives the scheduler an independent chain)
+GLHD void poseidon2_perm2(u64 s[12], u64 t[12]) {
+  p2_external_rc<true>(s, c_p2_ext);
+  p2_external_rc<true>(t, c_p2_ext);
+P2_UNROLL(P2_UNROLL_EXT)
+  for (int r = 0; r < 4; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) { s[i] = p2_sbox0(s[i]); t[i] = p2_sbox0(t[i]); }
+    if (r < 3) { p2_external_rc<true>(s, c_p2_ext + 12 * (r + 1)); p2_external_rc<true>(t, c_p2_ext + 12 * (r + 1)); }
+    else { p2_external(s); p2_external(t); }
+  }
+P2_UNROLL(P2_UNROLL_INT)
+  for (int r = 0; r < 22; r++) {
+    s[0] = p2_sbox(s[0], c_p2_int[r]);
+    t[0] = p2_sbox(t[0], c_p2_int[r]);
+    p2_internal(s);
+    p2_internal(t);
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) { s[i] = gl_addw(s[i], c_p2_ext[48 + i]); t[i] = gl_addw(t[i], c_p2_ext[48 + i]); }
+P2_UNROLL(P2_UNROLL_EXT)
+  for (int r = 4; r < 8; r++) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) { s[i] = p2_sbox0(s[i]); t[i] = p2_sbox0(t[i]); }
+    if (r < 7) { p2_external_rc<true>(s, c_p2_ext + 12 * (r + 1)); p2_external_rc<true>(t, c_p2_ext + 12 * (r + 1)); }
+    else { p2_external(s); p2_external(t); }
+  }
+#pragma unroll
+  for (int i = 0; i < 12; i++) { s[i] = gl_canon(s[i]); t[i] = gl_canon(t[i]); }
+}
+
 // Poseidon (WrapC), weak-representative form like Poseidon2 above. MDS: circulant
 // [17,15,41,16,2,28,13,13,39,18,34,20] + diag [8,0,...]; all entries < 2^6, so the 32-bit halves of the
 // limbs accumulate in u64 without overflow (< 2^41) and reduce once per row.

@@ -281,13 +281,18 @@ class TableBuild:
     subtree's row nodes bottom-up, level by level in batches, and returns. Workers run concurrently; the plan hands out an item once
     the subtrees below it are done."""
 
-    def __init__(self, params, sessions, batch=32, subtree_size=64, host_threads=0, keep_proofs=True, keep_nodes=()):
+    def __init__(self, params, sessions, batch=32, subtree_size=64, host_threads=0, keep_proofs=True, keep_nodes=(), group_rows=None):
         """keep_proofs: retain every row proof and cells-tree root after the run (what a checker re-proves sampled nodes from: ~130 KB
         per row); off, a proof is dropped as soon as its parent is proved -- the live set is the frontier of the tree, which is
         what a 2^17-row block needs -- except for the row-tree nodes listed in keep_nodes (their row proofs and cells roots stay:
         the nodes a checker samples from a large block, and their children)"""
         self.p, self.sessions, self.batch, self.subtree_size, self.keep_proofs = params, sessions, batch, subtree_size, keep_proofs
         self.keep_nodes = set(keep_nodes)
+        # Ready items of one wave are disjoint subtrees; a worker takes SEVERAL of them at a time (about group_rows rows) and proves
+        # them as one unit: the cells trees of all their rows in full batches, then their row nodes level by level with the levels
+        # of the different subtrees merged. (A subtree of a balanced tree over n rows has what n leaves it -- 40 rows for 20480
+        # rows cut at 64 -- and on its own fills a batch of 32 once and leaves 8 over at every tree position and level.)
+        self.group_rows = 4 * batch if group_rows is None else max(1, int(group_rows))
         self.host_threads = host_threads
         self.pool = queue.Queue()
         for s in sessions:
@@ -339,8 +344,9 @@ class TableBuild:
         return name, ([row_proofs[c][0] for c in kids], [row_proofs[c][1] for c in kids], inputs)
 
     def prove_item(self, table, wit, nodes, keys, row_proofs):
-        """one work-plan item: `keys` = the row-tree nodes of a spun-off subtree (any order). Children of its bottom nodes that lie
-        outside the subtree were proved by earlier items (row_proofs)."""
+        """one unit of work: `keys` = the row-tree nodes of one spun-off subtree -- or of several disjoint ones of the same wave (any
+        order; levels are counted inside `keys`, so the subtrees' levels merge). Children of bottom nodes that lie outside were
+        proved by earlier items (row_proofs)."""
         sess = self.pool.get()
         try:
             getattr(getattr(sess.prover, "ctx", None), "make_current", lambda: None)()  # this worker thread drives the session's GPU
@@ -393,13 +399,24 @@ class TableBuild:
                 if not wave:
                     break
                 futures, n_before = [], self.n_proofs
+                item_keys = []
                 for it in wave:
                     if it.subtree is not None:
-                        keys = [int(k) for k in it.subtree.nodes()]
+                        item_keys.append([int(k) for k in it.subtree.nodes()])
                         it.subtree.free()
                     else:
-                        keys = [int(it.k)]
-                    futures.append(ex.submit(self.prove_item, table, wit, nodes, keys, row_proofs))
+                        item_keys.append([int(it.k)])
+                # groups of whole items, about group_rows rows each, but no fewer groups than workers while the wave has the items
+                total = sum(len(k) for k in item_keys)
+                target = max(1, min(self.group_rows, -(-total // len(self.sessions))))
+                group = []
+                for keys in item_keys:
+                    group += keys
+                    if len(group) >= target:
+                        futures.append(ex.submit(self.prove_item, table, wit, nodes, group, row_proofs))
+                        group = []
+                if group:
+                    futures.append(ex.submit(self.prove_item, table, wit, nodes, group, row_proofs))
                 for f in futures:
                     f.result()  # re-raises a worker's failure (an unsatisfied witness makes prove() refuse, as the reference panics)
                 for it in wave:
