@@ -597,7 +597,7 @@ def main(argv=None):
     ap.add_argument("--table-batch", type=int, default=32, help="--workload table: proofs per prove() launch sequence of a worker")
     ap.add_argument("--subtree", type=int, default=64, help="--workload table: into_batched_workplan(subtree_size), the rows of one work-plan item")
     ap.add_argument("--group-rows", type=int, default=None, help="--workload table: rows a worker takes at a time = several work-plan items of one wave proved as one unit "
-                    "(cells trees in full batches, row-tree levels merged across the items); default 4 x --table-batch, 1 = one item at a time")
+                    "(cells trees in full batches, row-tree levels merged across the items); default 32 x --table-batch (capped at the wave's rows / workers), 1 = one item at a time")
     ap.add_argument("--host-witness", action="store_true", help="--workload table / recursion: replay the witness programs on host threads (mp2g_witness_program_run_rows) "
                     "instead of on the device (mp2g_witness_program_run_dev, the default): the A/B switch")
     ap.add_argument("--lean", action="store_true", help="--workload table: keep only the frontier of the row tree in host memory (automatic above 16384 rows); the "
@@ -1108,7 +1108,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                                       "region; value = framework proofs/s (5 per row). The full 2^20-row build does not fit one GPU in a bench run (extrapolated below); configs[2] at "
                                       "full size = `config2`; base degrees 12..15 = `by_base_degree`; roofline leg = configs[1] 2^22-point NTT",
                           "rows_per_rank": n_rows, "rows_per_step": args.rows, "row_tree_depth": depth, "warmup_rows_per_rank": args.warmup * args.rows,
-                          "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "group_rows": args.group_rows or 4 * args.table_batch, "pad_base_bits": args.pad_base_bits,
+                          "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "group_rows": args.group_rows or 32 * args.table_batch, "pad_base_bits": args.pad_base_bits,
                           "lean": bool(lean), "work_plan_waves": waves,  # per wave of the work plan: [items, framework proofs, seconds]
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "ranks_on_host": ranks_here, "shapes": shapes,
