@@ -24,6 +24,12 @@
 namespace mp2g {
 
 // large bodies are real functions: the SWU / scalar-mul kernels call them hundreds of times
+// EC_WAVES_ATTR (tools/dbg/ec_variants.sh): the occupancy the register allocator is held to on the kernels (the attribute is for
+// kernels only; the out-of-line bodies are compiled for any workgroup size, i.e. within 128 VGPRs); empty = the allocator's own
+// choice (it fills the 256 VGPRs a 128-lane block can have)
+#ifndef EC_WAVES_ATTR
+#define EC_WAVES_ATTR
+#endif
 #define GLN __device__ __noinline__
 struct gl5 { u64 c[5]; };
 
@@ -91,7 +97,33 @@ GLN gl5 gl5_mul_limbs(u64 x0, u64 x1, u64 x2, u64 x3, u64 x4, u64 y0, u64 y1, u6
 GLD gl5 gl5_mul(const gl5& a, const gl5& b) {
   return gl5_mul_limbs(a.c[0], a.c[1], a.c[2], a.c[3], a.c[4], b.c[0], b.c[1], b.c[2], b.c[3], b.c[4]);
 }
+// a^2 with the symmetry used: 15 products a_j a_k (j <= k) instead of 25 -- each enters output limb (j + k) mod 5 with the factor
+// (2 if j < k) * (3 if j + k >= 5, z^5 = 3) folded into the column accumulation. Squarings are over half of the multiset digest's
+// GF(p^5) operations (63 per square root, 5 of the 9 products of a point doubling).
+#ifndef EC_NO_SQR
+GLN gl5 gl5_sqr_limbs(u64 x0, u64 x1, u64 x2, u64 x3, u64 x4) {
+  const u64 a[5] = {x0, x1, x2, x3, x4};
+  gl5 r;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    gl_cols acc;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+#pragma unroll
+      for (int k = j; k < 5; k++) {
+        if ((j + k) % 5 != i) continue;
+        const u32 f = (j < k ? 2u : 1u) * (j + k >= 5 ? 3u : 1u);
+        if (f == 1) acc.add(a[j], a[k]); else acc.add_scaled(a[j], a[k], f);
+      }
+    }
+    r.c[i] = acc.value();
+  }
+  return r;
+}
+GLD gl5 gl5_sqr(const gl5& a) { return gl5_sqr_limbs(a.c[0], a.c[1], a.c[2], a.c[3], a.c[4]); }
+#else
 GLD gl5 gl5_sqr(const gl5& a) { return gl5_mul(a, a); }
+#endif
 // Frobenius powers: coefficient i times (3^((p-1)/5))^(i*e)
 GLD gl5 gl5_frob1(const gl5& a) {
   return gl5_make(a.c[0], gl_mul(a.c[1], 1041288259238279555ULL), gl_mul(a.c[2], 15820824984080659046ULL),
@@ -331,7 +363,7 @@ GLD void pt_emit(const pt& p, u64* w, u64* wei) {
 
 // ---- kernels ----------------------------------------------------------------------------------
 template <int V>
-__global__ void __launch_bounds__(128) map_to_curve_kernel(const u64* in, u32 in_len, u32 count, u64* w_out, u64* wei_out, u64* frac_out) {
+__global__ void __launch_bounds__(128) EC_WAVES_ATTR map_to_curve_kernel(const u64* in, u32 in_len, u32 count, u64* w_out, u64* wei_out, u64* frac_out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   pt p = map_to_curve<V>(in + (u64)i * in_len, in_len);
@@ -392,7 +424,7 @@ __global__ void emit_kernel(const u64* frac, u32 count, u64* w_out, u64* wei_out
   pt p = pt_load(frac + 20 * (u64)i);
   pt_emit(p, w_out ? w_out + 5 * (u64)i : nullptr, wei_out ? wei_out + 11 * (u64)i : nullptr);
 }
-__global__ void __launch_bounds__(128) scalar_mul_kernel(const u64* frac_in, const u32* scalars, u32 count, u64* frac_out) {
+__global__ void __launch_bounds__(128) EC_WAVES_ATTR scalar_mul_kernel(const u64* frac_in, const u32* scalars, u32 count, u64* frac_out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   u32 k[4];
@@ -401,7 +433,7 @@ __global__ void __launch_bounds__(128) scalar_mul_kernel(const u64* frac_in, con
 }
 // one lane per table row: sum_c D(id_c || value_c), row id, row_id * row digest
 template <int V>
-__global__ void __launch_bounds__(128) row_digest_kernel(const u64* col_ids, u32 n_cols, const u32* values, const u32* unique,
+__global__ void __launch_bounds__(128) EC_WAVES_ATTR row_digest_kernel(const u64* col_ids, u32 n_cols, const u32* values, const u32* unique,
                                                           u32 n_unique, u32 rows, u64* frac_out) {
   u32 r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;

@@ -268,6 +268,13 @@ struct gl_cols {
     gl_mul_wide(a, b, pl, ph);
     c0 += (u32)pl; c1 += pl >> 32; c2 += (u32)ph; c3 += ph >> 32;
   }
+  // f times the product a b for a small factor f (a symmetric term counted twice, a wrapped term times z^5 = 3: f <= 6): the
+  // factor multiplies the 32-bit words on their way into the columns (one multiply-add per column instead of one add)
+  GLHD void add_scaled(u64 a, u64 b, u32 f) {
+    u64 pl, ph;
+    gl_mul_wide(a, b, pl, ph);
+    c0 += (u64)(u32)pl * f; c1 += (pl >> 32) * f; c2 += (u64)(u32)ph * f; c3 += (ph >> 32) * f;
+  }
   // the sum as a canonical element: lo + hi 2^64 + top 2^128, 2^128 = -2^32 (mod p)
   GLHD u64 value() const {
     const u64 w1 = c1 + (c0 >> 32), w2 = c2 + (w1 >> 32), w3 = c3 + (w2 >> 32);

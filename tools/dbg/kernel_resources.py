@@ -1,12 +1,12 @@
 """VGPR / SGPR / LDS / scratch of every kernel of libmp2gpu.so, read from the gfx950 code objects' metadata (no GPU needed):
     python tools/dbg/kernel_resources.py > profiles/r03/kernel_resources.txt"""
-import os, re, shutil, subprocess, tempfile
+import os, re, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-lib = os.path.join(ROOT, "mapreduce-plonky2_amd", "libmp2gpu.so")
+lib = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] else os.path.join(ROOT, "mapreduce-plonky2_amd", "libmp2gpu.so")  # or a variant library
 llvm = "/opt/rocm/lib/llvm/bin"
 rows = []
 with tempfile.TemporaryDirectory() as d:
-    shutil.copy(lib, d)
+    shutil.copy(lib, os.path.join(d, "libmp2gpu.so"))
     subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", "libmp2gpu.so"], cwd=d, capture_output=True)
     for f in sorted(x for x in os.listdir(d) if "gfx950" in x):
         txt = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", os.path.join(d, f)], capture_output=True, text=True).stdout
