@@ -743,8 +743,10 @@ class TableRig:
         tb = T.TableBuild(self.params, self.sessions, batch=self.batch, subtree_size=self.subtree, host_threads=self.host_threads,
                           keep_proofs=not lean, keep_nodes=keep if lean else (), group_rows=self.group_rows)
         wit = T.TableWitness(self.ctx, table, spans, self.variant)
+        lib0 = tb.seconds_in_library()
         proof, name = tb.run(table, wit, root, nodes)
         self.n_proofs += tb.n_proofs
+        self.last_glue = {"worker_busy_s": round(tb.seconds_in_units, 2), "inside_libmp2gpu_s": round(tb.seconds_in_library() - lib0, 2)}
         return {"table": table, "root": root, "nodes": nodes, "spans": spans, "samples": samples, "build": tb, "wit": wit, "proof": proof, "name": name,
                 "digest_w": wit.root_digest_w[root]}
 
@@ -1054,6 +1056,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     setup_s, workers, host_threads, plan = rig.setup_s, len(rig.ctxs), rig.host_threads, rig.plan
     root_pis_out = [int(x) for x in cur[0][3]]
     waves = [[n_items, n_pr, round(sec, 2)] for n_items, n_pr, sec in st["build"].wave_log]
+    glue = dict(rig.last_glue)
+    glue["host_glue_share"] = round(1.0 - glue["inside_libmp2gpu_s"] / max(glue["worker_busy_s"], 1e-9), 4)
     del st
     rig.close()
 
@@ -1109,7 +1113,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                                       "full size = `config2`; base degrees 12..15 = `by_base_degree`; roofline leg = configs[1] 2^22-point NTT",
                           "rows_per_rank": n_rows, "rows_per_step": args.rows, "row_tree_depth": depth, "warmup_rows_per_rank": args.warmup * args.rows,
                           "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "group_rows": args.group_rows or 32 * args.table_batch, "pad_base_bits": args.pad_base_bits,
-                          "lean": bool(lean), "work_plan_waves": waves,  # per wave of the work plan: [items, framework proofs, seconds]
+                          "lean": bool(lean), "host_orchestration": glue,  # the workers' time in the timed block: total, inside the C ABI (mp2g_chain_run), the rest = Python glue
+                          "work_plan_waves": waves,  # per wave of the work plan: [items, framework proofs, seconds]
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "ranks_on_host": ranks_here, "shapes": shapes,
                           "device_memory_used_bytes": mem_total - mem_free, "device_memory_planned_bytes": plan["device_bytes_per_rank"],

@@ -8,6 +8,7 @@ There is no CPU fallback: loading fails loudly when the HIP library is missing, 
 Context() fails when no GPU is visible.
 """
 import ctypes
+import time
 import os
 import weakref
 
@@ -628,6 +629,7 @@ class ProofChain:
     def __init__(self, ctx, provers, programs, d_digests, capacity):
         n = len(provers)
         self.ctx, self.n_steps, self.capacity = ctx, n, capacity
+        self.seconds_in_run = 0.0
         self.provers, self.programs, self.d_digests = list(provers), list(programs), list(d_digests)  # keep the handles alive
         self.fps = [p.fp for p in provers]
         pr = (ctypes.c_void_p * n)(*[p.h for p in provers])
@@ -649,7 +651,9 @@ class ProofChain:
         proofs = np.empty((B, fp.proof_words), dtype=np.uint64)
         pis = np.empty((B, prog.n_public_inputs), dtype=np.uint64)
         arr = (ChainPatch * max(1, len(patches)))(*[ChainPatch(int(j), int(off), int(n), 0, int(ptr)) for j, off, ptr, n in patches])
+        t0 = time.perf_counter()
         _ck(load().mp2g_chain_run(self.h, _p(a), B, arr, len(patches), _p(caps), _p(openings), _p(proofs), _p(pis)))
+        self.seconds_in_run += time.perf_counter() - t0  # inside the library (the GIL is released): what is left of a worker's time is host glue
         self.last_batch = B
         return caps, openings, proofs, pis
 

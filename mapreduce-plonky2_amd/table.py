@@ -298,6 +298,7 @@ class TableBuild:
         for s in sessions:
             self.pool.put(s)
         self.n_proofs = 0
+        self.seconds_in_units = 0.0
         self.lock = threading.Lock()
 
     def _batched(self, fw, name, jobs, sess):
@@ -348,6 +349,7 @@ class TableBuild:
         order; levels are counted inside `keys`, so the subtrees' levels merge). Children of bottom nodes that lie outside were
         proved by earlier items (row_proofs)."""
         sess = self.pool.get()
+        t_unit = time.perf_counter()
         try:
             getattr(getattr(sess.prover, "ctx", None), "make_current", lambda: None)()  # this worker thread drives the session's GPU
             keyset = set(keys)
@@ -380,7 +382,14 @@ class TableBuild:
                                 if c is not None and c not in self.keep_nodes:
                                     row_proofs.pop(c, None)
         finally:
+            with self.lock:
+                self.seconds_in_units += time.perf_counter() - t_unit
             self.pool.put(sess)
+
+    def seconds_in_library(self):
+        """seconds the workers' chains spent inside mp2g_chain_run (GIL released) since they were created: against seconds_in_units
+        (the workers' busy time) it gives the share of host glue -- job assembly, numpy, the GIL -- in a worker's time"""
+        return sum(ch.seconds_in_run for s in self.sessions for ch in getattr(s.prover, "chains", {}).values())
 
     def run(self, table, wit, root, nodes):
         """drain the batched work plan of the row tree (rowtree.rs:78-337 with into_batched_workplan): returns (root proof, name)"""
