@@ -277,21 +277,25 @@ def test_hip_library_against_the_vectors(which, self_vectors, ctx, mp2):
         assert [int(x) for x in ctx.hash_no_pad([1, 2, 3, 4, 5, 6, 7, 8], v)] == h["two_to_one_1234_5678"]
     for log_n, s in d["fft"].items():
         x = u64(s["input"]).reshape(1, -1)
-        assert ctx.ntt(x, int(log_n), 1)[0].tolist() == s["fft"] and ctx.ntt(x, int(log_n), 1, inverse=True)[0].tolist() == s["ifft"]
-        assert ctx.ntt(x, int(log_n), 1, coset_shift=MULT_GEN)[0].tolist() == s["coset_fft"]
+        assert ctx.ntt(x)[0].tolist() == s["fft"] and ctx.ntt(x, inverse=True)[0].tolist() == s["ifft"]
+        assert ctx.ntt(x, coset_shift=MULT_GEN)[0].tolist() == s["coset_fft"]
+        padded = np.concatenate([x, np.zeros_like(x)], axis=1)
+        assert ctx.ntt(padded, coset_shift=MULT_GEN)[0].tolist() == s["lde1_coset_fft"]
     b = d["polynomial_batch"]
     pb = mp2.PolynomialBatch.from_values(ctx, u64(b["values"]), b["rate_bits"], b["cap_height"], dv)
     assert pb.coeffs.tolist() == b["coeffs"] and pb.cap.reshape(-1, 4).tolist() == b["cap"]
-    leaf, sib = pb.prove(b["proof_index"])
-    assert leaf.tolist() == b["leaves"][b["leaf_indices"].index(b["proof_index"])] and sib.reshape(-1, 4).tolist() == b["proof_siblings"]
+    leaves, sibs = pb.open(b["leaf_indices"])
+    assert leaves.tolist() == b["leaves"], "leaf i = evaluations at g w^bitrev(i)"
+    assert sibs[b["leaf_indices"].index(b["proof_index"])].tolist() == b["proof_siblings"]
     pb.free()
     ch = mp2.Challenger(ctx, dv)
-    ch.observe([1, 2, 3])
-    first = [int(ch.get()) for _ in range(2)]
-    ch.observe([7, 8, 9, 10])
-    ext = [int(ch.get()) for _ in range(2)]
-    ch.observe(list(range(11, 23)))
-    nine = [int(ch.get()) for _ in range(9)]
+    ch.observe_elements([1, 2, 3])
+    first = [int(x) for x in ch.get_n_challenges(2)[0]]
+    ch.observe_elements([7, 8, 9, 10])
+    ext = [int(x) for x in ch.get_n_challenges(2)[0]]
+    ch.observe_elements(list(range(11, 23)))
+    nine = [int(x) for x in ch.get_n_challenges(9)[0]]
+    ch.free()
     assert (first, ext, nine) == (d["challenger"]["first_two"], d["challenger"]["extension"], d["challenger"]["next_nine"])
     e = d["ecgfp5"]
     ws = []
