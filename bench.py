@@ -596,6 +596,8 @@ def main(argv=None):
     ap.add_argument("--workers", type=int, default=4, help="--workload table: concurrent work-plan items per rank, one host thread + GPU stream + prover set each")
     ap.add_argument("--table-batch", type=int, default=32, help="--workload table: proofs per prove() launch sequence of a worker")
     ap.add_argument("--subtree", type=int, default=64, help="--workload table: into_batched_workplan(subtree_size), the rows of one work-plan item")
+    ap.add_argument("--native-build", action="store_true", help="--workload table: the table build's scheduler in C++ (mp2g_forest_*: worker threads, level batching, "
+                    "job assembly, child proofs in a device pool) instead of table.TableBuild's Python unit loop")
     ap.add_argument("--group-rows", type=int, default=None, help="--workload table: rows a worker takes at a time = several work-plan items of one wave proved as one unit "
                     "(cells trees in full batches, row-tree levels merged across the items); default 32 x --table-batch (capped at the wave's rows / workers), 1 = one item at a time")
     ap.add_argument("--host-witness", action="store_true", help="--workload table / recursion: replay the witness programs on host threads (mp2g_witness_program_run_rows) "
@@ -711,8 +713,9 @@ class TableRig:
     """what a table build runs on at one base degree: `workers` GPU contexts (= streams) with a prover set and a proof session each,
     and the two circuit sets (table.TableParams) built for that degree. pad_bits = 0: the circuits at their natural degrees."""
 
-    def __init__(self, mods, local_rank, variant, workers, batch, subtree, host_witness, ranks_here, pad_bits=0, group_rows=None):
+    def __init__(self, mods, local_rank, variant, workers, batch, subtree, host_witness, ranks_here, pad_bits=0, group_rows=None, native=False):
         mp2, R, FW, C, T, IX = mods
+        self.native, self.native_build = bool(native) and not host_witness, None
         self.mods, self.variant, self.batch, self.subtree, self.pad_bits, self.group_rows = mods, variant, batch, subtree, pad_bits, group_rows
         self.ctxs = [mp2.Context(local_rank) for _ in range(max(1, workers))]
         self.ctx = self.ctxs[0]
@@ -740,15 +743,36 @@ class TableRig:
         table = T.SyntheticTable(n_rows, n_cols, seed=seed, block=block)
         root, nodes, spans = T.balanced_bst(n_rows)
         samples, keep = T.sample_nodes(nodes, spans)
-        tb = T.TableBuild(self.params, self.sessions, batch=self.batch, subtree_size=self.subtree, host_threads=self.host_threads,
-                          keep_proofs=not lean, keep_nodes=keep if lean else (), group_rows=self.group_rows)
         wit = T.TableWitness(self.ctx, table, spans, self.variant)
-        lib0 = tb.seconds_in_library()
-        proof, name = tb.run(table, wit, root, nodes)
-        self.n_proofs += tb.n_proofs
-        self.last_glue = {"worker_busy_s": round(tb.seconds_in_units, 2), "inside_libmp2gpu_s": round(tb.seconds_in_library() - lib0, 2)}
+        if self.native:
+            # the scheduler in C++ (csrc/forest.hip): nodes registered once, every wave of the plan one mp2g_forest_prove call
+            if self.native_build is None:
+                self.native_build = T.NativeTableBuild(self.params, self.provers, batch=self.batch, subtree_size=self.subtree, group_rows=self.group_rows)
+            tb = self.native_build
+            n0 = tb.n_proofs
+            t0 = time.perf_counter()
+            proof, name = tb.run(table, wit, root, nodes, keep=samples)
+            self.n_proofs += tb.n_proofs - n0
+            self.last_glue = {"scheduler": "native (mp2g_forest_*)", "block_s": round(time.perf_counter() - t0, 2),
+                              "inside_libmp2gpu_s": round(sum(sec for _, _, sec in tb.wave_log), 2)}
+        else:
+            tb = T.TableBuild(self.params, self.sessions, batch=self.batch, subtree_size=self.subtree, host_threads=self.host_threads,
+                              keep_proofs=not lean, keep_nodes=keep if lean else (), group_rows=self.group_rows)
+            lib0 = tb.seconds_in_library()
+            proof, name = tb.run(table, wit, root, nodes)
+            self.n_proofs += tb.n_proofs
+            self.last_glue = {"scheduler": "python (table.TableBuild)", "worker_busy_s": round(tb.seconds_in_units, 2),
+                              "inside_libmp2gpu_s": round(tb.seconds_in_library() - lib0, 2)}
         return {"table": table, "root": root, "nodes": nodes, "spans": spans, "samples": samples, "build": tb, "wit": wit, "proof": proof, "name": name,
                 "digest_w": wit.root_digest_w[root]}
+
+    def join_build(self):
+        """the TableBuild that proves a separator row above two blocks (its one-row cells tree and a full row node): the Python unit
+        loop over this rig's sessions, whichever scheduler built the blocks"""
+        mp2, R, FW, C, T, IX = self.mods
+        if getattr(self, "_join_build", None) is None:
+            self._join_build = T.TableBuild(self.params, self.sessions, batch=self.batch, subtree_size=self.subtree, host_threads=self.host_threads)
+        return self._join_build
 
     def check_root(self, st, verify=True):
         """the block root against the off-circuit side (tree hash, multiset digest = compute_table_row_digest of the block, min / max,
@@ -801,6 +825,8 @@ class TableRig:
         return samples
 
     def close(self):
+        if self.native_build is not None:
+            self.native_build.free()
         for p_ in self.provers:
             p_.free()
         for c in reversed(self.ctxs):
@@ -914,7 +940,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     n_cols, seed = 4, 0xC0FFEE04
     ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     rig = TableRig(mods, local_rank, VARIANT, args.workers, args.table_batch, args.subtree, args.host_witness, ranks_here, pad_bits=args.pad_base_bits,
-                   group_rows=args.group_rows)
+                   group_rows=args.group_rows, native=args.native_build)
     params, ctx = rig.params, rig.ctx
     n_rows = max(1, args.steps) * args.rows           # the timed block of this rank
     lean = args.lean or n_rows > 16384                # a block this large keeps the frontier of the tree + the sampled nodes only
@@ -939,9 +965,9 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                 # the root proof goes to the parent's rank from where the prover left it: device to device over RCCL
                 head = torch.from_numpy(np.concatenate([[names.index(cur[1])], np.asarray(cur[2], dtype=np.uint64).view(np.int64)]).astype(np.int64))
                 dist.send(head.to(dev) if nccl else head, rank - bit)
-                pv = st["build"].last_session.prover
+                pv = (st["build"].last_session or rig.sessions[0]).prover
                 ch = getattr(pv, "last_chain", None)
-                if ch is not None and not args.host_witness:
+                if ch is not None and not args.host_witness and not rig.native:
                     assert ch.last_batch == 1, "the chain's last run was the root alone: its proof 0 is the root"
                     out = pv.last_device_proof(0)
                 else:
@@ -952,7 +978,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
             dist.recv(head, rank + bit)
             head = head.cpu().numpy()
             other = sharding.recv_device_proof(dist, proof_sizes, rank + bit, dev)
-            cur = T.join_blocks(st["build"], ctx, cur, (other, names[int(head[0])], head[1:6].view(np.uint64)), 2 * (rank + bit) - 1, n_cols, seed_, VARIANT)
+            cur = T.join_blocks(rig.join_build(), ctx, cur, (other, names[int(head[0])], head[1:6].view(np.uint64)), 2 * (rank + bit) - 1, n_cols, seed_, VARIANT)
             rig.n_proofs += 5
         return st, cur
 
@@ -1057,7 +1083,10 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     root_pis_out = [int(x) for x in cur[0][3]]
     waves = [[n_items, n_pr, round(sec, 2)] for n_items, n_pr, sec in st["build"].wave_log]
     glue = dict(rig.last_glue)
-    glue["host_glue_share"] = round(1.0 - glue["inside_libmp2gpu_s"] / max(glue["worker_busy_s"], 1e-9), 4)
+    if "worker_busy_s" in glue:
+        glue["host_glue_share"] = round(1.0 - glue["inside_libmp2gpu_s"] / max(glue["worker_busy_s"], 1e-9), 4)
+    else:
+        glue["host_glue_share"] = round(1.0 - glue["inside_libmp2gpu_s"] / max(glue["block_s"], 1e-9), 4)  # registration (numpy) + the plan's waves
     del st
     rig.close()
 

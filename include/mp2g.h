@@ -473,6 +473,41 @@ int mp2g_chain_step_buffers(const mp2g_chain* chain, uint32_t step, uint64_t** d
 int mp2g_chain_device_proof(const mp2g_chain* chain, uint32_t b, const uint64_t* d_parts[4], uint32_t n_words[4]);
 void mp2g_chain_free(mp2g_chain* chain);
 
+/* ---- a forest of framework proofs: the native scheduler of a tree build (csrc/forest.hip) -------------------------------------
+ * Replaces the harness loops that prove every node of a tree children-before-parents, one RecursiveCircuits::generate_proof per
+ * node over its children's proofs (mp2-v1/tests/common/celltree.rs:54-189, rowtree.rs:78-337; recursion-framework/src/framework.rs)
+ * for a host that hands whole blocks of rows to one GPU. Circuits are described once: the words of the base circuit's witness
+ * inputs, how many child proofs a node takes and where each child's proof words lie in the inputs (a child's range = public inputs,
+ * the three proof caps, openings, FRI words: what mp2g_chain_device_proof lists), and n_const = the remaining words (circuit-set
+ * digest, the children's verifier data and membership proofs, the circuit's own inputs) in input order with the child ranges cut
+ * out. chains[worker * n_circuits + circuit]: one mp2g_chain per circuit on every worker's context (NULL = this worker never gets
+ * that circuit). Final proofs live in a device pool of `pool_slots` slots of `slot_words` words; a node's slot is returned when its
+ * parent is proved unless the node was registered with keep != 0, or on mp2g_forest_release.
+ * mp2g_forest_prove: units[u] = unit_nodes[unit_offsets[u] .. unit_offsets[u+1]) are proved by the workers in parallel, each unit
+ * level by level (levels counted inside the unit), every level's nodes of one circuit in batches of the chain's capacity. The units
+ * of ONE call must not depend on each other (the items of one wave of an update plan do not); children outside a unit must have
+ * been proved by an earlier call. A witness that violates a constraint fails the call as plonky2's prove() panics. */
+typedef struct mp2g_forest mp2g_forest;
+typedef struct {
+  uint32_t n_inputs;         /* witness inputs of the base circuit (chain step 0), in words */
+  uint32_t n_children;       /* child proofs of a node, <= 4 */
+  uint32_t child_offset[4];  /* word offset of each child's proof inside the inputs, increasing */
+  uint32_t n_const;          /* the node's own words: everything outside the children's ranges */
+} mp2g_forest_circuit;
+int mp2g_forest_create(uint32_t n_workers, mp2g_ctx* const* ctxs, uint32_t n_circuits, const mp2g_forest_circuit* circuits,
+                       mp2g_chain* const* chains, uint32_t slot_words, uint32_t pool_slots, mp2g_forest** out);
+int mp2g_forest_add_nodes(mp2g_forest* f, uint32_t circuit, uint32_t count, const uint64_t* ids, const uint64_t* child_ids /* [count][n_children] */,
+                          const uint64_t* consts /* [count][n_const] */, const uint8_t* keep /* [count] or NULL */);
+int mp2g_forest_prove(mp2g_forest* f, const uint64_t* unit_nodes, const uint32_t* unit_offsets /* [n_units + 1] */, uint32_t n_units);
+/* a proved node's final proof: its words in a parent's input order (public inputs, caps of oracles 1..3, openings, FRI words) on the
+ * host (words may be NULL to ask for the length) or where they lie on the device (valid until the slot is returned) */
+int mp2g_forest_proof(mp2g_forest* f, uint64_t id, uint64_t* words, uint32_t* n_words);
+int mp2g_forest_device_proof(mp2g_forest* f, uint64_t id, const uint64_t** d_words, uint32_t* n_words);
+int mp2g_forest_release(mp2g_forest* f, uint64_t id);
+uint64_t mp2g_forest_proved(const mp2g_forest* f);
+uint32_t mp2g_forest_free_slots(mp2g_forest* f);
+void mp2g_forest_free(mp2g_forest* f);
+
 /* ---- work plan: the reference's only scheduler --------------------------------------
  * Host-side, no GPU involved. Replaces ryhope/src/storage/updatetree.rs: UpdateTree (:19-242, arena
  * of nodes, node 0 = root, children ordered by arena index) and UpdatePlan (:422-541). Keys are u64

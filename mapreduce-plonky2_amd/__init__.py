@@ -681,6 +681,76 @@ class ProofChain:
             pass
 
 
+class ForestCircuit(ctypes.Structure):
+    _fields_ = [("n_inputs", ctypes.c_uint32), ("n_children", ctypes.c_uint32), ("child_offset", ctypes.c_uint32 * 4), ("n_const", ctypes.c_uint32)]
+
+
+class Forest:
+    """mp2g_forest: the native scheduler of a tree build (csrc/forest.hip). ctxs: one Context per worker; descriptors: [(n_inputs,
+    [child offsets], n_const)] per circuit; chains[w][c]: the ProofChain of circuit c on worker w's context (None = never used there)."""
+
+    def __init__(self, ctxs, descriptors, chains, slot_words, pool_slots):
+        self.ctxs, self.chains = list(ctxs), [list(row) for row in chains]  # keep the handles alive
+        nw, nc = len(ctxs), len(descriptors)
+        d = (ForestCircuit * nc)()
+        for i, (n_in, offs, n_const) in enumerate(descriptors):
+            d[i].n_inputs, d[i].n_children, d[i].n_const = int(n_in), len(offs), int(n_const)
+            for k, o in enumerate(offs):
+                d[i].child_offset[k] = int(o)
+        cx = (ctypes.c_void_p * nw)(*[c.h for c in ctxs])
+        ch = (ctypes.c_void_p * (nw * nc))(*[(self.chains[w][c].h if self.chains[w][c] is not None else None) for w in range(nw) for c in range(nc)])
+        self.h = ctypes.c_void_p()
+        _ck(load().mp2g_forest_create(nw, cx, nc, d, ch, int(slot_words), int(pool_slots), ctypes.byref(self.h)))
+        self.n_const = [int(x[2]) for x in descriptors]
+        self.n_children = [len(x[1]) for x in descriptors]
+
+    def add_nodes(self, circuit, ids, child_ids, consts, keep=None):
+        ids = _arr(ids)
+        n = ids.size
+        kids = _arr(child_ids).reshape(n, self.n_children[circuit]) if self.n_children[circuit] else None
+        cs = _arr(consts).reshape(n, self.n_const[circuit])
+        kp = np.ascontiguousarray(keep, dtype=np.uint8) if keep is not None else None
+        _ck(load().mp2g_forest_add_nodes(self.h, int(circuit), int(n), _p(ids), _p(kids) if kids is not None else None, _p(cs), _p(kp) if kp is not None else None))
+
+    def prove(self, units):
+        """units: lists of node ids, independent of each other; the workers take them from a queue (the call releases the GIL)"""
+        flat = _arr([i for u in units for i in u])
+        offs = _arr(np.cumsum([0] + [len(u) for u in units]), np.uint32)
+        _ck(load().mp2g_forest_prove(self.h, _p(flat), _p(offs), len(units)))
+
+    def proof_words(self, node_id):
+        n = ctypes.c_uint32()
+        _ck(load().mp2g_forest_proof(self.h, ctypes.c_uint64(int(node_id)), None, ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.uint64)
+        _ck(load().mp2g_forest_proof(self.h, ctypes.c_uint64(int(node_id)), _p(out), ctypes.byref(n)))
+        return out
+
+    def device_proof(self, node_id):
+        """(device address, words) of a proved node's proof in the pool: public inputs, caps of oracles 1..3, openings, FRI words"""
+        ptr, n = ctypes.c_void_p(), ctypes.c_uint32()
+        _ck(load().mp2g_forest_device_proof(self.h, ctypes.c_uint64(int(node_id)), ctypes.byref(ptr), ctypes.byref(n)))
+        return int(ptr.value), int(n.value)
+
+    def release(self, node_id):
+        _ck(load().mp2g_forest_release(self.h, ctypes.c_uint64(int(node_id))))
+
+    @property
+    def proved(self):
+        load().mp2g_forest_proved.restype = ctypes.c_uint64
+        return int(load().mp2g_forest_proved(self.h))
+
+    def free(self):
+        if self.h:
+            load().mp2g_forest_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 # ---- Ecgfp5 multiset digest (mp2-common/src/group_hashing) ---------------------------------
 def map_to_curve_batch(ctx, inputs, variant=POSEIDON2, weierstrass=False):
     """map_to_curve_point for each row of `inputs`; returns encodings [count][5] (and the 11-limb

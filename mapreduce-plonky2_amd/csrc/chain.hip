@@ -9,37 +9,13 @@
 // proof caps, openings and FRI proof words, plonky2's ProofWithPublicInputsTarget order -- are gathered from the prover's outputs
 // by four strided device copies. Child proofs that already live on the device (a previous chain's outputs, or tensors received
 // from another rank) are copied into the base step's inputs in place (mp2g_chain_patch). One synchronisation at the end.
-#include "ctx.h"
-#include "witness.h"
+#include "chain.h"
 #include <cstring>
 #include <new>
 
 using namespace mp2g;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define NEED(c, msg) do { if (!(c)) return fail("invalid argument: %s", msg); } while (0)
-
-struct mp2g_chain {
-  mp2g_ctx* ctx = nullptr;
-  uint32_t cap = 0, last_batch = 0;
-  struct Step {
-    mp2g_prover* pr = nullptr;
-    mp2g_witness_program* prog = nullptr;
-    const u64* d_digest = nullptr;
-    mp2g_fri_params P{};
-    size_t n_in = 0, n_probe = 0, cap_words = 0, n_open = 0, proof_words = 0;
-    DevBuf in, wires, probe, pi_hash, caps, openings, proof;
-  };
-  Step steps[8];  // DevBuf owns device memory and does not move
-  uint32_t n_steps = 0;
-  // pinned staging for the inputs on the way up and the last step's outputs on the way down (pageable copies would be staged by
-  // the runtime in small synchronous pieces)
-  u64* h_in = nullptr;
-  u64* h_out = nullptr;
-  ~mp2g_chain() {
-    if (h_in) (void)hipHostFree(h_in);
-    if (h_out) (void)hipHostFree(h_out);
-  }
-};
 
 extern "C" {
 int mp2g_chain_create(mp2g_ctx* c, uint32_t n_steps, mp2g_prover* const* provers, mp2g_witness_program* const* programs,
@@ -85,15 +61,23 @@ int mp2g_chain_create(mp2g_ctx* c, uint32_t n_steps, mp2g_prover* const* provers
 int mp2g_chain_run(mp2g_chain* ch, const uint64_t* inputs, uint32_t batch, const mp2g_chain_patch* patches, uint32_t n_patches,
                    uint64_t* caps, uint64_t* openings, uint64_t* proof, uint64_t* public_inputs) {
   NEED(ch && inputs && batch >= 1 && batch <= ch->cap && (patches || !n_patches), "chain / inputs / batch <= capacity");
+  memcpy(ch->h_in, inputs, (size_t)batch * ch->steps[0].n_in * sizeof(u64));
+  return chain_run_staged(ch, batch, patches, n_patches, nullptr, caps, openings, proof, public_inputs);
+}
+}  // extern "C"
+
+int mp2g::chain_run_staged(mp2g_chain* ch, uint32_t batch, const mp2g_chain_patch* patches, uint32_t n_patches, const ChainHooks* hooks,
+                           uint64_t* caps, uint64_t* openings, uint64_t* proof, uint64_t* public_inputs) {
+  NEED(ch && batch >= 1 && batch <= ch->cap && (patches || !n_patches), "chain / batch <= capacity");
   hipStream_t s = ch->ctx->stream;
   mp2g_chain::Step& s0 = ch->steps[0];
   for (uint32_t i = 0; i < n_patches; i++)
     NEED(patches[i].job < batch && patches[i].d_src && (size_t)patches[i].offset + patches[i].n_words <= s0.n_in, "patch outside the inputs");
-  memcpy(ch->h_in, inputs, (size_t)batch * s0.n_in * sizeof(u64));
   CK(hipMemcpyAsync(s0.in.p, ch->h_in, (size_t)batch * s0.n_in * sizeof(u64), hipMemcpyHostToDevice, s));
   for (uint32_t i = 0; i < n_patches; i++)
     CK(hipMemcpyAsync(s0.in.p + (size_t)patches[i].job * s0.n_in + patches[i].offset, patches[i].d_src, (size_t)patches[i].n_words * sizeof(u64),
                       hipMemcpyDeviceToDevice, s));
+  if (hooks && hooks->between) { int rc = hooks->between(hooks->user, ch, s); if (rc) return rc; }
   for (size_t k = 0; k < ch->n_steps; k++) {
     mp2g_chain::Step& st = ch->steps[k];
     if (k > 0) {  // the previous proof becomes this step's witness inputs: public inputs, caps of oracles 1..3, openings, FRI proof words
@@ -125,6 +109,7 @@ int mp2g_chain_run(mp2g_chain* ch, const uint64_t* inputs, uint32_t batch, const
   if (openings) CK(hipMemcpyAsync(ho, L.openings.p, n_op * 8, hipMemcpyDeviceToHost, s));
   if (proof) CK(hipMemcpyAsync(hp, L.proof.p, n_pf * 8, hipMemcpyDeviceToHost, s));
   if (public_inputs) CK(hipMemcpy2DAsync(hi, n_pi * 8, L.probe.p + 4, L.n_probe * 8, n_pi * 8, batch, hipMemcpyDeviceToHost, s));
+  if (hooks && hooks->after) { int rc = hooks->after(hooks->user, ch, s); if (rc) return rc; }
   CK(hipStreamSynchronize(s));
   if (caps) memcpy(caps, hc, n_caps * 8);
   if (openings) memcpy(openings, ho, n_op * 8);
@@ -139,6 +124,7 @@ int mp2g_chain_run(mp2g_chain* ch, const uint64_t* inputs, uint32_t batch, const
   return 0;
 }
 
+extern "C" {
 int mp2g_chain_step_buffers(const mp2g_chain* ch, uint32_t step, uint64_t** d_wires, uint64_t** d_probe, uint64_t** d_caps, uint64_t** d_openings,
                             uint64_t** d_proof) {
   NEED(ch && step < ch->n_steps, "chain / step");

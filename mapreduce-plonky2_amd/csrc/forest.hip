@@ -1,0 +1,373 @@
+// A forest of framework proofs proved bottom-up on the device: the native scheduler of a tree build (include/mp2g.h, mp2g_forest_*).
+//
+// Replaces the harness loops of the reference that prove every node of a tree children-before-parents, one
+// RecursiveCircuits::generate_proof per node over its children's proofs (mp2-v1/tests/common/celltree.rs:54-189 for a row's cells
+// tree, rowtree.rs:78-337 for the row tree; recursion-framework/src/framework.rs generate_proof) for a host that hands whole blocks of
+// rows to a GPU. A node is registered with its circuit, its children and the words of its witness inputs that are not child proofs
+// (circuit-set digest, the children's verifier data and membership proofs, the circuit's own inputs). Work arrives as UNITS -- lists of
+// nodes, e.g. the spun-off subtrees of one wave of the update plan (workplan.hip) -- which W worker threads (one mp2g_ctx = HIP stream and
+// one mp2g_chain per circuit each) take from a queue; a worker proves its unit level by level (levels counted inside the unit, so
+// several subtrees' levels merge), each level's nodes of one circuit in batches of the chains' capacity. Final proofs live in a device
+// pool (one fixed-size slot each: public inputs, the three proof caps, openings, FRI words -- the order a parent's witness inputs take
+// them in); a parent's inputs receive its children's slots by one gather kernel, a batch's outputs reach their slots by another, and a
+// slot is returned when the parent is proved. No proof visits the host unless it is asked for (mp2g_forest_proof).
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <exception>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+#include "chain.h"
+
+using namespace mp2g;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define NEED(c, msg) do { if (!(c)) return fail("invalid argument: %s", msg); } while (0)
+
+namespace {
+constexpr uint32_t MAX_CHILDREN = 4;
+struct Node {
+  uint64_t id = 0;
+  uint32_t circuit = 0;
+  uint32_t n_children = 0;
+  uint64_t child[MAX_CHILDREN] = {0, 0, 0, 0};
+  size_t consts = 0;        // offset into the circuit's constant store
+  int32_t slot = -1;        // pool slot of the proof, -1 = not proved (or released)
+  uint32_t proof_words = 0; // words of the proof in its slot
+  bool keep = false;        // the slot survives the parent (a checker downloads the proof later)
+  bool proved = false;
+};
+struct Circuit {
+  mp2g_forest_circuit d{};
+  std::vector<u64> consts;  // [nodes of this circuit][n_const]
+};
+// copy jobs of the two gather kernels: words [src, src + n) -> [dst, dst + n)
+struct Copy { const u64* src; u64* dst; uint32_t n; uint32_t pad; };
+__global__ void __launch_bounds__(256) forest_copy_kernel(const Copy* jobs) {
+  const Copy c = jobs[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < c.n; i += 256) c.dst[i] = c.src[i];
+}
+}  // namespace
+
+struct mp2g_forest {
+  uint32_t n_workers = 0, n_circuits = 0, slot_words = 0, pool_slots = 0;
+  std::vector<mp2g_ctx*> ctxs;
+  std::vector<mp2g_chain*> chains;  // [worker][circuit]
+  std::vector<Circuit> circuits;
+  std::unordered_map<uint64_t, uint32_t> index;
+  std::vector<Node> nodes;
+  DevBuf pool;
+  std::vector<int32_t> free_slots;
+  std::mutex mu;  // free_slots, node state that crosses workers (slot / proved of a child proved by another worker in an EARLIER call)
+  std::atomic<uint64_t> proved{0};
+  // per worker: pinned staging of the copy jobs and their device copy
+  struct Worker { Copy* h_jobs = nullptr; Copy* d_jobs = nullptr; uint32_t cap_jobs = 0; };
+  std::vector<Worker> workers;
+  ~mp2g_forest() {
+    for (auto& w : workers) { if (w.h_jobs) (void)hipHostFree(w.h_jobs); if (w.d_jobs) (void)hipFree(w.d_jobs); }
+  }
+};
+
+namespace {
+struct BatchCtx {  // what the chain hooks of one batch need
+  mp2g_forest* f; uint32_t worker; uint32_t n_between, n_after;  // jobs [0, n_between) patch the inputs, [n_between, n_between + n_after) store the outputs
+};
+int hook_copy(mp2g_forest* f, uint32_t w, uint32_t first, uint32_t count, hipStream_t s) {
+  if (!count) return 0;
+  hipLaunchKernelGGL(forest_copy_kernel, dim3(count), dim3(256), 0, s, f->workers[w].d_jobs + first);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : fail("forest copy kernel: %s", hipGetErrorString(e));
+}
+int hook_between(void* u, mp2g_chain*, hipStream_t s) { auto* b = (BatchCtx*)u; return hook_copy(b->f, b->worker, 0, b->n_between, s); }
+int hook_after(void* u, mp2g_chain*, hipStream_t s) { auto* b = (BatchCtx*)u; return hook_copy(b->f, b->worker, b->n_between, b->n_after, s); }
+
+// one unit on one worker; errors are returned as the library's code with mp2g_last_error() set by the failing call
+int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) {
+  if (!count) return 0;
+  CK(hipSetDevice(f->ctxs[w]->device));
+  std::vector<uint32_t> unit(count);
+  std::unordered_map<uint32_t, uint32_t> level;  // node index -> level inside the unit
+  for (uint32_t i = 0; i < count; i++) {
+    auto it = f->index.find(ids[i]);
+    if (it == f->index.end()) return fail("forest: unknown node %llu in a unit", (unsigned long long)ids[i]);
+    unit[i] = it->second;
+    level[it->second] = ~0u;
+  }
+  // levels by repeated relaxation over the unit (children may come after their parents in `ids`)
+  uint32_t max_level = 0;
+  {
+    std::vector<uint32_t> order(unit);
+    bool changed = true;
+    for (uint32_t i : unit) level[i] = 0;
+    for (uint32_t guard = 0; changed && guard <= count; guard++) {
+      changed = false;
+      for (uint32_t i : unit) {
+        const Node& n = f->nodes[i];
+        uint32_t l = 0;
+        for (uint32_t k = 0; k < n.n_children; k++) {
+          auto c = f->index.find(n.child[k]);
+          if (c == f->index.end()) return fail("forest: node %llu names an unknown child", (unsigned long long)n.id);
+          auto lv = level.find(c->second);
+          if (lv != level.end()) l = std::max(l, lv->second + 1);
+        }
+        if (l != level[i]) { level[i] = l; changed = true; }
+        max_level = std::max(max_level, l);
+      }
+    }
+    if (changed) return fail("forest: the unit's nodes form a cycle");
+  }
+  std::vector<std::vector<uint32_t>> by;  // [level * n_circuits + circuit] -> node indices
+  by.resize((size_t)(max_level + 1) * f->n_circuits);
+  for (uint32_t i : unit) by[(size_t)level[i] * f->n_circuits + f->nodes[i].circuit].push_back(i);
+  mp2g_forest::Worker& W = f->workers[w];
+  for (uint32_t lvl = 0; lvl <= max_level; lvl++) {
+    for (uint32_t c = 0; c < f->n_circuits; c++) {
+      const std::vector<uint32_t>& todo = by[(size_t)lvl * f->n_circuits + c];
+      if (todo.empty()) continue;
+      mp2g_chain* ch = f->chains[(size_t)w * f->n_circuits + c];
+      if (!ch) return fail("forest: worker %u has no chain for circuit %u", w, c);
+      const Circuit& C = f->circuits[c];
+      const mp2g_chain::Step& s0 = ch->steps[0];
+      const mp2g_chain::Step& L = ch->steps[ch->n_steps - 1];
+      const uint32_t n_pi = (uint32_t)(L.n_probe - 4), cw = (uint32_t)(3 * L.cap_words), ow = (uint32_t)(2 * L.n_open), pw = (uint32_t)L.proof_words;
+      const uint32_t out_words = n_pi + cw + ow + pw;
+      if (out_words > f->slot_words) return fail("forest: a proof of circuit %u has %u words, the pool's slots %u", c, out_words, f->slot_words);
+      for (size_t lo = 0; lo < todo.size(); lo += ch->cap) {
+        const uint32_t B = (uint32_t)std::min<size_t>(ch->cap, todo.size() - lo);
+        // slots for the batch's proofs
+        std::vector<int32_t> slots(B);
+        {
+          std::lock_guard<std::mutex> g(f->mu);
+          if (f->free_slots.size() < B) return fail("forest: the proof pool is exhausted (%u slots): release roots or create a larger pool", f->pool_slots);
+          for (uint32_t j = 0; j < B; j++) { slots[j] = f->free_slots.back(); f->free_slots.pop_back(); }
+        }
+        uint32_t nb = 0;
+        const uint32_t need_jobs = B * (C.d.n_children + 4);
+        if (need_jobs > W.cap_jobs) return fail("forest: internal: copy-job staging too small");
+        // inputs: the node's constant words around its children's ranges; the children come from their pool slots
+        for (uint32_t j = 0; j < B; j++) {
+          const Node& n = f->nodes[todo[lo + j]];
+          u64* dst = ch->h_in + (size_t)j * s0.n_in;
+          const u64* src = C.consts.data() + n.consts;
+          uint32_t at = 0;  // position in the inputs
+          for (uint32_t k = 0; k <= C.d.n_children; k++) {
+            const uint32_t end = k < C.d.n_children ? C.d.child_offset[k] : C.d.n_inputs;
+            if (end < at) return fail("forest: circuit %u: child ranges out of order", c);
+            memcpy(dst + at, src, (size_t)(end - at) * sizeof(u64));
+            src += end - at;
+            at = end;
+            if (k < C.d.n_children) {
+              Node* ch_node = nullptr;
+              {
+                std::lock_guard<std::mutex> g(f->mu);
+                ch_node = &f->nodes[f->index[n.child[k]]];
+                if (!ch_node->proved || ch_node->slot < 0) return fail("forest: child %llu of node %llu is not proved (or was released)", (unsigned long long)n.child[k], (unsigned long long)n.id);
+              }
+              if (at + ch_node->proof_words > C.d.n_inputs) return fail("forest: circuit %u: a child proof runs past the inputs", c);
+              W.h_jobs[nb++] = Copy{f->pool.p + (size_t)ch_node->slot * f->slot_words, s0.in.p + (size_t)j * s0.n_in + at, ch_node->proof_words, 0};
+              at += ch_node->proof_words;
+            }
+          }
+        }
+        const uint32_t n_between = nb;
+        // outputs -> slots, in a parent's input order: public inputs, caps of oracles 1..3, openings, FRI words
+        for (uint32_t j = 0; j < B; j++) {
+          u64* slot = f->pool.p + (size_t)slots[j] * f->slot_words;
+          W.h_jobs[nb++] = Copy{L.probe.p + (size_t)j * L.n_probe + 4, slot, n_pi, 0};
+          W.h_jobs[nb++] = Copy{L.caps.p + ((size_t)j * L.P.n_oracles + 1) * L.cap_words, slot + n_pi, cw, 0};
+          W.h_jobs[nb++] = Copy{L.openings.p + (size_t)j * L.n_open * 2, slot + n_pi + cw, ow, 0};
+          W.h_jobs[nb++] = Copy{L.proof.p + (size_t)j * L.proof_words, slot + n_pi + cw + ow, pw, 0};
+        }
+        CK(hipMemcpyAsync(W.d_jobs, W.h_jobs, (size_t)nb * sizeof(Copy), hipMemcpyHostToDevice, f->ctxs[w]->stream));
+        BatchCtx bc{f, w, n_between, nb - n_between};
+        ChainHooks hooks{&bc, hook_between, hook_after};
+        int rc = chain_run_staged(ch, B, nullptr, 0, &hooks, nullptr, nullptr, nullptr, nullptr);
+        if (rc) {
+          std::lock_guard<std::mutex> g(f->mu);
+          for (int32_t sl : slots) f->free_slots.push_back(sl);
+          return rc;
+        }
+        {
+          std::lock_guard<std::mutex> g(f->mu);
+          for (uint32_t j = 0; j < B; j++) {
+            Node& n = f->nodes[todo[lo + j]];
+            n.slot = slots[j]; n.proof_words = out_words; n.proved = true;
+            for (uint32_t k = 0; k < n.n_children; k++) {  // the children have served: their slots go back unless kept
+              Node& cn = f->nodes[f->index[n.child[k]]];
+              if (!cn.keep && cn.slot >= 0) { f->free_slots.push_back(cn.slot); cn.slot = -1; }
+            }
+          }
+        }
+        f->proved += B;
+      }
+    }
+  }
+  return 0;
+}
+}  // namespace
+
+// the error text of a worker thread travels to the caller's thread (mp2g_last_error is thread local)
+extern "C" const char* mp2g_last_error(void);
+
+extern "C" {
+int mp2g_forest_create(uint32_t n_workers, mp2g_ctx* const* ctxs, uint32_t n_circuits, const mp2g_forest_circuit* circuits,
+                       mp2g_chain* const* chains, uint32_t slot_words, uint32_t pool_slots, mp2g_forest** out) {
+  NEED(out && ctxs && circuits && chains && n_workers >= 1 && n_circuits >= 1 && slot_words >= 1 && pool_slots >= 1, "workers / circuits / chains / pool");
+  try {
+    std::unique_ptr<mp2g_forest> f(new mp2g_forest);
+    f->n_workers = n_workers; f->n_circuits = n_circuits; f->slot_words = slot_words; f->pool_slots = pool_slots;
+    f->ctxs.assign(ctxs, ctxs + n_workers);
+    f->chains.assign(chains, chains + (size_t)n_workers * n_circuits);
+    f->circuits.resize(n_circuits);
+    uint32_t max_jobs = 0;
+    for (uint32_t c = 0; c < n_circuits; c++) {
+      const mp2g_forest_circuit& d = circuits[c];
+      NEED(d.n_children <= MAX_CHILDREN && d.n_const <= d.n_inputs, "circuit descriptor");
+      f->circuits[c].d = d;
+      for (uint32_t w = 0; w < n_workers; w++) {
+        mp2g_chain* ch = f->chains[(size_t)w * n_circuits + c];
+        if (!ch) continue;
+        NEED(ch->steps[0].n_in == d.n_inputs, "a chain's base circuit takes another number of inputs than its descriptor says");
+        NEED(ch->ctx == ctxs[w], "a worker's chains live on the worker's context");
+        max_jobs = std::max(max_jobs, ch->cap * (d.n_children + 4));
+      }
+    }
+    for (uint32_t w = 0; w < n_workers; w++) NEED(ctxs[w] && ctxs[w]->device == ctxs[0]->device, "one forest = one GPU: every worker's context on the same device");
+    CK(hipSetDevice(ctxs[0]->device));
+    hipError_t e = f->pool.alloc((size_t)slot_words * pool_slots * sizeof(u64));
+    if (e != hipSuccess) return fail("forest pool of %u x %u words: %s", pool_slots, slot_words, hipGetErrorString(e));
+    f->free_slots.resize(pool_slots);
+    for (uint32_t i = 0; i < pool_slots; i++) f->free_slots[i] = (int32_t)(pool_slots - 1 - i);
+    f->workers.resize(n_workers);
+    for (auto& w : f->workers) {
+      w.cap_jobs = std::max(1u, max_jobs);
+      CK(hipHostMalloc((void**)&w.h_jobs, (size_t)w.cap_jobs * sizeof(Copy), hipHostMallocDefault));
+      CK(hipMalloc((void**)&w.d_jobs, (size_t)w.cap_jobs * sizeof(Copy)));
+    }
+    *out = f.release();
+    return 0;
+  } catch (const std::bad_alloc&) { return fail("out of memory"); } catch (...) { return fail("internal error"); }
+}
+
+int mp2g_forest_add_nodes(mp2g_forest* f, uint32_t circuit, uint32_t count, const uint64_t* ids, const uint64_t* child_ids, const uint64_t* consts,
+                          const uint8_t* keep) {
+  NEED(f && circuit < f->n_circuits && (ids || !count), "forest / circuit / ids");
+  Circuit& C = f->circuits[circuit];
+  NEED((child_ids || !C.d.n_children || !count) && (consts || !C.d.n_const || !count), "children / constant words");
+  try {
+    for (uint32_t i = 0; i < count; i++)
+      if (f->index.count(ids[i])) return fail("forest: node %llu registered twice", (unsigned long long)ids[i]);
+    for (uint32_t i = 0; i < count; i++) {
+      Node n;
+      n.id = ids[i]; n.circuit = circuit; n.n_children = C.d.n_children;
+      for (uint32_t k = 0; k < C.d.n_children; k++) n.child[k] = child_ids[(size_t)i * C.d.n_children + k];
+      n.consts = C.consts.size();
+      n.keep = keep && keep[i];
+      C.consts.insert(C.consts.end(), consts + (size_t)i * C.d.n_const, consts + (size_t)(i + 1) * C.d.n_const);
+      f->index.emplace(n.id, (uint32_t)f->nodes.size());
+      f->nodes.push_back(n);
+    }
+    return 0;
+  } catch (const std::bad_alloc&) { return fail("out of memory"); } catch (...) { return fail("internal error"); }
+}
+
+int mp2g_forest_prove(mp2g_forest* f, const uint64_t* unit_nodes, const uint32_t* unit_offsets, uint32_t n_units) {
+  NEED(f && (n_units == 0 || (unit_nodes && unit_offsets)), "forest / units");
+  if (!n_units) return 0;
+  std::atomic<uint32_t> next{0};
+  std::atomic<int> failed{0};
+  std::mutex err_mu;
+  std::string err;
+  auto work = [&](uint32_t w) {
+    try {
+      for (;;) {
+        if (failed.load()) return;
+        const uint32_t u = next.fetch_add(1);
+        if (u >= n_units) return;
+        int rc = prove_unit(f, w, unit_nodes + unit_offsets[u], unit_offsets[u + 1] - unit_offsets[u]);
+        if (rc) {
+          std::lock_guard<std::mutex> g(err_mu);
+          if (!failed.exchange(1)) err = mp2g_last_error();
+          return;
+        }
+      }
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> g(err_mu);
+      if (!failed.exchange(1)) err = std::string("internal error: ") + e.what();
+    } catch (...) {
+      std::lock_guard<std::mutex> g(err_mu);
+      if (!failed.exchange(1)) err = "internal error";
+    }
+  };
+  try {
+    const uint32_t n_threads = std::min(f->n_workers, n_units);
+    std::vector<std::thread> ts;
+    for (uint32_t w = 1; w < n_threads; w++) ts.emplace_back(work, w);
+    work(0);
+    for (auto& t : ts) t.join();
+  } catch (...) {
+    return fail("forest: could not start the worker threads");
+  }
+  if (failed.load()) return fail("%s", err.c_str());
+  return 0;
+}
+
+int mp2g_forest_proof(mp2g_forest* f, uint64_t id, uint64_t* words, uint32_t* n_words) {
+  NEED(f && n_words, "forest / outputs");
+  const u64* src = nullptr;
+  uint32_t n = 0;
+  {
+    std::lock_guard<std::mutex> g(f->mu);
+    auto it = f->index.find(id);
+    if (it == f->index.end()) return fail("forest: unknown node %llu", (unsigned long long)id);
+    const Node& nd = f->nodes[it->second];
+    if (!nd.proved || nd.slot < 0) return fail("forest: node %llu is not proved (or its proof was released)", (unsigned long long)id);
+    src = f->pool.p + (size_t)nd.slot * f->slot_words;
+    n = nd.proof_words;
+  }
+  *n_words = n;
+  if (!words) return 0;
+  CK(hipSetDevice(f->ctxs[0]->device));
+  CK(hipMemcpy(words, src, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int mp2g_forest_device_proof(mp2g_forest* f, uint64_t id, const uint64_t** d_words, uint32_t* n_words) {
+  NEED(f && d_words && n_words, "forest / outputs");
+  std::lock_guard<std::mutex> g(f->mu);
+  auto it = f->index.find(id);
+  if (it == f->index.end()) return fail("forest: unknown node %llu", (unsigned long long)id);
+  const Node& nd = f->nodes[it->second];
+  if (!nd.proved || nd.slot < 0) return fail("forest: node %llu is not proved (or its proof was released)", (unsigned long long)id);
+  *d_words = f->pool.p + (size_t)nd.slot * f->slot_words;
+  *n_words = nd.proof_words;
+  return 0;
+}
+
+int mp2g_forest_release(mp2g_forest* f, uint64_t id) {
+  NEED(f, "forest");
+  std::lock_guard<std::mutex> g(f->mu);
+  auto it = f->index.find(id);
+  if (it == f->index.end()) return fail("forest: unknown node %llu", (unsigned long long)id);
+  Node& nd = f->nodes[it->second];
+  if (nd.slot >= 0) { f->free_slots.push_back(nd.slot); nd.slot = -1; }
+  return 0;
+}
+
+uint64_t mp2g_forest_proved(const mp2g_forest* f) { return f ? f->proved.load() : 0; }
+uint32_t mp2g_forest_free_slots(mp2g_forest* f) {
+  if (!f) return 0;
+  std::lock_guard<std::mutex> g(f->mu);
+  return (uint32_t)f->free_slots.size();
+}
+
+void mp2g_forest_free(mp2g_forest* f) {
+  if (!f) return;
+  for (mp2g_ctx* c : f->ctxs) if (c) (void)hipStreamSynchronize(c->stream);
+  delete f;
+}
+}  // extern "C"

@@ -505,3 +505,190 @@ def expected_root_public_inputs(ctx, table, wit, root, nodes, spans, variant=0):
             row_h[k] = x
     lo, hi = spans[root]
     return _u64cat(row_h[root], wit.row_digest[root], NEUTRAL_FIELDS, u256_to_limbs([sec[lo]])[0], u256_to_limbs([sec[hi - 1]])[0], [0])
+
+
+# ---- the same build with the scheduler in C++ (csrc/forest.hip) -------------------------------------------------------------------------
+class NativeTableBuild:
+    """TableBuild with the unit loop in the library: the block's nodes (4 cells-tree nodes and 1 row-tree node per row) are registered
+    with mp2g_forest once -- circuit, children, and the words of their witness inputs that are not child proofs, assembled here with
+    numpy for the whole block at a time --, then every wave of the update plan goes down as units (groups of Ready items) in one
+    mp2g_forest_prove call: worker threads, level batching, job assembly, the hand-over of child proofs (device pool, gather kernels)
+    and the witness check all run in C++; no proof visits the host except the root and the nodes a checker asked to keep.
+    Same proofs as TableBuild, word for word (tests/test_gpu_table.py::test_native_build_equals_the_python_build)."""
+
+    CIRCUITS = ("cells_leaf", "cells_full", "cells_partial", "row_leaf", "row_full", "row_partial")
+    row_job = TableBuild.row_job  # CircuitInput of a row node from host proofs: what a checker re-proves kept nodes with
+
+    def __init__(self, params, provers, batch=32, subtree_size=64, group_rows=None, pool_slots=None):
+        self.p, self.provers, self.batch, self.subtree_size = params, provers, batch, subtree_size
+        self.group_rows = 32 * batch if group_rows is None else max(1, int(group_rows))
+        self.n_proofs = 0
+        self.wave_log = []
+        fws = {n: (params.cells if n.startswith("cells") else params.rows) for n in self.CIRCUITS}
+        self.chains = []
+        for pv in provers:
+            pv.ctx.make_current()
+            self.chains.append([pv._chain([c[0] for c in fws[n].chains[n]], fws[n].witness_programs(n), batch) for n in self.CIRCUITS])
+        # proof words of a final proof of either set, in a parent's input order (recursion.proof_inputs): public inputs, 3 caps, openings, FRI
+        def pw(fw):
+            ch = self.chains[0][self.CIRCUITS.index(next(n for n in self.CIRCUITS if fws[n] is fw))]
+            fp, prog = ch.fps[-1], ch.programs[-1]
+            return int(prog.n_public_inputs) + 3 * int(fp.cap_words) + 2 * int(fp.n_openings) + int(fp.proof_words), fp, int(prog.n_public_inputs)
+        (self.pw_cells, self.fp_cells, self.npi_cells), (self.pw_rows, self.fp_rows, self.npi_rows) = pw(params.cells), pw(params.rows)
+        mem = lambda fw: 5 * max(0, (fw.set_size - 1).bit_length())  # membership proof: index bits + 4-limb siblings
+        self.head = {"cells": 68, "rows": 68}                         # verifier data in front of a child proof: cap (16 x 4) + digest (4)
+        self.mem = {"cells": mem(params.cells), "rows": mem(params.rows)}
+        # children of every circuit as (set of the child, ...) in input order; the row circuits' last child is the row's cells root
+        self.kids = {"cells_leaf": (), "cells_full": ("cells", "cells"), "cells_partial": ("cells",), "row_leaf": ("cells",), "row_full": ("rows", "rows", "cells"),
+                     "row_partial": ("rows", "cells")}
+        own = {"cells_leaf": CELL_LEN + 22, "cells_full": CELL_LEN + 22, "cells_partial": CELL_LEN + 22, "row_leaf": ROW_LEN, "row_full": ROW_LEN, "row_partial": ROW_LEN + 1}
+        self.desc, self.offsets = [], {}
+        for i, n in enumerate(self.CIRCUITS):
+            at, offs = 4, []
+            for k in self.kids[n]:
+                at += self.head[k]
+                offs.append(at)
+                at += (self.pw_cells if k == "cells" else self.pw_rows) + self.mem[k]
+            n_in = at + own[n]
+            assert n_in == self.chains[0][i].programs[0].n_inputs, f"{n}: layout {n_in} != the witness program's {self.chains[0][i].programs[0].n_inputs} inputs"
+            n_const = n_in - sum(self.pw_cells if k == "cells" else self.pw_rows for k in self.kids[n])
+            self.desc.append((n_in, offs, n_const))
+            self.offsets[n] = offs
+        self.pool_slots = pool_slots
+        self.forest = None
+        self.last_session = None
+
+    # node ids: row-tree node of row k = k; cells-tree node (row k, position c) = (c << 40) | k
+    @staticmethod
+    def cell_id(k, c):
+        return (int(c) << 40) | int(k)
+
+    def _child_block(self, fw, name):
+        """verifier data and membership proof around a child proof of circuit `name` of set fw"""
+        vd = fw.vds[name]
+        bits, sib = fw.membership(vd[1])
+        return (_u64cat(vd[0], vd[1]), _u64cat(bits, sib))
+
+    def register(self, table, wit, root, nodes, keep=()):
+        """every node of the block, circuit by circuit (numpy over all rows at once)"""
+        p, C, rows = self.p, table.n_cols, table.rows
+        keep = set(keep)
+        set_c, set_r = np.asarray(p.cells.set_digest, dtype=np.uint64), np.asarray(p.rows.set_digest, dtype=np.uint64)
+        neutral = np.asarray(NEUTRAL_FIELDS, dtype=np.uint64)
+        ks = np.arange(rows, dtype=np.uint64)
+        cell_kind = {}
+        for c in range(1, C + 1):
+            kids = [x for x in sbbst_children(C, c) if x is not None]
+            cell_kind[c] = (("cells_leaf", "cells_partial", "cells_full")[len(kids)], kids)
+        blocks_c = {n: self._child_block(p.cells, n) for n in ("cells_leaf", "cells_full", "cells_partial")}
+        blocks_r = {n: self._child_block(p.rows, n) for n in ("row_leaf", "row_full", "row_partial")}
+        tile = lambda v: np.broadcast_to(np.asarray(v, dtype=np.uint64)[None, :], (rows, len(v)))
+        keep_cells = np.array([1 if k in keep else 0 for k in range(rows)], dtype=np.uint8)
+        for c in range(1, C + 1):
+            name, kids = cell_kind[c]
+            flat = np.concatenate([np.full((rows, 1), table.col_ids[c], dtype=np.uint64), table.values[:, c].astype(np.uint64), np.zeros((rows, 1), dtype=np.uint64),
+                                   wit.cell_digest[:, c - 1], tile(neutral)], axis=1)
+            parts = [tile(set_c)]
+            for kc in kids:
+                head, tail = blocks_c[cell_kind[kc][0]]
+                parts += [tile(head), tile(tail)]
+            consts = np.ascontiguousarray(np.concatenate(parts + [flat], axis=1))
+            child_ids = np.stack([(np.uint64(kc) << np.uint64(40)) | ks for kc in kids], axis=1) if kids else None
+            is_root = c == sbbst_root(C)
+            self.forest.add_nodes(self.CIRCUITS.index(name), (np.uint64(c) << np.uint64(40)) | ks, child_ids, consts, keep_cells if is_root else None)
+        root_c = sbbst_root(C)
+        root_name = cell_kind[root_c][0]
+        head_c, tail_c = blocks_c[root_name]
+        self.cells_root_name = root_name
+        # row nodes by kind; a child's verifier data and membership proof depend on the CHILD's circuit
+        self.row_name = {k: ("row_leaf", "row_partial", "row_full")[(l is not None) + (r is not None)] for k, (l, r) in nodes.items()}
+        for n in ("row_leaf", "row_partial", "row_full"):
+            ka = np.array(sorted(k for k, nm in self.row_name.items() if nm == n), dtype=np.int64)
+            m = len(ka)
+            if not m:
+                continue
+            cols, child_cols = [np.broadcast_to(set_r[None, :], (m, 4))], []
+            for side in ((), (None,), (0, 1))[("row_leaf", "row_partial", "row_full").index(n)]:
+                kid = np.array([(nodes[int(k)][side] if side is not None else next(x for x in nodes[int(k)] if x is not None)) for k in ka], dtype=np.int64)
+                child_cols.append(kid.astype(np.uint64))
+                cols.append(np.stack([blocks_r[self.row_name[int(x)]][0] for x in kid]))
+                cols.append(np.stack([blocks_r[self.row_name[int(x)]][1] for x in kid]))
+            cols += [np.broadcast_to(head_c[None, :], (m, head_c.size)), np.broadcast_to(tail_c[None, :], (m, tail_c.size))]
+            cols += [np.full((m, 1), table.col_ids[0], dtype=np.uint64), table.values[ka, 0].astype(np.uint64), np.zeros((m, 1), dtype=np.uint64),
+                     np.asarray(wit.unique[ka], dtype=np.uint64), np.stack([np.asarray(wit.row_digest[int(k)], dtype=np.uint64) for k in ka]),
+                     np.broadcast_to(neutral[None, :], (m, 11))]
+            if n == "row_partial":
+                cols.append(np.array([[1 if nodes[int(k)][0] is not None else 0] for k in ka], dtype=np.uint64))
+            consts = np.ascontiguousarray(np.concatenate(cols, axis=1))
+            child_ids = np.stack(child_cols + [(np.uint64(root_c) << np.uint64(40)) | ka.astype(np.uint64)], axis=1)
+            kp = np.array([1 if int(k) in keep else 0 for k in ka], dtype=np.uint8)
+            self.forest.add_nodes(self.CIRCUITS.index(n), ka.astype(np.uint64), child_ids, consts, kp)
+
+    def _host_proof(self, words, rows_set):
+        fp, n_pi = (self.fp_rows, self.npi_rows) if rows_set else (self.fp_cells, self.npi_cells)
+        cw, no = int(fp.cap_words), int(fp.n_openings)
+        caps = np.zeros((4, cw), dtype=np.uint64)
+        caps[1:4] = words[n_pi:n_pi + 3 * cw].reshape(3, cw)
+        at = n_pi + 3 * cw
+        return caps, words[at:at + 2 * no].reshape(no, 2).copy(), words[at + 2 * no:].copy(), words[:n_pi].copy()
+
+    def run(self, table, wit, root, nodes, keep=()):
+        """register the block, then drain the batched work plan wave by wave, every wave as one mp2g_forest_prove over groups of its
+        items; returns (root proof, name). Nodes in `keep` (and their children and cells roots) stay downloadable afterwards:
+        self.row_proofs / self.cells_roots hold them as host tuples, like TableBuild's."""
+        from . import Forest
+        C = table.n_cols
+        keep_rows = set(keep)
+        for k in list(keep_rows):
+            keep_rows.update(c for c in nodes[k] if c is not None)
+        keep_rows.add(root)
+        if self.forest is not None:
+            self.forest.free()
+        # the pool holds the frontier: per worker a unit's cells leaves (2 per row) while its full nodes are proved, plus the roots of
+        # the items of earlier waves and what the caller keeps
+        unit = max(1, min(self.group_rows, -(-table.rows // len(self.provers))))
+        slots = self.pool_slots or (len(self.provers) * (3 * unit + 4 * self.batch) + table.rows // max(1, self.subtree_size // 2) + 2 * len(keep_rows) + 256)
+        self.forest = Forest([pv.ctx for pv in self.provers], self.desc, self.chains, max(self.pw_cells, self.pw_rows), slots)
+        self.register(table, wit, root, nodes, keep_rows)
+        ut = W.UpdateTree.from_map(0, root, nodes)
+        plan = ut.into_batched_workplan(self.subtree_size) if self.subtree_size > 1 else ut.into_workplan()
+        n0 = 0
+        self.wave_log = []
+        while True:
+            t_wave = time.perf_counter()
+            wave = W.drain_wave(plan)
+            if not wave:
+                break
+            item_keys = []
+            for it in wave:
+                if it.subtree is not None:
+                    item_keys.append([int(k) for k in it.subtree.nodes()])
+                    it.subtree.free()
+                else:
+                    item_keys.append([int(it.k)])
+            total = sum(len(k) for k in item_keys)
+            target = max(1, min(self.group_rows, -(-total // len(self.provers))))
+            units, group = [], []
+            for keys in item_keys:
+                group += keys
+                if len(group) >= target:
+                    units.append(group)
+                    group = []
+            if group:
+                units.append(group)
+            before = self.forest.proved
+            self.forest.prove([[self.cell_id(k, c) for k in u for c in range(1, C + 1)] + list(u) for u in units])
+            for it in wave:
+                plan.done(it.k)
+            self.wave_log.append((len(wave), self.forest.proved - before, time.perf_counter() - t_wave))
+        assert plan.completed()
+        plan.free()
+        self.n_proofs += self.forest.proved - n0
+        self.row_proofs = {k: (self._host_proof(self.forest.proof_words(k), True), self.row_name[k]) for k in keep_rows}
+        self.cells_roots = {k: (self._host_proof(self.forest.proof_words(self.cell_id(k, sbbst_root(C))), False), self.cells_root_name) for k in keep_rows}
+        return self.row_proofs[root]
+
+    def free(self):
+        if self.forest is not None:
+            self.forest.free()
+            self.forest = None

@@ -260,3 +260,60 @@ def test_bench_gpus_8_three_join_levels():
     assert line["n_gpus"] == 8 and line["config"]["join_levels"] == 3 and "3 join level" in line["config"]["sharding"]
     assert line["config"]["rccl_ranks"] == 8 and line["config"]["ranks_on_host"] == 8 and line["config"]["backend"] == "gloo"
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * (8 * 2 + 7)) < 1e-6 and line["verified"] >= 8 * 10
+
+
+def test_native_build_equals_the_python_build(ctx, mp2, params):
+    """table.NativeTableBuild (the scheduler in C++: mp2g_forest_*, worker threads, level batching, child proofs in a device pool)
+    against table.TableBuild (the Python unit loop) on the same 37-row block: the same root proof word for word, the same kept row
+    proofs and cells roots, 5 framework proofs per row; the root exposes the off-circuit tree and verifies; an unsatisfied witness
+    fails the native build as it fails the Python one (plonky2's prove() panics)."""
+    n = 37
+    table = T.SyntheticTable(n, 4, seed=0xC0FFEE04, block=2)
+    root, nodes, spans = T.balanced_bst(n)
+    samples, keep = T.sample_nodes(nodes, spans)
+    ctxs = [mp2.Context(0) for _ in range(2)]
+    provers = [FW.GpuProver(c, capacity=8) for c in ctxs]
+    wit = T.TableWitness(ctx, table, spans)
+    py = T.TableBuild(params, [R.ProofSession(p) for p in provers], batch=8, subtree_size=8, host_threads=4)
+    want, want_name = py.run(table, wit, root, nodes)
+    nb = T.NativeTableBuild(params, provers, batch=8, subtree_size=8, group_rows=16)
+    got, got_name = nb.run(table, wit, root, nodes, keep=samples)
+    assert got_name == want_name and nb.n_proofs == 5 * n == py.n_proofs
+    assert all(np.array_equal(a, b) for a, b in zip(got, want)), "root proof"
+    for k in keep | {root}:
+        assert nb.row_proofs[k][1] == py.row_proofs[k][1]
+        assert all(np.array_equal(a, b) for a, b in zip(nb.row_proofs[k][0], py.row_proofs[k][0])), f"row {k}"
+        assert all(np.array_equal(a, b) for a, b in zip(nb.cells_roots[k][0], py.cells_roots[k][0])), f"cells root of row {k}"
+    pis = got[3]
+    assert np.array_equal(pis[:T.ROWS_IO], T.expected_root_public_inputs(ctx, table, wit, root, nodes, spans))
+    wckt, wcap, wdig = params.rows.chains[got_name][-1]
+    assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *got[:3]) == 0
+    assert len(nb.wave_log) == len(py.wave_log) and [w[:2] for w in nb.wave_log] == [w[:2] for w in py.wave_log]
+    # a second block through the same object (new forest, same chains)
+    again, _ = nb.run(table, wit, root, nodes, keep=samples)
+    assert all(np.array_equal(a, b) for a, b in zip(again, want)) and nb.n_proofs == 10 * n
+    # a witness that violates a constraint: the value limb of one cell out of u32 range
+    bad = T.SyntheticTable(n, 4, seed=0xC0FFEE04, block=2)
+    bad_wit = T.TableWitness(ctx, bad, spans)
+    bad_wit.unique = bad_wit.unique.copy()
+    bad_wit.cell_digest = bad_wit.cell_digest.copy()
+    bad.col_ids = bad.col_ids.copy()
+    vals = bad.values.astype(np.uint64)
+    vals[5, 2, 3] = 1 << 33
+    bad.values = vals
+    with pytest.raises(mp2.Mp2gError, match="witness"):
+        nb.run(bad, bad_wit, root, nodes)
+    nb.free()
+    for p in provers:
+        p.free()
+    for c in ctxs:
+        c.close()
+
+
+def test_bench_native_build():
+    """python bench.py --native-build: the same line (block root checked against the off-circuit tree and the oracle's verifier, one
+    framework proof of every circuit kind re-proved by the oracle bit for bit from the kept nodes), the scheduler named in it"""
+    line = _bench(["--rows", "8", "--steps", "2", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "8", "--native-build", "--no-cpu-baseline",
+                   "--config2-leaves", "0", "--degree-sweep", "", "--no-leaves-leg"])
+    assert line["config"]["host_orchestration"]["scheduler"].startswith("native") and line["verified"] >= 16
+    assert abs(line["value"] * line["ms_per_step"] * 2 / 1e3 - 5 * 16) < 1e-6
