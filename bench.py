@@ -493,7 +493,7 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
     # HBM-side bytes of the same two launches from the TCC counters (collected in separate
     # --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/rNN/ntt_traffic.json)
     traffic = None
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "ntt_traffic.json")) as f:
                 traffic = json.load(f)["ntt_2p22_forward_bitrev"]["traffic_bytes"]
