@@ -701,6 +701,8 @@ class Forest:
         ch = (ctypes.c_void_p * (nw * nc))(*[(self.chains[w][c].h if self.chains[w][c] is not None else None) for w in range(nw) for c in range(nc)])
         self.h = ctypes.c_void_p()
         _ck(load().mp2g_forest_create(nw, cx, nc, d, ch, int(slot_words), int(pool_slots), ctypes.byref(self.h)))
+        for c in self.ctxs:  # the forest holds raw pointers to every worker's context and chains: whichever closes first frees it
+            c._adopt(self)
         self.n_const = [int(x[2]) for x in descriptors]
         self.n_children = [len(x[1]) for x in descriptors]
 
@@ -740,7 +742,7 @@ class Forest:
         return int(load().mp2g_forest_proved(self.h))
 
     def free(self):
-        if self.h:
+        if self.h and all(c.h for c in self.ctxs):
             load().mp2g_forest_free(self.h)
         self.h = None
 

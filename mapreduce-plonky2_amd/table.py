@@ -624,10 +624,13 @@ class NativeTableBuild:
             kp = np.array([1 if int(k) in keep else 0 for k in ka], dtype=np.uint8)
             self.forest.add_nodes(self.CIRCUITS.index(n), ka.astype(np.uint64), child_ids, consts, kp)
 
-    def _host_proof(self, words, rows_set):
+    def _host_proof(self, words, rows_set, name):
+        """(caps, openings, FRI words, public inputs) of a pooled proof, as the prover hands them out: the cap of oracle 0 (verifier
+        data, not part of a proof's words) is the circuit's constants_sigmas cap"""
         fp, n_pi = (self.fp_rows, self.npi_rows) if rows_set else (self.fp_cells, self.npi_cells)
         cw, no = int(fp.cap_words), int(fp.n_openings)
         caps = np.zeros((4, cw), dtype=np.uint64)
+        caps[0] = np.asarray((self.p.rows if rows_set else self.p.cells).vds[name][0], dtype=np.uint64).ravel()
         caps[1:4] = words[n_pi:n_pi + 3 * cw].reshape(3, cw)
         at = n_pi + 3 * cw
         return caps, words[at:at + 2 * no].reshape(no, 2).copy(), words[at + 2 * no:].copy(), words[:n_pi].copy()
@@ -684,8 +687,8 @@ class NativeTableBuild:
         assert plan.completed()
         plan.free()
         self.n_proofs += self.forest.proved - n0
-        self.row_proofs = {k: (self._host_proof(self.forest.proof_words(k), True), self.row_name[k]) for k in keep_rows}
-        self.cells_roots = {k: (self._host_proof(self.forest.proof_words(self.cell_id(k, sbbst_root(C))), False), self.cells_root_name) for k in keep_rows}
+        self.row_proofs = {k: (self._host_proof(self.forest.proof_words(k), True, self.row_name[k]), self.row_name[k]) for k in keep_rows}
+        self.cells_roots = {k: (self._host_proof(self.forest.proof_words(self.cell_id(k, sbbst_root(C))), False, self.cells_root_name), self.cells_root_name) for k in keep_rows}
         return self.row_proofs[root]
 
     def free(self):
