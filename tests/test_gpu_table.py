@@ -317,3 +317,13 @@ def test_bench_native_build():
                    "--config2-leaves", "0", "--degree-sweep", "", "--no-leaves-leg"])
     assert line["config"]["host_orchestration"]["scheduler"].startswith("native") and line["verified"] >= 16
     assert abs(line["value"] * line["ms_per_step"] * 2 / 1e3 - 5 * 16) < 1e-6
+
+
+def test_bench_gpus_2_native_build():
+    """two ranks (gloo, sharing this box's GPU) with the native scheduler building each rank's block: the block roots leave the forests'
+    device pools as host proofs, the separator row above them is proved through the Python unit loop over the same chains; the run asserts
+    the joined root's digest (the whole table's) and min"""
+    line = _bench(["--gpus", "2", "--rows", "8", "--steps", "1", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "4", "--no-leaves-leg",
+                   "--no-cpu-baseline", "--native-build"], env={"MP2G_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["config"]["host_orchestration"]["scheduler"].startswith("native")
+    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * 17) < 1e-6 and line["verified"] >= 2 * 13
