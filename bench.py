@@ -596,8 +596,10 @@ def main(argv=None):
     ap.add_argument("--workers", type=int, default=4, help="--workload table: concurrent work-plan items per rank, one host thread + GPU stream + prover set each")
     ap.add_argument("--table-batch", type=int, default=32, help="--workload table: proofs per prove() launch sequence of a worker")
     ap.add_argument("--subtree", type=int, default=64, help="--workload table: into_batched_workplan(subtree_size), the rows of one work-plan item")
-    ap.add_argument("--native-build", action="store_true", help="--workload table: the table build's scheduler in C++ (mp2g_forest_*: worker threads, level batching, "
-                    "job assembly, child proofs in a device pool) instead of table.TableBuild's Python unit loop")
+    ap.add_argument("--native-build", action="store_true", default=True, help="--workload table: the table build's scheduler in C++ (mp2g_forest_*: worker threads, "
+                    "level batching, job assembly, child proofs in a device pool): the default")
+    ap.add_argument("--python-build", dest="native_build", action="store_false", help="--workload table: table.TableBuild's Python unit loop over mp2g_chain_run "
+                    "instead of the native scheduler (the A/B switch; also what --host-witness uses)")
     ap.add_argument("--group-rows", type=int, default=None, help="--workload table: rows a worker takes at a time = several work-plan items of one wave proved as one unit "
                     "(cells trees in full batches, row-tree levels merged across the items); default 32 x --table-batch (capped at the wave's rows / workers), 1 = one item at a time")
     ap.add_argument("--host-witness", action="store_true", help="--workload table / recursion: replay the witness programs on host threads (mp2g_witness_program_run_rows) "

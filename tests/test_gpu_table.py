@@ -176,7 +176,7 @@ def test_bench_default_workload_is_the_table_build():
     assert line["config2"]["framework_proofs"] == 127 and line["config2"]["value"] > 0 and line["config2"]["root_verified"]
     k12 = line["by_base_degree"]["12"]
     assert k12["value"] > 0 and k12["root_verified"] and all(ch[0] >= 12 for ch in k12["shapes"].values()) and k12["shapes"]["cells_leaf"][0] == 12 and k12["shapes"]["cells_leaf"][-1] == 12
-    assert line["config"]["device_memory_used_bytes"] > 0
+    assert line["config"]["device_memory_used_bytes"] > 0 and line["config"]["host_orchestration"]["scheduler"].startswith("native")
 
 
 def test_bench_gpus_2_starts_its_own_ranks():
@@ -310,20 +310,23 @@ def test_native_build_equals_the_python_build(ctx, mp2, params):
         c.close()
 
 
-def test_bench_native_build():
-    """python bench.py --native-build: the same line (block root checked against the off-circuit tree and the oracle's verifier, one
-    framework proof of every circuit kind re-proved by the oracle bit for bit from the kept nodes), the scheduler named in it"""
-    line = _bench(["--rows", "8", "--steps", "2", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "8", "--native-build", "--no-cpu-baseline",
+def test_bench_python_build():
+    """python bench.py --python-build: the same line by the Python unit loop (the default is the native scheduler: the test of the
+    default workload above asserts that): block root checked against the off-circuit tree and the oracle's verifier, one framework
+    proof of every circuit kind re-proved by the oracle bit for bit, the scheduler named in the line"""
+    line = _bench(["--rows", "8", "--steps", "2", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "8", "--python-build", "--no-cpu-baseline",
                    "--config2-leaves", "0", "--degree-sweep", "", "--no-leaves-leg"])
-    assert line["config"]["host_orchestration"]["scheduler"].startswith("native") and line["verified"] >= 16
+    assert line["config"]["host_orchestration"]["scheduler"].startswith("python") and line["verified"] >= 16
+    assert 0 <= line["config"]["host_orchestration"]["host_glue_share"] < 1
     assert abs(line["value"] * line["ms_per_step"] * 2 / 1e3 - 5 * 16) < 1e-6
 
 
-def test_bench_gpus_2_native_build():
-    """two ranks (gloo, sharing this box's GPU) with the native scheduler building each rank's block: the block roots leave the forests'
-    device pools as host proofs, the separator row above them is proved through the Python unit loop over the same chains; the run asserts
-    the joined root's digest (the whole table's) and min"""
+def test_bench_gpus_2_python_build():
+    """two ranks (gloo, sharing this box's GPU) with `--python-build`: table.TableBuild's Python unit loop over mp2g_chain_run instead of the
+    native scheduler (the default, which the other multi-rank tests run: there the block roots leave the forests' device pools as host
+    proofs and the separator rows above them are proved through the Python unit loop over the same chains); the run asserts the joined
+    root's digest (the whole table's) and min"""
     line = _bench(["--gpus", "2", "--rows", "8", "--steps", "1", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "4", "--no-leaves-leg",
-                   "--no-cpu-baseline", "--native-build"], env={"MP2G_BENCH_BACKEND": "gloo"})
-    assert line["n_gpus"] == 2 and line["config"]["host_orchestration"]["scheduler"].startswith("native")
+                   "--no-cpu-baseline", "--python-build"], env={"MP2G_BENCH_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["config"]["host_orchestration"]["scheduler"].startswith("python")
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * 17) < 1e-6 and line["verified"] >= 2 * 13

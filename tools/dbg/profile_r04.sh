@@ -22,7 +22,7 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --kernel-trace --o
 python3 $R/bench.py --workload recursion --batch 128 --trees 8 --steps 3 --warmup 1 > $O/recursion.json 2> $O/recursion.err
 python3 $R/bench.py --steps 2 --warmup 1 --host-witness --no-leaves-leg --no-verify --config2-leaves 0 --degree-sweep "" --no-cpu-baseline > $O/bench_host_witness.json 2> $O/bench_host_witness.err
 python3 $R/bench.py --workload leaves > $O/leaves.json 2> $O/leaves.err
-python3 $R/bench.py --steps 20 --warmup 5 --group-rows 1 --no-leaves-leg --no-verify --config2-leaves 0 --degree-sweep "" --no-cpu-baseline > $O/bench_ungrouped.json 2> $O/bench_ungrouped.err   # one work-plan item per worker unit: round 3's schedule
+python3 $R/bench.py --steps 20 --warmup 5 --python-build --group-rows 1 --no-leaves-leg --no-verify --config2-leaves 0 --degree-sweep "" --no-cpu-baseline > $O/bench_ungrouped.json 2> $O/bench_ungrouped.err   # one work-plan item per worker unit: round 3's schedule
 python3 $R/tools/dbg/witness_dev_timing.py > $O/witness_dev_timing.txt 2>&1
 # keep only the summaries (the raw traces exceed the merge limit)
 find $O -name "*kernel_trace.csv" -size +20M -delete
