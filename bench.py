@@ -969,11 +969,21 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                 dist.send(head.to(dev) if nccl else head, rank - bit)
                 pv = (st["build"].last_session or rig.sessions[0]).prover
                 ch = getattr(pv, "last_chain", None)
-                if ch is not None and not args.host_witness and not rig.native:
+                own_root = cur[0] is st["proof"]  # this rank's block root (not a joined tree: those are proved by the Python unit loop)
+                if rig.native and own_root:
+                    # the block root where the native scheduler left it: its slot of the forest's device pool, split into the four ranges
+                    ptr, n_words = st["build"].forest.device_proof(st["root"])
+                    assert n_words == sum(proof_sizes)
+                    parts, at = [], 0
+                    for n_ in proof_sizes:
+                        parts.append((ptr + 8 * at, n_))
+                        at += n_
+                    out = R.DeviceProof(parts, keep=st["build"].forest)
+                elif ch is not None and not args.host_witness and not rig.native:
                     assert ch.last_batch == 1, "the chain's last run was the root alone: its proof 0 is the root"
                     out = pv.last_device_proof(0)
                 else:
-                    out = cur[0]  # the host-witness back end leaves no chain outputs on the device: the host proof goes (uploaded for RCCL)
+                    out = cur[0]  # no chain outputs left on the device for it (host-witness back end; a joined tree under the native scheduler): the host proof goes (uploaded for RCCL)
                 sharding.send_device_proof(dist, pv.ctx, out, rank - bit, dev)
                 break
             head = torch.zeros(6, dtype=torch.int64, device=dev)

@@ -330,3 +330,48 @@ def test_bench_gpus_2_python_build():
                    "--no-cpu-baseline", "--python-build"], env={"MP2G_BENCH_BACKEND": "gloo"})
     assert line["n_gpus"] == 2 and line["config"]["host_orchestration"]["scheduler"].startswith("python")
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * 17) < 1e-6 and line["verified"] >= 2 * 13
+
+
+def test_forest_refuses_what_it_cannot_prove(ctx, mp2, params):
+    """mp2g_forest_* error behaviour (csrc/forest.hip): a node registered twice, a unit naming an unknown node, a node whose child was
+    never proved, a pool too small for a batch, a proof asked for before it exists -- each returns the library's error with a message
+    and leaves the forest usable; released roots give their slots back"""
+    nb = T.NativeTableBuild(params, [FW.GpuProver(ctx, capacity=4)], batch=4, subtree_size=4, group_rows=4, pool_slots=6)
+    n = 2
+    table = T.SyntheticTable(n, 4, seed=0xC0FFEE04, block=4)
+    root, nodes, spans = T.balanced_bst(n)
+    wit = T.TableWitness(ctx, table, spans)
+    F = mp2.Forest([nb.provers[0].ctx], nb.desc, nb.chains, max(nb.pw_cells, nb.pw_rows), 6)
+    nb.forest = F
+    nb.register(table, wit, root, nodes, keep={root})
+    with pytest.raises(mp2.Mp2gError, match="registered twice"):
+        nb.register(table, wit, root, nodes, keep={root})
+    with pytest.raises(mp2.Mp2gError, match="unknown node"):
+        F.prove([[12345]])
+    with pytest.raises(mp2.Mp2gError, match="not proved"):
+        F.prove([[nb.cell_id(0, 2)]])  # the cells-tree full node of row 0 before its leaves
+    with pytest.raises(mp2.Mp2gError, match="not proved"):
+        F.proof_words(root)
+    # 2 rows x 4 cells-tree nodes: the four leaves of both rows fill 4 of 6 slots, the two full nodes need 2 more while the leaves are
+    # still alive, then slots come back; the whole block passes through 6 slots only because children are released as parents are proved
+    F.prove([[nb.cell_id(k, c) for k in range(n) for c in range(1, 5)] + list(range(n))])
+    assert F.proved == 5 * n
+    words = F.proof_words(root)
+    pis = words[:T.ROWS_IO + 4]
+    assert np.array_equal(pis[:T.ROWS_IO], T.expected_root_public_inputs(ctx, table, wit, root, nodes, spans))
+    load = mp2.load()
+    assert load.mp2g_forest_free_slots(F.h) == 6 - 2  # the kept root and its kept cells root
+    F.release(root)
+    assert load.mp2g_forest_free_slots(F.h) == 6 - 1
+    with pytest.raises(mp2.Mp2gError, match="not proved"):
+        F.proof_words(root)
+    # a pool that cannot hold one batch
+    small = mp2.Forest([nb.provers[0].ctx], nb.desc, nb.chains, max(nb.pw_cells, nb.pw_rows), 3)
+    nb.forest = small
+    nb.register(table, wit, root, nodes)
+    with pytest.raises(mp2.Mp2gError, match="pool is exhausted"):
+        small.prove([[nb.cell_id(k, c) for k in range(n) for c in range(1, 5)] + list(range(n))])
+    small.free()
+    nb.forest = F
+    nb.free()
+    nb.provers[0].free()
