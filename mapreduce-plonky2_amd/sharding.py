@@ -20,8 +20,8 @@ import numpy as np
 
 # device bytes a prover holds per proof in flight and per row of its circuit: the x8 LDEs of the 135 wire, 20 Z / partial-product
 # and 16 quotient polynomials with their coefficients, the Merkle levels of the four oracles, FRI layers, witness slots
-# (calibrated on the bench's table build: `device_memory_used_bytes` in its JSON)
-PROOF_BYTES_PER_ROW = 14 * 1024
+# (calibrated on the bench's table build: `device_memory_used_bytes` in its JSON -- 160 GB measured at 4 workers x 32 proofs in flight)
+PROOF_BYTES_PER_ROW = 16 * 1024
 HBM_BYTES = 288 * 10**9
 
 
