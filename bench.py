@@ -1108,7 +1108,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         by_degree = {}
         def at_degree(k):
             bk = max(4, args.table_batch >> max(0, k - 12))  # proofs in flight per worker shrink with the degree: the same device memory at every k
-            rk = TableRig(mods, local_rank, VARIANT, args.workers, bk, args.subtree, args.host_witness, ranks_here, pad_bits=k, group_rows=args.group_rows)
+            rk = TableRig(mods, local_rank, VARIANT, args.workers, bk, args.subtree, args.host_witness, ranks_here, pad_bits=k, group_rows=args.group_rows, native=args.native_build)
             try:
                 rk.build(min(64, args.sweep_rows), 0, seed ^ 0x5A5A5A, n_cols, False)
                 for c in rk.ctxs:

@@ -146,9 +146,12 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
           for (uint32_t j = 0; j < B; j++) { slots[j] = f->free_slots.back(); f->free_slots.pop_back(); }
         }
         uint32_t nb = 0;
+        // from here on the batch owns its slots: every failure path gives them back
+        auto give_back = [&]() { std::lock_guard<std::mutex> g(f->mu); for (int32_t sl : slots) f->free_slots.push_back(sl); };
         const uint32_t need_jobs = B * (C.d.n_children + 4);
-        if (need_jobs > W.cap_jobs) return fail("forest: internal: copy-job staging too small");
+        if (need_jobs > W.cap_jobs) { give_back(); return fail("forest: internal: copy-job staging too small"); }
         // inputs: the node's constant words around its children's ranges; the children come from their pool slots
+        int arc = [&]() -> int {
         for (uint32_t j = 0; j < B; j++) {
           const Node& n = f->nodes[todo[lo + j]];
           u64* dst = ch->h_in + (size_t)j * s0.n_in;
@@ -173,6 +176,9 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
             }
           }
         }
+        return 0;
+        }();
+        if (arc) { give_back(); return arc; }
         const uint32_t n_between = nb;
         // outputs -> slots, in a parent's input order: public inputs, caps of oracles 1..3, openings, FRI words
         for (uint32_t j = 0; j < B; j++) {
@@ -182,15 +188,14 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
           W.h_jobs[nb++] = Copy{L.openings.p + (size_t)j * L.n_open * 2, slot + n_pi + cw, ow, 0};
           W.h_jobs[nb++] = Copy{L.proof.p + (size_t)j * L.proof_words, slot + n_pi + cw + ow, pw, 0};
         }
-        CK(hipMemcpyAsync(W.d_jobs, W.h_jobs, (size_t)nb * sizeof(Copy), hipMemcpyHostToDevice, f->ctxs[w]->stream));
+        {
+          hipError_t e = hipMemcpyAsync(W.d_jobs, W.h_jobs, (size_t)nb * sizeof(Copy), hipMemcpyHostToDevice, f->ctxs[w]->stream);
+          if (e != hipSuccess) { give_back(); return fail("forest: copy jobs upload: %s", hipGetErrorString(e)); }
+        }
         BatchCtx bc{f, w, n_between, nb - n_between};
         ChainHooks hooks{&bc, hook_between, hook_after};
         int rc = chain_run_staged(ch, B, nullptr, 0, &hooks, nullptr, nullptr, nullptr, nullptr);
-        if (rc) {
-          std::lock_guard<std::mutex> g(f->mu);
-          for (int32_t sl : slots) f->free_slots.push_back(sl);
-          return rc;
-        }
+        if (rc) { give_back(); return rc; }
         {
           std::lock_guard<std::mutex> g(f->mu);
           for (uint32_t j = 0; j < B; j++) {
