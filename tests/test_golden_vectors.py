@@ -102,3 +102,37 @@ def test_hip_reproduces_golden(ctx, mp2):
     col_ids, values, unique = digest_inputs()
     dw, _ = mp2.compute_table_row_digest(ctx, col_ids, values, unique)
     assert dw.tolist() == G["row_digest_10x4"]["encoding"]
+
+
+def _commitment_inputs():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_golden_commitment", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "gen_golden_commitment.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.inputs()
+
+
+GC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "commitment_vectors.json")))
+
+
+def test_oracle_reproduces_golden_commitment():
+    pid, primary, col_ids, values, uniq, old = _commitment_inputs()
+    unique = np.ascontiguousarray(values[:, uniq, :])
+    for name, v in (("poseidon2", 0), ("poseidon", 1)):
+        for key, oc in (("fresh", None), ("update", old)):
+            o = np.zeros(32, dtype=np.uint8)
+            ob = np.frombuffer(oc, dtype=np.uint8).copy() if oc is not None else None
+            O.lib().orc_update_off_chain_data_commitment(v, ctypes.c_uint64(pid), O.p(O.arr(primary, np.uint32)), O.p(col_ids), O.sz(3), O.p(O.arr(values, np.uint32)),
+                                                         O.p(O.arr(unique, np.uint32)), O.sz(2), O.sz(9), O.p(ob) if ob is not None else None, O.p(o))
+            assert o.tobytes().hex() == GC[name][key], (name, key)
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_golden_commitment(ctx):
+    import importlib
+    dg = importlib.import_module("mapreduce-plonky2_amd.digest")
+    pid, primary, col_ids, values, uniq, old = _commitment_inputs()
+    ucols = [col_ids[i] for i in uniq]
+    for name, v in (("poseidon2", 0), ("poseidon", 1)):
+        assert dg.update_off_chain_data_commitment(ctx, pid, primary, col_ids, values, ucols, None, v).hex() == GC[name]["fresh"]
+        assert dg.update_off_chain_data_commitment(ctx, pid, primary, col_ids, values, ucols, old, v).hex() == GC[name]["update"]
