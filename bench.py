@@ -756,7 +756,7 @@ class TableRig:
             proof, name = tb.run(table, wit, root, nodes, keep=samples)
             self.n_proofs += tb.n_proofs - n0
             self.last_glue = {"scheduler": "native (mp2g_forest_*)", "block_s": round(time.perf_counter() - t0, 2),
-                              "inside_libmp2gpu_s": round(sum(sec for _, _, sec in tb.wave_log), 2)}
+                              "inside_libmp2gpu_s": round(tb.seconds_in_prove, 2)}  # mp2g_forest_prove_plan: the plan's waves, units, batches
         else:
             tb = T.TableBuild(self.params, self.sessions, batch=self.batch, subtree_size=self.subtree, host_threads=self.host_threads,
                               keep_proofs=not lean, keep_nodes=keep if lean else (), group_rows=self.group_rows)
@@ -1093,7 +1093,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     mem_free, mem_total = ctx.mem_info()  # with every prover of the run still alive: what the planner's estimate is calibrated on
     setup_s, workers, host_threads, plan = rig.setup_s, len(rig.ctxs), rig.host_threads, rig.plan
     root_pis_out = [int(x) for x in cur[0][3]]
-    waves = [[n_items, n_pr, round(sec, 2)] for n_items, n_pr, sec in st["build"].wave_log]
+    waves = [[n_items, n_pr, (round(sec, 2) if sec is not None else None)] for n_items, n_pr, sec in st["build"].wave_log]
     glue = dict(rig.last_glue)
     if "worker_busy_s" in glue:
         glue["host_glue_share"] = round(1.0 - glue["inside_libmp2gpu_s"] / max(glue["worker_busy_s"], 1e-9), 4)
@@ -1155,7 +1155,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                           "rows_per_rank": n_rows, "rows_per_step": args.rows, "row_tree_depth": depth, "warmup_rows_per_rank": args.warmup * args.rows,
                           "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "group_rows": args.group_rows or 32 * args.table_batch, "pad_base_bits": args.pad_base_bits,
                           "lean": bool(lean), "host_orchestration": glue,  # the workers' time in the timed block: total, inside the C ABI (mp2g_chain_run), the rest = Python glue
-                          "work_plan_waves": waves,  # per wave of the work plan: [items, framework proofs, seconds]
+                          "work_plan_waves": waves,  # (the native scheduler drains the plan inside the library and reports the items per wave only)  # per wave of the work plan: [items, framework proofs, seconds]
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "ranks_on_host": ranks_here, "shapes": shapes,
                           "device_memory_used_bytes": mem_total - mem_free, "device_memory_planned_bytes": plan["device_bytes_per_rank"],

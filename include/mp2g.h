@@ -499,6 +499,13 @@ int mp2g_forest_create(uint32_t n_workers, mp2g_ctx* const* ctxs, uint32_t n_cir
 int mp2g_forest_add_nodes(mp2g_forest* f, uint32_t circuit, uint32_t count, const uint64_t* ids, const uint64_t* child_ids /* [count][n_children] */,
                           const uint64_t* consts /* [count][n_const] */, const uint8_t* keep /* [count] or NULL */);
 int mp2g_forest_prove(mp2g_forest* f, const uint64_t* unit_nodes, const uint32_t* unit_offsets /* [n_units + 1] */, uint32_t n_units);
+/* the harness loop over an update plan (declared below), inside the library: drain the Ready items of a wave, group them into units of
+ * about group_nodes plan nodes (never fewer units than workers), prove, mark done, until the plan is finished. A plan node k stands for
+ * forest node k and its n_satellites satellite nodes ((j + 1) << satellite_shift) | k (a row and that row's cells-tree nodes).
+ * waves / items_per_wave[max_waves] (may be NULL) receive the number of waves and the items of each. */
+struct mp2g_update_plan;
+int mp2g_forest_prove_plan(mp2g_forest* f, struct mp2g_update_plan* plan, uint32_t group_nodes, uint32_t n_satellites, uint32_t satellite_shift,
+                           uint32_t* waves, uint32_t* items_per_wave, uint32_t max_waves);
 /* a proved node's final proof: its words in a parent's input order (public inputs, caps of oracles 1..3, openings, FRI words) on the
  * host (words may be NULL to ask for the length) or where they lie on the device (valid until the slot is returned) */
 int mp2g_forest_proof(mp2g_forest* f, uint64_t id, uint64_t* words, uint32_t* n_words);

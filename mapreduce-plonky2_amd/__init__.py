@@ -720,6 +720,14 @@ class Forest:
         offs = _arr(np.cumsum([0] + [len(u) for u in units]), np.uint32)
         _ck(load().mp2g_forest_prove(self.h, _p(flat), _p(offs), len(units)))
 
+    def prove_plan(self, plan, group_nodes, n_satellites=0, satellite_shift=40):
+        """drain an UpdatePlan (workplan.py) inside the library: the Ready items of every wave grouped into units of ~group_nodes plan
+        nodes, proved, marked done, until the plan is finished. A plan node k = forest node k + its satellites ((j + 1) << shift) | k.
+        Returns the items of every wave."""
+        waves, per = ctypes.c_uint32(), (ctypes.c_uint32 * 64)()
+        _ck(load().mp2g_forest_prove_plan(self.h, plan.h, int(group_nodes), int(n_satellites), int(satellite_shift), ctypes.byref(waves), per, 64))
+        return [int(per[i]) for i in range(min(64, waves.value))]
+
     def proof_words(self, node_id):
         n = ctypes.c_uint32()
         _ck(load().mp2g_forest_proof(self.h, ctypes.c_uint64(int(node_id)), None, ctypes.byref(n)))

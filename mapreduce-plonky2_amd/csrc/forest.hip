@@ -321,6 +321,71 @@ int mp2g_forest_prove(mp2g_forest* f, const uint64_t* unit_nodes, const uint32_t
   return 0;
 }
 
+// The reference harness's loop (mp2-v1/tests/common/rowtree.rs:78-337 with into_batched_workplan): drain every item that is Ready,
+// prove it, mark it done, until the plan is finished -- with the items of a wave grouped into units of about group_nodes plan nodes
+// (never fewer units than workers while the wave has the items). A plan node k stands for the forest node k and for its n_satellites
+// satellite nodes ((j + 1) << satellite_shift) | k, j < n_satellites (a row and the cells-tree nodes of that row).
+int mp2g_forest_prove_plan(mp2g_forest* f, mp2g_update_plan* plan, uint32_t group_nodes, uint32_t n_satellites, uint32_t satellite_shift,
+                           uint32_t* waves, uint32_t* items_per_wave, uint32_t max_waves) {
+  NEED(f && plan && satellite_shift < 64 && (!n_satellites || satellite_shift > 0), "forest / plan / satellites");
+  try {
+    uint32_t n_waves = 0;
+    for (;;) {
+      // one wave: every item that is Ready now (a batched plan drained without `done` in between hands the same subtree out once per
+      // leaf anchor it holds: repeats are dropped, as workplan.drain_wave does)
+      std::vector<std::vector<uint64_t>> items;
+      std::vector<uint64_t> roots;
+      for (;;) {
+        uint64_t k = 0;
+        int end = 0;
+        mp2g_update_tree* sub = nullptr;
+        const int st = mp2g_update_plan_next(plan, &k, &end, &sub);
+        if (st < 0) return 1;
+        if (st != MP2G_PLAN_READY) break;
+        if (std::find(roots.begin(), roots.end(), k) != roots.end()) { if (sub) mp2g_update_tree_free(sub); continue; }
+        std::vector<uint64_t> keys;
+        if (sub) {
+          keys.resize(mp2g_update_tree_size(sub));
+          const int rc = mp2g_update_tree_nodes(sub, keys.data(), nullptr, nullptr);
+          mp2g_update_tree_free(sub);
+          if (rc) return rc;
+        } else {
+          keys.push_back(k);
+        }
+        roots.push_back(k);
+        items.push_back(std::move(keys));
+      }
+      if (items.empty()) break;
+      size_t total = 0;
+      for (auto& it : items) total += it.size();
+      const size_t target = std::max<size_t>(1, std::min<size_t>(group_nodes ? group_nodes : 1, (total + f->n_workers - 1) / f->n_workers));
+      std::vector<uint64_t> nodes;
+      std::vector<uint32_t> offs{0};
+      size_t in_group = 0;
+      for (auto& it : items) {
+        for (uint64_t k : it) {
+          for (uint32_t j = 0; j < n_satellites; j++) nodes.push_back(((uint64_t)(j + 1) << satellite_shift) | k);
+          nodes.push_back(k);
+        }
+        in_group += it.size();
+        if (in_group >= target) { offs.push_back((uint32_t)nodes.size()); in_group = 0; }
+      }
+      if (in_group) offs.push_back((uint32_t)nodes.size());
+      const int rc = mp2g_forest_prove(f, nodes.data(), offs.data(), (uint32_t)offs.size() - 1);
+      if (rc) return rc;
+      for (uint64_t k : roots) {
+        const int rd = mp2g_update_plan_done(plan, k);
+        if (rd) return rd;
+      }
+      if (items_per_wave && n_waves < max_waves) items_per_wave[n_waves] = (uint32_t)items.size();
+      n_waves++;
+    }
+    if (!mp2g_update_plan_completed(plan)) return fail("forest: the work plan stalled with items not done");
+    if (waves) *waves = n_waves;
+    return 0;
+  } catch (const std::bad_alloc&) { return fail("out of memory"); } catch (...) { return fail("internal error"); }
+}
+
 int mp2g_forest_proof(mp2g_forest* f, uint64_t id, uint64_t* words, uint32_t* n_words) {
   NEED(f && n_words, "forest / outputs");
   const u64* src = nullptr;

@@ -655,38 +655,15 @@ class NativeTableBuild:
         self.register(table, wit, root, nodes, keep_rows)
         ut = W.UpdateTree.from_map(0, root, nodes)
         plan = ut.into_batched_workplan(self.subtree_size) if self.subtree_size > 1 else ut.into_workplan()
-        n0 = 0
-        self.wave_log = []
-        while True:
-            t_wave = time.perf_counter()
-            wave = W.drain_wave(plan)
-            if not wave:
-                break
-            item_keys = []
-            for it in wave:
-                if it.subtree is not None:
-                    item_keys.append([int(k) for k in it.subtree.nodes()])
-                    it.subtree.free()
-                else:
-                    item_keys.append([int(it.k)])
-            total = sum(len(k) for k in item_keys)
-            target = max(1, min(self.group_rows, -(-total // len(self.provers))))
-            units, group = [], []
-            for keys in item_keys:
-                group += keys
-                if len(group) >= target:
-                    units.append(group)
-                    group = []
-            if group:
-                units.append(group)
-            before = self.forest.proved
-            self.forest.prove([[self.cell_id(k, c) for k in u for c in range(1, C + 1)] + list(u) for u in units])
-            for it in wave:
-                plan.done(it.k)
-            self.wave_log.append((len(wave), self.forest.proved - before, time.perf_counter() - t_wave))
+        # the harness loop (drain the Ready items, prove, mark done) runs inside the library: a row key k stands for the row node k and
+        # its C cells-tree nodes (c << 40) | k
+        t0 = time.perf_counter()
+        items = self.forest.prove_plan(plan, self.group_rows, n_satellites=C, satellite_shift=40)
+        self.wave_log = [(n_items, None, None) for n_items in items]
+        self.seconds_in_prove = time.perf_counter() - t0
         assert plan.completed()
         plan.free()
-        self.n_proofs += self.forest.proved - n0
+        self.n_proofs += self.forest.proved
         self.row_proofs = {k: (self._host_proof(self.forest.proof_words(k), True, self.row_name[k]), self.row_name[k]) for k in keep_rows}
         self.cells_roots = {k: (self._host_proof(self.forest.proof_words(self.cell_id(k, sbbst_root(C))), False, self.cells_root_name), self.cells_root_name) for k in keep_rows}
         return self.row_proofs[root]

@@ -288,7 +288,7 @@ def test_native_build_equals_the_python_build(ctx, mp2, params):
     assert np.array_equal(pis[:T.ROWS_IO], T.expected_root_public_inputs(ctx, table, wit, root, nodes, spans))
     wckt, wcap, wdig = params.rows.chains[got_name][-1]
     assert C.verify(wckt, C.oracle_params(wckt), wdig, O.hash_n_to_m_no_pad(pis, 4), *got[:3]) == 0
-    assert len(nb.wave_log) == len(py.wave_log) and [w[:2] for w in nb.wave_log] == [w[:2] for w in py.wave_log]
+    assert [w[0] for w in nb.wave_log] == [w[0] for w in py.wave_log], "the same waves of work-plan items"
     # a second block through the same object (new forest, same chains)
     again, _ = nb.run(table, wit, root, nodes, keep=samples)
     assert all(np.array_equal(a, b) for a, b in zip(again, want)) and nb.n_proofs == 10 * n
