@@ -221,7 +221,7 @@ GLN bool gl5_sqrt(gl5 x, gl5& out) {
   out = gl5_scale(gl5_inv(e), s);
   return true;
 }
-GLD bool gl5_is_square(const gl5& x) { return gl_is_square(gl5_norm(x)); }
+GLN bool gl5_is_square(const gl5& x) { return gl_is_square(gl5_norm(x)); }
 GLD bool gl5_sgn0(const gl5& x) {
   bool sign = false, zero = true;
 #pragma unroll
@@ -294,8 +294,14 @@ GLD void pt_to_weierstrass(const pt& p, u64 out[11]) {
   for (int i = 0; i < 5; i++) { out[i] = x.c[i]; out[5 + i] = y.c[i]; }
   out[10] = 0;
 }
-// k * p, k = 128-bit little-endian (k[0] least significant)
+// k * p, k = 128-bit little-endian (k[0] least significant).
+// Signed 4-bit windows: the scalar recoded into 33 digits in [-8, 8], {0..8} * p in the lane's scratch, four doublings and one
+// complete addition (of +-table[|digit|]; -P = (X : Z : -U : T)) per digit: 128 doublings + 32 additions + 7 for the table. The
+// bit-serial double-and-add this replaces (EC_MUL_BITSERIAL) paid close to 128 additions: a wave takes the "bit set" branch
+// whenever any of its 64 lanes has the bit. The projective representative differs from the bit-serial one; every consumer reads
+// points through the canonical encodings (pt_emit / pt_to_weierstrass) or adds them.
 GLD pt pt_mul128(const pt& p, const u32 k[4]) {
+#ifdef EC_MUL_BITSERIAL
   pt acc = pt_neutral();
 #pragma unroll 1
   for (int i = 127; i >= 0; i--) {
@@ -303,6 +309,31 @@ GLD pt pt_mul128(const pt& p, const u32 k[4]) {
     if ((k[i >> 5] >> (i & 31)) & 1) acc = pt_add(acc, p);
   }
   return acc;
+#else
+  pt tab[9];
+  tab[0] = pt_neutral(); tab[1] = p; tab[2] = pt_dbl(p); tab[3] = pt_add(tab[2], p); tab[4] = pt_dbl(tab[2]);
+  tab[5] = pt_add(tab[4], p); tab[6] = pt_dbl(tab[3]); tab[7] = pt_add(tab[6], p); tab[8] = pt_dbl(tab[4]);
+  u32 mag[4] = {0, 0, 0, 0}, neg[4] = {0, 0, 0, 0}, carry = 0;
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    const u32 d = ((k[i >> 3] >> ((i & 7) * 4)) & 15) + carry;  // 0..16
+    carry = d > 8;
+    mag[i >> 3] |= (carry ? 16 - d : d) << ((i & 7) * 4);
+    neg[i >> 3] |= carry << (i & 7);
+  }
+  pt acc = tab[carry];  // the 33rd digit
+#pragma unroll
+  for (int w = 3; w >= 0; w--) {
+#pragma unroll 1
+    for (int i = 7; i >= 0; i--) {
+      acc = pt_dbl(pt_dbl(pt_dbl(pt_dbl(acc))));
+      pt q = tab[(mag[w] >> (i * 4)) & 15];
+      if ((neg[w] >> i) & 1) q.U = gl5_neg(q.U);
+      acc = pt_add(acc, q);
+    }
+  }
+  return acc;
+#endif
 }
 
 // sswu_value.rs:31-77
@@ -322,15 +353,41 @@ GLN pt simple_swu(gl5 u) {
   gl5 x2 = gl5_mul(denom_part, x1);
   gl5 gx1 = gl5_add(gl5_add(gl5_mul(x1, gl5_sqr(x1)), gl5_mul(a_sw, x1)), b_sw);
   gl5 x_sw = x1, y_pos;
+#ifdef EC_SWU_PLAIN
   if (!gl5_sqrt(gx1, y_pos)) {
     gl5 gx2 = gl5_add(gl5_add(gl5_mul(x2, gl5_sqr(x2)), gl5_mul(a_sw, x2)), b_sw);
     x_sw = x2;
     gl5_sqrt(gx2, y_pos);
   }
+#else
+  // which candidate has a square g(x) is a Legendre symbol (a norm to GF(p) and 63 base-field squarings), an eighth of the square
+  // root whose failure would say the same: one square root per point instead of one and a half
+  if (gl5_is_square(gx1)) {
+    gl5_sqrt(gx1, y_pos);
+  } else {
+    gl5 gx2 = gl5_add(gl5_add(gl5_mul(x2, gl5_sqr(x2)), gl5_mul(a_sw, x2)), b_sw);
+    x_sw = x2;
+    gl5_sqrt(gx2, y_pos);
+  }
+#endif
   gl5 x_cand = gl5_sub(x_sw, two_thirds);
   gl5 y_cand = gl5_sgn0(u) == gl5_sgn0(y_pos) ? y_pos : gl5_neg(y_pos);
   pt p;
+#ifdef EC_SWU_PLAIN
   pt_decode(gl5_mul(y_cand, gl5_inv(x_cand)), p);
+#else
+  // Point::decode(w), w = y / x, without its square root: (x_cand, y_cand) is on y^2 = x (x^2 + a x + b), so w^2 - a = x + b / x and
+  // the two roots of decode's quadratic x^2 - (w^2 - a) x + b are x_cand and b / x_cand; decode keeps the non-square one (their
+  // product b = 263 z is a non-square, so exactly one is). The general path stays for the degenerate encodings.
+  const gl5 xi = gl5_inv(x_cand);
+  const gl5 w = gl5_mul(y_cand, xi);
+  if (gl5_is_zero(w) || gl5_is_zero(x_cand)) {
+    pt_decode(w, p);
+  } else {
+    p.X = gl5_is_square(x_cand) ? gl5_mul_kz(xi, EC_B1) : x_cand;
+    p.Z = gl5_from(1); p.U = gl5_from(1); p.T = w;
+  }
+#endif
   return p;
 }
 template <int V>
