@@ -733,6 +733,7 @@ class TableRig:
         free, total = self.ctx.mem_info()
         self.plan = sharding.plan_rank_resources(self.params.shapes(), len(self.ctxs), batch, ranks_here, os.cpu_count() or 1, hbm_bytes=total)
         if not self.plan["fits"] and not os.environ.get("MP2G_BENCH_BACKEND"):
+            self.close()
             raise SystemExit(f"bench.py: {len(self.ctxs)} workers x {batch} proofs in flight need ~{self.plan['device_bytes_per_rank'] / 1e9:.0f} GB of device memory at "
                              f"these circuit shapes, the GPU has {total / 1e9:.0f} GB: lower --table-batch or --workers")
         self.host_threads = self.plan["host_threads_per_worker"]
@@ -1108,7 +1109,14 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         by_degree = {}
         def at_degree(k):
             bk = max(4, args.table_batch >> max(0, k - 12))  # proofs in flight per worker shrink with the degree: the same device memory at every k
-            rk = TableRig(mods, local_rank, VARIANT, args.workers, bk, args.subtree, args.host_witness, ranks_here, pad_bits=k, group_rows=args.group_rows, native=args.native_build)
+            while True:
+                try:
+                    rk = TableRig(mods, local_rank, VARIANT, args.workers, bk, args.subtree, args.host_witness, ranks_here, pad_bits=k, group_rows=args.group_rows, native=args.native_build)
+                    break
+                except SystemExit:  # the resource plan refused this many proofs in flight at these shapes (row_full is a degree above the rest)
+                    if bk <= 4:
+                        raise
+                    bk = max(4, 3 * bk // 4)
             try:
                 rk.build(min(64, args.sweep_rows), 0, seed ^ 0x5A5A5A, n_cols, False)
                 for c in rk.ctxs:
@@ -1144,13 +1152,15 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                "ms_per_step": dt / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u64 (Goldilocks field)", "data": "synthetic", "verified": verified,
                "rows_per_s": rows_per_s,
-               "table_2p20_rows_extrapolated_s": (1 << 20) / rows_per_s + (digest_ms or 0) / 1e3,
+               "table_2p20_rows_extrapolated_s": (1 << 20) / rows_per_s + (digest_ms or 0) / 1e3,  # = the measured time when this run is the whole table
+               "table_rows_total": world * n_rows,
                "table_digest_2p20_rows_ms": digest_ms,
                "config": {"workload": f"table: configs[3], ONE contiguous block of {n_rows} rows per rank (= {args.steps} steps x {args.rows} rows; row tree {depth} levels deep, one work plan) "
                                       f"-- per row {n_cols} cells-tree proofs (2 leaves, 1 full, 1 partial) + 1 row-tree proof (leaf / partial / full + the cells root through the "
                                       "cells-set verifier gadget), all REAL framework proofs = witness program + base prove() + wrap chain to 2^12 rows, witness check on; row tree "
                                       "scheduled by the batched UpdateTree work plan; the rows' multiset digests (map-to-curve, row ids, accumulation up both trees) inside the timed "
-                                      "region; value = framework proofs/s (5 per row). The full 2^20-row build does not fit one GPU in a bench run (extrapolated below); configs[2] at "
+                                      "region; value = framework proofs/s (5 per row). " + ("THIS IS the full 2^20-row build of configs[3]" if world * n_rows >= 1 << 20 else
+                                      "The full 2^20-row build does not fit one GPU in a bench run (extrapolated below; measured once: profiles/r04/bench_r04_table_2p20_rows.json)") + "; configs[2] at "
                                       "full size = `config2`; base degrees 12..15 = `by_base_degree`; roofline leg = configs[1] 2^22-point NTT",
                           "rows_per_rank": n_rows, "rows_per_step": args.rows, "row_tree_depth": depth, "warmup_rows_per_rank": args.warmup * args.rows,
                           "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "group_rows": args.group_rows or 32 * args.table_batch, "pad_base_bits": args.pad_base_bits,
@@ -1158,6 +1168,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                           "work_plan_waves": waves,  # (the native scheduler drains the plan inside the library and reports the items per wave only)  # per wave of the work plan: [items, framework proofs, seconds]
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "ranks_on_host": ranks_here, "shapes": shapes,
+                          "host_peak_rss_bytes": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss * 1024,
                           "device_memory_used_bytes": mem_total - mem_free, "device_memory_planned_bytes": plan["device_bytes_per_rank"],
                           "setup_s": round(setup_s, 1), "hasher": "Poseidon2", "backend": (dist.get_backend() if dist is not None else None), "rccl_ranks": rccl_ranks,
                           "join_levels": n_levels,

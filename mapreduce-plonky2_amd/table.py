@@ -27,6 +27,7 @@ C cells-tree proofs + 1 row-tree proof, same verifier counts, same public-input 
 base prove() and the wrap chain; the proving work per proof is a lower bound of the reference's (its leaf logic has the
 curve gadgets on top).
 """
+import os
 import queue
 import threading
 import time
@@ -658,7 +659,11 @@ class NativeTableBuild:
         # the harness loop (drain the Ready items, prove, mark done) runs inside the library: a row key k stands for the row node k and
         # its C cells-tree nodes (c << 40) | k
         t0 = time.perf_counter()
-        items = self.forest.prove_plan(plan, self.group_rows, n_satellites=C, satellite_shift=40)
+        stop = self._progress_writer(t0, 5 * table.rows)
+        try:
+            items = self.forest.prove_plan(plan, self.group_rows, n_satellites=C, satellite_shift=40)
+        finally:
+            stop()
         self.wave_log = [(n_items, None, None) for n_items in items]
         self.seconds_in_prove = time.perf_counter() - t0
         assert plan.completed()
@@ -667,6 +672,29 @@ class NativeTableBuild:
         self.row_proofs = {k: (self._host_proof(self.forest.proof_words(k), True, self.row_name[k]), self.row_name[k]) for k in keep_rows}
         self.cells_roots = {k: (self._host_proof(self.forest.proof_words(self.cell_id(k, sbbst_root(C))), False, self.cells_root_name), self.cells_root_name) for k in keep_rows}
         return self.row_proofs[root]
+
+    def _progress_writer(self, t0, total):
+        """MP2G_PROGRESS_FILE=path: a line (seconds, proofs so far, of how many) every 30 s while a long block is proved (the forest's
+        counter is an atomic the workers bump per batch), so that a run cut off by a time limit still says how far it came"""
+        path = os.environ.get("MP2G_PROGRESS_FILE")
+        if not path:
+            return lambda: None
+        import threading
+        done, forest = threading.Event(), self.forest
+
+        def loop():
+            while not done.wait(30.0):
+                with open(path, "a") as f:
+                    f.write(f"{time.perf_counter() - t0:.1f} s  {forest.proved} / {total} proofs\n")
+        th = threading.Thread(target=loop, daemon=True)
+        th.start()
+
+        def stop():
+            done.set()
+            th.join()
+            with open(path, "a") as f:
+                f.write(f"{time.perf_counter() - t0:.1f} s  {forest.proved} / {total} proofs (plan done)\n")
+        return stop
 
     def free(self):
         if self.forest is not None:
