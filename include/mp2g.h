@@ -241,7 +241,8 @@ int mp2g_row_digests(mp2g_ctx* ctx, int variant, const uint64_t* col_ids, uint32
                      const uint32_t* unique, uint32_t n_unique, uint32_t rows, uint64_t* out_w /* [rows][5] */,
                      uint64_t* out_weierstrass /* [rows][11] */);
 /* same with device-resident inputs; d_frac_out [20] receives the sum in fractional coordinates
- * (X:Z:U:T) for further accumulation, out_w / out_weierstrass are host pointers (may be NULL) */
+ * (X:Z:U:T) for further accumulation -- a representative of the point, not a canonical form: compare points through out_w
+ * (Point::encode) or out_weierstrass; out_w / out_weierstrass are host pointers (may be NULL) */
 int mp2g_row_digest_batch_dev(mp2g_ctx* ctx, int variant, const uint64_t* d_col_ids, uint32_t n_cols,
                               const uint32_t* d_values, const uint32_t* d_unique, uint32_t n_unique, uint32_t rows,
                               uint64_t* d_frac_out, uint64_t out_w[5], uint64_t out_weierstrass[11]);

@@ -30,6 +30,11 @@ namespace mp2g {
 #ifndef EC_WAVES_ATTR
 #define EC_WAVES_ATTR
 #endif
+// EC_LB: the launch bound DECLARED on the three heavy kernels (they are always launched with 128 lanes). The bound reaches the
+// out-of-line bodies too (the flat work-group size propagates to callees): 1024 would hold everything to 128 VGPRs, 768 to 168
+#ifndef EC_LB
+#define EC_LB 128
+#endif
 #define GLN __device__ __noinline__
 struct gl5 { u64 c[5]; };
 
@@ -361,13 +366,15 @@ GLN pt simple_swu(gl5 u) {
   }
 #else
   // which candidate has a square g(x) is a Legendre symbol (a norm to GF(p) and 63 base-field squarings), an eighth of the square
-  // root whose failure would say the same: one square root per point instead of one and a half
-  if (gl5_is_square(gx1)) {
-    gl5_sqrt(gx1, y_pos);
-  } else {
-    gl5 gx2 = gl5_add(gl5_add(gl5_mul(x2, gl5_sqr(x2)), gl5_mul(a_sw, x2)), b_sw);
-    x_sw = x2;
-    gl5_sqrt(gx2, y_pos);
+  // root whose failure would say the same. Every lane computes g(x2) (three products) and the wave takes ONE square root, of the
+  // lane's own choice: branching on the symbol would send a wave through gl5_sqrt twice, its lanes split over the two candidates.
+  {
+    const bool first = gl5_is_square(gx1);
+    const gl5 gx2 = gl5_add(gl5_add(gl5_mul(x2, gl5_sqr(x2)), gl5_mul(a_sw, x2)), b_sw);
+    gl5 g;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { g.c[i] = first ? gx1.c[i] : gx2.c[i]; x_sw.c[i] = first ? x1.c[i] : x2.c[i]; }
+    gl5_sqrt(g, y_pos);
   }
 #endif
   gl5 x_cand = gl5_sub(x_sw, two_thirds);
@@ -420,7 +427,7 @@ GLD void pt_emit(const pt& p, u64* w, u64* wei) {
 
 // ---- kernels ----------------------------------------------------------------------------------
 template <int V>
-__global__ void __launch_bounds__(128) EC_WAVES_ATTR map_to_curve_kernel(const u64* in, u32 in_len, u32 count, u64* w_out, u64* wei_out, u64* frac_out) {
+__global__ void __launch_bounds__(EC_LB) EC_WAVES_ATTR map_to_curve_kernel(const u64* in, u32 in_len, u32 count, u64* w_out, u64* wei_out, u64* frac_out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   pt p = map_to_curve<V>(in + (u64)i * in_len, in_len);
@@ -481,7 +488,7 @@ __global__ void emit_kernel(const u64* frac, u32 count, u64* w_out, u64* wei_out
   pt p = pt_load(frac + 20 * (u64)i);
   pt_emit(p, w_out ? w_out + 5 * (u64)i : nullptr, wei_out ? wei_out + 11 * (u64)i : nullptr);
 }
-__global__ void __launch_bounds__(128) EC_WAVES_ATTR scalar_mul_kernel(const u64* frac_in, const u32* scalars, u32 count, u64* frac_out) {
+__global__ void __launch_bounds__(EC_LB) EC_WAVES_ATTR scalar_mul_kernel(const u64* frac_in, const u32* scalars, u32 count, u64* frac_out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   u32 k[4];
@@ -490,7 +497,7 @@ __global__ void __launch_bounds__(128) EC_WAVES_ATTR scalar_mul_kernel(const u64
 }
 // one lane per table row: sum_c D(id_c || value_c), row id, row_id * row digest
 template <int V>
-__global__ void __launch_bounds__(128) EC_WAVES_ATTR row_digest_kernel(const u64* col_ids, u32 n_cols, const u32* values, const u32* unique,
+__global__ void __launch_bounds__(EC_LB) EC_WAVES_ATTR row_digest_kernel(const u64* col_ids, u32 n_cols, const u32* values, const u32* unique,
                                                           u32 n_unique, u32 rows, u64* frac_out) {
   u32 r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
