@@ -75,7 +75,14 @@ def test_scalar_mul_batch(ctx, mp2):
     rng = np.random.default_rng(3)
     scalars = [int.from_bytes(rng.bytes(16), "little") for _ in range(40)]
     scalars[0], scalars[1], scalars[2] = 0, 1, (1 << 128) - 1
+    # the digit boundaries of the signed 4-bit windows (csrc/ecgfp5.hip pt_mul128): all digits 8 (the largest positive one, no carry),
+    # all 9 (every digit negative, a carry into every next one and into the 33rd), a carry chain through 7s that ends in an 8,
+    # single digits at either end, 2^127 (top digit 8), and the neutral point as the base
+    edge = [int("8" * 32, 16), int("9" * 32, 16), int("7" * 31 + "9", 16), int("f" * 31 + "8", 16), 8, 9, 15, 16, 1 << 127, (1 << 127) + 8, 0xF << 124, 0x8 << 124 | 0x8]
+    scalars[3:3 + len(edge)] = edge
+    w[20] = 0  # Point::NEUTRAL encodes to zero
     got = mp2.scalar_mul_batch(ctx, w, scalars)
+    assert not got[20].any()
     for i in range(40):
         kl = O.arr([(scalars[i] >> (32 * j)) & 0xFFFFFFFF for j in range(4)], np.uint32)
         want = np.zeros(5, dtype=np.uint64)
