@@ -147,3 +147,22 @@ def test_base_degree_padding_and_reference_gate_set():
     bad[2, row] ^= 1  # the comparison gate's result bit
     c2, o2, p2, _ = C.prove_witness(padded, fp, cd, bad, padded.pi_hash)
     assert C.verify(padded, fp, cd, padded.pi_hash, c2, o2, p2) != 0, "a violated extra gate row must not verify"
+
+
+def test_progress_file_of_a_long_block(tmp_path, monkeypatch):
+    """MP2G_PROGRESS_FILE: the native build's progress writer reads the forest's atomic counter from a side thread and always leaves a
+    last line when the plan is done (what a run cut off by a time limit is read from: profiles/r04/table_2p20_rows_progress.txt)"""
+    import time
+    import types
+    T = importlib.import_module("mapreduce-plonky2_amd.table")
+    path = tmp_path / "progress.txt"
+    fake = types.SimpleNamespace(forest=types.SimpleNamespace(proved=40))
+    monkeypatch.delenv("MP2G_PROGRESS_FILE", raising=False)
+    T.NativeTableBuild._progress_writer(fake, time.perf_counter(), 50)()  # off: nothing written, nothing started
+    assert not path.exists()
+    monkeypatch.setenv("MP2G_PROGRESS_FILE", str(path))
+    stop = T.NativeTableBuild._progress_writer(fake, time.perf_counter(), 50)
+    fake.forest.proved = 50
+    stop()
+    lines = path.read_text().splitlines()
+    assert len(lines) == 1 and lines[0].endswith("50 / 50 proofs (plan done)")
