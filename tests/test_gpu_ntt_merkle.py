@@ -111,6 +111,26 @@ def test_ntt_2p22_config2(ctx):
                           O.fft(a, coset_shift=O.MULT_GEN)[:, O.bitrev_perm(n)])
 
 
+def test_commit_135_x_2p15_config2(ctx, mp2):
+    """BASELINE config 2(ii) at full size: 135 polynomials of 2^15 values, seed 0xC0FFEE02 -> coefficients, LDE to 2^18 leaves of 135
+    limbs, Poseidon2 Merkle cap of height 4: every coefficient, the cap and openings at the ends and inside against the oracle"""
+    w, log_n = 135, 15
+    vals = O.rand_field((w, 1 << log_n), 0xC0FFEE02)
+    b = mp2.PolynomialBatch.from_values(ctx, vals, 3, 4, mp2.POSEIDON2)
+    coeffs = O.fft(vals, inverse=True)
+    assert np.array_equal(b.coeffs, coeffs)
+    leaves = O.lde_leaves(coeffs, 3)
+    cap = O.merkle_cap(O.merkle_build(leaves, 4, 0), 4)
+    assert np.array_equal(b.cap, cap)
+    N = 1 << (log_n + 3)
+    idx = [0, 1, N - 1, N // 3, N // 2, 12345, N - 2]
+    got_leaves, sib = b.open(idx)
+    for k, i in enumerate(idx):
+        assert np.array_equal(got_leaves[k], leaves[i])
+        assert O.merkle_verify(got_leaves[k], i, sib[k], cap, 0)
+    b.free()
+
+
 @pytest.mark.parametrize("log_n,w", [(3, 2), (6, 5), (10, 7), (12, 9), (13, 3), (15, 2)])
 def test_lde_leaves_match_oracle(ctx, log_n, w):
     c = O.rand_field((w, 1 << log_n), 31 + log_n)
