@@ -269,6 +269,41 @@ GLN pt pt_dbl(const pt& p) {
   r.T = gl5_sub(gl5_sub(gl5_dbl(X1), gl5_small(t4, 4)), r.Z);
   return r;
 }
+// Four successive doublings (one window of pt_mul128). The first leaves the fractional coordinates for Jacobian ones, x = X / Z^2 and
+// w = 1 / u = W / Z, in which doubling is 1M + 7S:  D = W^2 - 2X - 2Z^2,  X' = 16 b (WZ)^4,  W' = 2 W^4 - 4 (WZ)^2 - D^2,  Z' = 2 D W Z
+// (the same map as pt_dbl, x' = 4 b w^2 / D_a^2 and w' = (2 w^4 - 4 w^2 - D_a^2) / (2 w D_a) with D_a = w^2 - 2x - 2, on those
+// coordinates); (X : Z^2 : Z : W) are fractional coordinates again. 4M + 6S, then 3 x (1M + 7S), then 1S: 595 base products against
+// 4 x (4M + 5S) = 700. The neutral element has Z = 0 in the Jacobian form and is put back by hand. (-DEC_DBL_PLAIN: four pt_dbl.)
+GLN pt pt_dbl4(const pt& p) {
+#ifdef EC_DBL_PLAIN
+  return pt_dbl(pt_dbl(pt_dbl(pt_dbl(p))));
+#else
+  gl5 X, W, Z;
+  {
+    gl5 t1 = gl5_mul(p.Z, p.T), t2 = gl5_mul(t1, p.T);
+    gl5 X1 = gl5_sqr(t2), Z1 = gl5_mul(t1, p.U), t3 = gl5_sqr(p.U);
+    gl5 W1 = gl5_sub(t2, gl5_mul(gl5_dbl(gl5_add(p.X, p.Z)), t3));
+    gl5 z2 = gl5_sqr(Z1), w2 = gl5_sqr(W1);
+    Z = gl5_sub(gl5_sub(gl5_sqr(gl5_add(W1, Z1)), z2), w2);    // 2 W1 Z1
+    X = gl5_mul_kz(gl5_sqr(z2), 16 * EC_B1);                    // 16 b Z1^4
+    W = gl5_sub(gl5_sub(gl5_dbl(X1), gl5_small(z2, 4)), w2);    // 2 X1 - 4 Z1^2 - W1^2
+  }
+#pragma unroll 1
+  for (int i = 0; i < 3; i++) {
+    gl5 w2 = gl5_sqr(W), z2 = gl5_sqr(Z);
+    gl5 wz2 = gl5_sub(gl5_sub(gl5_sqr(gl5_add(W, Z)), w2), z2);  // 2 W Z
+    gl5 D = gl5_sub(gl5_sub(w2, gl5_dbl(X)), gl5_dbl(z2));
+    gl5 a = gl5_sqr(wz2);                                         // 4 (WZ)^2
+    X = gl5_mul_kz(gl5_sqr(a), EC_B1);
+    W = gl5_sub(gl5_sub(gl5_dbl(gl5_sqr(w2)), a), gl5_sqr(D));
+    Z = gl5_mul(D, wz2);
+  }
+  if (gl5_is_zero(Z)) return pt_neutral();
+  pt r;
+  r.X = X; r.Z = gl5_sqr(Z); r.U = Z; r.T = W;
+  return r;
+#endif
+}
 GLD gl5 pt_encode(const pt& p) { return gl5_mul(p.T, gl5_inv(p.U)); }  // neutral -> 0
 // decode(w): x^2 - (w^2 - a) x + b = 0, keep the non-square root; (x, 1, 1, w)
 GLN bool pt_decode(gl5 w, pt& out) {
@@ -300,8 +335,9 @@ GLD void pt_to_weierstrass(const pt& p, u64 out[11]) {
   out[10] = 0;
 }
 // k * p, k = 128-bit little-endian (k[0] least significant).
-// Signed 4-bit windows: the scalar recoded into 33 digits in [-8, 8], {0..8} * p in the lane's scratch, four doublings and one
-// complete addition (of +-table[|digit|]; -P = (X : Z : -U : T)) per digit: 128 doublings + 32 additions + 7 for the table. The
+// Signed 4-bit windows: the scalar recoded into 33 digits in [-8, 8], {0..8} * p in the lane's scratch, four doublings (pt_dbl4:
+// a run in Jacobian coordinates) and one complete addition (of +-table[|digit|]; -P = (X : Z : -U : T)) per digit: 128 doublings +
+// 32 additions + 7 for the table. The
 // bit-serial double-and-add this replaces (EC_MUL_BITSERIAL) paid close to 128 additions: a wave takes the "bit set" branch
 // whenever any of its 64 lanes has the bit. The projective representative differs from the bit-serial one; every consumer reads
 // points through the canonical encodings (pt_emit / pt_to_weierstrass) or adds them.
@@ -331,7 +367,7 @@ GLD pt pt_mul128(const pt& p, const u32 k[4]) {
   for (int w = 3; w >= 0; w--) {
 #pragma unroll 1
     for (int i = 7; i >= 0; i--) {
-      acc = pt_dbl(pt_dbl(pt_dbl(pt_dbl(acc))));
+      acc = pt_dbl4(acc);
       pt q = tab[(mag[w] >> (i * 4)) & 15];
       if ((neg[w] >> i) & 1) q.U = gl5_neg(q.U);
       acc = pt_add(acc, q);
