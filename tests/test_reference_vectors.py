@@ -216,6 +216,25 @@ def test_ecgfp5_group(which, self_vectors):
 
 
 @pytest.mark.parametrize("which", SOURCES)
+def test_table_digest_commitment_and_cell_hashes(which, self_vectors):
+    """mp2-v1's off-chain half of table creation on the file's own six rows: row_unique_data, compute_table_row_digest
+    (values_extraction/mod.rs:499-571), off_chain_data_commitment and its incremental update (api.rs:556-612: groups of equal primary
+    values in increasing order, add_primary_index_to_digest, the flattened hash chain, 32 little-endian u32 bytes) and
+    MerkleCell::aggregate (indexing/cell.rs:120-157) with no, one and two children"""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "ref_vectors"))
+    import self_vectors as SV
+    d = _load(which, self_vectors)
+    if "table" not in d:
+        pytest.skip("a vector file written before the `table` section was added to the dumper")
+    want = d["table"]
+    got = SV.table_section(VARIANT[d["default_hasher"]], given=want)
+    for key in ("row_unique_data_row0", "row_digest", "commitment_rows_0_to_3", "commitment_updated_with_rows_4_5", "cells_tree"):
+        assert got[key] == want[key], key
+    # the dumper's rows come from the SplitMix64 stream this repository's workload generator uses: the same rows are made here
+    assert SV.table_section(VARIANT[d["default_hasher"]])["rows"] == want["rows"], "rand_field(96, 0xC0FFEE04), four u64 words per value, least significant first"
+
+
+@pytest.mark.parametrize("which", SOURCES)
 def test_one_complete_proof(which, self_vectors):
     """the reference's proof of a 2^5-row circuit: (i) the wire format -- csrc/wire.hip parses the reference's bincode bytes and writes
     them back identically; (ii) verifier data -- constants_sigmas cap and circuit digest from the preprocessed polynomials; (iii) the
@@ -308,6 +327,31 @@ def test_hip_library_against_the_vectors(which, self_vectors, ctx, mp2):
         assert w.tolist() == e[key]["encode"] and wei.tolist() == e[key]["fields"], key
     w, wei = mp2.scalar_mul_batch(ctx, ws[0].reshape(1, 5), [int(e["hash_to_int"]["value"])], weierstrass=True)
     assert w[0].tolist() == e["scalar_mul_0"]["encode"] and wei[0].tolist() == e["scalar_mul_0"]["fields"]
+    # the off-chain half of table creation: row digest, commitment chain, cells-tree node hashes
+    if "table" in d:
+        sys.path.insert(0, os.path.join(ROOT, "tools", "ref_vectors"))
+        import self_vectors as SV
+        DG = importlib.import_module("mapreduce-plonky2_amd.digest")
+        IX = importlib.import_module("mapreduce-plonky2_amd.indexing")
+        t = d["table"]
+        ids, uq = [int(x) for x in t["column_ids"]], [int(x) for x in t["row_unique_columns"]]
+        values = np.array([[SV.u256_words(x) for x in r["values"]] for r in t["rows"]], dtype=np.uint32)
+        primary = np.array([SV.u256_words(r["primary"]) for r in t["rows"]], dtype=np.uint32)
+        unique = np.ascontiguousarray(values[:, [ids.index(u_) for u_ in uq]])
+        w, wei = mp2.compute_table_row_digest(ctx, ids, values, unique, dv)
+        assert w.tolist() == t["row_digest"]["encode"] and wei.tolist() == t["row_digest"]["fields"], "compute_table_row_digest"
+        assert [int(x) for x in ctx.hash_no_pad(unique[0].reshape(-1).astype(np.uint64), dv)] == t["row_unique_data_row0"]
+        first = DG.off_chain_data_commitment(ctx, int(t["primary_id"]), primary[:4], ids, values[:4], uq, dv)
+        assert bytes(first).hex() == t["commitment_rows_0_to_3"], "off_chain_data_commitment"
+        second = DG.update_off_chain_data_commitment(ctx, int(t["primary_id"]), primary[4:], ids, values[4:], uq, bytes(first), dv)
+        assert bytes(second).hex() == t["commitment_updated_with_rows_4_5"], "update_off_chain_data_commitment"
+        empty = IX.empty_poseidon_hash(ctx, dv)
+        v0 = [int(x) for x in t["rows"][0]["values"]]
+        hexof = lambda h: np.asarray(h, dtype="<u8").tobytes().hex()
+        leaves = IX.cell_node_hashes(ctx, [empty, empty], [empty, empty], [ids[1], ids[3]], [v0[1], v0[3]], dv)
+        assert [hexof(leaves[0]), hexof(leaves[1])] == [t["cells_tree"]["leaf_column_1"], t["cells_tree"]["leaf_column_3"]]
+        above = IX.cell_node_hashes(ctx, [leaves[0], leaves[0]], [empty, leaves[1]], [ids[2], ids[2]], [v0[2], v0[2]], dv)
+        assert [hexof(above[0]), hexof(above[1])] == [t["cells_tree"]["column_2_over_left_child"], t["cells_tree"]["column_2_over_both"]]
     # prove() of the reference's witness
     p = d["proof"]
     ckt = circuit_of(p, dv)

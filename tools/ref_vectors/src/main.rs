@@ -199,6 +199,62 @@ fn ecgfp5_section() -> Value {
     })
 }
 
+/// The off-chain half of table creation on a six-row table (mp2-v1): row_unique_data and
+/// compute_table_row_digest (values_extraction/mod.rs:499-571), off_chain_data_commitment and its incremental update
+/// (api.rs:556-612: rows grouped by primary value, add_primary_index_to_digest, the flattened hash chain), and the cells-tree node hash
+/// MerkleCell::aggregate (indexing/cell.rs:120-157) with no, one and two children. The rows are written out (U256 as decimal strings),
+/// so the consumer needs no generator of its own.
+fn table_section() -> Result<Value> {
+    use alloy::primitives::U256;
+    use mp2_v1::{
+        api::{off_chain_data_commitment, update_off_chain_data_commitment, TableRow},
+        indexing::cell::{Cell, MerkleCell},
+        values_extraction::{compute_table_row_digest, row_unique_data},
+    };
+    use ryhope::NodePayload;
+    let primary_id = 1000u64;
+    let ids = [1001u64, 1002, 1003, 1004];
+    let primaries = [5u64, 7, 5, 9, 7, 7]; // three groups, not in order: the commitment sorts them (api.rs:562-570)
+    let stream = splitmix_field(6 * 4 * 4, 0xC0FFEE04);
+    // four u64 words of the stream per value, least significant first
+    let value = |r: usize, c: usize| -> U256 {
+        let w = &stream[(r * 4 + c) * 4..][..4];
+        U256::from_limbs([u(w[0]), u(w[1]), u(w[2]), u(w[3])])
+    };
+    let rows: Vec<TableRow> = (0..6)
+        .map(|r| TableRow::new(Cell::new(primary_id, U256::from(primaries[r])), (0..4).map(|c| Cell::new(ids[c], value(r, c))).collect()))
+        .collect();
+    let unique = [ids[0]];
+    let unique_row0 = row_unique_data([value(0, 0).to_be_bytes_trimmed_vec().as_slice()]);
+    let digest = compute_table_row_digest(&rows, &unique)?;
+    let commitment = off_chain_data_commitment(&rows[..4], &unique)?;
+    let updated = update_off_chain_data_commitment(&rows[4..], Some(commitment), &unique)?;
+    let mut leaf = MerkleCell::<u64>::new(ids[1], value(0, 1), 0);
+    leaf.aggregate([None, None].into_iter());
+    let mut other = MerkleCell::<u64>::new(ids[3], value(0, 3), 0);
+    other.aggregate([None, None].into_iter());
+    let mut left_only = MerkleCell::<u64>::new(ids[2], value(0, 2), 0);
+    left_only.aggregate([Some(leaf.clone()), None].into_iter());
+    let mut both = MerkleCell::<u64>::new(ids[2], value(0, 2), 0);
+    both.aggregate([Some(leaf.clone()), Some(other.clone())].into_iter());
+    Ok(json!({
+        "primary_id": primary_id,
+        "column_ids": ids,
+        "row_unique_columns": unique,
+        "rows": (0..6).map(|r| json!({"primary": primaries[r].to_string(), "values": (0..4).map(|c| value(r, c).to_string()).collect_vec()})).collect_vec(),
+        "row_unique_data_row0": hash_limbs(HashOut::<F>::from(unique_row0)),
+        "row_digest": point_json(digest),
+        "commitment_rows_0_to_3": hex::encode(commitment.0),
+        "commitment_updated_with_rows_4_5": hex::encode(updated.0),
+        "cells_tree": {
+            "leaf_column_1": hex::encode(leaf.hash.0),
+            "leaf_column_3": hex::encode(other.hash.0),
+            "column_2_over_left_child": hex::encode(left_only.hash.0),
+            "column_2_over_both": hex::encode(both.hash.0),
+        },
+    }))
+}
+
 /// One complete proof of a 2^5-row circuit under standard_recursion_config and everything a foreign prover needs to redo it:
 /// the gate list with selectors, the preprocessed polynomials' values on H, the full wire matrix, the verifier data and the
 /// proof as mp2-common/src/proof.rs:84-88 serialises it (bincode). The PoW witness is whatever rayon's find_any returned:
@@ -270,6 +326,7 @@ fn main() -> Result<()> {
         "polynomial_batch": batch_section(),
         "challenger": challenger_section(),
         "ecgfp5": ecgfp5_section(),
+        "table": table_section()?,
         "proof": proof_section()?,
     });
     let mut file = File::create(&out)?;
