@@ -220,7 +220,8 @@ def test_table_digest_commitment_and_cell_hashes(which, self_vectors):
     """mp2-v1's off-chain half of table creation on the file's own six rows: row_unique_data, compute_table_row_digest
     (values_extraction/mod.rs:499-571), off_chain_data_commitment and its incremental update (api.rs:556-612: groups of equal primary
     values in increasing order, add_primary_index_to_digest, the flattened hash chain, 32 little-endian u32 bytes) and
-    MerkleCell::aggregate (indexing/cell.rs:120-157) with no, one and two children"""
+    MerkleCell::aggregate (indexing/cell.rs:120-157) and RowPayload::aggregate (indexing/row.rs:257-317: the hash and the min / max of
+    the secondary index) with no, one and two children"""
     sys.path.insert(0, os.path.join(ROOT, "tools", "ref_vectors"))
     import self_vectors as SV
     d = _load(which, self_vectors)
@@ -228,7 +229,7 @@ def test_table_digest_commitment_and_cell_hashes(which, self_vectors):
         pytest.skip("a vector file written before the `table` section was added to the dumper")
     want = d["table"]
     got = SV.table_section(VARIANT[d["default_hasher"]], given=want)
-    for key in ("row_unique_data_row0", "row_digest", "commitment_rows_0_to_3", "commitment_updated_with_rows_4_5", "cells_tree"):
+    for key in ("row_unique_data_row0", "row_digest", "commitment_rows_0_to_3", "commitment_updated_with_rows_4_5", "cells_tree", "row_tree"):
         assert got[key] == want[key], key
     # the dumper's rows come from the SplitMix64 stream this repository's workload generator uses: the same rows are made here
     assert SV.table_section(VARIANT[d["default_hasher"]])["rows"] == want["rows"], "rand_field(96, 0xC0FFEE04), four u64 words per value, least significant first"
@@ -352,6 +353,15 @@ def test_hip_library_against_the_vectors(which, self_vectors, ctx, mp2):
         assert [hexof(leaves[0]), hexof(leaves[1])] == [t["cells_tree"]["leaf_column_1"], t["cells_tree"]["leaf_column_3"]]
         above = IX.cell_node_hashes(ctx, [leaves[0], leaves[0]], [empty, leaves[1]], [ids[2], ids[2]], [v0[2], v0[2]], dv)
         assert [hexof(above[0]), hexof(above[1])] == [t["cells_tree"]["column_2_over_left_child"], t["cells_tree"]["column_2_over_both"]]
+        # row-tree nodes: the secondary index is the first of the other columns; min / max are the file's (the CPU test derives them)
+        rt, sec = t["row_tree"], [int(r["values"][0]) for r in t["rows"]]
+        croot = [above[1]]
+        la = IX.row_node_hashes(ctx, [empty], [empty], [sec[0]], [sec[0]], [ids[0]], [sec[0]], croot, dv)[0]
+        lb = IX.row_node_hashes(ctx, [empty], [empty], [sec[2]], [sec[2]], [ids[0]], [sec[2]], croot, dv)[0]
+        assert [hexof(la), hexof(lb)] == [rt["leaf_row_0"]["hash"], rt["leaf_row_2"]["hash"]]
+        for key, (l_, r_) in (("row_1_over_left_child", (la, empty)), ("row_1_over_right_child", (empty, lb)), ("row_1_over_both", (la, lb))):
+            h = IX.row_node_hashes(ctx, [l_], [r_], [int(rt[key]["min"])], [int(rt[key]["max"])], [ids[0]], [sec[1]], croot, dv)[0]
+            assert hexof(h) == rt[key]["hash"], key
     # prove() of the reference's witness
     p = d["proof"]
     ckt = circuit_of(p, dv)

@@ -186,7 +186,21 @@ def table_section(v, given=None):
 
     leaf1, leaf3 = cell(empty, empty, 1), cell(empty, empty, 3)
     hexof = lambda h: np.asarray(h, dtype="<u8").tobytes().hex()
-    return {"primary_id": primary_id, "column_ids": ids, "row_unique_columns": unique_ids, "rows": rows,
+    cells_root = cell(leaf1, leaf3, 2)
+    sec = lambda r: int(rows[r]["values"][0])  # the secondary index is column 0 of the other columns
+
+    def row(r, left, right):  # RowPayload::aggregate: (hash, min, max) nodes; H(hL || hR || min || max || id || value || cells root)
+        lo = left[1] if left else sec(r)
+        hi = right[2] if right else sec(r)
+        h = O.hash_n_to_m_no_pad(list(left[0] if left else empty) + list(right[0] if right else empty) + u256_words(lo) + u256_words(hi) + [ids[0]]
+                                 + u256_words(sec(r)) + list(cells_root), 4, v)
+        return (h, lo, hi)
+
+    row_a, row_b = row(0, None, None), row(2, None, None)
+    row_json = lambda t: {"hash": hexof(t[0]), "min": str(t[1]), "max": str(t[2])}
+    row_tree = {"leaf_row_0": row_json(row_a), "leaf_row_2": row_json(row_b), "row_1_over_left_child": row_json(row(1, row_a, None)),
+                "row_1_over_right_child": row_json(row(1, None, row_b)), "row_1_over_both": row_json(row(1, row_a, row_b))}
+    return {"row_tree": row_tree, "primary_id": primary_id, "column_ids": ids, "row_unique_columns": unique_ids, "rows": rows,
             "row_unique_data_row0": ints(O.hash_n_to_m_no_pad([int(x) for x in unique[0].reshape(-1)], 4, v)),
             "row_digest": {"encode": ints(w), "fields": ints(wei)},
             "commitment_rows_0_to_3": first.hex(), "commitment_updated_with_rows_4_5": commitment(4, n, first).hex(),

@@ -202,7 +202,8 @@ fn ecgfp5_section() -> Value {
 /// The off-chain half of table creation on a six-row table (mp2-v1): row_unique_data and
 /// compute_table_row_digest (values_extraction/mod.rs:499-571), off_chain_data_commitment and its incremental update
 /// (api.rs:556-612: rows grouped by primary value, add_primary_index_to_digest, the flattened hash chain), and the cells-tree node hash
-/// MerkleCell::aggregate (indexing/cell.rs:120-157) with no, one and two children. The rows are written out (U256 as decimal strings),
+/// MerkleCell::aggregate (indexing/cell.rs:120-157) and the row-tree node hash RowPayload::aggregate (indexing/row.rs:257-317) with no,
+/// one and two children. The rows are written out (U256 as decimal strings),
 /// so the consumer needs no generator of its own.
 fn table_section() -> Result<Value> {
     use alloy::primitives::U256;
@@ -237,7 +238,32 @@ fn table_section() -> Result<Value> {
     left_only.aggregate([Some(leaf.clone()), None].into_iter());
     let mut both = MerkleCell::<u64>::new(ids[2], value(0, 2), 0);
     both.aggregate([Some(leaf.clone()), Some(other.clone())].into_iter());
+    // row-tree nodes (indexing/row.rs:257-317): H(hL || hR || min || max || id || value || cells root), min / max of the secondary index
+    // following the children; the cells root is any 32 bytes here (the node over two children above)
+    use mp2_v1::indexing::row::{CellCollection, CellInfo, RowPayload};
+    let row_payload = |r: usize| {
+        let cells: std::collections::HashMap<u64, CellInfo<u64>> = (0..4).map(|c| (ids[c], CellInfo::new(value(r, c), 0u64))).collect();
+        RowPayload::<u64>::new(CellCollection(cells), ids[0], Some(both.hash), Some(ids[2]), Default::default())
+    };
+    let mut row_a = row_payload(0);
+    row_a.aggregate([None, None].into_iter());
+    let mut row_b = row_payload(2);
+    row_b.aggregate([None, None].into_iter());
+    let mut row_left_only = row_payload(1);
+    row_left_only.aggregate([Some(row_a.clone()), None].into_iter());
+    let mut row_right_only = row_payload(1);
+    row_right_only.aggregate([None, Some(row_b.clone())].into_iter());
+    let mut row_both = row_payload(1);
+    row_both.aggregate([Some(row_a.clone()), Some(row_b.clone())].into_iter());
+    let row_json = |p: &RowPayload<u64>| json!({"hash": hex::encode(p.hash.0), "min": p.min.to_string(), "max": p.max.to_string()});
     Ok(json!({
+        "row_tree": {
+            "leaf_row_0": row_json(&row_a),
+            "leaf_row_2": row_json(&row_b),
+            "row_1_over_left_child": row_json(&row_left_only),
+            "row_1_over_right_child": row_json(&row_right_only),
+            "row_1_over_both": row_json(&row_both),
+        },
         "primary_id": primary_id,
         "column_ids": ids,
         "row_unique_columns": unique,
