@@ -50,6 +50,21 @@ def gate_id(g):
     if k == PC.RANDOM_ACCESS:
         return (f"RandomAccessGate {{ bits: {g.p0}, num_copies: {g.p1}, num_extra_constants: {g.p2}, _phantom: "
                 "PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>")
+    if k == PC.ARITHMETIC_EXT:
+        return f"ArithmeticExtensionGate {{ num_ops: {g.p0} }}"
+    if k == PC.MUL_EXT:
+        return f"MulExtensionGate {{ num_ops: {g.p0} }}"
+    if k == PC.REDUCING:
+        return f"ReducingGate {{ num_coeffs: {g.p0} }}"
+    if k == PC.REDUCING_EXT:
+        return f"ReducingExtensionGate {{ num_coeffs: {g.p0} }}"
+    if k == PC.EXPONENTIATION:
+        return f"ExponentiationGate {{ num_power_bits: {g.p0}, _phantom: PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }}<D=2>"
+    if k == PC.COSET_INTERPOLATION:  # (the reference's string also lists the barycentric weights; a reader takes the two parameters)
+        return (f"CosetInterpolationGate {{ subgroup_bits: {g.p0}, degree: {g.p1}, _phantom: "
+                "PhantomData<plonky2_field::goldilocks_field::GoldilocksField> }<D=2>")
+    if k == PC.POSEIDON_MDS:
+        return "PoseidonMdsGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)<WIDTH=12>"
     raise ValueError(f"no id string for gate kind {k}")
 
 
@@ -208,16 +223,10 @@ def table_section(v, given=None):
                            "column_2_over_both": hexof(cell(leaf1, leaf3, 2))}}
 
 
-def proof_section(v):
-    """the circuit of main.rs's proof_section built by recursion.Builder and proved by the oracle (smallest PoW witness)"""
+def dump_circuit(ckt, v):
+    """prove (oracle, smallest PoW witness), verify, and write out what main.rs's dump_circuit writes; also returns what a wrap needs"""
     mp2 = importlib.import_module("mapreduce-plonky2_amd")
     FW = importlib.import_module("mapreduce-plonky2_amd.framework")
-    b = R.Builder(hasher=v)
-    x, y = b.add_virtual(3), b.add_virtual(0x123456789ABCDEF0)
-    s = b.add(b.mul(x, y), x)
-    t = b.mul_add(s, b.constant(0xC0FFEE), y)
-    b.register_public_inputs([x, t])
-    ckt = b.build(min_log_n=5)
     cap = O.merkle_cap(O.merkle_build(O.lde_leaves(O.fft(ckt.pre, inverse=True), 3), 4, v), 4)
     dom = np.zeros(4, dtype=np.uint64)
     e = O.arr(np.zeros(0, dtype=np.uint64))
@@ -229,11 +238,30 @@ def proof_section(v):
     caps[0] = cap.reshape(-1)
     wire = mp2.serialize_proof(FW.circuit_fri_params(ckt, v), ckt.num_constants, caps, openings, proof, ckt.public_inputs)
     groups = sorted({(g.selector_index, g.group_start, g.group_end) for g in ckt.gates})
-    return {"degree_bits": ckt.log_n, "config": "CircuitConfig::standard_recursion_config()", "gates": [gate_id(g) for g in ckt.gates],
-            "selector_indices": [g.selector_index for g in ckt.gates], "selector_groups": [[s_, e_] for _, s_, e_ in groups], "num_constants": ckt.num_constants,
-            "k_is": [pow(MULT_GEN, j, O.P) for j in range(80)], "constants_sigmas": [ints(r) for r in ckt.pre], "wires": [ints(r) for r in ckt.wires],
-            "public_inputs": ints(ckt.public_inputs), "circuit_digest": ints(digest), "constants_sigmas_cap": [ints(h) for h in cap.reshape(-1, 4)],
-            "proof_bincode_hex": wire.hex(), "pow_witness": int(proof[-1])}
+    doc = {"degree_bits": ckt.log_n, "config": "CircuitConfig::standard_recursion_config()", "gates": [gate_id(g) for g in ckt.gates],
+           "selector_indices": [g.selector_index for g in ckt.gates], "selector_groups": [[s_, e_] for _, s_, e_ in groups], "num_constants": ckt.num_constants,
+           "k_is": [pow(MULT_GEN, j, O.P) for j in range(80)], "constants_sigmas": [ints(r) for r in ckt.pre], "wires": [ints(r) for r in ckt.wires],
+           "public_inputs": ints(ckt.public_inputs), "circuit_digest": ints(digest), "constants_sigmas_cap": [ints(h) for h in cap.reshape(-1, 4)],
+           "proof_bincode_hex": wire.hex(), "pow_witness": int(proof[-1])}
+    return doc, (fp, cap, digest, caps, openings, proof)
+
+
+def proof_sections(v):
+    """main.rs's proof_section: the small circuit built by recursion.Builder and, for the Poseidon2 configuration, the first
+    wrapping step over its proof (recursion.wrap_circuit = wrap_circuit.rs:64-99 at wrap_step 0). This repository's in-circuit
+    verifier hashes with Poseidon2, so a file for the `original_poseidon` configuration carries no `proof_recursive` from here."""
+    b = R.Builder(hasher=v)
+    x, y = b.add_virtual(3), b.add_virtual(0x123456789ABCDEF0)
+    s = b.add(b.mul(x, y), x)
+    t = b.mul_add(s, b.constant(0xC0FFEE), y)
+    b.register_public_inputs([x, t])
+    ckt = b.build(min_log_n=5)
+    first, (fp, cap, digest, caps, openings, proof) = dump_circuit(ckt, v)
+    if v != 0:
+        return first, None
+    inner = R.InnerCircuit(ckt, fp, cap, digest, len(ckt.public_inputs))
+    wrap = R.wrap_circuit(inner, caps, openings, proof, ckt.public_inputs)
+    return first, dump_circuit(wrap, v)[0]
 
 
 def make(hasher="poseidon2"):
@@ -244,7 +272,7 @@ def make(hasher="poseidon2"):
                       "root_of_unity_log3": pow(TWO_GEN, 1 << 29, O.P), "root_of_unity_log6": pow(TWO_GEN, 1 << 26, O.P)},
             "hashers": {"poseidon2": hasher_section(0), "poseidon": hasher_section(1)}, "identifier_block_column": int(block[0]),
             "fft": {"3": fft_section(3), "10": fft_section(10)}, "polynomial_batch": batch_section(v), "challenger": challenger_script(v),
-            "ecgfp5": ecgfp5_section(v), "table": table_section(v), "proof": proof_section(v)}
+            "ecgfp5": ecgfp5_section(v), "table": table_section(v), **{k: p for k, p in zip(("proof", "proof_recursive"), proof_sections(v)) if p is not None}}
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ use plonky2::{
     fri::oracle::PolynomialBatch,
     gates::noop::NoopGate,
     hash::{
-        hash_types::HashOut,
+        hash_types::{HashOut, MerkleCapTarget},
         hashing::PlonkyPermutation,
         merkle_tree::MerkleTree,
     },
@@ -40,8 +40,9 @@ use plonky2::{
     },
     plonk::{
         circuit_builder::CircuitBuilder,
-        circuit_data::CircuitConfig,
+        circuit_data::{CircuitConfig, CircuitData, VerifierCircuitTarget},
         config::{GenericConfig, Hasher, PoseidonGoldilocksConfig},
+        proof::ProofWithPublicInputs,
     },
     util::timing::TimingTree,
 };
@@ -285,9 +286,9 @@ fn table_section() -> Result<Value> {
 /// the gate list with selectors, the preprocessed polynomials' values on H, the full wire matrix, the verifier data and the
 /// proof as mp2-common/src/proof.rs:84-88 serialises it (bincode). The PoW witness is whatever rayon's find_any returned:
 /// compare everything before it bit for bit, then verify the whole proof.
-fn proof_section() -> Result<Value> {
+fn proof_section() -> Result<(Value, Value)> {
     let config = CircuitConfig::standard_recursion_config();
-    let mut b = CircuitBuilder::<F, D>::new(config);
+    let mut b = CircuitBuilder::<F, D>::new(config.clone());
     let x = b.add_virtual_target();
     let y = b.add_virtual_target();
     let xy = b.mul(x, y);
@@ -303,6 +304,30 @@ fn proof_section() -> Result<Value> {
     let mut pw = PartialWitness::new();
     pw.set_target(x, f(3));
     pw.set_target(y, f(0x1234_5678_9ABC_DEF0));
+    let (first, proof) = dump_circuit(&data, pw)?;
+    // The first wrapping step of the recursion framework over that proof (recursion-framework/src/universal_verifier_gadget/
+    // wrap_circuit.rs:64-99 with wrap_step == 0): the inner verifier data as constants, the inner public inputs exposed. Its gate
+    // list is the recursive verifier's -- Poseidon2 / BaseSum / RandomAccess / Reducing / ArithmeticExtension / CosetInterpolation
+    // ... -- so a foreign prover that reproduces THIS proof from the wire matrix has every one of those constraint evaluators right.
+    let mut b2 = CircuitBuilder::<F, D>::new(config);
+    let pt = b2.add_virtual_proof_with_pis(&data.common);
+    let inner = VerifierCircuitTarget {
+        constants_sigmas_cap: MerkleCapTarget(data.verifier_only.constants_sigmas_cap.0.iter().map(|h| b2.constant_hash(*h)).collect_vec()),
+        circuit_digest: b2.constant_hash(data.verifier_only.circuit_digest),
+    };
+    b2.verify_proof::<C>(&pt, &inner, &data.common);
+    for pi in pt.public_inputs.iter() {
+        b2.register_public_input(*pi);
+    }
+    let data2 = b2.build::<C>();
+    let mut pw2 = PartialWitness::new();
+    pw2.set_proof_with_pis_target(&pt, &proof);
+    let (second, _) = dump_circuit(&data2, pw2)?;
+    Ok((first, second))
+}
+
+/// prove, verify, and write out what a foreign prover needs to redo the proof (see proof_section)
+fn dump_circuit(data: &CircuitData<F, C, D>, pw: PartialWitness<F>) -> Result<(Value, ProofWithPublicInputs<F, C, D>)> {
     let n = data.common.degree();
     let witness = generate_partial_witness(pw.clone(), &data.prover_only, &data.common).full_witness();
     let wires: Vec<Vec<u64>> = (0..data.common.config.num_wires).map(|c| (0..n).map(|r| u(witness.get_wire(r, c))).collect()).collect();
@@ -311,7 +336,7 @@ fn proof_section() -> Result<Value> {
     let pre = &data.prover_only.constants_sigmas_commitment;
     let pre_values: Vec<Vec<u64>> = pre.polynomials.iter().map(|p| us(&p.clone().fft().values)).collect();
     let sel = &data.common.selectors_info;
-    Ok(json!({
+    let doc = json!({
         "degree_bits": data.common.degree_bits(),
         "config": "CircuitConfig::standard_recursion_config()",
         "gates": data.common.gates.iter().map(|g| g.0.id()).collect_vec(),
@@ -326,12 +351,14 @@ fn proof_section() -> Result<Value> {
         "constants_sigmas_cap": data.verifier_only.constants_sigmas_cap.0.iter().map(|h| hash_limbs(*h)).collect_vec(),
         "proof_bincode_hex": hex::encode(serialize_proof(&proof)?),
         "pow_witness": u(proof.proof.opening_proof.pow_witness),
-    }))
+    });
+    Ok((doc, proof))
 }
 
 fn main() -> Result<()> {
     let out = env::args().nth(1).unwrap_or_else(|| "reference_vectors.json".to_string());
     let default_hasher = if cfg!(feature = "original_poseidon") { "poseidon" } else { "poseidon2" };
+    let proof = proof_section()?;
     let doc = json!({
         "schema": 1,
         "source": "reference (Lagrange-Labs/mapreduce-plonky2 v3.0.0 workspace, its Cargo.lock)",
@@ -353,7 +380,8 @@ fn main() -> Result<()> {
         "challenger": challenger_section(),
         "ecgfp5": ecgfp5_section(),
         "table": table_section()?,
-        "proof": proof_section()?,
+        "proof": proof.0,
+        "proof_recursive": proof.1,
     });
     let mut file = File::create(&out)?;
     file.write_all(serde_json::to_string(&doc)?.as_bytes())?;
