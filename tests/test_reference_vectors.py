@@ -4,7 +4,9 @@ plonky2_ecgfp5, mp2-common, mp2-v1): consumes `tests/golden/reference_vectors.js
 no Rust toolchain, so the files do not exist yet and the reference-backed cases SKIP with that reason). Every "parity unpinned"
 row of DESIGN.md section 2 has a check here: field constants, both permutations and their sponges, Merkle helpers, the column-id
 formula, FFT ordering, PolynomialBatch leaves / cap / Merkle proof, the challenger, Ecgfp5 map-to-curve / add / scalar mul /
-Weierstrass form, and one complete proof (bincode bytes, bit-exact given the reference's proof-of-work witness).
+Weierstrass form, the off-chain half of table creation (row digest, off-chain data commitment and its update, cells-tree and
+row-tree node hashes), one complete proof (bincode bytes, bit-exact given the reference's proof-of-work witness) and the first
+wrapping step of the recursion framework over it (a 2^12-row recursive verifier, its full wire matrix and proof).
 
 The consumer itself is exercised on every run with a file of the same schema made from THIS repository's oracle
 (tools/ref_vectors/self_vectors.py): that proves the test reads the schema and drives every section -- not parity.
