@@ -614,6 +614,13 @@ def main(argv=None):
     ap.add_argument("--sweep-rows", type=int, default=256, help="rows of the block timed at every base degree of --degree-sweep")
     ap.add_argument("--config2-leaves", type=int, default=1024, help="--workload table at N = 1: leaves of the BASELINE configs[2] leg (2-to-1 aggregation of real leaf proofs, "
                     "2 x leaves - 1 framework proofs) reported as `config2`; 0 = skip")
+    ap.add_argument("--resume-dir", default=None, help="--workload table at N = 1: build the table as --table-blocks blocks of --steps x --rows rows ACROSS CALLS -- every "
+                    "block's root proof is kept in this directory as ProofWithVK bytes (mapreduce-plonky2_amd/proofstore.py: the reference's proof store, "
+                    "mp2-v1/tests/common/proof_storage.rs), blocks already there are skipped, and once all are present the join levels (separator rows) are "
+                    "proved, the root is verified and the record is written (--record). One call does as many blocks as fit --max-seconds")
+    ap.add_argument("--table-blocks", type=int, default=8, help="--resume-dir: blocks of the table (a power of two; block b holds the prefix 2 b, separator rows the odd ones)")
+    ap.add_argument("--max-seconds", type=float, default=3000.0, help="--resume-dir: do not start another block when the call would run past this many seconds")
+    ap.add_argument("--record", default=None, help="--resume-dir: where the record of the completed table goes (default: <resume-dir>/table_record.json)")
     ap.add_argument("--workload", choices=("table", "leaves", "tree", "recursion", "ntt"), default="table",
                     help="table (default, the headline): BASELINE configs[3] sampled -- per row 4 cells-tree + 1 row-tree REAL framework proofs, work-plan "
                          "scheduled, witness generation inside the timed region (run_table). leaves: prove() only on synthetic circuits with resident witnesses "
@@ -657,6 +664,9 @@ def main(argv=None):
         out = run_ntt_leg(args, local_rank, clocks)
         clocks.close()
         return out
+    if args.workload == "table" and args.resume_dir:
+        assert world == 1, "--resume-dir builds the blocks one after another on one GPU (with N ranks, every rank builds its block in one call: --gpus N)"
+        return run_table_resumable(args, local_rank, VARIANT, clocks)
     if args.workload == "table":
         return run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks)
     return run_leaves(args, rank, local_rank, world, dist, torch, VARIANT, clocks)
@@ -1199,6 +1209,173 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     if side_errors:  # the headline stands (exit code 0); the line names the failed legs in `side_leg_errors` and in their own fields
         print(f"bench.py: side leg(s) failed: {', '.join(side_errors)}", file=sys.stderr)
     return out
+
+
+def run_table_resumable(args, local_rank, VARIANT, clocks):
+    """BASELINE configs[3] at FULL size on one GPU, across calls: the table is `--table-blocks` contiguous blocks of `--steps` x
+    `--rows` rows (block b = the rows with prefix 2 b, exactly the blocks `--gpus N` deals to N ranks) plus the separator rows that
+    join them (prefixes 2 s + 1). Every call builds the blocks that are not yet in the proof store (`--resume-dir`) for as long as
+    `--max-seconds` allows -- a block = run_table's timed block: one work plan, 5 real framework proofs per row, the root checked
+    against the off-circuit tree hash / digest / min / max and by the oracle's verifier before it is stored as ProofWithVK bytes
+    (mp2g_proof_with_vk_serialize; the reference's harness does the same per node: mp2-v1/tests/common/rowtree.rs:78-337 with
+    proof_storage.rs:139-140) --; the call that finds all blocks present takes them out of the store (mp2g_proof_with_vk_deserialize),
+    proves the log2(blocks) join levels, verifies the root and writes the record. The single-GPU rehearsal of the 8-rank run."""
+    assert VARIANT == 0
+    t_call = time.perf_counter()
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    R = importlib.import_module("mapreduce-plonky2_amd.recursion")
+    FW = importlib.import_module("mapreduce-plonky2_amd.framework")
+    C = importlib.import_module("mapreduce-plonky2_amd.circuits")
+    T = importlib.import_module("mapreduce-plonky2_amd.table")
+    IX = importlib.import_module("mapreduce-plonky2_amd.indexing")
+    PS = importlib.import_module("mapreduce-plonky2_amd.proofstore")
+    mods = (mp2, R, FW, C, T, IX)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import circuits as OC
+    import oracle as O
+    n_cols, seed, blocks = 4, 0xC0FFEE04, args.table_blocks
+    assert blocks >= 1 and blocks & (blocks - 1) == 0, "--table-blocks: a power of two (binary join levels)"
+    n_rows = max(1, args.steps) * args.rows
+    table_id = f"synthetic_{seed:x}_{blocks}x{n_rows}"
+    store = PS.ProofStore(args.resume_dir)
+    rig = TableRig(mods, local_rank, VARIANT, args.workers, args.table_batch, args.subtree, False, 1, pad_bits=args.pad_base_bits,
+                   group_rows=args.group_rows, native=args.native_build)
+    params, ctx = rig.params, rig.ctx
+    final_ckt = params.rows.chains["row_leaf"][-1][0]
+    final_fp = FW.circuit_fri_params(final_ckt, VARIANT)
+    n_pis = T.ROWS_IO + 4
+    ints = lambda v: sum(int(x) << (32 * (7 - j)) for j, x in enumerate(v))
+
+    def block_key(b, table):
+        # RowProofIdentifier {table, primary, tree_key} (proof_storage.rs:41-46): the tree key of a block's root = the secondary-index value of its root row
+        root, _, _ = T.balanced_bst(table.rows)
+        return PS.ProofKey.row(table_id, 1, f"{ints(table.values[root, 0]):064x}")
+
+    # ---- blocks: build what the store does not hold yet ---------------------------------------------------------------------
+    tables = {b: T.SyntheticTable(n_rows, n_cols, seed, 2 * b) for b in range(blocks)}
+    keys = {b: block_key(b, tables[b]) for b in range(blocks)}
+    built, warm, est = [], False, None
+    for b in range(blocks):
+        if store.contains(keys[b]):
+            continue
+        elapsed = time.perf_counter() - t_call
+        if est is not None and elapsed + 1.15 * est > args.max_seconds:
+            break
+        if not warm and args.warmup > 0:  # creates the provers of every circuit, outside the block's clock
+            rig.build(args.warmup * args.rows, 2 * b, seed ^ 0x5A5A5A, n_cols, args.warmup * args.rows > 16384)
+            warm = True
+        for c in rig.ctxs:
+            c.sync()
+        n0, t0 = rig.n_proofs, time.perf_counter()
+        st = rig.build(n_rows, 2 * b, seed, n_cols, n_rows > 16384)
+        for c in rig.ctxs:
+            c.sync()
+        dt = time.perf_counter() - t0
+        est = dt
+        want, w_all = rig.check_root(st, verify=True)
+        caps, openings, fri, pis = st["proof"]
+        vk_cap, vk_dig = params.rows.vds[st["name"]]
+        blob = mp2.serialize_proof_with_vk(mp2.serialize_proof(final_fp, final_ckt.num_constants, caps, openings, fri, pis), vk_cap, vk_dig)
+        note = {"block": b, "prefix": 2 * b, "rows": n_rows, "framework_proofs": rig.n_proofs - n0, "gpu_seconds": dt, "proofs_per_s": (rig.n_proofs - n0) / dt,
+                "circuit": st["name"], "digest_w": [int(x) for x in st["digest_w"]], "digest_weierstrass": [int(x) for x in pis[4:15]],
+                "min": f"{ints(st['table'].values[0, 0]):064x}", "max": f"{ints(st['table'].values[-1, 0]):064x}", "root_verified_by_oracle": True,
+                "clocks": clocks.read(local_rank), "workers": len(rig.ctxs), "batch": args.table_batch, "host": os.uname().nodename, "unix_time": time.time()}
+        store.store_proof(keys[b], blob, note)
+        built.append(b)
+        print(f"bench.py: block {b} of {blocks}: {n_rows} rows, {rig.n_proofs - n0} framework proofs in {dt:.1f} s = {(rig.n_proofs - n0) / dt:.1f} proofs/s, root stored "
+              f"({len(blob)} B)", file=sys.stderr, flush=True)
+        del st
+    missing = [b for b in range(blocks) if not store.contains(keys[b])]
+    if missing:
+        out = {"resume_dir": args.resume_dir, "blocks_built_this_call": built, "blocks_missing": missing, "call_seconds": time.perf_counter() - t_call}
+        print(json.dumps(out))
+        rig.close()
+        clocks.close()
+        return out
+
+    # ---- every block is in the store: take the roots out, check each, prove the join levels ----------------------------------
+    names = list(params.rows.circuits)
+    by_digest = {tuple(int(x) for x in params.rows.vds[n][1]): n for n in names}
+    cur, notes, ws = {}, {}, {}
+    for b in range(blocks):
+        proof, vk_cap, vk_dig = mp2.deserialize_proof_with_vk(final_fp, final_ckt.num_constants, store.get_proof_exact(keys[b]), n_pis)
+        name = by_digest[tuple(int(x) for x in vk_dig)]  # the verifier key names the circuit (KeyError: not a circuit of this set)
+        assert np.array_equal(vk_cap.ravel(), np.asarray(params.rows.vds[name][0], dtype=np.uint64).ravel()), "stored verifier key: cap"
+        pis = proof[3]
+        # the stored root against the table, not against its note: digest of the block's rows, min / max, circuit-set digest; the oracle verifies it
+        w_b, wei_b = mp2.compute_table_row_digest(ctx, tables[b].col_ids, tables[b].values, tables[b].values[:, 0:1])
+        assert np.array_equal(wei_b, pis[4:15]), f"block {b}: stored root's digest != compute_table_row_digest of the block"
+        assert np.array_equal(pis[26:34], T.u256_to_limbs([ints(tables[b].values[0, 0])])[0]) and np.array_equal(pis[34:42], T.u256_to_limbs([ints(tables[b].values[-1, 0])])[0]), "min / max"
+        assert np.array_equal(pis[T.ROWS_IO:], np.asarray(params.rows.set_digest, dtype=np.uint64)), "circuit-set digest"
+        wckt, _, wdig = params.rows.chains[name][-1]
+        rc = OC.verify(wckt, OC.oracle_params(wckt), np.asarray(wdig, dtype=np.uint64), O.hash_n_to_m_no_pad(pis, 4), *proof[:3])
+        if rc:
+            raise SystemExit(f"bench.py: the oracle's verifier rejects the stored root of block {b} (code {rc})")
+        cur[b], notes[b], ws[b] = (proof, name, w_b), store.note(keys[b]), w_b
+    for c in rig.ctxs:
+        c.sync()
+    n_levels, seps, t0 = blocks.bit_length() - 1, [], time.perf_counter()
+    for lvl in range(n_levels):
+        bit = 1 << lvl
+        for b in range(0, blocks, 2 * bit):
+            sep = 2 * (b + bit) - 1
+            cur[b] = T.join_blocks(rig.join_build(), ctx, cur[b], cur[b + bit], sep, n_cols, seed, VARIANT)
+            seps.append(sep)
+    for c in rig.ctxs:
+        c.sync()
+    join_s = time.perf_counter() - t0
+    root_proof, root_name, root_w = cur[0]
+    root_pis = root_proof[3]
+    for sp in seps:
+        tb = T.SyntheticTable(1, n_cols, seed, sp)
+        ws[-sp] = mp2.compute_table_row_digest(ctx, tb.col_ids, tb.values, tb.values[:, 0:1])[0]
+    whole_w, whole_wei = mp2.curve_sum(ctx, np.stack([ws[k] for k in sorted(ws)]), weierstrass=True)
+    assert np.array_equal(whole_wei, root_pis[4:15]), "root digest != compute_table_row_digest of the whole table (blocks and separator rows)"
+    assert np.array_equal(root_pis[26:34], T.u256_to_limbs([ints(tables[0].values[0, 0])])[0]), "root min != the table's smallest secondary value"
+    assert np.array_equal(root_pis[34:42], T.u256_to_limbs([ints(tables[blocks - 1].values[-1, 0])])[0]), "root max != the table's largest secondary value"
+    assert np.array_equal(root_pis[T.ROWS_IO:], np.asarray(params.rows.set_digest, dtype=np.uint64)), "circuit-set digest"
+    wckt, _, wdig = params.rows.chains[root_name][-1]
+    rc = OC.verify(wckt, OC.oracle_params(wckt), np.asarray(wdig, dtype=np.uint64), O.hash_n_to_m_no_pad(root_pis, 4), *root_proof[:3])
+    if rc:
+        raise SystemExit(f"bench.py: the oracle's verifier rejects the table's root (code {rc})")
+    vk_cap, vk_dig = params.rows.vds[root_name]
+    root_blob = mp2.serialize_proof_with_vk(mp2.serialize_proof(final_fp, final_ckt.num_constants, *root_proof), vk_cap, vk_dig)
+    store.store_proof(PS.ProofKey.row(table_id, 1, "root"), root_blob, {"rows": blocks * n_rows + len(seps), "circuit": root_name})
+    block_s = sum(notes[b]["gpu_seconds"] for b in range(blocks))
+    block_proofs = sum(notes[b]["framework_proofs"] for b in range(blocks))
+    total_proofs, total_s = block_proofs + (n_cols + 1) * len(seps), block_s + join_s
+    out = {"metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build, 1/2/4/8 GPU",
+           "value": total_proofs / total_s, "unit": "proofs/s", "n_gpus": 1, "higher_is_better": True, "dtype": "u64 (Goldilocks field)", "data": "synthetic",
+           "table_rows_total": blocks * n_rows + len(seps), "framework_proofs": total_proofs, "gpu_seconds": total_s, "gpu_seconds_blocks": block_s,
+           "gpu_seconds_join_levels": join_s, "join_levels": n_levels, "separator_rows": len(seps),
+           "config": {"workload": f"table: configs[3] COMPLETED -- {blocks} contiguous blocks of {n_rows} rows + {len(seps)} separator rows = {blocks * n_rows + len(seps)} rows, "
+                                  f"{total_proofs} real framework proofs ({n_cols} cells-tree + 1 row-tree per row: witness program + base prove() + wrap chain to 2^12 rows, witness check "
+                                  "on), built block by block on ONE MI355X across calls; block roots kept as ProofWithVK bytes in a proof store between the calls, re-checked against "
+                                  "the table and the oracle's verifier when taken out, then joined by log2(blocks) levels of separator rows; gpu_seconds = the sum of the blocks' "
+                                  "timed regions (each as bench.py's timed block: barrier to barrier, provers created before) + the join levels",
+                      "blocks": blocks, "rows_per_block": n_rows, "value_columns": n_cols, "workers": len(rig.ctxs), "batch": args.table_batch, "subtree_size": args.subtree,
+                      "shapes": params.shapes(), "hasher": "Poseidon2", "table_id": table_id},
+           "blocks": [{k: notes[b][k] for k in ("block", "rows", "framework_proofs", "gpu_seconds", "proofs_per_s", "circuit", "host", "unix_time", "clocks")} for b in range(blocks)],
+           "root_circuit": root_name, "root_public_inputs": [int(x) for x in root_pis], "root_proof_with_vk_bytes": len(root_blob),
+           "root_proof_with_vk_fnv1a64": f"{fnv1a64(root_blob):016x}",
+           "root_digest_w": [int(x) for x in whole_w],
+           "verified": "every stored block root: digest = compute_table_row_digest of its rows, min / max, circuit-set digest, the oracle's verifier; the table's root: "
+                       "digest = compute_table_row_digest of all rows (blocks + separators), min of block 0, max of the last block, circuit-set digest, the oracle's verifier",
+           "resume_dir": args.resume_dir, "blocks_built_this_call": built, "call_seconds": time.perf_counter() - t_call}
+    rec = args.record or os.path.join(args.resume_dir, "table_record.json")
+    with open(rec, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+    rig.close()
+    clocks.close()
+    return out
+
+
+def fnv1a64(data):
+    h = 0xCBF29CE484222325
+    for b in np.frombuffer(bytes(data), dtype=np.uint8).tolist():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
 
 
 def run_leaves(args, rank, local_rank, world, dist, torch, VARIANT, clocks, brief=False):

@@ -269,6 +269,14 @@ int mp2g_proof_deserialize(const mp2g_fri_params* params, uint32_t num_constants
  * u64, the cap hashes, the circuit digest). vk_cap_len must be a power of two. */
 int mp2g_proof_with_vk_serialize(const uint8_t* proof_bytes, size_t proof_len, const uint64_t* vk_cap,
                                  uint32_t vk_cap_len, const uint64_t vk_circuit_digest[4], uint8_t* out, size_t* out_len);
+/* ProofWithVK::deserialize (mp2-common/src/proof.rs:54-57), the inverse: the proof's parts as mp2g_proof_deserialize hands
+ * them out, then the verifier key -- vk_cap [vk_cap_len][4] (the caller states the cap length it expects: a blob with
+ * another cap height is refused) and the circuit digest. What a proof store (mp2-v1/tests/common/proof_storage.rs:139-140
+ * `get_proof_exact`) returns is fed to this before the proof enters its parent's witness. */
+int mp2g_proof_with_vk_deserialize(const mp2g_fri_params* params, uint32_t num_constants, const uint8_t* bytes, size_t len,
+                                   uint64_t* caps, uint64_t* openings, uint64_t* fri_proof, uint64_t* public_inputs,
+                                   uint32_t n_public_inputs, uint64_t* vk_cap, uint32_t vk_cap_len,
+                                   uint64_t vk_circuit_digest[4]);
 
 /* ---- permutation argument: replaces plonk/prover.rs all_wires_permutation_partial_products ---- */
 /* wires [wires_w][n] and sigmas [num_routed][n]: subgroup values (natural order); only the first

@@ -882,6 +882,24 @@ def serialize_proof_with_vk(proof_bytes, vk_cap, vk_circuit_digest):
     return out.tobytes()
 
 
+def deserialize_proof_with_vk(fp, num_constants, data, n_public_inputs, vk_cap_len=None):
+    """ProofWithVK::deserialize (mp2-common/src/proof.rs:54-57): (caps, openings, fri words, public inputs) with caps[0] = the
+    verifier key's constants_sigmas cap (what the prover hands out for a proof it made), and the key's circuit digest."""
+    buf = np.frombuffer(data, dtype=np.uint8).copy()
+    n_cap = (1 << fp.cap_height) if vk_cap_len is None else int(vk_cap_len)
+    caps = np.zeros((fp.n_oracles, fp.cap_words), dtype=np.uint64)
+    openings = np.zeros((fp.n_openings, 2), dtype=np.uint64)
+    fri = np.zeros(fp.proof_words, dtype=np.uint64)
+    pis = np.zeros(n_public_inputs, dtype=np.uint64)
+    vk_cap = np.zeros((n_cap, 4), dtype=np.uint64)
+    dig = np.zeros(4, dtype=np.uint64)
+    _ck(load().mp2g_proof_with_vk_deserialize(ctypes.byref(fp), num_constants, _p(buf), ctypes.c_size_t(buf.size), _p(caps), _p(openings),
+                                              _p(fri), _p(pis), n_public_inputs, _p(vk_cap), n_cap, _p(dig)))
+    if vk_cap.size == caps[0].size:
+        caps[0] = vk_cap.ravel()
+    return (caps, openings, fri, pis), vk_cap, dig
+
+
 # ---- recursion-framework pieces that sit on the path ------------------------------------------
 # recursion-framework/src/universal_verifier_gadget/mod.rs:27-40, circuit_builder.rs:26
 CIRCUIT_SET_CAP_HEIGHT = 0

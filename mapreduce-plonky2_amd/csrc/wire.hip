@@ -172,4 +172,24 @@ int mp2g_proof_with_vk_serialize(const uint8_t* proof_bytes, size_t proof_len, c
   *out_len = w.pos;
   return 0;
 }
+int mp2g_proof_with_vk_deserialize(const mp2g_fri_params* p, uint32_t num_constants, const uint8_t* bytes, size_t len, uint64_t* caps,
+                                   uint64_t* openings, uint64_t* fri_proof, uint64_t* public_inputs, uint32_t n_pis, uint64_t* vk_cap,
+                                   uint32_t vk_cap_len, uint64_t vk_circuit_digest[4]) {
+  // ProofWithVK::deserialize (mp2-common/src/proof.rs:54-57): the proof, then the verifier key as a byte string whose
+  // content is VerifierOnlyCircuitData::to_bytes (cap height, the cap's hashes, the circuit digest)
+  int rc = shape_check(p, num_constants);
+  if (rc) return rc;
+  NEED(bytes && caps && openings && fri_proof && (public_inputs || !n_pis) && vk_cap && vk_circuit_digest, "pointers");
+  uint32_t height = 0;
+  while (((uint32_t)1 << height) < vk_cap_len && height < 31) height++;
+  NEED(vk_cap_len >= 1 && ((uint32_t)1 << height) == vk_cap_len, "vk_cap_len must be a power of two");
+  Reader r{bytes, len};
+  walk<Reader, uint64_t*>(r, p, num_constants, caps, openings, fri_proof, public_inputs, n_pis, rlen);
+  r.expect_len(8 + (uint64_t)vk_cap_len * 32 + 32);
+  r.expect_len(height);
+  r.u64s(vk_cap, (size_t)vk_cap_len * 4);
+  r.u64s(vk_circuit_digest, 4);
+  if (!r.ok || r.pos != len) return fail("malformed ProofWithVK bytes (shape mismatch, non-canonical element, another cap height or trailing data)");
+  return 0;
+}
 }  // extern "C"

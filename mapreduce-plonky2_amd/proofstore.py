@@ -1,0 +1,116 @@
+"""A proof store keyed by ProofKey: the host-side mirror of the reference's test harness store
+(mp2-v1/tests/common/proof_storage.rs:58-140 `ProofKey`, `ProofStorage::{store_proof, get_proof_exact, move_proof}`, :211-274 the
+key-value implementation). The reference keeps every proof of a table build in it so that a later step (a parent node, a later
+block, another process) picks a child up as serialized `ProofWithVK` bytes (mp2-common/src/proof.rs:42-57); here it is what lets a
+table too large for one GPU lease be built block by block across calls -- every block's root goes in as ProofWithVK bytes
+(mp2g_proof_with_vk_serialize), the join levels take them out (mp2g_proof_with_vk_deserialize).
+
+A directory of files, not a storage engine: one file per key, written to a temporary name and renamed, so a call that is cut off
+leaves either the whole proof or nothing."""
+import json
+import os
+
+# ProofKey variants of proof_storage.rs:58-79 that sit on the table-creation path
+KINDS = ("cell_tree", "row_tree", "index_tree", "ivc")
+
+
+class ProofKey:
+    """proof_storage.rs:58-79. `kind` is the prefix the reference mixes into the key's hash (:93-140); the identifier fields are
+    CellProofIdentifier {table, primary, secondary, tree_key} / RowProofIdentifier {table, primary, tree_key} /
+    IndexProofIdentifier {table, tree_key} (:19-53)."""
+
+    def __init__(self, kind, **ident):
+        assert kind in KINDS, kind
+        self.kind, self.ident = kind, dict(sorted(ident.items()))
+
+    @classmethod
+    def cell(cls, table, primary, secondary, tree_key):
+        return cls("cell_tree", table=table, primary=int(primary), secondary=str(secondary), tree_key=int(tree_key))
+
+    @classmethod
+    def row(cls, table, primary, tree_key):
+        return cls("row_tree", table=table, primary=int(primary), tree_key=str(tree_key))
+
+    @classmethod
+    def index(cls, table, tree_key):
+        return cls("index_tree", table=table, tree_key=int(tree_key))
+
+    def canonical(self):
+        return self.kind + "." + ".".join(f"{k}={v}" for k, v in self.ident.items())
+
+    def compute_hash(self):
+        """proof_storage.rs:82-90 hashes the key with Rust's DefaultHasher; any stable 64-bit hash serves the store: FNV-1a"""
+        h = 0xCBF29CE484222325
+        for b in self.canonical().encode():
+            h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    def __eq__(self, other):
+        return isinstance(other, ProofKey) and self.canonical() == other.canonical()
+
+    def __hash__(self):
+        return hash(self.canonical())
+
+    def __repr__(self):
+        return f"ProofKey({self.canonical()})"
+
+
+class ProofStore:
+    """ProofStorage (proof_storage.rs:139-140) over a directory. Files: <kind>_<hash:016x>.bin = the proof bytes,
+    <kind>_<hash:016x>.json = the key in clear and what the caller wants kept beside the proof (never read back for the proof
+    itself: a loaded proof is checked against its verifier key and public inputs, not against the note)."""
+
+    def __init__(self, path):
+        self.path = path
+        os.makedirs(path, exist_ok=True)
+
+    def _file(self, key, ext):
+        return os.path.join(self.path, f"{key.kind}_{key.compute_hash():016x}.{ext}")
+
+    def _write(self, name, data):
+        tmp = name + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(data)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, name)
+
+    def store_proof(self, key, proof, note=None):
+        """store_proof(key, proof): overwrites an earlier proof under the same key (proof_storage.rs:30-33: the latest one counts)"""
+        self._write(self._file(key, "json"), json.dumps({"key": key.canonical(), "bytes": len(proof), "note": note or {}}).encode())
+        self._write(self._file(key, "bin"), bytes(proof))
+
+    def contains(self, key):
+        return os.path.exists(self._file(key, "bin"))
+
+    def get_proof_exact(self, key):
+        """get_proof_exact(key): the bytes, or KeyError naming the key (proof_storage.rs:262-272 `proof with key .. not found`)"""
+        try:
+            with open(self._file(key, "bin"), "rb") as f:
+                return f.read()
+        except FileNotFoundError:
+            raise KeyError(f"proof with key {key!r} not found in {self.path}") from None
+
+    def note(self, key):
+        try:
+            with open(self._file(key, "json")) as f:
+                return json.load(f)["note"]
+        except FileNotFoundError:
+            raise KeyError(f"proof with key {key!r} not found in {self.path}") from None
+
+    def move_proof(self, old_key, new_key):
+        """move_proof(old, new): a silent no-op when the old key holds nothing (proof_storage.rs:236-260)"""
+        if not self.contains(old_key):
+            return
+        proof, note = self.get_proof_exact(old_key), self.note(old_key)
+        self.store_proof(new_key, proof, note)
+        os.remove(self._file(old_key, "bin"))
+        os.remove(self._file(old_key, "json"))
+
+    def keys(self):
+        out = []
+        for name in sorted(os.listdir(self.path)):
+            if name.endswith(".json"):
+                with open(os.path.join(self.path, name)) as f:
+                    out.append(json.load(f)["key"])
+        return out

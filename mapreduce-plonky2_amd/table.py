@@ -89,6 +89,28 @@ def sbbst_span(n, k):
     return k - (1 << layer) + 1, min(n, k + (1 << layer) - 1)
 
 
+def cells_tree_live_peak(n_cols):
+    """the most proofs of ONE row's cells tree alive at a time when the tree is proved level by level (levels = heights) and a child
+    is dropped once its parent is proved: what a unit of the native build holds per row in the proof pool while it proves the
+    cells trees (the root stays until the row node is proved)"""
+    height = {}
+
+    def h(k):
+        if k not in height:
+            height[k] = 1 + max([h(c) for c in sbbst_children(n_cols, k) if c is not None], default=-1)
+        return height[k]
+
+    for k in range(1, n_cols + 1):
+        h(k)
+    alive, peak = 0, 0
+    for lvl in range(max(height.values()) + 1):
+        here = [k for k in height if height[k] == lvl]
+        alive += len(here)
+        peak = max(peak, alive)
+        alive -= sum(c is not None for k in here for c in sbbst_children(n_cols, k))
+    return peak
+
+
 def balanced_bst(n):
     """the BST a full rebuild gives over n keys in sorted order (node = midpoint of its range): root, {key: (left, right)},
     {key: (lo, hi)} with the subtree of `key` = keys [lo, hi)"""
@@ -650,8 +672,11 @@ class NativeTableBuild:
             self.forest.free()
         # the pool holds the frontier: per worker a unit's cells leaves (2 per row) while its full nodes are proved, plus the roots of
         # the items of earlier waves and what the caller keeps
+        # (per row of a unit: the widest live set of its cells tree, level by level -- 3 proofs for 4 value columns, 9 for 20 --, and
+        # never less than the cells root + the row node beside it)
         unit = max(1, min(self.group_rows, -(-table.rows // len(self.provers))))
-        slots = self.pool_slots or (len(self.provers) * (3 * unit + 4 * self.batch) + table.rows // max(1, self.subtree_size // 2) + 2 * len(keep_rows) + 256)
+        per_row = max(2, cells_tree_live_peak(C))
+        slots = self.pool_slots or (len(self.provers) * (per_row * unit + 4 * self.batch) + table.rows // max(1, self.subtree_size // 2) + 2 * len(keep_rows) + 256)
         self.forest = Forest([pv.ctx for pv in self.provers], self.desc, self.chains, max(self.pw_cells, self.pw_rows), slots)
         self.register(table, wit, root, nodes, keep_rows)
         ut = W.UpdateTree.from_map(0, root, nodes)
@@ -659,7 +684,7 @@ class NativeTableBuild:
         # the harness loop (drain the Ready items, prove, mark done) runs inside the library: a row key k stands for the row node k and
         # its C cells-tree nodes (c << 40) | k
         t0 = time.perf_counter()
-        stop = self._progress_writer(t0, 5 * table.rows)
+        stop = self._progress_writer(t0, (C + 1) * table.rows)
         try:
             items = self.forest.prove_plan(plan, self.group_rows, n_satellites=C, satellite_shift=40)
         finally:

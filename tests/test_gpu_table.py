@@ -191,6 +191,26 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * 17) < 1e-6
 
 
+def test_bench_resume_dir_builds_the_table_across_calls(tmp_path):
+    """`bench.py --resume-dir`: the table as 2 blocks of 8 rows built in TWO calls (the first is held to one block), block roots kept as
+    ProofWithVK bytes in the proof store, the second call re-checks the stored root, builds the other block, proves the separator row
+    and verifies the root -- which must be the root `--gpus 2` gets for the same table with one rank per block"""
+    import glob
+    common = ["--rows", "8", "--steps", "1", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "4", "--table-blocks", "2",
+              "--resume-dir", str(tmp_path / "store")]
+    first = _bench(common + ["--max-seconds", "0"])
+    assert first["blocks_built_this_call"] == [0] and first["blocks_missing"] == [1]
+    assert len(glob.glob(str(tmp_path / "store" / "row_tree_*.bin"))) == 1
+    rec = _bench(common)
+    assert rec["blocks_built_this_call"] == [1] and rec["table_rows_total"] == 17 and rec["framework_proofs"] == 5 * 17 and rec["join_levels"] == 1
+    assert os.path.exists(str(tmp_path / "store" / "table_record.json")) and len(glob.glob(str(tmp_path / "store" / "row_tree_*.bin"))) == 3
+    again = _bench(common)  # a third call finds everything there: no block built, the same root
+    assert again["blocks_built_this_call"] == [] and again["root_proof_with_vk_fnv1a64"] == rec["root_proof_with_vk_fnv1a64"]
+    two = _bench(["--gpus", "2", "--rows", "8", "--steps", "1", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "4", "--no-leaves-leg",
+                  "--no-cpu-baseline", "--no-verify"], env={"MP2G_BENCH_BACKEND": "gloo"})
+    assert two["config"]["root_public_inputs"] == rec["root_public_inputs"]
+
+
 @pytest.mark.parametrize("n_cols,rows", [(1, 2), (6, 3)])
 def test_other_column_counts(ctx, mp2, params, n_cols, rows):
     """the cells tree follows ryhope's sbbst for any number of value columns: one column = a lone leaf; six columns = leaves 1, 3, 5, a

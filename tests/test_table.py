@@ -41,6 +41,14 @@ def test_sbbst_shape_restates_ryhope():
         assert seen == list(range(1, n + 1))  # a BST over 1..n holding every position once
 
 
+def test_cells_tree_live_peak():
+    """the proof pool of the native build is sized from the table's width: the widest live set of a row's cells tree when it is proved
+    level by level and children are dropped with their parents (4 columns: two leaves + the full node above them)"""
+    assert [T.cells_tree_live_peak(c) for c in (1, 2, 3, 4)] == [1, 2, 3, 3]
+    for c in (6, 7, 10, 20):
+        assert c // 2 < T.cells_tree_live_peak(c) <= c
+
+
 def test_balanced_bst_spans():
     for n in (1, 2, 3, 7, 8, 100):
         root, nodes, spans = T.balanced_bst(n)

@@ -67,6 +67,50 @@ def test_proof_with_vk_blob(mp2):
         mp2.serialize_proof_with_vk(proof, cap[:12], dig)
 
 
+def test_proof_with_vk_round_trip(mp2):
+    """mp2g_proof_with_vk_deserialize is the inverse of serialize_proof + serialize_proof_with_vk (ProofWithVK::deserialize,
+    mp2-common/src/proof.rs:54-57): the proof's parts, the key's cap and digest; a blob with another cap height, a truncated or a
+    padded one is refused"""
+    ofp, fp = make_fp(mp2)
+    n = 1 << fp.log_n
+    vals = [O.rand_field((w, n), 40 + i) for i, w in enumerate((5, 9, 4, 3))]
+    cd, ph = O.rand_field(4, 1), O.rand_field(4, 2)
+    caps, openings, proof = O.pcs_prove(ofp, vals, cd, ph)
+    pis = O.rand_field(7, 3)
+    blob = mp2.serialize_proof_with_vk(mp2.serialize_proof(fp, 2, caps, openings, proof, pis), caps[0].reshape(-1, 4), cd)
+    (c2, o2, p2, pi2), vk_cap, dig = mp2.deserialize_proof_with_vk(fp, 2, blob, 7)
+    assert np.array_equal(c2, caps) and np.array_equal(o2, openings) and np.array_equal(p2, proof) and np.array_equal(pi2, pis)
+    assert np.array_equal(vk_cap.ravel(), caps[0]) and np.array_equal(dig, cd)
+    assert O.pcs_verify(ofp, dig, ph, c2, o2, p2) == 0
+    for bad in (blob[:-8], blob + bytes(8)):
+        with pytest.raises(mp2.Mp2gError):
+            mp2.deserialize_proof_with_vk(fp, 2, bad, 7)
+    with pytest.raises(mp2.Mp2gError):
+        mp2.deserialize_proof_with_vk(fp, 2, blob, 7, vk_cap_len=8)
+
+
+def test_proof_store(tmp_path):
+    """proofstore.py = the harness store of mp2-v1/tests/common/proof_storage.rs: store / get_proof_exact / move_proof by ProofKey;
+    a second store over the same directory (another call) finds what the first one kept; a missing key is an error naming it"""
+    PS = __import__("importlib").import_module("mapreduce-plonky2_amd.proofstore")
+    st = PS.ProofStore(str(tmp_path / "s"))
+    k1, k2 = PS.ProofKey.row("t", 1, "00ff"), PS.ProofKey.cell("t", 1, "00ff", 3)
+    assert k1 != k2 and k1 == PS.ProofKey.row("t", 1, "00ff") and k1.compute_hash() != PS.ProofKey.row("t", 2, "00ff").compute_hash()
+    st.store_proof(k1, b"abc", {"rows": 3})
+    st.store_proof(k2, bytes(range(200)))
+    st.store_proof(k1, b"abcd", {"rows": 4})  # the latest proof under a key counts
+    again = PS.ProofStore(str(tmp_path / "s"))
+    assert again.get_proof_exact(k1) == b"abcd" and again.note(k1) == {"rows": 4} and again.get_proof_exact(k2) == bytes(range(200))
+    assert again.contains(k2) and not again.contains(PS.ProofKey.index("t", 9))
+    with pytest.raises(KeyError, match="index_tree"):
+        again.get_proof_exact(PS.ProofKey.index("t", 9))
+    k3 = PS.ProofKey.row("t", 2, "00ff")
+    again.move_proof(k1, k3)
+    again.move_proof(PS.ProofKey.index("t", 9), k1)  # silent
+    assert not again.contains(k1) and again.get_proof_exact(k3) == b"abcd" and len(again.keys()) == 2
+    assert not [f for f in __import__("os").listdir(str(tmp_path / "s")) if f.endswith(".tmp")]
+
+
 def fnv1a(data):
     h = 1469598103934665603
     for b in data:
