@@ -52,6 +52,67 @@ def test_round_constants_regenerate():
     assert poseidon2_rc12()[0][0] == [int(x, 16) for x in k["poseidon2_ext_row0"]]
 
 
+def test_constant_tables_against_a_second_generator(tmp_path):
+    """oracle/constants.h and csrc/perm_constants.h are written by ONE Python generator (tools/gen_constants.py): a slip there would be
+    common to the product and its checker. oracle/constgen.c derives the same tables again from the published procedures (Grain LFSR;
+    ChaCha8 + rand's uniform sampling; repeated squaring) in C, sharing no code with the Python tools: every generated table of both
+    headers must equal its output, and the two headers' literal tables (MDS rows, the Poseidon2 diagonal) must equal each other and
+    the published values"""
+    import re
+    import subprocess
+    exe = str(tmp_path / "constgen")
+    subprocess.check_call(["gcc", "-O2", "-o", exe, os.path.join(O.ROOT, "oracle", "constgen.c")])
+    gen = {}
+    for ln in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines():
+        name, count, *vals = ln.split()
+        gen[name] = [int(x, 16) for x in vals]
+        assert len(gen[name]) == int(count)
+    assert {k: len(v) for k, v in gen.items()} == {"POSEIDON_RC": 360, "POSEIDON2_RC_EXT": 96, "POSEIDON2_RC_INT": 22, "GL_TWO_GEN_POW2": 33}
+
+    def tables(path):
+        out = {}
+        for m in re.finditer(r"uint64_t (\w+)\[(\d+)\] = \{(.*?)\};", open(path).read(), re.S):
+            out[m.group(1)] = [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]+)ULL", m.group(3))]
+            assert len(out[m.group(1)]) == int(m.group(2))
+        return out
+
+    checker = tables(os.path.join(O.ROOT, "oracle", "constants.h"))
+    product = tables(os.path.join(O.ROOT, "mapreduce-plonky2_amd", "csrc", "perm_constants.h"))
+    assert set(checker) == set(product) == set(gen) | {"POSEIDON_MDS_CIRC", "POSEIDON_MDS_DIAG", "POSEIDON2_DIAG_M1"}
+    for name, want in gen.items():
+        assert checker[name] == want, f"oracle/constants.h: {name}"
+        assert product[name] == want, f"csrc/perm_constants.h: {name}"
+    for name in ("POSEIDON_MDS_CIRC", "POSEIDON_MDS_DIAG", "POSEIDON2_DIAG_M1"):
+        assert checker[name] == product[name]
+    assert checker["POSEIDON_MDS_CIRC"] == [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20] and checker["POSEIDON_MDS_DIAG"] == [8] + [0] * 11
+    assert checker["POSEIDON2_DIAG_M1"][0] == 0xc3b6c08e23ba9300 and checker["POSEIDON2_DIAG_M1"][11] == 0xd27dbb6944917b60
+    assert all(0 < v < P for v in checker["POSEIDON2_DIAG_M1"])
+    # the tables the library and the oracle actually COMPUTE with: one permutation of each against a plain-Python permutation over the
+    # second generator's tables (Poseidon2: external layer first, 4 full / 22 partial / 4 full rounds)
+    def m4(x):
+        t0, t1 = (x[0] + x[1]) % P, (x[2] + x[3]) % P
+        t2, t3 = (2 * x[1] + t1) % P, (2 * x[3] + t0) % P
+        t4, t5 = (4 * t1 + t3) % P, (4 * t0 + t2) % P
+        return [(t3 + t5) % P, t5, (t2 + t4) % P, t4]
+
+    def ext(s):
+        b = [m4(s[4 * i:4 * i + 4]) for i in range(3)]
+        tot = [(b[0][j] + b[1][j] + b[2][j]) % P for j in range(4)]
+        return [(b[i][j] + tot[j]) % P for i in range(3) for j in range(4)]
+
+    s = ext(list(range(12)))
+    e, d = gen["POSEIDON2_RC_EXT"], checker["POSEIDON2_DIAG_M1"]
+    for r in range(4):
+        s = ext([pow((x + e[12 * r + i]) % P, 7, P) for i, x in enumerate(s)])
+    for r in range(22):
+        s[0] = pow((s[0] + gen["POSEIDON2_RC_INT"][r]) % P, 7, P)
+        tot = sum(s) % P
+        s = [(x * d[i] + tot) % P for i, x in enumerate(s)]
+    for r in range(4, 8):
+        s = ext([pow((x + e[12 * r + i]) % P, 7, P) for i, x in enumerate(s)])
+    assert [int(x) for x in O.perm(np.arange(12, dtype=np.uint64), 0)] == s
+
+
 def test_field_constants():
     assert pow(O.MULT_GEN, (P - 1) >> 32, P) == 7277203076849721926
     for q in (2, 3, 5, 17, 257, 65537):
