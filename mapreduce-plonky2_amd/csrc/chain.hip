@@ -66,14 +66,14 @@ int mp2g_chain_run(mp2g_chain* ch, const uint64_t* inputs, uint32_t batch, const
 }
 }  // extern "C"
 
-int mp2g::chain_run_staged(mp2g_chain* ch, uint32_t batch, const mp2g_chain_patch* patches, uint32_t n_patches, const ChainHooks* hooks,
-                           uint64_t* caps, uint64_t* openings, uint64_t* proof, uint64_t* public_inputs) {
-  NEED(ch && batch >= 1 && batch <= ch->cap && (patches || !n_patches), "chain / batch <= capacity");
+// the launch sequence of a batch: upload, patches, `between`, every step (witness replay, prove, hand-over to the next step);
+// h_flags: the steps' witness-check flags go to pinned host memory behind their prove() (chain_enqueue)
+static int chain_steps(mp2g_chain* ch, uint32_t batch, const u64* h_in, const mp2g_chain_patch* patches, uint32_t n_patches, const ChainHooks* hooks,
+                       uint32_t* h_flags, hipEvent_t uploaded) {
   hipStream_t s = ch->ctx->stream;
   mp2g_chain::Step& s0 = ch->steps[0];
-  for (uint32_t i = 0; i < n_patches; i++)
-    NEED(patches[i].job < batch && patches[i].d_src && (size_t)patches[i].offset + patches[i].n_words <= s0.n_in, "patch outside the inputs");
-  CK(hipMemcpyAsync(s0.in.p, ch->h_in, (size_t)batch * s0.n_in * sizeof(u64), hipMemcpyHostToDevice, s));
+  CK(hipMemcpyAsync(s0.in.p, h_in, (size_t)batch * s0.n_in * sizeof(u64), hipMemcpyHostToDevice, s));
+  if (uploaded) CK(hipEventRecord(uploaded, s));
   for (uint32_t i = 0; i < n_patches; i++)
     CK(hipMemcpyAsync(s0.in.p + (size_t)patches[i].job * s0.n_in + patches[i].offset, patches[i].d_src, (size_t)patches[i].n_words * sizeof(u64),
                       hipMemcpyDeviceToDevice, s));
@@ -96,8 +96,59 @@ int mp2g::chain_run_staged(mp2g_chain* ch, uint32_t batch, const mp2g_chain_patc
     const uint64_t* vals[3] = {st.wires.p, nullptr, nullptr};
     rc = mp2g_prover_prove_dev(st.pr, vals, st.d_digest, st.pi_hash.p, st.caps.p, st.openings.p, st.proof.p);
     if (rc) return rc;
+    if (h_flags && mp2g_prover_witness_check_enabled(st.pr)) {
+      rc = prover_flags_to_host_async(st.pr, h_flags + k * ch->cap);
+      if (rc) return rc;
+    }
   }
   ch->last_batch = batch;
+  return 0;
+}
+
+int mp2g::chain_input_buffer(mp2g_chain* ch, uint32_t which, u64** out) {
+  NEED(ch && out && which < 2, "chain / buffer");
+  if (which == 1 && !ch->h_in_alt)
+    CK(hipHostMalloc((void**)&ch->h_in_alt, (size_t)ch->cap * ch->steps[0].n_in * sizeof(u64), hipHostMallocDefault));
+  if (!ch->in_ev[which]) CK(hipEventCreateWithFlags(&ch->in_ev[which], hipEventDisableTiming));
+  if (ch->in_ev_set[which]) CK(hipEventSynchronize(ch->in_ev[which]));  // the buffer's previous upload has left it
+  *out = which ? ch->h_in_alt : ch->h_in;
+  return 0;
+}
+
+int mp2g::chain_enqueue(mp2g_chain* ch, uint32_t batch, uint32_t which, const ChainHooks* hooks, uint32_t* h_flags) {
+  NEED(ch && batch >= 1 && batch <= ch->cap && which < 2 && ch->in_ev[which] && (which == 0 || ch->h_in_alt), "chain / batch <= capacity / buffer from chain_input_buffer");
+  int rc = chain_steps(ch, batch, which ? ch->h_in_alt : ch->h_in, nullptr, 0, hooks, h_flags, ch->in_ev[which]);
+  ch->in_ev_set[which] = true;  // (also after a failure half way: waiting on a recorded event is harmless, on an unrecorded one immediate)
+  if (rc) return rc;
+  if (hooks && hooks->after) { rc = hooks->after(hooks->user, ch, ch->ctx->stream); if (rc) return rc; }
+  return 0;
+}
+
+int mp2g::chain_flags_check(const mp2g_chain* ch, uint32_t batch, const uint32_t* h_flags) {
+  for (size_t k = 0; k < ch->n_steps; k++) {
+    if (!mp2g_prover_witness_check_enabled(ch->steps[k].pr)) continue;
+    for (uint32_t b = 0; b < batch; b++) {
+      const uint32_t h = h_flags[k * ch->cap + b];
+      if (h)
+        return fail("invalid witness: proof %u of the batch (step %zu of its chain) violates%s%s%s", b, k, (h & 1) ? " a copy constraint" : "",
+                    (h & 2) ? " a gate constraint" : "", (h & 4) ? " the lookup argument" : "");
+    }
+  }
+  return 0;
+}
+
+int mp2g::chain_run_staged(mp2g_chain* ch, uint32_t batch, const mp2g_chain_patch* patches, uint32_t n_patches, const ChainHooks* hooks,
+                           uint64_t* caps, uint64_t* openings, uint64_t* proof, uint64_t* public_inputs) {
+  NEED(ch && batch >= 1 && batch <= ch->cap && (patches || !n_patches), "chain / batch <= capacity");
+  hipStream_t s = ch->ctx->stream;
+  mp2g_chain::Step& s0 = ch->steps[0];
+  for (uint32_t i = 0; i < n_patches; i++)
+    NEED(patches[i].job < batch && patches[i].d_src && (size_t)patches[i].offset + patches[i].n_words <= s0.n_in, "patch outside the inputs");
+  if (ch->in_ev_set[0]) CK(hipEventSynchronize(ch->in_ev[0]));  // (a caller that mixes the two entry points: h_in's queued upload first)
+  {
+    int rc = chain_steps(ch, batch, ch->h_in, patches, n_patches, hooks, nullptr, nullptr);
+    if (rc) return rc;
+  }
   mp2g_chain::Step& L = ch->steps[ch->n_steps - 1];
   const size_t n_caps = (size_t)batch * L.P.n_oracles * L.cap_words, n_op = (size_t)batch * L.n_open * 2, n_pf = (size_t)batch * L.proof_words,
                n_pi = L.n_probe - 4;

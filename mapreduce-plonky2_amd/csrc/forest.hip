@@ -13,7 +13,11 @@
 // slot is returned when the parent is proved. No proof visits the host unless it is asked for (mp2g_forest_proof).
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <exception>
 #include <memory>
 #include <mutex>
@@ -25,6 +29,8 @@
 #include "chain.h"
 
 using namespace mp2g;
+// the error text of a worker thread travels to the caller's thread (mp2g_last_error is thread local)
+extern "C" const char* mp2g_last_error(void);
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 #define NEED(c, msg) do { if (!(c)) return fail("invalid argument: %s", msg); } while (0)
 
@@ -63,27 +69,48 @@ struct mp2g_forest {
   DevBuf pool;
   std::vector<int32_t> free_slots;
   std::mutex mu;  // free_slots, node state that crosses workers (slot / proved of a child proved by another worker in an EARLIER call)
+  std::condition_variable slots_back;  // a worker that found the pool empty waits here for another worker's parents to be proved
+  uint32_t active = 0, waiting = 0;    // worker threads inside mp2g_forest_prove / of those, waiting for slots (under mu)
   std::atomic<uint64_t> proved{0};
-  // per worker: pinned staging of the copy jobs and their device copy
-  struct Worker { Copy* h_jobs = nullptr; Copy* d_jobs = nullptr; uint32_t cap_jobs = 0; };
+  bool pipelined = true;  // MP2G_FOREST_SYNC=1: one batch at a time with a synchronisation behind each (the A/B switch)
+  // per worker: a ring of batch records -- pinned staging of the copy jobs and of the witness-check flags, their device copy, the event
+  // behind the batch's last launch. A worker queues batch k + 1 (and k + 2) while batch k runs: the stream never drains between the
+  // batches of a unit (recursion-framework/src/circuit_builder.rs:286-311 semantics are untouched: the same proofs, checked one batch late)
+  static constexpr uint32_t RING = 3;
+  struct Slot { Copy* h_jobs = nullptr; Copy* d_jobs = nullptr; uint32_t* h_flags = nullptr; hipEvent_t done = nullptr; };
+  struct Worker { Slot ring[RING]; uint32_t cap_jobs = 0; uint32_t seq = 0; };
   std::vector<Worker> workers;
   ~mp2g_forest() {
-    for (auto& w : workers) { if (w.h_jobs) (void)hipHostFree(w.h_jobs); if (w.d_jobs) (void)hipFree(w.d_jobs); }
+    for (auto& w : workers)
+      for (auto& r : w.ring) {
+        if (r.h_jobs) (void)hipHostFree(r.h_jobs);
+        if (r.d_jobs) (void)hipFree(r.d_jobs);
+        if (r.h_flags) (void)hipHostFree(r.h_flags);
+        if (r.done) (void)hipEventDestroy(r.done);
+      }
   }
 };
 
 namespace {
 struct BatchCtx {  // what the chain hooks of one batch need
-  mp2g_forest* f; uint32_t worker; uint32_t n_between, n_after;  // jobs [0, n_between) patch the inputs, [n_between, n_between + n_after) store the outputs
+  const Copy* d_jobs; uint32_t n_between, n_after;  // jobs [0, n_between) patch the inputs, [n_between, n_between + n_after) store the outputs
 };
-int hook_copy(mp2g_forest* f, uint32_t w, uint32_t first, uint32_t count, hipStream_t s) {
+int hook_copy(const Copy* d_jobs, uint32_t count, hipStream_t s) {
   if (!count) return 0;
-  hipLaunchKernelGGL(forest_copy_kernel, dim3(count), dim3(256), 0, s, f->workers[w].d_jobs + first);
+  hipLaunchKernelGGL(forest_copy_kernel, dim3(count), dim3(256), 0, s, d_jobs);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : fail("forest copy kernel: %s", hipGetErrorString(e));
 }
-int hook_between(void* u, mp2g_chain*, hipStream_t s) { auto* b = (BatchCtx*)u; return hook_copy(b->f, b->worker, 0, b->n_between, s); }
-int hook_after(void* u, mp2g_chain*, hipStream_t s) { auto* b = (BatchCtx*)u; return hook_copy(b->f, b->worker, b->n_between, b->n_after, s); }
+int hook_between(void* u, mp2g_chain*, hipStream_t s) { auto* b = (BatchCtx*)u; return hook_copy(b->d_jobs, b->n_between, s); }
+int hook_after(void* u, mp2g_chain*, hipStream_t s) { auto* b = (BatchCtx*)u; return hook_copy(b->d_jobs + b->n_between, b->n_after, s); }
+
+// a batch that has been queued on the worker's stream and not yet confirmed
+struct InFlight {
+  uint32_t ring = 0, B = 0, out_words = 0;
+  mp2g_chain* ch = nullptr;
+  std::vector<uint32_t> nodes;   // node indices, in batch order
+  std::vector<int32_t> slots;    // their pool slots
+};
 
 // one unit on one worker; errors are returned as the library's code with mp2g_last_error() set by the failing call
 int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) {
@@ -95,7 +122,8 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
     auto it = f->index.find(ids[i]);
     if (it == f->index.end()) return fail("forest: unknown node %llu in a unit", (unsigned long long)ids[i]);
     unit[i] = it->second;
-    level[it->second] = ~0u;
+    if (!level.emplace(it->second, ~0u).second) return fail("forest: node %llu is listed twice in a unit", (unsigned long long)ids[i]);
+    if (f->nodes[it->second].proved) return fail("forest: node %llu is already proved", (unsigned long long)ids[i]);
   }
   // levels by repeated relaxation over the unit (children may come after their parents in `ids`)
   uint32_t max_level = 0;
@@ -124,37 +152,105 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
   by.resize((size_t)(max_level + 1) * f->n_circuits);
   for (uint32_t i : unit) by[(size_t)level[i] * f->n_circuits + f->nodes[i].circuit].push_back(i);
   mp2g_forest::Worker& W = f->workers[w];
+  hipStream_t stream = f->ctxs[w]->stream;
+  std::deque<InFlight> flight;  // queued batches, oldest first
+  const uint32_t depth = f->pipelined ? mp2g_forest::RING - 1 : 0;  // batches that may stay queued behind the one being assembled
+
+  // the oldest queued batch has run: its witness-check flags, then its children's slots go back (a slot returns when the parent is proved)
+  auto confirm_oldest = [&]() -> int {
+    InFlight& b = flight.front();
+    hipError_t e = hipEventSynchronize(W.ring[b.ring].done);
+    if (e != hipSuccess) return fail("forest: a batch of worker %u failed on the device: %s", w, hipGetErrorString(e));
+    int rc = chain_flags_check(b.ch, b.B, W.ring[b.ring].h_flags);
+    if (rc) return rc;
+    {
+      std::lock_guard<std::mutex> g(f->mu);
+      for (uint32_t i : b.nodes) {
+        const Node& n = f->nodes[i];
+        for (uint32_t k = 0; k < n.n_children; k++) {
+          Node& cn = f->nodes[f->index[n.child[k]]];
+          if (!cn.keep && cn.slot >= 0) { f->free_slots.push_back(cn.slot); cn.slot = -1; }
+        }
+      }
+    }
+    f->slots_back.notify_all();
+    f->proved += b.B;
+    flight.pop_front();
+    return 0;
+  };
+  // a failure: nothing queued counts -- the stream is drained, the queued batches' nodes are unproved again and their slots free
+  auto roll_back = [&]() {
+    (void)hipStreamSynchronize(stream);
+    std::lock_guard<std::mutex> g(f->mu);
+    for (InFlight& b : flight) {
+      for (uint32_t i : b.nodes) { Node& n = f->nodes[i]; n.proved = false; n.slot = -1; n.proof_words = 0; }
+      for (int32_t sl : b.slots) f->free_slots.push_back(sl);
+    }
+    flight.clear();
+    f->slots_back.notify_all();
+  };
+#define UNIT_FAIL(expr) do { int rc_ = (expr); if (rc_) { std::string msg_ = mp2g_last_error(); roll_back(); return fail("%s", msg_.c_str()); } } while (0)
+
   for (uint32_t lvl = 0; lvl <= max_level; lvl++) {
     for (uint32_t c = 0; c < f->n_circuits; c++) {
       const std::vector<uint32_t>& todo = by[(size_t)lvl * f->n_circuits + c];
       if (todo.empty()) continue;
       mp2g_chain* ch = f->chains[(size_t)w * f->n_circuits + c];
-      if (!ch) return fail("forest: worker %u has no chain for circuit %u", w, c);
+      if (!ch) UNIT_FAIL(fail("forest: worker %u has no chain for circuit %u", w, c));
       const Circuit& C = f->circuits[c];
       const mp2g_chain::Step& s0 = ch->steps[0];
       const mp2g_chain::Step& L = ch->steps[ch->n_steps - 1];
       const uint32_t n_pi = (uint32_t)(L.n_probe - 4), cw = (uint32_t)(3 * L.cap_words), ow = (uint32_t)(2 * L.n_open), pw = (uint32_t)L.proof_words;
       const uint32_t out_words = n_pi + cw + ow + pw;
-      if (out_words > f->slot_words) return fail("forest: a proof of circuit %u has %u words, the pool's slots %u", c, out_words, f->slot_words);
+      if (out_words > f->slot_words) UNIT_FAIL(fail("forest: a proof of circuit %u has %u words, the pool's slots %u", c, out_words, f->slot_words));
       for (size_t lo = 0; lo < todo.size(); lo += ch->cap) {
         const uint32_t B = (uint32_t)std::min<size_t>(ch->cap, todo.size() - lo);
-        // slots for the batch's proofs
+        while (flight.size() > depth) UNIT_FAIL(confirm_oldest());
+        // slots for the batch's proofs. An empty pool is not yet a failure: this worker's queued batches hold children whose slots
+        // return once they are confirmed, and other workers return slots as their parents are proved -- only when every worker of
+        // the call waits is the pool too small for the frontier
         std::vector<int32_t> slots(B);
-        {
-          std::lock_guard<std::mutex> g(f->mu);
-          if (f->free_slots.size() < B) return fail("forest: the proof pool is exhausted (%u slots): release roots or create a larger pool", f->pool_slots);
-          for (uint32_t j = 0; j < B; j++) { slots[j] = f->free_slots.back(); f->free_slots.pop_back(); }
+        for (;;) {
+          {
+            std::unique_lock<std::mutex> g(f->mu);
+            if (f->free_slots.size() >= B) {
+              for (uint32_t j = 0; j < B; j++) { slots[j] = f->free_slots.back(); f->free_slots.pop_back(); }
+              break;
+            }
+            if (flight.empty()) {
+              f->waiting++;
+              bool stuck = false;
+              while (f->free_slots.size() < B) {
+                if (f->waiting >= f->active) { stuck = true; break; }
+                f->slots_back.wait_for(g, std::chrono::milliseconds(20));
+              }
+              f->waiting--;
+              if (stuck) {
+                g.unlock();
+                f->slots_back.notify_all();
+                UNIT_FAIL(fail("forest: the proof pool is exhausted (%u slots): release roots or create a larger pool", f->pool_slots));
+              }
+              continue;
+            }
+          }
+          UNIT_FAIL(confirm_oldest());
         }
+        const uint32_t ring = W.seq++ % mp2g_forest::RING;  // free: at most RING - 1 batches are queued
+        mp2g_forest::Slot& R = W.ring[ring];
         uint32_t nb = 0;
         // from here on the batch owns its slots: every failure path gives them back
         auto give_back = [&]() { std::lock_guard<std::mutex> g(f->mu); for (int32_t sl : slots) f->free_slots.push_back(sl); };
         const uint32_t need_jobs = B * (C.d.n_children + 4);
-        if (need_jobs > W.cap_jobs) { give_back(); return fail("forest: internal: copy-job staging too small"); }
+        if (need_jobs > W.cap_jobs) { give_back(); UNIT_FAIL(fail("forest: internal: copy-job staging too small")); }
+        // the chain's input buffers alternate: the one filled now is not the one whose upload may still be queued
+        const uint32_t which = f->pipelined ? (ch->in_flip++ & 1) : 0;
+        u64* h_in = nullptr;
+        { int rc = chain_input_buffer(ch, which, &h_in); if (rc) { give_back(); UNIT_FAIL(rc); } }
         // inputs: the node's constant words around its children's ranges; the children come from their pool slots
         int arc = [&]() -> int {
         for (uint32_t j = 0; j < B; j++) {
           const Node& n = f->nodes[todo[lo + j]];
-          u64* dst = ch->h_in + (size_t)j * s0.n_in;
+          u64* dst = h_in + (size_t)j * s0.n_in;
           const u64* src = C.consts.data() + n.consts;
           uint32_t at = 0;  // position in the inputs
           for (uint32_t k = 0; k <= C.d.n_children; k++) {
@@ -171,52 +267,58 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
                 if (!ch_node->proved || ch_node->slot < 0) return fail("forest: child %llu of node %llu is not proved (or was released)", (unsigned long long)n.child[k], (unsigned long long)n.id);
               }
               if (at + ch_node->proof_words > C.d.n_inputs) return fail("forest: circuit %u: a child proof runs past the inputs", c);
-              W.h_jobs[nb++] = Copy{f->pool.p + (size_t)ch_node->slot * f->slot_words, s0.in.p + (size_t)j * s0.n_in + at, ch_node->proof_words, 0};
+              R.h_jobs[nb++] = Copy{f->pool.p + (size_t)ch_node->slot * f->slot_words, s0.in.p + (size_t)j * s0.n_in + at, ch_node->proof_words, 0};
               at += ch_node->proof_words;
             }
           }
+          // the descriptor and the children's proofs must account for every input word and every constant word of the node
+          if (at != C.d.n_inputs || src != C.consts.data() + n.consts + C.d.n_const)
+            return fail("forest: circuit %u: the node's constant words and its children's proofs do not add up to the circuit's %u inputs", c, C.d.n_inputs);
         }
         return 0;
         }();
-        if (arc) { give_back(); return arc; }
+        if (arc) { give_back(); UNIT_FAIL(arc); }
         const uint32_t n_between = nb;
         // outputs -> slots, in a parent's input order: public inputs, caps of oracles 1..3, openings, FRI words
         for (uint32_t j = 0; j < B; j++) {
           u64* slot = f->pool.p + (size_t)slots[j] * f->slot_words;
-          W.h_jobs[nb++] = Copy{L.probe.p + (size_t)j * L.n_probe + 4, slot, n_pi, 0};
-          W.h_jobs[nb++] = Copy{L.caps.p + ((size_t)j * L.P.n_oracles + 1) * L.cap_words, slot + n_pi, cw, 0};
-          W.h_jobs[nb++] = Copy{L.openings.p + (size_t)j * L.n_open * 2, slot + n_pi + cw, ow, 0};
-          W.h_jobs[nb++] = Copy{L.proof.p + (size_t)j * L.proof_words, slot + n_pi + cw + ow, pw, 0};
+          R.h_jobs[nb++] = Copy{L.probe.p + (size_t)j * L.n_probe + 4, slot, n_pi, 0};
+          R.h_jobs[nb++] = Copy{L.caps.p + ((size_t)j * L.P.n_oracles + 1) * L.cap_words, slot + n_pi, cw, 0};
+          R.h_jobs[nb++] = Copy{L.openings.p + (size_t)j * L.n_open * 2, slot + n_pi + cw, ow, 0};
+          R.h_jobs[nb++] = Copy{L.proof.p + (size_t)j * L.proof_words, slot + n_pi + cw + ow, pw, 0};
         }
         {
-          hipError_t e = hipMemcpyAsync(W.d_jobs, W.h_jobs, (size_t)nb * sizeof(Copy), hipMemcpyHostToDevice, f->ctxs[w]->stream);
-          if (e != hipSuccess) { give_back(); return fail("forest: copy jobs upload: %s", hipGetErrorString(e)); }
+          hipError_t e = hipMemcpyAsync(R.d_jobs, R.h_jobs, (size_t)nb * sizeof(Copy), hipMemcpyHostToDevice, stream);
+          if (e != hipSuccess) { give_back(); UNIT_FAIL(fail("forest: copy jobs upload: %s", hipGetErrorString(e))); }
         }
-        BatchCtx bc{f, w, n_between, nb - n_between};
+        memset(R.h_flags, 0, (size_t)ch->n_steps * ch->cap * sizeof(uint32_t));
+        BatchCtx bc{R.d_jobs, n_between, nb - n_between};
         ChainHooks hooks{&bc, hook_between, hook_after};
-        int rc = chain_run_staged(ch, B, nullptr, 0, &hooks, nullptr, nullptr, nullptr, nullptr);
-        if (rc) { give_back(); return rc; }
+        int rc = chain_enqueue(ch, B, which, &hooks, R.h_flags);
+        if (!rc) { hipError_t e = hipEventRecord(R.done, stream); if (e != hipSuccess) rc = fail("forest: event record: %s", hipGetErrorString(e)); }
+        if (rc) { std::string msg = mp2g_last_error(); (void)hipStreamSynchronize(stream); give_back(); roll_back(); return fail("%s", msg.c_str()); }
+        // queued: later levels of this unit (the same stream) may name these nodes as children from now on; nobody else sees them
+        // before the unit returns
+        InFlight fl;
+        fl.ring = ring; fl.B = B; fl.out_words = out_words; fl.ch = ch; fl.slots = slots;
+        fl.nodes.assign(todo.begin() + lo, todo.begin() + lo + B);
         {
           std::lock_guard<std::mutex> g(f->mu);
           for (uint32_t j = 0; j < B; j++) {
             Node& n = f->nodes[todo[lo + j]];
             n.slot = slots[j]; n.proof_words = out_words; n.proved = true;
-            for (uint32_t k = 0; k < n.n_children; k++) {  // the children have served: their slots go back unless kept
-              Node& cn = f->nodes[f->index[n.child[k]]];
-              if (!cn.keep && cn.slot >= 0) { f->free_slots.push_back(cn.slot); cn.slot = -1; }
-            }
           }
         }
-        f->proved += B;
+        flight.push_back(std::move(fl));
       }
     }
   }
+  while (!flight.empty()) UNIT_FAIL(confirm_oldest());
+#undef UNIT_FAIL
   return 0;
 }
 }  // namespace
 
-// the error text of a worker thread travels to the caller's thread (mp2g_last_error is thread local)
-extern "C" const char* mp2g_last_error(void);
 
 extern "C" {
 int mp2g_forest_create(uint32_t n_workers, mp2g_ctx* const* ctxs, uint32_t n_circuits, const mp2g_forest_circuit* circuits,
@@ -248,11 +350,18 @@ int mp2g_forest_create(uint32_t n_workers, mp2g_ctx* const* ctxs, uint32_t n_cir
     f->free_slots.resize(pool_slots);
     for (uint32_t i = 0; i < pool_slots; i++) f->free_slots[i] = (int32_t)(pool_slots - 1 - i);
     f->workers.resize(n_workers);
+    uint32_t max_flags = 1;
+    for (mp2g_chain* ch : f->chains) if (ch) max_flags = std::max(max_flags, ch->n_steps * ch->cap);
     for (auto& w : f->workers) {
       w.cap_jobs = std::max(1u, max_jobs);
-      CK(hipHostMalloc((void**)&w.h_jobs, (size_t)w.cap_jobs * sizeof(Copy), hipHostMallocDefault));
-      CK(hipMalloc((void**)&w.d_jobs, (size_t)w.cap_jobs * sizeof(Copy)));
+      for (auto& r : w.ring) {
+        CK(hipHostMalloc((void**)&r.h_jobs, (size_t)w.cap_jobs * sizeof(Copy), hipHostMallocDefault));
+        CK(hipMalloc((void**)&r.d_jobs, (size_t)w.cap_jobs * sizeof(Copy)));
+        CK(hipHostMalloc((void**)&r.h_flags, (size_t)max_flags * sizeof(uint32_t), hipHostMallocDefault));
+        CK(hipEventCreateWithFlags(&r.done, hipEventDisableTiming));
+      }
     }
+    { const char* e = getenv("MP2G_FOREST_SYNC"); f->pipelined = !(e && atoi(e)); }
     *out = f.release();
     return 0;
   } catch (const std::bad_alloc&) { return fail("out of memory"); } catch (...) { return fail("internal error"); }
@@ -264,8 +373,12 @@ int mp2g_forest_add_nodes(mp2g_forest* f, uint32_t circuit, uint32_t count, cons
   Circuit& C = f->circuits[circuit];
   NEED((child_ids || !C.d.n_children || !count) && (consts || !C.d.n_const || !count), "children / constant words");
   try {
-    for (uint32_t i = 0; i < count; i++)
-      if (f->index.count(ids[i])) return fail("forest: node %llu registered twice", (unsigned long long)ids[i]);
+    {
+      std::unordered_map<uint64_t, uint32_t> seen;
+      seen.reserve(count);
+      for (uint32_t i = 0; i < count; i++)
+        if (f->index.count(ids[i]) || !seen.emplace(ids[i], i).second) return fail("forest: node %llu registered twice", (unsigned long long)ids[i]);
+    }
     for (uint32_t i = 0; i < count; i++) {
       Node n;
       n.id = ids[i]; n.circuit = circuit; n.n_children = C.d.n_children;
@@ -287,7 +400,9 @@ int mp2g_forest_prove(mp2g_forest* f, const uint64_t* unit_nodes, const uint32_t
   std::atomic<int> failed{0};
   std::mutex err_mu;
   std::string err;
+  auto leave = [&]() { { std::lock_guard<std::mutex> g(f->mu); if (f->active) f->active--; } f->slots_back.notify_all(); };
   auto work = [&](uint32_t w) {
+    struct Leave { decltype(leave)& fn; ~Leave() { fn(); } } on_exit{leave};  // a worker that is gone cannot return slots: the waiters must know
     try {
       for (;;) {
         if (failed.load()) return;
@@ -310,6 +425,7 @@ int mp2g_forest_prove(mp2g_forest* f, const uint64_t* unit_nodes, const uint32_t
   };
   try {
     const uint32_t n_threads = std::min(f->n_workers, n_units);
+    { std::lock_guard<std::mutex> g(f->mu); f->active = n_threads; f->waiting = 0; }
     std::vector<std::thread> ts;
     for (uint32_t w = 1; w < n_threads; w++) ts.emplace_back(work, w);
     work(0);

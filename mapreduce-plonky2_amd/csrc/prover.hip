@@ -672,6 +672,14 @@ int mp2g_prover_witness_status(mp2g_prover* pr, uint32_t* flags) {
                   (h[b] & 2) ? " a gate constraint" : "", (h[b] & 4) ? " the lookup argument" : "");
   return 0;
 }
+}  // extern "C"
+namespace mp2g { int prover_flags_to_host_async(mp2g_prover* pr, uint32_t* h_dst); }
+int mp2g::prover_flags_to_host_async(mp2g_prover* pr, uint32_t* h_dst) {
+  NEED(pr && pr->wcheck && h_dst, "prover with the witness check on / destination");
+  CK(hipMemcpyAsync(h_dst, pr->wflags.p, pr->B * sizeof(u32), hipMemcpyDeviceToHost, pr->ctx->stream));
+  return 0;
+}
+extern "C" {
 int mp2g_prover_enable_timing(mp2g_prover* pr, int on) {
   NEED(pr, "prover");
   if (on)

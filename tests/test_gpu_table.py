@@ -323,6 +323,39 @@ def test_native_build_equals_the_python_build(ctx, mp2, params):
     bad.values = vals
     with pytest.raises(mp2.Mp2gError, match="witness"):
         nb.run(bad, bad_wit, root, nodes)
+    # ... and the failed build left the workers usable: the queued batches were rolled back, the good block proves again
+    once_more, _ = nb.run(table, wit, root, nodes, keep=samples)
+    assert all(np.array_equal(a, b) for a, b in zip(once_more, want))
+
+
+def test_pipelined_units_equal_the_synchronous_ones(ctx, mp2, params, monkeypatch):
+    """the forest's workers queue the next batches of a unit while one runs (csrc/forest.hip: a ring of three batch records per worker,
+    two input buffers per chain, witness flags and slot hand-backs confirmed one batch late); MP2G_FOREST_SYNC=1 keeps a
+    synchronisation behind every batch. Same proofs either way, also through a pool that only holds the frontier because slots come
+    back (a worker that finds it empty waits for them instead of failing), and with 6 value columns (pool sized from the width)"""
+    pa = params
+    for n_cols, seed, n in ((4, 0xC0FFEE04, 29), (6, 0xC0FFEE0A, 11)):
+        table = T.SyntheticTable(n, n_cols, seed=seed, block=8)
+        root, nodes, spans = T.balanced_bst(n)
+        wit = T.TableWitness(ctx, table, spans)
+        ctxs = [mp2.Context(0) for _ in range(2)]
+        provers = [FW.GpuProver(c, capacity=4) for c in ctxs]
+        roots = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("MP2G_FOREST_SYNC", mode)
+            nb = T.NativeTableBuild(pa, provers, batch=4, subtree_size=4, group_rows=8)
+            roots[mode], _ = nb.run(table, wit, root, nodes)
+            assert nb.n_proofs == (n_cols + 1) * n
+            nb.free()
+        assert all(np.array_equal(a, b) for a, b in zip(roots["0"], roots["1"]))
+        # a pool of 40 / 56 slots for 145 / 77 proofs: two workers x (a unit's 8 rows x 3 / 5 live cells proofs + queued batches) do not fit at once
+        monkeypatch.setenv("MP2G_FOREST_SYNC", "0")
+        tight = T.NativeTableBuild(pa, provers, batch=4, subtree_size=4, group_rows=8, pool_slots=40 if n_cols == 4 else 56)
+        got, _ = tight.run(table, wit, root, nodes)
+        assert all(np.array_equal(a, b) for a, b in zip(got, roots["1"]))
+        tight.free()
+        for p_ in provers:
+            p_.free()
     nb.free()
     for p in provers:
         p.free()
