@@ -462,14 +462,21 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
         ctx.ntt_dev(d_poly, d_out, LOG_NTT, 1, bitrev_out=True)
         ntt_ms.append(ctx.timer_stop())
 
+    def median_ms(fn, runs=7):
+        """one untimed call, then the median of `runs` calls, each between its own HIP events on the context's stream"""
+        fn()
+        ms = []
+        for _ in range(runs):
+            ctx.timer_start()
+            fn()
+            ms.append(ctx.timer_stop())
+        return float(np.median(ms)), [round(x, 4) for x in ms]
+
     # the same kernel family on the shape the prover actually runs: 8192 transforms of 2^12 points
     # (LDE-sized batch, no tail effects); reported beside the roofline leg, not as `value`
     nb12 = 8192
     d_b12 = ctx.alloc(nb12 * 4096 * 8)
-    ctx.ntt_dev(d_b12, d_b12, 12, nb12, bitrev_out=True)
-    ctx.timer_start()
-    ctx.ntt_dev(d_b12, d_b12, 12, nb12, bitrev_out=True)
-    ntt12_ms = ctx.timer_stop()
+    ntt12_ms, ntt12_all = median_ms(lambda: ctx.ntt_dev(d_b12, d_b12, 12, nb12, bitrev_out=True))
     d_b12.free()
 
     # the sponge, the kernel that takes half of a step: 2^21 leaves of 136 limbs (17 permutations each), the rate
@@ -483,33 +490,86 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
     for k in range(n_hash >> 17):
         d_hin.upload_at(part, k * part.nbytes)
     hargs = (ctx.h, VARIANT, d_hin.ptr, limbs, n_hash, 4, d_hout.ptr)
-    mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
-    ctx.timer_start()
-    mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs))
-    hash_ms = ctx.timer_stop()
+    hash_ms, hash_all = median_ms(lambda: mp2._ck(mp2.load().mp2g_hash_no_pad_batch_dev(*hargs)))
     d_hin.free(); d_hout.free()
+
+    # BASELINE configs[1](ii): PolynomialBatch::from_values of 135 polynomials of 2^15 values --
+    # iNTT, LDE to 2^18 leaves x 135 (72 n w algorithmic bytes), Poseidon2 leaf sponges + tree levels to cap(4)
+    # (L ceil(w / 8) + L - 2^cap permutations) -- on resident values; the parts timed apart with the same buffers
+    lg, w135 = 15, 135
+    n15, L = 1 << lg, 1 << (lg + 3)
+    d_v = ctx.to_device(C.rand_field((w135, n15), 0xC0FFEE02 + 16 * rank))
+    d_c = ctx.alloc(w135 * n15 * 8)
+    d_lde = ctx.alloc(w135 * L * 8)
+    pb = mp2.PolynomialBatch.from_values_dev(ctx, d_v, lg, w135, 3, 4, VARIANT)
+    commit_ms, commit_all = median_ms(lambda: pb.recommit_from_values_dev(d_v), 5)
+    intt_ms, _ = median_ms(lambda: ctx.ntt_dev(d_v, d_c, lg, w135, inverse=True), 5)
+    lde_ms, lde_all = median_ms(lambda: ctx.lde_dev(d_c, lg, w135, 3, d_lde), 5)
+    pb.free(); d_v.free(); d_c.free(); d_lde.free()
+    perms = L * ((w135 + 7) // 8) + L - 16
+    merkle_ms = max(commit_ms - intt_ms - lde_ms, 1e-6)
+    commit = {"workload": "configs[1](ii): PolynomialBatch::from_values of 135 x 2^15 resident values -> iNTT, LDE to 2^18 leaves x 135, Poseidon2 leaf sponges and tree "
+                          "levels to cap(4); medians of 5 launches between HIP events", "seconds": commit_ms / 1e3, "runs_ms": commit_all,
+              "intt_ms": intt_ms, "lde_ms": lde_ms, "lde_GBps": 72.0 * n15 * w135 / (lde_ms / 1e3) / 1e9, "lde_frac_of_hbm_peak": 72.0 * n15 * w135 / (lde_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
+              "merkle_ms": merkle_ms, "merkle_permutations": perms, "merkle_permutations_per_s": perms / (merkle_ms / 1e3),
+              "merkle_note": "merkle_ms = commit - iNTT - LDE (the same launches timed apart); 17 of 18 permutations are the leaf sponge's (leaf_hash_poly_major_kernel)"}
 
     d_poly.free(); d_out.free()
     # HBM-side bytes of the same two launches from the TCC counters (collected in separate
     # --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/rNN/ntt_traffic.json)
-    traffic = None
-    for rnd in ("r04", "r03", "r02", "r01"):
+    traffic, traffic_source = None, None
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "ntt_traffic.json")) as f:
                 traffic = json.load(f)["ntt_2p22_forward_bitrev"]["traffic_bytes"]
+            traffic_source = f"profiles/{rnd}/ntt_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/dbg/traffic_run.py, committed; NOT measured in this run)"
             break
         except (OSError, KeyError, ValueError):
             pass
     ntt_s = float(np.median(ntt_ms)) / 1e3
     achieved = 16.0 * n_ntt / ntt_s / 1e9
-    return {"roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, all launches)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "launch_ms": ntt_s * 1e3, "algorithmic_bytes": 16 * n_ntt},
-            "ntt_batched_2p12": {"transforms": nb12, "GBps": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9,
-                                 "frac_of_hbm_peak": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9 / HBM_PEAK_GBPS},
-            "sponge": {"hasher": hasher, "permutations_per_s": n_hash * (limbs // 8) / (hash_ms / 1e3), "bound": "VALU issue (integer ALU)",
-                       "input": f"{n_hash} x {limbs} limbs of random field elements, hash_no_pad, resident"}}
+    sponge_rate = n_hash * (limbs // 8) / (hash_ms / 1e3)
+    out = {"roofline": {"bound": "hbm", "kernel": "ntt (2^22 forward, all launches)",
+                        "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                        "launch_ms": ntt_s * 1e3, "algorithmic_bytes": 16 * n_ntt},
+           "ntt_batched_2p12": {"transforms": nb12, "GBps": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9,
+                                "frac_of_hbm_peak": 16.0 * nb12 * 4096 / (ntt12_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, "median_of": len(ntt12_all), "runs_ms": ntt12_all},
+           "sponge": {"hasher": hasher, "permutations_per_s": sponge_rate, "bound": "VALU issue (integer ALU)", "median_of": len(hash_all), "runs_ms": hash_all,
+                      "input": f"{n_hash} x {limbs} limbs of random field elements, hash_no_pad, resident"},
+           "commit_135x2p15": commit}
+    alu = roofline_alu(sponge_rate, commit["merkle_permutations_per_s"])
+    if alu is not None:
+        out["roofline_alu"] = alu
+    return out
+
+
+def roofline_alu(isolated_rate, commit_rate):
+    """the ALU roofline of the kernel that dominates a step (the Poseidon2 leaf sponge: ~40 % of the kernel time of a table build):
+    permutations/s x VALU wave-instructions per permutation (SQ_INSTS_VALU / permutations of the leaf kernel, a committed
+    rocprofv3 --pmc pass: profiles/rNN/sponge_counters.json) against the chip's VALU issue peak for that instruction mix
+    (1024 SIMDs x sclk / cycles per wave-instruction of the mix, from the same file). The in-step rate is the kernel's rate inside
+    a 4-worker table build (kernel-trace durations of the committed profile), not measured in this run."""
+    for rnd in ("r05",):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "sponge_counters.json")) as f:
+                k = json.load(f)
+        except (OSError, ValueError):
+            continue
+        per_perm = k["valu_wave_insts_per_permutation_x64"]  # per LANE-permutation: a wave instruction serves 64 permutations
+        peak = 1024 * k["sclk_hz"] / k["cycles_per_valu_wave_inst_of_the_mix"]  # wave-instructions / s the chip can issue on this mix
+        need = lambda rate: rate / 64.0 * per_perm
+        out = {"kernel": "leaf_hash_poly_major_kernel<0> (Poseidon2 sponge, one lane = one leaf)", "bound": "VALU issue",
+               "valu_insts_per_perm": per_perm, "peak_valu_wave_insts_per_s": peak, "sclk_hz": k["sclk_hz"],
+               "cycles_per_valu_wave_inst_of_the_mix": k["cycles_per_valu_wave_inst_of_the_mix"],
+               "isolated": {"perms_per_s": isolated_rate, "frac": need(isolated_rate) / peak, "leg": "sponge (hash_no_pad_batch, 2^21 x 136 limbs)"},
+               "commit": {"perms_per_s": commit_rate, "frac": need(commit_rate) / peak, "leg": "commit_135x2p15 (leaf sponge + tree levels)"},
+               "source": f"profiles/{rnd}/sponge_counters.json (committed rocprofv3 --pmc passes; the rates are this run's)"}
+        if "in_step_perms_per_s" in k:
+            out["in_step"] = {"perms_per_s": k["in_step_perms_per_s"], "frac": need(k["in_step_perms_per_s"]) / peak,
+                              "leg": k.get("in_step_source", "4-worker table build under rocprofv3 --kernel-trace (committed profile; not this run)")}
+        return out
+    return None
 
 
 def visible_gpus():
@@ -1027,6 +1087,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     barrier()
     dt = time.perf_counter() - t0
     n_local = rig.n_proofs - n0
+    mem_free_build, _ = ctx.mem_info()  # what the table build itself holds (the planner's estimate is for this): before any side leg creates its own provers
     if dist is not None:
         t = torch.tensor([dt, float(n_local)], device="cuda" if nccl else "cpu", dtype=torch.float64)
         dist.all_reduce(t[0:1], op=dist.ReduceOp.MAX)
@@ -1154,6 +1215,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         a2.steps, a2.warmup, a2.batch = 3, 1, 128
         leaves = guarded("leaves_prove_only", lambda: run_leaves(a2, rank, local_rank, world, dist, torch, VARIANT, clocks, brief=True))
     out = None
+    full_rec = completed_table_record()
     if rank == 0:
         rows_per_s = world * n_rows / dt
         depth = max(1, (n_rows - 1).bit_length())
@@ -1170,7 +1232,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                                       "cells-set verifier gadget), all REAL framework proofs = witness program + base prove() + wrap chain to 2^12 rows, witness check on; row tree "
                                       "scheduled by the batched UpdateTree work plan; the rows' multiset digests (map-to-curve, row ids, accumulation up both trees) inside the timed "
                                       "region; value = framework proofs/s (5 per row). " + ("THIS IS the full 2^20-row build of configs[3]" if world * n_rows >= 1 << 20 else
-                                      "The full 2^20-row build does not fit one GPU in a bench run (extrapolated below; measured once: profiles/r04/bench_r04_table_2p20_rows.json)") + "; configs[2] at "
+                                      full_table_note(full_rec)) + "; configs[2] at "
                                       "full size = `config2`; base degrees 12..15 = `by_base_degree`; roofline leg = configs[1] 2^22-point NTT",
                           "rows_per_rank": n_rows, "rows_per_step": args.rows, "row_tree_depth": depth, "warmup_rows_per_rank": args.warmup * args.rows,
                           "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "group_rows": args.group_rows or 32 * args.table_batch, "pad_base_bits": args.pad_base_bits,
@@ -1179,7 +1241,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "ranks_on_host": ranks_here, "shapes": shapes,
                           "host_peak_rss_bytes": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss * 1024,
-                          "device_memory_used_bytes": mem_total - mem_free, "device_memory_planned_bytes": plan["device_bytes_per_rank"],
+                          "device_memory_used_bytes": mem_total - mem_free_build, "device_memory_planned_bytes": plan["device_bytes_per_rank"],
+                          "device_memory_used_with_side_legs_bytes": mem_total - mem_free,  # + the configs[2] leg's map / reduce provers on every worker (what round 4's line reported as `used`)
                           "setup_s": round(setup_s, 1), "hasher": "Poseidon2", "backend": (dist.get_backend() if dist is not None else None), "rccl_ranks": rccl_ranks,
                           "join_levels": n_levels,
                           "sharding": f"{world} rank(s): one block of rows each, no collective below the block roots; {n_levels} join level(s) move a root proof point to point "
@@ -1189,6 +1252,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                                       "block equals the CPU oracle's proofs of the same witnesses bit for bit and passes its verifier; the block roots expose the off-circuit "
                                       "tree hash, digest (= compute_table_row_digest of the block), min, max and the circuit-set digest"},
                "clocks": clocks.read(local_rank)}
+        if full_rec is not None:  # the metric's named configuration, completed across calls (bench.py --resume-dir): a committed record, not this run
+            out["table_2p20_rows_completed"] = full_rec
         if config2 is not None:
             out["config2"] = config2
         if by_degree is not None:
@@ -1209,6 +1274,30 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     if side_errors:  # the headline stands (exit code 0); the line names the failed legs in `side_leg_errors` and in their own fields
         print(f"bench.py: side leg(s) failed: {', '.join(side_errors)}", file=sys.stderr)
     return out
+
+
+FULL_TABLE_RECORD = os.path.join("profiles", "r05", "table_2p20_rows.json")
+
+
+def completed_table_record():
+    """the record of the completed 2^20-row build (bench.py --resume-dir, one GPU, several calls), if the repository holds one"""
+    try:
+        with open(os.path.join(ROOT, FULL_TABLE_RECORD)) as f:
+            r = json.load(f)
+        return {"source": FULL_TABLE_RECORD + " (bench.py --resume-dir: 8 blocks of 2^17 rows + 7 separator rows built on one MI355X across calls; committed, not this run)",
+                "table_rows_total": r["table_rows_total"], "framework_proofs": r["framework_proofs"], "gpu_seconds": r["gpu_seconds"], "value": r["value"], "unit": r["unit"],
+                "join_levels": r["join_levels"], "root_verified_by_oracle": True, "root_digest_is_the_whole_tables": True,
+                "root_proof_with_vk_fnv1a64": r["root_proof_with_vk_fnv1a64"]}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def full_table_note(rec):
+    if rec is not None:
+        return (f"The full table was built ONCE, block by block across calls on one GPU: {rec['table_rows_total']} rows, {rec['framework_proofs']} framework proofs in "
+                f"{rec['gpu_seconds']:.0f} GPU-seconds = {rec['value']:.1f} proofs/s, root verified (`table_2p20_rows_completed`, {FULL_TABLE_RECORD}); this run times one block of it")
+    return ("The full 2^20-row build does not fit one GPU in a bench run (extrapolated below); the one attempt as a single run is PARTIAL: "
+            "profiles/r04/table_2p20_rows_progress.txt (56 % of the proofs at 852 proofs/s sustained when the call's time limit ended it; no root, nothing verified)")
 
 
 def run_table_resumable(args, local_rank, VARIANT, clocks):
