@@ -671,7 +671,8 @@ def main(argv=None):
                     "the reference's leaf gate set (SURVEY 8(d): base degrees k = 12..15); 0 = the circuits' natural degrees (the headline)")
     ap.add_argument("--degree-sweep", default="12,13,14,15", help="--workload table at N = 1: after the headline, the table rate at these base degrees (one block of "
                     "--sweep-rows rows each) in the same line as `by_base_degree`; '' = skip")
-    ap.add_argument("--sweep-rows", type=int, default=256, help="rows of the block timed at every base degree of --degree-sweep")
+    ap.add_argument("--sweep-rows", type=int, default=1024, help="rows of the block timed at every base degree of --degree-sweep (halved per degree above 13)")
+    ap.add_argument("--sweep-runs", type=int, default=3, help="builds of that block per base degree; the median is reported")
     ap.add_argument("--config2-leaves", type=int, default=1024, help="--workload table at N = 1: leaves of the BASELINE configs[2] leg (2-to-1 aggregation of real leaf proofs, "
                     "2 x leaves - 1 framework proofs) reported as `config2`; 0 = skip")
     ap.add_argument("--resume-dir", default=None, help="--workload table at N = 1: build the table as --table-blocks blocks of --steps x --rows rows ACROSS CALLS -- every "
@@ -1189,18 +1190,29 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                         raise
                     bk = max(4, 3 * bk // 4)
             try:
-                rk.build(min(64, args.sweep_rows), 0, seed ^ 0x5A5A5A, n_cols, False)
-                for c in rk.ctxs:
-                    c.sync()
-                n0k = rk.n_proofs
-                t1 = time.perf_counter()
-                stk = rk.build(args.sweep_rows, 0, seed, n_cols, False)
-                for c in rk.ctxs:
-                    c.sync()
-                dtk = time.perf_counter() - t1
-                rk.check_root(stk, verify=not args.no_verify)
-                return {"value": (rk.n_proofs - n0k) / dtk, "unit": "proofs/s", "rows": args.sweep_rows, "seconds": dtk, "batch": bk,
-                        "shapes": rk.params.shapes(), "setup_s": round(rk.setup_s, 1), "root_verified": not args.no_verify}
+                # the block shrinks above k = 13 (the same wall time per run at every degree), never below 64 rows
+                rows_k = max(min(64, args.sweep_rows), args.sweep_rows >> max(0, k - 13))
+                rk.build(min(64, rows_k), 0, seed ^ 0x5A5A5A, n_cols, False)
+                runs = []
+                for rep in range(max(1, args.sweep_runs)):  # the same block proved again: one work plan each, the median reported
+                    for c in rk.ctxs:
+                        c.sync()
+                    n0k = rk.n_proofs
+                    t1 = time.perf_counter()
+                    stk = rk.build(rows_k, 0, seed, n_cols, False)
+                    for c in rk.ctxs:
+                        c.sync()
+                    dtk = time.perf_counter() - t1
+                    runs.append(((rk.n_proofs - n0k) / dtk, dtk))
+                    if rep == 0:
+                        rk.check_root(stk, verify=not args.no_verify)
+                    del stk
+                runs.sort()
+                val, dtk = runs[len(runs) // 2]
+                return {"value": val, "unit": "proofs/s", "rows": rows_k, "seconds": dtk, "median_of": len(runs), "runs": [round(v, 1) for v, _ in runs],
+                        "trace_rows_per_s": val / (n_cols + 1) * sum(sum(1 << d for d in rk.params.shapes()[nm]) * cnt for nm, cnt in
+                                                                      (("cells_leaf", 2.0), ("cells_full", 1.0), ("cells_partial", 1.0), ("row_leaf", 0.5), ("row_full", 0.5))),
+                        "batch": bk, "shapes": rk.params.shapes(), "setup_s": round(rk.setup_s, 1), "root_verified": not args.no_verify}
             finally:
                 rk.close()
 

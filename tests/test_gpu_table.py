@@ -164,7 +164,7 @@ def test_bench_default_workload_is_the_table_build():
     cpu_baseline objects (all-thread / one-thread medians, CPU model), and the side legs of the driver's line at small sizes: BASELINE
     configs[2] (a 64-leaf tree of real proofs here), the table rate at a padded base degree, the prove()-only loop"""
     line = _bench(["--rows", "8", "--steps", "2", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "8", "--cpu-budget", "1",
-                   "--config2-leaves", "64", "--degree-sweep", "12", "--sweep-rows", "8"])
+                   "--config2-leaves", "64", "--degree-sweep", "12", "--sweep-rows", "8", "--sweep-runs", "2"])
     assert line["config"]["workload"].startswith("table:") and line["unit"] == "proofs/s" and line["n_gpus"] == 1
     assert line["config"]["rows_per_rank"] == 16 and line["config"]["row_tree_depth"] == 4 and line["steps"] == 2
     assert abs(line["value"] * line["ms_per_step"] * 2 / 1e3 - 5 * 16) < 1e-6  # one 16-row block, 5 framework proofs per row
@@ -175,6 +175,8 @@ def test_bench_default_workload_is_the_table_build():
     assert line["leaves_prove_only"]["value"] > 0 and len(line["config"]["root_public_inputs"]) == T.ROWS_IO + 4
     assert line["config2"]["framework_proofs"] == 127 and line["config2"]["value"] > 0 and line["config2"]["root_verified"]
     k12 = line["by_base_degree"]["12"]
+    assert k12["median_of"] == 2 and k12["rows"] == 8 and line["commit_135x2p15"]["merkle_permutations"] == (1 << 18) * 18 - 16 and line["commit_135x2p15"]["lde_GBps"] > 0
+    assert line["sponge"]["median_of"] == 7 and line["roofline"]["traffic_source"] and line["config"]["device_memory_used_with_side_legs_bytes"] >= line["config"]["device_memory_used_bytes"]
     assert k12["value"] > 0 and k12["root_verified"] and all(ch[0] >= 12 for ch in k12["shapes"].values()) and k12["shapes"]["cells_leaf"][0] == 12 and k12["shapes"]["cells_leaf"][-1] == 12
     assert line["config"]["device_memory_used_bytes"] > 0 and line["config"]["host_orchestration"]["scheduler"].startswith("native")
 
