@@ -1,0 +1,43 @@
+# Round-5 evidence run, in parts (each part one gpurun call or several chained): outputs under gpurun_out/r05/.
+# usage: profile_r05.sh <part> ...   parts: bench | trace | k13 | pmc | sponge | sweep | ntt
+set -u
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r05
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+QUIET="--no-leaves-leg --no-verify --config2-leaves 0 --degree-sweep= --no-cpu-baseline"
+keep_small() { find $O -name "*kernel_trace.csv" -size +20M -delete; find $O -name "*_agent_info.csv" -delete; find $O -name "*.db" -delete; }
+for part in "$@"; do
+case $part in
+bench)   # the driver's command
+  python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json ;;
+trace)   # kernel durations of a table step, four workers and one (un-overlapped), natural degrees
+  for wk in 4 1; do
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof$wk -- python3 $R/bench.py --steps 2 --warmup 1 --rows 1024 --workers $wk $QUIET > $O/prof$wk.json 2> $O/prof$wk.err
+    python3 $R/tools/dbg/trace_by_grid.py $(ls -t $O/prof$wk/*/*_kernel_trace.csv | head -1) 80 > $O/prof${wk}_by_grid.txt
+  done ;;
+k13)     # the reference-equivalent regime: every base circuit padded to 2^13 rows with the reference's leaf gate set
+  for wk in 4 1; do
+    timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/k13_prof$wk -- python3 $R/bench.py --pad-base-bits 13 --table-batch 16 --steps 1 --warmup 1 --rows 1024 --workers $wk $QUIET > $O/k13_prof$wk.json 2> $O/k13_prof$wk.err
+    python3 $R/tools/dbg/trace_by_grid.py $(ls -t $O/k13_prof$wk/*/*_kernel_trace.csv | head -1) 80 > $O/k13_prof${wk}_by_grid.txt
+  done ;;
+pmc)     # is the chip ALU-saturated in a 4-worker step? chip-wide SQ counters, program directly after --
+  timeout 900 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $O/pmc4 -- python3 $R/bench.py --steps 1 --warmup 1 --rows 512 --workers 4 $QUIET > $O/pmc4.json 2> $O/pmc4.err
+  timeout 900 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $O/pmc1 -- python3 $R/bench.py --steps 1 --warmup 1 --rows 512 --workers 1 $QUIET > $O/pmc1.json 2> $O/pmc1.err ;;
+sponge)  # the leaf sponge alone: instructions per permutation, cycles per instruction
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sponge_pmc -- python3 $R/tools/dbg/commit_only.py > $O/sponge_pmc.txt 2> $O/sponge_pmc.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sponge_trace -- python3 $R/tools/dbg/commit_only.py > $O/sponge_trace.txt 2> $O/sponge_trace.err ;;
+sweep)   # workers x batch with the pipelined forest, and the synchronous one beside it
+  for cfg in "4 32 0" "4 32 1" "3 48 0" "2 64 0" "2 64 1" "1 32 0" "1 32 1" "1 64 0"; do
+    set -- $cfg
+    MP2G_FOREST_SYNC=$3 python3 $R/bench.py --steps 10 --warmup 2 --rows 1024 --workers $1 --table-batch $2 $QUIET 2> $O/sweep.err | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('workers $1 batch $2 sync $3:', round(d['value'],1), 'proofs/s')" >> $O/sweep.txt
+  done; cat $O/sweep.txt ;;
+ntt)
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ntt -- python3 $R/bench.py --workload ntt --steps 20 --warmup 2 > $O/ntt.json 2> $O/ntt.err
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/traffic_$c -- python3 $R/tools/dbg/traffic_run.py > /dev/null 2> $O/traffic_$c.err
+  done ;;
+esac
+done
+keep_small
+ls $O | head -60
