@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256) leaf_hash_poly_major_kernel(const u64* __
   d[0] = make_ulonglong2(s[0], s[1]);
   d[1] = make_ulonglong2(s[2], s[3]);
 }
+#ifdef MP2G_EXPERIMENT_LEAF_ILP2  // compiled into variant libraries only (tools/dbg/build_variant.sh ilp2 "-DMP2G_EXPERIMENT_LEAF_ILP2" merkle.hip)
 // Two sponges per lane (leaves i and i + n/2: both loads stay coalesced streams): the experiment the round-3 review asked for
 // (MP2G_LEAF_ILP2=1; tools/dbg/sponge_ilp2.sh holds the numbers). Poseidon2 only, n even, w > 4.
 // the body shared by the two builds below
@@ -81,6 +82,7 @@ __global__ void __launch_bounds__(256) leaf_hash_poly_major_ilp2_kernel(const u6
 // ... and held to the three waves per SIMD of the single-sponge kernel (168 VGPRs, the rest spilled)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 leaf_hash_poly_major_ilp2_w3_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ digests, u64 in_bstride, u64 out_bstride) { LEAF_ILP2_BODY }
+#endif
 template <int V>
 __global__ void __launch_bounds__(256) leaf_hash_row_major_kernel(const u64* __restrict__ leaves, u32 len, u64 n, u64* __restrict__ digests) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -236,13 +238,15 @@ static inline dim3 grid1(u64 n, u32 block, u32 batch = 1) { return dim3((u32)((n
 hipError_t leaf_hash_poly_major(hipStream_t st, int variant, const u64* values, u32 w, u64 stride, u64 n, u64* digests,
                                 u32 batch, u64 in_bstride, u64 out_bstride) {
   if (!n || !batch) return hipSuccess;
-  static int ilp2 = -1;  // A/B switch of the two-sponges-per-lane kernel
-  if (ilp2 < 0) { const char* e = getenv("MP2G_LEAF_ILP2"); ilp2 = e ? atoi(e) : 0; }
+#ifdef MP2G_EXPERIMENT_LEAF_ILP2
+  // A/B switch of the two-sponges-per-lane kernels: exists in variant libraries only, the product has one leaf kernel and no switch
+  static const int ilp2 = [] { const char* e = getenv("MP2G_LEAF_ILP2"); return e ? atoi(e) : 0; }();
   if (ilp2 && variant == MP2G_POSEIDON2 && w > 4 && (n & 1) == 0) {
     if (ilp2 == 2) hipLaunchKernelGGL(leaf_hash_poly_major_ilp2_w3_kernel, grid1(n >> 1, 256, batch), dim3(256), 0, st, values, w, stride, n, digests, in_bstride, out_bstride);
     else hipLaunchKernelGGL(leaf_hash_poly_major_ilp2_kernel, grid1(n >> 1, 256, batch), dim3(256), 0, st, values, w, stride, n, digests, in_bstride, out_bstride);
     return hipGetLastError();
   }
+#endif
   LAUNCH_V(leaf_hash_poly_major_kernel, grid1(n, 256, batch), dim3(256), st, values, w, stride, n, digests, in_bstride, out_bstride);
   return hipGetLastError();
 }

@@ -160,9 +160,11 @@ static void batch_poly(const orc_fri_params* P, int batch, size_t j, uint32_t* o
 // levels[o] = Merkle levels. Challenger state continues the caller's transcript.
 // The proof-of-work witness is the smallest one, or the one armed with orc_set_pow_witness (the reference's search
 // is a non-deterministic find_any; parity is defined given the witness).
-static gl_t g_pow_override;
-static int g_pow_override_armed;
-// the NEXT proof made by this library (one proof, then the search is back) takes `witness` as its proof-of-work witness
+// (thread-local: the oracle proves on several threads in bench.py's CPU legs, and an armed witness must reach the proof of the thread
+// that armed it, not whichever proof comes first; test-only -- tests/test_reference_vectors.py)
+static _Thread_local gl_t g_pow_override;
+static _Thread_local int g_pow_override_armed;
+// the NEXT proof made ON THIS THREAD (one proof, then the search is back) takes `witness` as its proof-of-work witness
 void orc_set_pow_witness(gl_t witness) { g_pow_override = witness; g_pow_override_armed = 1; }
 void orc_fri_prove(const orc_fri_params* P, gl_t* const* coeffs, gl_t* const* leaves, gl_t* const* levels,
                    gl2_t zeta, orc_challenger* ch, gl_t* proof) {

@@ -2,6 +2,8 @@
 # the two-sponges-per-lane experiment on the leaf sponge (merkle.hip, MP2G_LEAF_ILP2 = 0 one sponge per lane / 1 two sponges, 2 waves
 # per SIMD / 2 two sponges held to 3 waves per SIMD): kernel durations under rocprofv3 for 2^20 leaves of 135 limbs, then the table bench
 R=$GRAFT_REPO_ROOT
+# the experiment lives in a variant library (the product has no switch)
+export MP2G_LIB=$($R/tools/dbg/build_variant.sh ilp2 "-DMP2G_EXPERIMENT_LEAF_ILP2" merkle.hip | tail -1)
 cd /tmp && export TMPDIR=/tmp
 for m in 0 1 2; do
   export MP2G_LEAF_ILP2=$m
