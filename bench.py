@@ -1380,7 +1380,7 @@ def run_table_resumable(args, local_rank, VARIANT, clocks):
         note = {"block": b, "prefix": 2 * b, "rows": n_rows, "framework_proofs": rig.n_proofs - n0, "gpu_seconds": dt, "proofs_per_s": (rig.n_proofs - n0) / dt,
                 "circuit": st["name"], "digest_w": [int(x) for x in st["digest_w"]], "digest_weierstrass": [int(x) for x in pis[4:15]],
                 "min": f"{ints(st['table'].values[0, 0]):064x}", "max": f"{ints(st['table'].values[-1, 0]):064x}", "root_verified_by_oracle": True,
-                "clocks": clocks.read(local_rank), "workers": len(rig.ctxs), "batch": args.table_batch, "host": os.uname().nodename, "unix_time": time.time()}
+                "clocks": clocks.read(local_rank), "library_sha16": lib_sha16(mp2.LIB_PATH), "workers": len(rig.ctxs), "batch": args.table_batch, "host": os.uname().nodename, "unix_time": time.time()}
         store.store_proof(keys[b], blob, note)
         built.append(b)
         print(f"bench.py: block {b} of {blocks}: {n_rows} rows, {rig.n_proofs - n0} framework proofs in {dt:.1f} s = {(rig.n_proofs - n0) / dt:.1f} proofs/s, root stored "
@@ -1470,6 +1470,12 @@ def run_table_resumable(args, local_rank, VARIANT, clocks):
     rig.close()
     clocks.close()
     return out
+
+
+def lib_sha16(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def fnv1a64(data):
