@@ -1082,12 +1082,13 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     if args.warmup > 0:  # the warm-up block creates the provers of every circuit (with --warmup 0 that falls into the timed region)
         block(args.warmup * args.rows, seed ^ 0x5A5A5A, args.lean or args.warmup * args.rows > 16384)
     barrier()
-    n0 = rig.n_proofs
+    n0, perms0 = rig.n_proofs, mp2.leaf_permutations_queued()
     t0 = time.perf_counter()
     st, cur = block(n_rows, seed, lean)
     barrier()
     dt = time.perf_counter() - t0
     n_local = rig.n_proofs - n0
+    leaf_perms = mp2.leaf_permutations_queued() - perms0
     mem_free_build, _ = ctx.mem_info()  # what the table build itself holds (the planner's estimate is for this): before any side leg creates its own provers
     if dist is not None:
         t = torch.tensor([dt, float(n_local)], device="cuda" if nccl else "cpu", dtype=torch.float64)
@@ -1253,6 +1254,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "ranks_on_host": ranks_here, "shapes": shapes,
                           "host_peak_rss_bytes": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss * 1024,
+                          "leaf_sponge_permutations": leaf_perms,  # queued by this rank's timed block (mp2g_stat_leaf_permutations): per framework proof, x value = the sponge work per second
                           "device_memory_used_bytes": mem_total - mem_free_build, "device_memory_planned_bytes": plan["device_bytes_per_rank"],
                           "device_memory_used_with_side_legs_bytes": mem_total - mem_free,  # + the configs[2] leg's map / reduce provers on every worker (what round 4's line reported as `used`)
                           "setup_s": round(setup_s, 1), "hasher": "Poseidon2", "backend": (dist.get_backend() if dist is not None else None), "rccl_ranks": rccl_ranks,

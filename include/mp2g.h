@@ -33,6 +33,10 @@ typedef struct mp2g_batch mp2g_batch; /* plonky2 PolynomialBatch (fri/oracle.rs)
 #define MP2G_POSEIDON2 0
 #define MP2G_POSEIDON 1
 
+/* Diagnostic: Poseidon / Poseidon2 permutations queued by the Merkle leaf sponge (every commitment of every prove() on every
+ * context) since the library was loaded -- a host-side count. Divided into the leaf kernel's time in a kernel trace it is the
+ * sponge's rate inside a proving step (bench.py `roofline_alu`). Replaces nothing in the reference. */
+uint64_t mp2g_stat_leaf_permutations(void);
 /* ---- library / context ------------------------------------------------------------------ */
 const char* mp2g_last_error(void);
 int mp2g_device_count(void);

@@ -41,6 +41,7 @@ def load():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.mp2g_last_error.restype = ctypes.c_char_p
         _lib.mp2g_ctx_stream.restype = ctypes.c_void_p
+        _lib.mp2g_stat_leaf_permutations.restype = ctypes.c_uint64
         _lib.mp2g_ctx_stream.argtypes = [ctypes.c_void_p]
     return _lib
 
@@ -846,6 +847,11 @@ def row_digests(ctx, col_ids, values, unique, variant=POSEIDON2):
     wei = np.empty((rows, 11), dtype=np.uint64)
     _ck(load().mp2g_row_digests(ctx.h, variant, _p(ids), n_cols, _p(v), _p(u), n_unique, rows, _p(w), _p(wei)))
     return w, wei
+
+
+def leaf_permutations_queued():
+    """permutations the Merkle leaf sponge has queued since the library was loaded (mp2g_stat_leaf_permutations)"""
+    return int(load().mp2g_stat_leaf_permutations())
 
 
 # ---- proof wire format (mp2-common/src/proof.rs) ---------------------------------------------

@@ -68,6 +68,7 @@ void mp2g_ctx_destroy(mp2g_ctx* c) {
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
+uint64_t mp2g_stat_leaf_permutations(void) { return mp2g::leaf_permutations_queued(); }
 int mp2g_ctx_sync(mp2g_ctx* c) { NEED(c, "ctx"); CK(hipStreamSynchronize(c->stream)); return 0; }
 void* mp2g_ctx_stream(mp2g_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int mp2g_ctx_set_stream(mp2g_ctx* c, void* stream) {

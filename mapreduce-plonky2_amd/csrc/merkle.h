@@ -28,4 +28,6 @@ hipError_t gather_rows(hipStream_t st, const u64* values, u32 w, u64 stride, con
 // in[p][i] (p < w, rows `stride` apart) -> out[i][p], for `batch` matrices in_bstride / out_bstride words apart
 hipError_t transpose_to_leaves(hipStream_t st, const u64* values, u32 w, u64 stride, u64 n_leaves, u64* out, u32 batch = 1, u64 in_bstride = 0,
                                u64 out_bstride = 0);
+// permutations queued by leaf_hash_poly_major since the library was loaded (host-side count)
+unsigned long long leaf_permutations_queued();
 }  // namespace mp2g

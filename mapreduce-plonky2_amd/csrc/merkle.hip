@@ -11,6 +11,7 @@
 // polynomial-major in HBM so that lane i reading limb p of leaf i is a perfectly coalesced
 // 8 B/lane stream (no transposed copy of the 8n x w matrix is ever materialised).
 #include "merkle.h"
+#include <atomic>
 #include <cstdlib>
 #include "poseidon_wave.cuh"
 
@@ -235,9 +236,15 @@ __global__ void __launch_bounds__(256) transpose_kernel(const u64* __restrict__ 
   } while (0)
 static inline dim3 grid1(u64 n, u32 block, u32 batch = 1) { return dim3((u32)((n + block - 1) / block), batch); }
 
+// permutations queued by leaf_hash_poly_major since the library was loaded (a host-side count: mp2g_stat_leaf_permutations; with the
+// kernel's total time from a kernel trace it gives the sponge's rate INSIDE a proving step)
+static std::atomic<unsigned long long> g_leaf_perms{0};
+unsigned long long leaf_permutations_queued() { return g_leaf_perms.load(std::memory_order_relaxed); }
+
 hipError_t leaf_hash_poly_major(hipStream_t st, int variant, const u64* values, u32 w, u64 stride, u64 n, u64* digests,
                                 u32 batch, u64 in_bstride, u64 out_bstride) {
   if (!n || !batch) return hipSuccess;
+  if (w > 4) g_leaf_perms.fetch_add((unsigned long long)n * batch * ((w + 7) / 8), std::memory_order_relaxed);
 #ifdef MP2G_EXPERIMENT_LEAF_ILP2
   // A/B switch of the two-sponges-per-lane kernels: exists in variant libraries only, the product has one leaf kernel and no switch
   static const int ilp2 = [] { const char* e = getenv("MP2G_LEAF_ILP2"); return e ? atoi(e) : 0; }();
