@@ -31,6 +31,18 @@ __global__ void __launch_bounds__(256) leaf_hash_poly_major_kernel(const u64* __
     for (u32 p = 0; p < w; p++) s[p] = values[p * stride + i];
   } else {
     const u64* v = values + i;
+#ifdef LEAF_ONE_COPY
+    // ONE copy of the permutation in the kernel's text (46 KB instead of 92: the instruction cache two CUs share holds 64 KB, and
+    // inside a proving step other streams' kernels compete for it): the short last chunk takes the same loop body, its loads
+    // guarded by wave-uniform compares
+#pragma clang loop unroll(disable)
+    for (u32 p = 0; p < w; p += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (p + k < w) s[k] = v[(u64)(p + k) * stride];
+      perm<V>(s);
+    }
+#else
     u32 p = 0;
     for (; p + 8 <= w; p += 8) {
 #pragma unroll
@@ -43,6 +55,7 @@ __global__ void __launch_bounds__(256) leaf_hash_poly_major_kernel(const u64* __
         if (p + k < w) s[k] = v[(u64)(p + k) * stride];
       perm<V>(s);
     }
+#endif
   }
   ulonglong2* d = reinterpret_cast<ulonglong2*>(digests + 4 * i);
   d[0] = make_ulonglong2(s[0], s[1]);
