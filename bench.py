@@ -556,12 +556,16 @@ def roofline_alu(isolated_rate, commit_rate):
                 k = json.load(f)
         except (OSError, ValueError):
             continue
-        per_perm = k["valu_wave_insts_per_permutation_x64"]  # per LANE-permutation: a wave instruction serves 64 permutations
-        peak = 1024 * k["sclk_hz"] / k["cycles_per_valu_wave_inst_of_the_mix"]  # wave-instructions / s the chip can issue on this mix
+        try:
+            per_perm = k["valu_insts_per_perm"]  # VALU instructions of ONE permutation (one lane); a wave instruction serves 64 of them
+            peak = k["peak_valu_wave_insts_per_s"]  # 1024 SIMDs x sclk / 2 cycles per wave64 instruction on a SIMD-32 (sclk = shader cycles of the profiled launch / its duration)
+        except KeyError:
+            continue
         need = lambda rate: rate / 64.0 * per_perm
-        out = {"kernel": "leaf_hash_poly_major_kernel<0> (Poseidon2 sponge, one lane = one leaf)", "bound": "VALU issue",
+        out = {"kernel": "leaf_hash_poly_major_kernel<0> (Poseidon2 sponge, one lane = one leaf)", "bound": "VALU issue", "unit": "VALU wave-instructions/s",
                "valu_insts_per_perm": per_perm, "peak_valu_wave_insts_per_s": peak, "sclk_hz": k["sclk_hz"],
-               "cycles_per_valu_wave_inst_of_the_mix": k["cycles_per_valu_wave_inst_of_the_mix"],
+               "cycles_per_valu_wave_inst_at_peak": k["cycles_per_valu_wave_inst_of_the_mix"], "cycles_per_valu_wave_inst_achieved_alone": k.get("cycles_per_valu_wave_inst_achieved"),
+               "add32_stream_wave_insts_per_s_measured": k.get("add32_wave_insts_per_s_measured"),
                "isolated": {"perms_per_s": isolated_rate, "frac": need(isolated_rate) / peak, "leg": "sponge (hash_no_pad_batch, 2^21 x 136 limbs)"},
                "commit": {"perms_per_s": commit_rate, "frac": need(commit_rate) / peak, "leg": "commit_135x2p15 (leaf sponge + tree levels)"},
                "source": f"profiles/{rnd}/sponge_counters.json (committed rocprofv3 --pmc passes; the rates are this run's)"}
@@ -1174,6 +1178,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     else:
         glue["host_glue_share"] = round(1.0 - glue["inside_libmp2gpu_s"] / max(glue["block_s"], 1e-9), 4)  # registration (numpy) + the plan's waves
     del st
+    perms_total = mp2.leaf_permutations_queued()  # everything this process hashed up to here (warm-up, timed block, checks, side legs so far): what a kernel trace of the run holds
     rig.close()
 
     # the table rate bracketed by base degree: every base circuit padded to 2^k rows + the reference's leaf gate set
@@ -1254,7 +1259,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                           "witness_generation": "host threads (mp2g_witness_program_run_rows)" if args.host_witness else "device (mp2g_witness_program_run_dev: level-scheduled witness programs, one block per proof; base -> wrap hand-off by device copies)",
                           "host_threads_per_worker": host_threads, "host_cores": os.cpu_count(), "ranks_on_host": ranks_here, "shapes": shapes,
                           "host_peak_rss_bytes": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss * 1024,
-                          "leaf_sponge_permutations": leaf_perms,  # queued by this rank's timed block (mp2g_stat_leaf_permutations): per framework proof, x value = the sponge work per second
+                          "leaf_sponge_permutations": leaf_perms, "leaf_sponge_permutations_process_total": perms_total,  # queued by this rank's timed block (mp2g_stat_leaf_permutations): per framework proof, x value = the sponge work per second
                           "device_memory_used_bytes": mem_total - mem_free_build, "device_memory_planned_bytes": plan["device_bytes_per_rank"],
                           "device_memory_used_with_side_legs_bytes": mem_total - mem_free,  # + the configs[2] leg's map / reduce provers on every worker (what round 4's line reported as `used`)
                           "setup_s": round(setup_s, 1), "hasher": "Poseidon2", "backend": (dist.get_backend() if dist is not None else None), "rccl_ranks": rccl_ranks,
