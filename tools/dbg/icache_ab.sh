@@ -7,6 +7,7 @@
 #   onecopy         -DLEAF_ONE_COPY                     one copy of the permutation in the leaf kernel (49 KB)
 #   onecopy_u2      -DLEAF_ONE_COPY -DP2_UNROLL_INT=2   + internal rounds unrolled by 2 instead of 11 (27 KB)
 #   u2              -DP2_UNROLL_INT=2                   two copies of the short form (53 KB)
+#   onecopy_u2_all  the same flags on fri.hip too (the proof-of-work search, the FRI layers' leaf sponge)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05; mkdir -p $O
 QUIET="--no-leaves-leg --no-verify --config2-leaves 0 --degree-sweep= --no-cpu-baseline"
@@ -22,5 +23,6 @@ unset MP2G_LIB; run base
 export MP2G_LIB=$($R/tools/dbg/build_variant.sh onecopy "-DLEAF_ONE_COPY" merkle.hip | tail -1); run onecopy
 export MP2G_LIB=$($R/tools/dbg/build_variant.sh onecopy_u2 "-DLEAF_ONE_COPY -DP2_UNROLL_INT=2" merkle.hip | tail -1); run onecopy_u2
 export MP2G_LIB=$($R/tools/dbg/build_variant.sh u2 "-DP2_UNROLL_INT=2" merkle.hip | tail -1); run u2
+export MP2G_LIB=$($R/tools/dbg/build_variant.sh onecopy_u2_all "-DLEAF_ONE_COPY -DP2_UNROLL_INT=2" merkle.hip fri.hip | tail -1); run onecopy_u2_all   # + the PoW search and the FRI-layer leaves
 unset MP2G_LIB; run base_again
 } 2>&1 | tee $O/icache_ab.txt
