@@ -308,7 +308,7 @@ __global__ void soa_to_aos_kernel(u32 n, const u64* in, u64 in_bstride, u32 n_in
 
 // ---- proof of work ----------------------------------------------------------------------------
 // witness[b * POW_STRIDE] = min { w : perm(state with w at position n_in)[7] has >= bits leading zeros }.
-// POW_BLOCKS blocks of 256 lanes per proof sweep the candidates in order (four blocks share a CU, so one block's poll and
+// Several blocks of 256 lanes per proof (fri_pow sizes the grid) sweep the candidates in order (four blocks share a CU, so one block's poll and
 // barrier leave the ALUs to the other three; with one 1024-lane block per CU 37 % of the wave cycles were parked: 3.45 -> 3.08 ms
 // per 64 base proofs. Handing the candidates out in chunks from a per-proof counter so that the blocks of finished proofs help the
 // stragglers was measured too and lost, 4.6-11.9 ms: the helpers gang up on a proof and overshoot its nonce). Blocks of one proof
@@ -316,7 +316,6 @@ __global__ void soa_to_aos_kernel(u32 n, const u64* in, u64 in_bstride, u32 n_in
 // block reads it back with a returning (no-op) atomicMin -- the per-XCD L2s are not coherent, a
 // plain or sc1 load of a word that another XCD updates atomically can stay stale for seconds,
 // while an atomic executes at the coherence point. Each proof's word sits in its own 128-B line.
-#define POW_BLOCKS 64
 #define POW_THREADS 256
 #define POW_STRIDE 16
 template <int V>
@@ -449,10 +448,14 @@ hipError_t fri_soa_to_aos(hipStream_t s, u32 B, u32 n, const u64* in, u64 in_bst
 }
 hipError_t fri_pow(hipStream_t s, int variant, const ChState* st, u32 B, u32 bits, u64* witness) {
   hipLaunchKernelGGL(fill_u64_kernel, dim3((B * POW_STRIDE + 63) / 64), dim3(64), 0, s, witness, ~(u64)0, B * POW_STRIDE);
-  // blocks per proof: 2^14 candidates per sweep when many proofs share the chip, up to 2^18 for a
-  // lone proof (its search is otherwise confined to 16 CUs and dominates single-proof latency)
-  u32 blocks = 4096 / (B ? B : 1);
-  if (blocks < POW_BLOCKS) blocks = POW_BLOCKS;
+  // blocks per proof. The search returns the SMALLEST witness, so every candidate below it is evaluated whatever the order -- and so is
+  // the rest of the sweep it lies in: with G candidates per sweep and proof the expected work is 2^bits + G / 2 permutations. The
+  // launch is sized to fill the chip once over all proofs (2^18 lanes: 256 CUs x 4 blocks; MP2G_POW_LANES overrides it for A/B runs)
+  // instead of 2^20 lanes as before (a batch of 32 proofs: G = 2^13 instead of 2^15, 1.06 x 2^16 permutations a proof instead of
+  // 1.25 x); a lone proof keeps its 2^18-candidate sweeps (its search is otherwise confined to a few CUs and dominates its latency)
+  static const u32 lanes = [] { const char* e = getenv("MP2G_POW_LANES"); const long v = e ? atol(e) : 0; return (u32)(v >= 256 ? v : 1 << 18); }();
+  u32 blocks = lanes / POW_THREADS / (B ? B : 1);
+  if (blocks < 8) blocks = 8;
   if (blocks > 1024) blocks = 1024;
   dim3 g(blocks, B), bl(POW_THREADS);
   if (variant == MP2G_POSEIDON2) hipLaunchKernelGGL((pow_kernel<MP2G_POSEIDON2>), g, bl, 0, s, st, bits, (unsigned long long*)witness);
