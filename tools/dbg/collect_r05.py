@@ -28,7 +28,7 @@ def kernel_rows(path):
     """rocprofv3 --stats kernel_stats.csv -> {short name: (calls, total ns, avg ns, percentage)}"""
     out = {}
     for r in csv.DictReader(open(path)):
-        k = r["Name"].split("(")[0].replace("void mp2g::", "").replace("mp2g::", "")
+        k = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void mp2g::", "").replace("mp2g::", "")
         out[k] = (int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["Percentage"]))
     return out
 
@@ -129,6 +129,15 @@ if os.path.exists(f"{src}/sponge_pmc_summary.json"):
         out["in_step_perms_per_s"] = out["in_step_perms_per_s_table_1worker"]
         out["in_step_source"] = ("profiles/r05/table_1worker_kernel_stats.csv: permutations queued by the process (mp2g_stat_leaf_permutations) / the leaf kernel's summed duration, ONE worker "
                                  "(un-overlapped launches; with four workers a launch's duration includes the time it shares the chip)")
+    if "SQ_INSTS_VALU_total" in summary.get("step_counters", {}):
+        # every VALU wave-instruction of a 512-row table build (all kernels; step_counters_4workers.json) per framework proof: with the
+        # build's proofs/s it is the rate at which the whole chip issues VALU instructions during a build
+        line = last_json_line(f"{src}/pmc4.json")
+        share = 1.0
+        if line and line["config"].get("leaf_sponge_permutations_process_total"):
+            share = line["config"]["leaf_sponge_permutations"] / line["config"]["leaf_sponge_permutations_process_total"]  # the timed block's part of the process (the rest: prover creation)
+        out["step_valu_wave_insts_per_framework_proof"] = summary["step_counters"]["SQ_INSTS_VALU_total"] * share / summary["step_counters"]["framework_proofs_in_the_run"]
+        out["step_source"] = "profiles/r05/step_counters_4workers.json: SQ_INSTS_VALU summed over every dispatch of a 512-row table build (2560 framework proofs), scaled by the timed block's share of the process's sponge work"
     json.dump(out, open(f"{dst}/sponge_counters.json", "w"), indent=1)
     summary["sponge_counters"] = {k_: out[k_] for k_ in ("valu_insts_per_perm", "cycles_per_valu_wave_inst_achieved", "isolated_perms_per_s_kernel_trace", "sclk_hz", "in_step_perms_per_s") if k_ in out}
     if "SQ_INSTS_VALU_total" in summary.get("step_counters", {}):

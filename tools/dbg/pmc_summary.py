@@ -6,7 +6,7 @@ by, tot, n_rows = {}, {}, 0
 for f in glob.glob(sys.argv[1] + "/*/*_counter_collection.csv"):
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            k = r["Kernel_Name"].split("(")[0].replace("void mp2g::", "").replace("mp2g::", "")
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void mp2g::", "").replace("mp2g::", "")
             c, v = r["Counter_Name"], float(r["Counter_Value"])
             e = by.setdefault(k, {"dispatches": set(), "counters": {}})
             e["dispatches"].add(r["Dispatch_Id"])

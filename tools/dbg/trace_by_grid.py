@@ -7,7 +7,7 @@ total = 0.0
 first, last = None, 0
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        k = r["Kernel_Name"].split("(")[0].replace("void mp2g::", "").replace("mp2g::", "")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void mp2g::", "").replace("mp2g::", "")
         g = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         d = (e - s) / 1e3
