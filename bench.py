@@ -661,7 +661,9 @@ def main(argv=None):
     ap.add_argument("--trees", type=int, default=8, help="--workload recursion: independent trees per rank and step, one host thread + GPU stream each")
     ap.add_argument("--rows", type=int, default=1024, help="--workload table: table rows per rank and step (5 framework proofs each)")
     ap.add_argument("--workers", type=int, default=4, help="--workload table: concurrent work-plan items per rank, one host thread + GPU stream + prover set each")
-    ap.add_argument("--table-batch", type=int, default=32, help="--workload table: proofs per prove() launch sequence of a worker")
+    ap.add_argument("--table-batch", type=int, default=48, help="--workload table: proofs per prove() launch sequence of a worker (round 5: 4 x 48 in flight = 238 GB of the "
+                    "GPU's 288 does 912 proofs/s where 4 x 32 = 162 GB does 842: the per-batch latency kernels -- witness replay, transcript, tree tops -- are paid once per 48 proofs; "
+                    "profiles/r05/variants_ab.txt)")
     ap.add_argument("--subtree", type=int, default=64, help="--workload table: into_batched_workplan(subtree_size), the rows of one work-plan item")
     ap.add_argument("--native-build", action="store_true", default=True, help="--workload table: the table build's scheduler in C++ (mp2g_forest_*: worker threads, "
                     "level batching, job assembly, child proofs in a device pool): the default")
@@ -908,6 +910,25 @@ class TableRig:
     def close(self):
         if self.native_build is not None:
             self.native_build.free()
+        for p_ in self.provers:
+            p_.free()
+        for c in reversed(self.ctxs):
+            c.close()
+
+
+class WorkerRig:
+    """`workers` GPU contexts with a prover set and a proof session each -- what a leg that brings its own circuits runs on (the
+    configs[2] leg: it runs after the table's rig is closed, so that its provers do not come on top of the table's)"""
+
+    def __init__(self, mods, local_rank, variant, workers, batch, host_threads):
+        mp2, R, FW, C, T, IX = mods
+        self.mods, self.variant, self.batch, self.host_threads = mods, variant, batch, host_threads
+        self.ctxs = [mp2.Context(local_rank) for _ in range(max(1, workers))]
+        self.ctx = self.ctxs[0]
+        self.provers = [FW.GpuProver(c, variant, witness_check=True, capacity=batch, device_witness=True) for c in self.ctxs]
+        self.sessions = [R.ProofSession(p) for p in self.provers]
+
+    def close(self):
         for p_ in self.provers:
             p_.free()
         for c in reversed(self.ctxs):
@@ -1168,7 +1189,6 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
             side_errors.append(name)
             return {"error": f"{type(e).__name__}: {e}"[:400]}
 
-    config2 = guarded("config2", lambda: config2_leg(rig, args.config2_leaves)) if side and args.config2_leaves > 0 else None
     legs = kernel_legs(ctx, mp2, C, VARIANT, args.hasher, rank) if rank == 0 else None
     shapes = params.shapes()
     mem_free, mem_total = ctx.mem_info()  # with every prover of the run still alive: what the planner's estimate is calibrated on
@@ -1183,6 +1203,20 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     del st
     perms_total = mp2.leaf_permutations_queued()  # everything this process hashed up to here (warm-up, timed block, checks, side legs so far): what a kernel trace of the run holds
     rig.close()
+
+    # BASELINE configs[2] at full size, on workers of its own (the table's provers are gone: the two circuit families never share the GPU)
+    config2 = None
+    if side and args.config2_leaves > 0:
+        def c2():
+            r2 = WorkerRig(mods, local_rank, VARIANT, workers, args.table_batch, host_threads)
+            try:
+                out2 = config2_leg(r2, args.config2_leaves)
+                f2, t2 = r2.ctx.mem_info()
+                out2["device_memory_used_bytes"] = t2 - f2
+                return out2
+            finally:
+                r2.close()
+        config2 = guarded("config2", c2)
 
     # the table rate bracketed by base degree: every base circuit padded to 2^k rows + the reference's leaf gate set
     by_degree = None
@@ -1264,7 +1298,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                           "host_peak_rss_bytes": __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss * 1024,
                           "leaf_sponge_permutations": leaf_perms, "leaf_sponge_permutations_process_total": perms_total,  # queued by this rank's timed block (mp2g_stat_leaf_permutations): per framework proof, x value = the sponge work per second
                           "device_memory_used_bytes": mem_total - mem_free_build, "device_memory_planned_bytes": plan["device_bytes_per_rank"],
-                          "device_memory_used_with_side_legs_bytes": mem_total - mem_free,  # + the configs[2] leg's map / reduce provers on every worker (what round 4's line reported as `used`)
+                          "device_memory_note": "`used` = with every prover of the table build alive, before any side leg; the configs[2] leg runs on provers of its own after the table's are freed (round 4 kept both alive: its `used` was 33 GB above the plan)",
                           "setup_s": round(setup_s, 1), "hasher": "Poseidon2", "backend": (dist.get_backend() if dist is not None else None), "rccl_ranks": rccl_ranks,
                           "join_levels": n_levels,
                           "sharding": f"{world} rank(s): one block of rows each, no collective below the block roots; {n_levels} join level(s) move a root proof point to point "

@@ -450,10 +450,12 @@ hipError_t fri_pow(hipStream_t s, int variant, const ChState* st, u32 B, u32 bit
   hipLaunchKernelGGL(fill_u64_kernel, dim3((B * POW_STRIDE + 63) / 64), dim3(64), 0, s, witness, ~(u64)0, B * POW_STRIDE);
   // blocks per proof. The search returns the SMALLEST witness, so every candidate below it is evaluated whatever the order -- and so is
   // the rest of the sweep it lies in: with G candidates per sweep and proof the expected work is 2^bits + G / 2 permutations. The
-  // launch is sized to fill the chip once over all proofs (2^18 lanes: 256 CUs x 4 blocks; MP2G_POW_LANES overrides it for A/B runs)
-  // instead of 2^20 lanes as before (a batch of 32 proofs: G = 2^13 instead of 2^15, 1.06 x 2^16 permutations a proof instead of
-  // 1.25 x); a lone proof keeps its 2^18-candidate sweeps (its search is otherwise confined to a few CUs and dominates its latency)
-  static const u32 lanes = [] { const char* e = getenv("MP2G_POW_LANES"); const long v = e ? atol(e) : 0; return (u32)(v >= 256 ? v : 1 << 18); }();
+  // launch is sized to 2^19 lanes over all proofs of the batch (MP2G_POW_LANES overrides it for A/B runs) instead of 2^20 as in
+  // rounds 1-4 (a batch of 32 proofs: G = 2^14 instead of 2^15, 1.125 x 2^16 permutations a proof instead of 1.25 x). Measured on
+  // the table build (profiles/r05/variants_ab.txt, two alternating repetitions): 2^20 lanes 841.8 / 839.4 proofs/s, 2^19 845.0 /
+  // 842.3, 2^18 840.8 / 838.3, 2^17 824.1 / 823.6 -- narrower sweeps save candidates and pay for it in polls and part-filled
+  // launches; the search is 7 % of a build's VALU instructions either way. A lone proof keeps sweeps of 2^18 candidates
+  static const u32 lanes = [] { const char* e = getenv("MP2G_POW_LANES"); const long v = e ? atol(e) : 0; return (u32)(v >= 256 ? v : 1 << 19); }();
   u32 blocks = lanes / POW_THREADS / (B ? B : 1);
   if (blocks < 8) blocks = 8;
   if (blocks > 1024) blocks = 1024;
