@@ -1223,7 +1223,9 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     if side and args.degree_sweep:
         by_degree = {}
         def at_degree(k):
-            bk = max(4, args.table_batch >> max(0, k - 12))  # proofs in flight per worker shrink with the degree: the same device memory at every k
+            # with the provers' shared scratch (the default) the full batch fits at every degree; provers with buffers of their own
+            # (MP2G_SHARE_SCRATCH=0) halve the proofs in flight per degree step to keep the device memory constant
+            bk = args.table_batch if sharding.scratch_is_shared() else max(4, args.table_batch >> max(0, k - 12))
             while True:
                 try:
                     rk = TableRig(mods, local_rank, VARIANT, args.workers, bk, args.subtree, args.host_witness, ranks_here, pad_bits=k, group_rows=args.group_rows, native=args.native_build)

@@ -2,6 +2,7 @@
 // and polynomial commitments. Host-side mirror of plonky2's PolynomialBatch / MerkleTree as the
 // reference uses them behind `prove()` (recursion-framework/src/circuit_builder.rs:308).
 #include "ctx.h"
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -41,6 +42,7 @@ int mp2g_ctx_create(int device, mp2g_ctx** out) {
   mp2g_ctx* c = new (std::nothrow) mp2g_ctx();
   if (!c) return fail("out of memory");
   c->device = device;
+  { const char* sh = getenv("MP2G_SHARE_SCRATCH"); c->share_scratch = !(sh && atoi(sh) == 0); }  // ctx.h: the provers' working memory, shared per context
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) {
     c->own_stream = true;

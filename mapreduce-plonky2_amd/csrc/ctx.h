@@ -12,17 +12,23 @@ int params_check(const mp2g_fri_params* p);  // prover.hip: every bound the layo
 struct DevBuf {
   u64* p = nullptr;
   size_t bytes = 0;
+  bool borrowed = false;  // p points into memory another DevBuf owns (a context's prover scratch): never freed here
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  ~DevBuf() { if (p && !borrowed) (void)hipFree(p); }
   hipError_t alloc(size_t b) {
-    if (p) { (void)hipFree(p); p = nullptr; }
+    if (p && !borrowed) (void)hipFree(p);
+    p = nullptr; borrowed = false;
     bytes = 0;
     hipError_t e = hipMalloc((void**)&p, b ? b : 8);
     if (e != hipSuccess) { p = nullptr; return e; }  // bytes stays 0: the next caller that needs the buffer retries the allocation
     bytes = b;
     return hipSuccess;
+  }
+  void borrow(u64* q, size_t b) {
+    if (p && !borrowed) (void)hipFree(p);
+    p = q; bytes = b; borrowed = true;
   }
 };
 }  // namespace mp2g
@@ -35,6 +41,13 @@ struct mp2g_ctx {
   mp2g::NttEngine ntt;
   mp2g::DevBuf wit_vals;  // slot tables of the device witness executor (mp2g_witness_program_run_dev), grown on demand
   mp2g::DevBuf wit_rows;  // its row-major staging wire matrices
+  // The provers' per-batch working buffers (coefficients, LDE values, Merkle levels of oracles 1.., quotient values, FRI layers):
+  // everything a prove() recomputes from its inputs and nobody reads once its kernels have run. All provers of a context run on
+  // the context's ONE stream, so they can use the same memory one after the other: the scratch is as large as the largest
+  // prover needs, not the sum over the circuits (a table build holds 17 provers per worker and runs one at a time: 238 GB -> 64 GB
+  // at 4 x 48 proofs in flight). MP2G_SHARE_SCRATCH=0 gives every prover buffers of its own again (the A/B switch).
+  mp2g::DevBuf prover_scratch;
+  bool share_scratch = true;
 };
 struct mp2g_tree {
   mp2g_ctx* ctx = nullptr;

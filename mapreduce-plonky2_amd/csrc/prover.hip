@@ -62,6 +62,19 @@ struct mp2g_prover {
     if (gexec) (void)hipGraphExecDestroy(gexec);
     gexec = nullptr;
   }
+  // working buffers that live in the context's shared scratch (ctx.h): what each asked for; bound to addresses at every prove
+  std::vector<std::pair<DevBuf*, size_t>> shared;
+  const u64* bound_base = nullptr;
+  size_t bound_total = 0;
+  // a per-batch working buffer: in the shared scratch (recorded, bound later) or, with sharing off, memory of its own
+  hipError_t want(DevBuf& d, size_t bytes) {
+    if (!ctx->share_scratch) return d.alloc(bytes);
+    for (auto& e : shared)
+      if (e.first == &d) { e.second = bytes; bound_base = nullptr; return hipSuccess; }
+    shared.emplace_back(&d, bytes);
+    bound_base = nullptr;
+    return hipSuccess;
+  }
   ~mp2g_prover() {
     drop_graph();
     for (hipEvent_t e : ev)
@@ -246,26 +259,28 @@ static int prover_create_impl(mp2g_ctx* c, const mp2g_fri_params* params, uint32
   pr->final_off = pr->q_off + P.num_queries * pr->q_words;
   pr->n_open = mp2g_fri_n_openings(&P);
   hipError_t e = hipSuccess;
-  auto A = [&](DevBuf& d, size_t words) { if (e == hipSuccess) e = d.alloc(words * sizeof(u64)); };
+  auto A = [&](DevBuf& d, size_t words) { if (e == hipSuccess) e = d.alloc(words * sizeof(u64)); };       // the prover's own (small, or persistent)
+  auto S = [&](DevBuf& d, size_t words) { if (e == hipSuccess) e = pr->want(d, words * sizeof(u64)); };  // per-batch working memory
   for (uint32_t o = 0; o < P.n_oracles && alloc_oracles; o++) {
-    size_t nb = o == 0 ? 1 : B;
-    A(pr->coeffs[o], nb * P.oracle_w[o] * n);
-    A(pr->values[o], nb * P.oracle_w[o] * N);
-    A(pr->levels[o], nb * pr->levels_words);
+    if (o == 0) {  // the preprocessed oracle: committed once, read by every prove
+      A(pr->coeffs[o], (size_t)P.oracle_w[o] * n); A(pr->values[o], (size_t)P.oracle_w[o] * N); A(pr->levels[o], pr->levels_words);
+    } else {
+      S(pr->coeffs[o], B * P.oracle_w[o] * n); S(pr->values[o], B * P.oracle_w[o] * N); S(pr->levels[o], B * pr->levels_words);
+    }
   }
   if (e == hipSuccess) e = pr->ch.alloc(B * sizeof(ChState));
   A(pr->chal, B * 8); A(pr->zeta, B * 2); A(pr->alpha, B * 2); A(pr->betas, B * 16);
-  A(pr->comp, B * 4 * n); A(pr->quot, B * 4 * n); A(pr->final_poly, B * 2 * n);
+  S(pr->comp, B * 4 * n); S(pr->quot, B * 4 * n); S(pr->final_poly, B * 2 * n);
   A(pr->witness, B * FRI_POW_STRIDE); A(pr->qchal, B * (P.num_queries ? P.num_queries : 1));
   size_t m = N, nc = n;
   uint32_t clg = lg;
-  A(pr->fvals[0], B * 2 * m);
+  S(pr->fvals[0], B * 2 * m);
   for (uint32_t li = 0; li < P.n_layers; li++) {
     clg -= P.arity_bits[li];
-    A(pr->flevels[li], B * merkle_levels_words(clg, P.cap_height));
+    S(pr->flevels[li], B * merkle_levels_words(clg, P.cap_height));
     m >>= P.arity_bits[li]; nc >>= P.arity_bits[li];
-    A(pr->fvals[li + 1], B * 2 * m);
-    A(pr->fcoeffs[li + 1], B * 2 * nc);
+    S(pr->fvals[li + 1], B * 2 * m);
+    S(pr->fcoeffs[li + 1], B * 2 * nc);
   }
   if (e != hipSuccess) { delete pr; return fail("prover_create: %s", hipGetErrorString(e)); }
   *out = pr;
@@ -325,8 +340,8 @@ int mp2g_prover_enable_permutation(mp2g_prover* pr, uint32_t num_routed, uint32_
   NEED(P.zs_count >= 1 && P.zs_count <= 2, "1 or 2 challenges");
   NEED(P.oracle_w[2] == P.zs_count * (num_routed / degree + P.num_lookup_polys), "oracle_w[2] must be zs_count * (num_routed/degree + num_lookup_polys)");
   const size_t n = (size_t)1 << P.log_n;
-  CK(pr->zs_values.alloc((size_t)pr->Bcap * P.oracle_w[2] * n * sizeof(u64)));
-  CK(pr->chunk_q.alloc((size_t)pr->Bcap * P.zs_count * (num_routed / degree) * n * sizeof(u64)));
+  CK(pr->want(pr->zs_values, (size_t)pr->Bcap * P.oracle_w[2] * n * sizeof(u64)));
+  CK(pr->want(pr->chunk_q, (size_t)pr->Bcap * P.zs_count * (num_routed / degree) * n * sizeof(u64)));
   CK(pr->bg.alloc((size_t)pr->Bcap * 8 * sizeof(u64)));  // betas, gammas (+ the 2 * num_challenges extra lookup challenges)
   CK(pr->alphas.alloc((size_t)pr->Bcap * 2 * sizeof(u64)));
   pr->num_routed = num_routed; pr->degree = degree;
@@ -339,7 +354,7 @@ int mp2g_prover_enable_quotient(mp2g_prover* pr) {
   NEED(P.n_oracles == 4 && P.rate_bits == 3, "needs the four plonky2 oracles and rate_bits 3 (quotient degree factor 8)");
   NEED(P.oracle_w[3] == P.zs_count * 8, "oracle_w[3] must be zs_count * 8 quotient chunks");
   NEED(P.log_n + 3 <= 24, "log_n <= 21");
-  CK(pr->qvals.alloc((size_t)pr->Bcap * P.zs_count * ((size_t)8 << P.log_n) * sizeof(u64)));
+  CK(pr->want(pr->qvals, (size_t)pr->Bcap * P.zs_count * ((size_t)8 << P.log_n) * sizeof(u64)));
   pr->quotient = true;
   pr->drop_graph();
   return 0;
@@ -429,10 +444,34 @@ extern "C" {
 
 static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const uint64_t* d_circuit_digest,
                       const uint64_t* d_pi_hash, uint64_t* d_caps, uint64_t* d_openings, uint64_t* d_proof);
+// The prover's working buffers get their addresses in the context's shared scratch (ctx.h) -- before anything of this prove() is
+// queued: a scratch that has to grow first waits for the stream (earlier provers' kernels may still run in the old one).
+static int bind_scratch(mp2g_prover* pr) {
+  if (pr->shared.empty()) return 0;
+  mp2g_ctx* c = pr->ctx;
+  size_t total = 0;
+  for (auto& e : pr->shared) total += (e.second + 255) & ~(size_t)255;
+  if (c->prover_scratch.bytes < total) {
+    CK(hipStreamSynchronize(c->stream));
+    hipError_t e = c->prover_scratch.alloc(total);
+    if (e != hipSuccess) return fail("prover scratch of %zu bytes: %s", total, hipGetErrorString(e));
+  }
+  if (pr->bound_base == c->prover_scratch.p && pr->bound_total == total) return 0;
+  size_t off = 0;
+  for (auto& e : pr->shared) {
+    e.first->borrow(c->prover_scratch.p + off / sizeof(u64), e.second);
+    off += (e.second + 255) & ~(size_t)255;
+  }
+  pr->bound_base = c->prover_scratch.p;
+  pr->bound_total = total;
+  pr->drop_graph();  // a captured launch sequence holds the old addresses
+  return 0;
+}
 int mp2g_prover_prove_dev(mp2g_prover* pr, const uint64_t* const* d_values, const uint64_t* d_circuit_digest,
                           const uint64_t* d_pi_hash, uint64_t* d_caps, uint64_t* d_openings, uint64_t* d_proof) {
   NEED(pr && d_values && d_circuit_digest && d_pi_hash && d_caps && d_openings && d_proof, "prover/pointers");
   NEED(pr->have_pre, "call mp2g_prover_set_preprocessed_dev first");
+  { int rcb = bind_scratch(pr); if (rcb) return rcb; }
   if (!pr->graph_on || pr->timing || pr->plain_calls == 0) {
     pr->plain_calls++;
     return prove_impl(pr, d_values, d_circuit_digest, d_pi_hash, d_caps, d_openings, d_proof);
@@ -798,7 +837,8 @@ int mp2g_fri_prove(mp2g_ctx* c, const mp2g_fri_params* params, mp2g_batch* const
   hipError_t e = dproof.alloc(pr->proof_words * sizeof(u64));
   if (e == hipSuccess) e = hipMemcpyAsync(pr->zeta.p, zeta, 2 * sizeof(u64), hipMemcpyHostToDevice, c->stream);
   if (e != hipSuccess) return fail("fri_prove setup: %s", hipGetErrorString(e));
-  rc = fri_tail(pr, sh, (ChState*)ch->st.p, dproof.p);
+  rc = bind_scratch(pr);
+  if (!rc) rc = fri_tail(pr, sh, (ChState*)ch->st.p, dproof.p);
   if (!rc) {
     e = hipMemcpyAsync(proof, dproof.p, pr->proof_words * sizeof(u64), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

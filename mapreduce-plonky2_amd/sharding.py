@@ -18,25 +18,40 @@ CPU tests); no arithmetic happens in this module.
 import numpy as np
 
 
-# device bytes a prover holds per proof in flight and per row of its circuit: the x8 LDEs of the 135 wire, 20 Z / partial-product
-# and 16 quotient polynomials with their coefficients, the Merkle levels of the four oracles, FRI layers, witness slots
-# (calibrated on the bench's table build: `device_memory_used_bytes` in its JSON -- 160 GB measured at 4 workers x 32 proofs in flight)
-PROOF_BYTES_PER_ROW = 16 * 1024
+# Device bytes per proof in flight (round 5: the provers of a context share one scratch -- csrc/ctx.h `prover_scratch`):
+#  * the scratch holds the working set of ONE prove() at a time: per row of the LARGEST circuit step of the build the x8 LDEs of the
+#    135 wire, 20 Z / partial-product and 16 quotient polynomials with their coefficients, the Merkle levels of those three oracles,
+#    the FRI layers, the quotient values, plus the witness executor's row-major staging matrix;
+#  * every chain step keeps its own hand-over buffers: the wire matrix (135 words per row), inputs, probe, caps, openings, proof words
+#    -- per row of EVERY step of every circuit.
+# With MP2G_SHARE_SCRATCH=0 every prover owns its working set: the first figure is paid per row of every step of every circuit (rounds
+# 1-4: 16 KB x the sum of the rows; 160 GB measured at 4 workers x 32 proofs in flight).
+SCRATCH_BYTES_PER_ROW = 17 * 1024
+CHAIN_BYTES_PER_ROW = 3 * 512
+PROOF_BYTES_PER_ROW = 16 * 1024  # unshared provers
 HBM_BYTES = 288 * 10**9
 
 
-def plan_rank_resources(shapes, workers, batch, ranks_on_host, host_cpus, hbm_bytes=HBM_BYTES):
+def scratch_is_shared():
+    import os
+    return os.environ.get("MP2G_SHARE_SCRATCH", "1") != "0"
+
+
+def plan_rank_resources(shapes, workers, batch, ranks_on_host, host_cpus, hbm_bytes=HBM_BYTES, shared=None):
     """What ONE rank of a node takes for a table / recursion build: `shapes` = {circuit: [log2 rows of the base circuit and of every
     wrap step]} (TableParams.shapes()), `workers` proving threads (GPU streams with a prover set each) holding `batch` proofs in
     flight per circuit chain. Returns the host threads per worker (the node's hardware threads over the workers of all ranks on the
     host: never more threads than the host has), their total over the node, and the device bytes the rank's provers need -- each
     rank has a GPU of its own, so this is compared with ONE GPU's memory. `fits` false = shrink `batch` or `workers`."""
+    shared = scratch_is_shared() if shared is None else shared
     rows = sum(1 << int(k) for chain in shapes.values() for k in chain)
-    device_bytes = int(workers) * int(batch) * rows * PROOF_BYTES_PER_ROW
+    widest = max(1 << int(k) for chain in shapes.values() for k in chain)
+    per_proof = (SCRATCH_BYTES_PER_ROW * widest + CHAIN_BYTES_PER_ROW * rows) if shared else PROOF_BYTES_PER_ROW * rows
+    device_bytes = int(workers) * int(batch) * per_proof
     workers_on_host = max(1, int(workers) * max(1, int(ranks_on_host)))
     host_threads = max(1, int(host_cpus) // workers_on_host)
     return {"host_threads_per_worker": host_threads, "host_threads_on_node": host_threads * workers_on_host, "worker_threads_on_node": workers_on_host,
-            "device_bytes_per_rank": device_bytes, "fits": device_bytes <= 0.9 * hbm_bytes}
+            "device_bytes_per_rank": device_bytes, "shared_scratch": bool(shared), "fits": device_bytes <= 0.9 * hbm_bytes}
 
 
 def shard_range(n_items, rank, world):
