@@ -213,6 +213,17 @@ def test_bench_resume_dir_builds_the_table_across_calls(tmp_path):
     assert two["config"]["root_public_inputs"] == rec["root_public_inputs"]
 
 
+def test_shared_prover_scratch_changes_no_proof(tmp_path):
+    """the provers of a context take their working buffers from one shared scratch (csrc/ctx.h; the default) or own them
+    (MP2G_SHARE_SCRATCH=0): the same 8-row table built both ways ends in the same root proof byte for byte, and the shared build plans and
+    uses less device memory"""
+    common = ["--rows", "8", "--steps", "1", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "4", "--table-blocks", "1"]
+    shared = _bench(common + ["--resume-dir", str(tmp_path / "a")])
+    own = _bench(common + ["--resume-dir", str(tmp_path / "b")], env={"MP2G_SHARE_SCRATCH": "0"})
+    assert shared["root_proof_with_vk_fnv1a64"] == own["root_proof_with_vk_fnv1a64"] and shared["root_public_inputs"] == own["root_public_inputs"]
+    assert shared["table_rows_total"] == 8 and shared["join_levels"] == 0
+
+
 @pytest.mark.parametrize("n_cols,rows", [(1, 2), (6, 3)])
 def test_other_column_counts(ctx, mp2, params, n_cols, rows):
     """the cells tree follows ryhope's sbbst for any number of value columns: one column = a lone leaf; six columns = leaves 1, 3, 5, a

@@ -144,6 +144,26 @@ if os.path.exists(f"{src}/sponge_pmc_summary.json"):
         sc = summary["step_counters"]
         sc["valu_wave_insts_per_framework_proof"] = sc["SQ_INSTS_VALU_total"] / sc["framework_proofs_in_the_run"]
 
+# ---- HBM traffic of the 2^22 NTT (TCC counters, separate passes; FETCH_SIZE calibrated in the same run on scale_powers_kernel, which
+# reads exactly 32768 KB with 8 B / lane loads: the guide's correction for that access pattern)
+if os.path.exists(f"{src}/traffic_FETCH_SIZE_summary.json") and os.path.exists(f"{src}/traffic_WRITE_SIZE_summary.json"):
+    fs = json.load(open(f"{src}/traffic_FETCH_SIZE_summary.json"))["kernels"]
+    ws = json.load(open(f"{src}/traffic_WRITE_SIZE_summary.json"))["kernels"]
+    per = lambda d, k, c: d[k][c] / d[k]["dispatches"]
+    sp = next(k for k in fs if "scale_powers" in k)
+    cal = 32768.0 / per(fs, sp, "FETCH_SIZE")
+    cols = next(k for k in fs if "ntt_cols" in k and "kernel<10" in k)
+    rows_k = next(k for k in fs if "ntt_rows" in k and "nat" not in k and "kernel<12, 0" in k)
+    fetch = (per(fs, cols, "FETCH_SIZE") + per(fs, rows_k, "FETCH_SIZE")) * cal * 1024
+    write = (per(ws, cols, "WRITE_SIZE") + per(ws, rows_k, "WRITE_SIZE")) * 1024
+    json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, in a separate pass, WRITE_SIZE) --kernel-trace --output-format csv -- python3 tools/dbg/traffic_run.py (tools/dbg/profile_r05.sh ntt)",
+               "units": "KB per dispatch as reported (mean over the dispatches of each kernel); FETCH_SIZE scaled by the factor calibrated in this same run on scale_powers_kernel",
+               "fetch_calibration_factor": cal,
+               "ntt_2p22_forward_bitrev": {"fetch_bytes_corrected": fetch, "write_bytes": write, "traffic_bytes": fetch + write, "algorithmic_bytes": 16 << 22,
+                                           "note": f"two launches ({cols}, {rows_k}); pass A also streams the 32 MiB 4-step twiddle table"}},
+              open(f"{dst}/ntt_traffic.json", "w"), indent=1)
+    summary["ntt_traffic_bytes"] = fetch + write
+
 # ---- the completed 2^20-row table
 rec = os.path.join(ROOT, "gpurun_out", "table_2p20_rows.json")
 if os.path.exists(rec):

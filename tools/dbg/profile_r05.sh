@@ -41,8 +41,10 @@ sweep)   # workers x batch with the pipelined forest, and the synchronous one be
   done; cat $O/sweep.txt ;;
 ntt)
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ntt -- python3 $R/bench.py --workload ntt --steps 20 --warmup 2 > $O/ntt.json 2> $O/ntt.err
-  for c in FETCH_SIZE WRITE_SIZE; do
+  for c in FETCH_SIZE WRITE_SIZE; do   # separate passes, no trace domains beside the counters (MI355X_MICROARCH.md, HBM / rocprofv3)
     timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/traffic_$c -- python3 $R/tools/dbg/traffic_run.py > /dev/null 2> $O/traffic_$c.err
+    python3 $R/tools/dbg/pmc_summary.py $O/traffic_$c $O/traffic_${c}_summary.json "tools/dbg/traffic_run.py: 6 calibration calls of scale_powers_kernel (exactly 32768 KB read), 10 forward 2^22 NTTs"
+    rm -rf $O/traffic_$c
   done ;;
 esac
 done
