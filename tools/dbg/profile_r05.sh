@@ -40,7 +40,7 @@ sweep)   # workers x batch with the pipelined forest, and the synchronous one be
     MP2G_FOREST_SYNC=$3 python3 $R/bench.py --steps 10 --warmup 2 --rows 1024 --workers $1 --table-batch $2 $QUIET 2> $O/sweep.err | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('workers $1 batch $2 sync $3:', round(d['value'],1), 'proofs/s')" >> $O/sweep.txt
   done; cat $O/sweep.txt ;;
 ntt)
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ntt -- python3 $R/bench.py --workload ntt --steps 20 --warmup 2 > $O/ntt.json 2> $O/ntt.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ntt -- python3 $R/bench.py --workload ntt --steps 50 --warmup 1000 > $O/ntt.json 2> $O/ntt.err   # as bench.py's roofline leg: 1000 untimed transforms (the clocks settle), 50 timed
   for c in FETCH_SIZE WRITE_SIZE; do   # separate passes, no trace domains beside the counters (MI355X_MICROARCH.md, HBM / rocprofv3)
     timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/traffic_$c -- python3 $R/tools/dbg/traffic_run.py > /dev/null 2> $O/traffic_$c.err
     python3 $R/tools/dbg/pmc_summary.py $O/traffic_$c $O/traffic_${c}_summary.json "tools/dbg/traffic_run.py: 6 calibration calls of scale_powers_kernel (exactly 32768 KB read), 10 forward 2^22 NTTs"
