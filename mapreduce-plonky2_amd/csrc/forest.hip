@@ -474,7 +474,20 @@ int mp2g_forest_prove_plan(mp2g_forest* f, mp2g_update_plan* plan, uint32_t grou
       if (items.empty()) break;
       size_t total = 0;
       for (auto& it : items) total += it.size();
-      const size_t target = std::max<size_t>(1, std::min<size_t>(group_nodes ? group_nodes : 1, (total + f->n_workers - 1) / f->n_workers));
+      // units of about group_nodes plan nodes, never fewer units than workers -- and SHRINKING towards the end of the wave (half of
+      // what is left per worker, down to a sixth of group_nodes): the workers pull units in order, and a wave ends when the last
+      // unit does; with units of one size the last ones run beside idle workers (a 2^16-row block: the last 9 % of the proofs at
+      // 0.73 of the rate, profiles/r05/block_2p16_progress.txt). MP2G_FOREST_FIXED_UNITS=1 keeps one size (the A/B switch).
+      static const bool fixed_units = [] { const char* e = getenv("MP2G_FOREST_FIXED_UNITS"); return e && atoi(e); }();
+      const size_t cap = std::max<size_t>(1, std::min<size_t>(group_nodes ? group_nodes : 1, (total + f->n_workers - 1) / f->n_workers));
+      const size_t floor_nodes = std::max<size_t>(1, (group_nodes ? group_nodes : 1) / 6);
+      size_t assigned = 0;
+      auto target_now = [&]() -> size_t {
+        if (fixed_units) return cap;
+        const size_t guided = (total - assigned) / (2 * (size_t)f->n_workers);
+        return std::min(cap, std::max(floor_nodes, guided));
+      };
+      size_t target = target_now();
       std::vector<uint64_t> nodes;
       std::vector<uint32_t> offs{0};
       size_t in_group = 0;
@@ -484,7 +497,7 @@ int mp2g_forest_prove_plan(mp2g_forest* f, mp2g_update_plan* plan, uint32_t grou
           nodes.push_back(k);
         }
         in_group += it.size();
-        if (in_group >= target) { offs.push_back((uint32_t)nodes.size()); in_group = 0; }
+        if (in_group >= target) { offs.push_back((uint32_t)nodes.size()); assigned += in_group; in_group = 0; target = target_now(); }
       }
       if (in_group) offs.push_back((uint32_t)nodes.size());
       const int rc = mp2g_forest_prove(f, nodes.data(), offs.data(), (uint32_t)offs.size() - 1);
