@@ -40,6 +40,12 @@ uint64_t mp2g_stat_leaf_permutations(void);
 /* ---- library / context ------------------------------------------------------------------ */
 const char* mp2g_last_error(void);
 int mp2g_device_count(void);
+/* A context = one device, one HIP stream, ONE host thread proving at a time. Every prover created on a context takes its
+ * per-batch working buffers (LDE values, Merkle levels, quotient values, FRI layers ...) from the context's shared scratch,
+ * which is safe because their launches are ordered on that one stream: a host that wants several proofs in flight
+ * concurrently creates one context per worker thread. Environment: MP2G_SHARE_SCRATCH=0 gives every prover buffers of
+ * its own (about three times the device memory of a table build; the same proofs). Fails when no HIP device is visible:
+ * there is no CPU path. */
 int mp2g_ctx_create(int device, mp2g_ctx** out);
 void mp2g_ctx_destroy(mp2g_ctx* ctx);
 int mp2g_ctx_sync(mp2g_ctx* ctx);
@@ -511,6 +517,10 @@ int mp2g_forest_create(uint32_t n_workers, mp2g_ctx* const* ctxs, uint32_t n_cir
                        mp2g_chain* const* chains, uint32_t slot_words, uint32_t pool_slots, mp2g_forest** out);
 int mp2g_forest_add_nodes(mp2g_forest* f, uint32_t circuit, uint32_t count, const uint64_t* ids, const uint64_t* child_ids /* [count][n_children] */,
                           const uint64_t* consts /* [count][n_const] */, const uint8_t* keep /* [count] or NULL */);
+/* (one mp2g_forest_prove / mp2g_forest_prove_plan call at a time per forest: the call starts the forest's worker threads itself.
+ * Inside it a worker keeps up to two batches queued behind the running one; a node counts as proved, and its children's pool
+ * slots return, when its batch has been CONFIRMED -- witness flags read, one batch late; a failure rolls the queued batches back.
+ * A worker that finds the pool empty waits for slots and fails only when every worker of the call waits.) */
 int mp2g_forest_prove(mp2g_forest* f, const uint64_t* unit_nodes, const uint32_t* unit_offsets /* [n_units + 1] */, uint32_t n_units);
 /* the harness loop over an update plan (declared below), inside the library: drain the Ready items of a wave, group them into units of
  * about group_nodes plan nodes (never fewer units than workers), prove, mark done, until the plan is finished. A plan node k stands for
