@@ -517,6 +517,13 @@ int mp2g_forest_create(uint32_t n_workers, mp2g_ctx* const* ctxs, uint32_t n_cir
                        mp2g_chain* const* chains, uint32_t slot_words, uint32_t pool_slots, mp2g_forest** out);
 int mp2g_forest_add_nodes(mp2g_forest* f, uint32_t circuit, uint32_t count, const uint64_t* ids, const uint64_t* child_ids /* [count][n_children] */,
                           const uint64_t* consts /* [count][n_const] */, const uint8_t* keep /* [count] or NULL */);
+/* How mp2g_forest_prove_plan cuts one wave of Ready items into units (a host that drives mp2g_forest_prove itself can use the same
+ * cut): the items in order and whole, units of about group_nodes plan nodes (item i counts item_sizes[i]), at least as many units as
+ * workers, shrinking towards the end of the wave (half of what is left per worker, never below group_nodes / 6) so that the last
+ * units do not run beside idle workers. unit u = items [unit_first_item[u], unit_first_item[u + 1]); unit_first_item has room for
+ * n_items + 1 entries. Pure host arithmetic: needs no GPU. */
+int mp2g_forest_group_units(const uint32_t* item_sizes, uint32_t n_items, uint32_t n_workers, uint32_t group_nodes,
+                            uint32_t* unit_first_item, uint32_t* n_units);
 /* (one mp2g_forest_prove / mp2g_forest_prove_plan call at a time per forest: the call starts the forest's worker threads itself.
  * Inside it a worker keeps up to two batches queued behind the running one; a node counts as proved, and its children's pool
  * slots return, when its batch has been CONFIRMED -- witness flags read, one batch late; a failure rolls the queued batches back.

@@ -437,6 +437,36 @@ int mp2g_forest_prove(mp2g_forest* f, const uint64_t* unit_nodes, const uint32_t
   return 0;
 }
 
+// Units of one wave: the wave's items (item i = item_sizes[i] plan nodes, kept whole) in order, in units of about group_nodes
+// nodes, never fewer units than workers -- and SHRINKING towards the end of the wave (half of what is left per worker, down to a
+// sixth of group_nodes): the workers pull units in order, and a wave ends when the last unit does; with units of one size the last
+// ones run beside idle workers (a 2^16-row block: the last 9 % of the proofs at 0.73 of the rate, profiles/r05/block_2p16_progress.txt).
+// MP2G_FOREST_FIXED_UNITS=1 keeps one size (the A/B switch). unit u = items [unit_first_item[u], unit_first_item[u + 1]).
+int mp2g_forest_group_units(const uint32_t* item_sizes, uint32_t n_items, uint32_t n_workers, uint32_t group_nodes, uint32_t* unit_first_item,
+                            uint32_t* n_units) {
+  NEED((item_sizes || !n_items) && unit_first_item && n_units && n_workers >= 1, "items / outputs / workers");
+  static const bool fixed_units = [] { const char* e = getenv("MP2G_FOREST_FIXED_UNITS"); return e && atoi(e); }();
+  size_t total = 0;
+  for (uint32_t i = 0; i < n_items; i++) total += item_sizes[i];
+  const size_t cap = std::max<size_t>(1, std::min<size_t>(group_nodes ? group_nodes : 1, (total + n_workers - 1) / n_workers));
+  const size_t floor_nodes = std::max<size_t>(1, (group_nodes ? group_nodes : 1) / 6);
+  size_t assigned = 0, in_group = 0;
+  auto target_now = [&]() -> size_t {
+    if (fixed_units) return cap;
+    return std::min(cap, std::max(floor_nodes, (total - assigned) / (2 * (size_t)n_workers)));
+  };
+  size_t target = target_now();
+  uint32_t nu = 0;
+  unit_first_item[0] = 0;
+  for (uint32_t i = 0; i < n_items; i++) {
+    in_group += item_sizes[i];
+    if (in_group >= target) { unit_first_item[++nu] = i + 1; assigned += in_group; in_group = 0; target = target_now(); }
+  }
+  if (in_group) unit_first_item[++nu] = n_items;
+  *n_units = nu;
+  return 0;
+}
+
 // The reference harness's loop (mp2-v1/tests/common/rowtree.rs:78-337 with into_batched_workplan): drain every item that is Ready,
 // prove it, mark it done, until the plan is finished -- with the items of a wave grouped into units of about group_nodes plan nodes
 // (never fewer units than workers while the wave has the items). A plan node k stands for the forest node k and for its n_satellites
@@ -472,34 +502,20 @@ int mp2g_forest_prove_plan(mp2g_forest* f, mp2g_update_plan* plan, uint32_t grou
         items.push_back(std::move(keys));
       }
       if (items.empty()) break;
-      size_t total = 0;
-      for (auto& it : items) total += it.size();
-      // units of about group_nodes plan nodes, never fewer units than workers -- and SHRINKING towards the end of the wave (half of
-      // what is left per worker, down to a sixth of group_nodes): the workers pull units in order, and a wave ends when the last
-      // unit does; with units of one size the last ones run beside idle workers (a 2^16-row block: the last 9 % of the proofs at
-      // 0.73 of the rate, profiles/r05/block_2p16_progress.txt). MP2G_FOREST_FIXED_UNITS=1 keeps one size (the A/B switch).
-      static const bool fixed_units = [] { const char* e = getenv("MP2G_FOREST_FIXED_UNITS"); return e && atoi(e); }();
-      const size_t cap = std::max<size_t>(1, std::min<size_t>(group_nodes ? group_nodes : 1, (total + f->n_workers - 1) / f->n_workers));
-      const size_t floor_nodes = std::max<size_t>(1, (group_nodes ? group_nodes : 1) / 6);
-      size_t assigned = 0;
-      auto target_now = [&]() -> size_t {
-        if (fixed_units) return cap;
-        const size_t guided = (total - assigned) / (2 * (size_t)f->n_workers);
-        return std::min(cap, std::max(floor_nodes, guided));
-      };
-      size_t target = target_now();
+      std::vector<uint32_t> sizes(items.size()), first(items.size() + 1);
+      for (size_t i = 0; i < items.size(); i++) sizes[i] = (uint32_t)items[i].size();
+      uint32_t n_units = 0;
+      { const int rg = mp2g_forest_group_units(sizes.data(), (uint32_t)sizes.size(), f->n_workers, group_nodes, first.data(), &n_units); if (rg) return rg; }
       std::vector<uint64_t> nodes;
       std::vector<uint32_t> offs{0};
-      size_t in_group = 0;
-      for (auto& it : items) {
-        for (uint64_t k : it) {
-          for (uint32_t j = 0; j < n_satellites; j++) nodes.push_back(((uint64_t)(j + 1) << satellite_shift) | k);
-          nodes.push_back(k);
-        }
-        in_group += it.size();
-        if (in_group >= target) { offs.push_back((uint32_t)nodes.size()); assigned += in_group; in_group = 0; target = target_now(); }
+      for (uint32_t u = 0; u < n_units; u++) {
+        for (uint32_t i = first[u]; i < first[u + 1]; i++)
+          for (uint64_t k : items[i]) {
+            for (uint32_t j = 0; j < n_satellites; j++) nodes.push_back(((uint64_t)(j + 1) << satellite_shift) | k);
+            nodes.push_back(k);
+          }
+        offs.push_back((uint32_t)nodes.size());
       }
-      if (in_group) offs.push_back((uint32_t)nodes.size());
       const int rc = mp2g_forest_prove(f, nodes.data(), offs.data(), (uint32_t)offs.size() - 1);
       if (rc) return rc;
       for (uint64_t k : roots) {

@@ -176,3 +176,32 @@ def test_from_map():
     assert len(wp.UpdateTree.from_map(0, 1, {})) == 0
     with pytest.raises(mp2.Mp2gError):
         wp.UpdateTree.from_map(0, 1, {1: (2, 2), 2: (None, None)})  # duplicated key found
+
+
+def test_forest_units_shrink_towards_the_end_of_a_wave(mp2):
+    """mp2g_forest_group_units (pure host arithmetic, no GPU): the items of a wave stay whole and in order; units are capped at
+    group_nodes and at an even share per worker; towards the end of the wave they shrink to half of what is left per worker and never
+    below group_nodes / 6 -- so the last units are short and no worker idles for a whole unit"""
+    import ctypes
+    import numpy as np
+    lib = mp2.load()
+
+    def units(sizes, workers, group):
+        a = np.asarray(sizes, dtype=np.uint32)
+        first = np.zeros(len(a) + 1, dtype=np.uint32)
+        n = ctypes.c_uint32()
+        mp2._ck(lib.mp2g_forest_group_units(mp2._p(a), len(a), workers, group, mp2._p(first), ctypes.byref(n)))
+        f = first[:n.value + 1].tolist()
+        assert f[0] == 0 and f[-1] == len(a) and all(x < y for x, y in zip(f, f[1:]))
+        return [int(a[lo:hi].sum()) for lo, hi in zip(f, f[1:])]
+
+    # the driver's block: 512 subtrees of 40 rows, 4 workers, units of <= 1536 rows
+    u = units([40] * 512, 4, 1536)
+    assert sum(u) == 20480 and max(u) == 1560 and u[0] == 1560          # whole items: 39 x 40 rows pass the 1536 mark
+    assert u[-1] <= 280 and min(u[:-1]) >= 256                          # the tail: a sixth of the cap (the last unit takes what is left)
+    assert all(x >= y for x, y in zip(u, u[1:-1]))                      # never growing
+    assert sum(1 for x in u if x < 1536) >= 6
+    # a narrow wave: at least one unit per worker, an even share each
+    assert units([63] * 16, 4, 1536) == [252] * 4
+    # one item, no items
+    assert units([64], 4, 1536) == [64] and units([], 4, 1536) == []
