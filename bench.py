@@ -680,7 +680,7 @@ def main(argv=None):
                     "the reference's leaf gate set (SURVEY 8(d): base degrees k = 12..15); 0 = the circuits' natural degrees (the headline)")
     ap.add_argument("--degree-sweep", default="12,13,14,15", help="--workload table at N = 1: after the headline, the table rate at these base degrees (one block of "
                     "--sweep-rows rows each) in the same line as `by_base_degree`; '' = skip")
-    ap.add_argument("--sweep-rows", type=int, default=1024, help="rows of the block timed at every base degree of --degree-sweep (halved per degree above 13)")
+    ap.add_argument("--sweep-rows", type=int, default=1024, help="rows of the block timed at every base degree of --degree-sweep (halved above k = 14)")
     ap.add_argument("--sweep-runs", type=int, default=3, help="builds of that block per base degree; the median is reported")
     ap.add_argument("--config2-leaves", type=int, default=1024, help="--workload table at N = 1: leaves of the BASELINE configs[2] leg (2-to-1 aggregation of real leaf proofs, "
                     "2 x leaves - 1 framework proofs) reported as `config2`; 0 = skip")
@@ -1235,8 +1235,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                         raise
                     bk = max(4, 3 * bk // 4)
             try:
-                # the block shrinks above k = 13 (the same wall time per run at every degree), never below 64 rows
-                rows_k = max(min(64, args.sweep_rows), args.sweep_rows >> max(0, k - 13))
+                # the full block up to k = 14 (1024 rows by default), half of it at k = 15 (a run there is 15 s as it is), never below 64 rows
+                rows_k = max(min(64, args.sweep_rows), args.sweep_rows >> max(0, k - 14))
                 rk.build(min(64, rows_k), 0, seed ^ 0x5A5A5A, n_cols, False)
                 runs = []
                 for rep in range(max(1, args.sweep_runs)):  # the same block proved again: one work plan each, the median reported
