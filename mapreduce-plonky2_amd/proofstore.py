@@ -68,7 +68,9 @@ class ProofStore:
         return os.path.join(self.path, f"{key.kind}_{key.compute_hash():016x}.{ext}")
 
     def _write(self, name, data):
-        tmp = name + ".tmp"
+        # a temporary name of this writer's own: two ranks storing under one key must not share it (the later rename wins, whole)
+        import threading
+        tmp = f"{name}.{os.getpid()}.{threading.get_ident()}.tmp"
         with open(tmp, "wb") as f:
             f.write(data)
             f.flush()

@@ -1,6 +1,7 @@
 """Worker for tests/test_distributed_gloo.py: world_size ranks over gloo on CPU. The local compute
 step is played by the CPU oracle (tests may use it); what is under test is the product's sharding /
 collective plumbing in mapreduce-plonky2_amd/sharding.py, which bench.py uses unchanged over RCCL."""
+import hashlib
 import importlib
 import os
 import sys
@@ -114,6 +115,29 @@ def main():
         counts = sh.all_gather_words(dist, [len(proved_here)])
         assert int(counts.sum()) == len(parent), "every node is proved exactly once across the ranks"
         assert world == 1 or int(counts.min()) > 0, "no rank may sit idle on a 60-node tree"
+    # ---- the proof store shared by the ranks of a host (mapreduce-plonky2_amd/proofstore.py; mp2-v1/tests/common/proof_storage.rs): every
+    # rank keeps its block root under its own ProofKey and re-writes one key all ranks share (the latest proof under a key counts, and
+    # a reader never sees half a proof: files are renamed into place); rank 0 then takes every rank's proof out, as the call that
+    # joins the blocks of `bench.py --resume-dir` does
+    import tempfile
+    PS = importlib.import_module("mapreduce-plonky2_amd.proofstore")
+    path = [tempfile.mkdtemp(prefix="mp2g_store_") if rank == 0 else None]
+    dist.broadcast_object_list(path, src=0)
+    store = PS.ProofStore(path[0])
+    blob = lambda r: hashlib.sha256(bytes([r])).digest() * 4096  # 128 KB: the size of a ProofWithVK blob
+    store.store_proof(PS.ProofKey.row("gloo_table", 1, f"{rank:064x}"), blob(rank), {"block": rank})
+    shared = PS.ProofKey.row("gloo_table", 1, "shared")
+    for _ in range(8):
+        store.store_proof(shared, blob(rank))
+        got = store.get_proof_exact(shared)
+        assert len(got) == 32 * 4096 and got[:32] * 4096 == got, "a reader saw a torn proof"
+    dist.barrier()
+    if rank == 0:
+        for r in range(world):
+            assert store.get_proof_exact(PS.ProofKey.row("gloo_table", 1, f"{r:064x}")) == blob(r) and store.note(PS.ProofKey.row("gloo_table", 1, f"{r:064x}")) == {"block": r}
+        assert len(store.keys()) == world + 1
+        import shutil
+        shutil.rmtree(path[0])
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} ok")
