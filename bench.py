@@ -700,6 +700,9 @@ def main(argv=None):
                          "reduce circuits of recursion-framework/tests/integration.rs with universal verifiers, wrapped to the shared "
                          "shape; witnesses by the recorded witness programs on host threads, inside the timed region")
     args = ap.parse_args(argv)
+    if args.resume_dir and (args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1):
+        raise SystemExit("bench.py: --resume-dir builds the blocks one after another on ONE GPU (the single-GPU rehearsal of the N-rank run); "
+                         "with N GPUs every rank builds its block in one call: drop --resume-dir and pass --gpus N")
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
     clocks = ClockReader()  # before anything initialises the GPU

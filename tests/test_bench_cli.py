@@ -19,3 +19,12 @@ def test_gpus_n_without_devices_is_refused_with_a_message():
 def test_default_workload_is_the_table_build():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "table (default, the headline)" in " ".join(r.stdout.split())
+
+
+def test_resume_dir_is_a_single_gpu_mode(tmp_path):
+    """`--resume-dir` builds the table's blocks one after another on one GPU; asked for together with several GPUs it says so before
+    any rank is started or any GPU touched"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MP2G_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--resume-dir", str(tmp_path / "s")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "--resume-dir builds the blocks one after another on ONE GPU" in r.stderr + r.stdout
+    assert not (tmp_path / "s").exists()
