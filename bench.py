@@ -4,14 +4,15 @@
     python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Default workload (`--workload table`, run_table below): BASELINE configs[3] as ONE contiguous block of `--steps` x `--rows` table
-rows per rank (a step = `--rows` rows; the driver's `--steps 20` = a 20480-row block, row tree 15 levels deep, one work plan).
+Default workload (`--workload table`, run_table below): BASELINE configs[3] as ONE contiguous block of table rows per rank. Without
+`--rows` (the driver's command) the block is 2^17 rows -- a step is 1/`--steps` of it -- so that `--gpus 8` builds the metric's
+whole 2^20-row table (8 blocks + 7 separator rows, three join levels) and 1 / 2 / 4 GPUs the same block per rank; with `--rows R` a
+step is R rows and the block `--steps` x R. The warm-up block is `--warmup` steps, at most 5120 rows. One work plan per block.
 Per row the reference proves 4 cells-tree nodes and 1 row-tree node, each a framework proof (witness generation, base prove(),
 wrap chain to 2^12 rows: recursion-framework/src/circuit_builder.rs:286-311, wrap_circuit.rs:122-148); here they are REAL
 circuits with the reference's tree logic (mapreduce-plonky2_amd/table.py), their witnesses replayed on the device
 (mp2g_witness_program_run_dev), the row tree scheduled by ryhope's batched work plan (mp2g_update_plan_*), the rows' multiset
-digests computed inside the timed region. value = framework proofs per second (5 per row); the 2^20-row build is extrapolated
-from it (it does not fit one GPU in a bench run). At N = 1 the same JSON line carries BASELINE's other single-GPU configurations:
+digests computed inside the timed region. value = framework proofs per second (5 per row). At N = 1 the same JSON line carries BASELINE's other single-GPU configurations:
 `config2` = configs[2] at full size (1024 real leaf proofs aggregated 2-to-1: 2047 framework proofs), `by_base_degree` = the table
 rate with every base circuit padded to 2^k rows, k = 12..15, and carrying the reference's leaf gate set (the
 reference's real base degrees lie there), `leaves_prove_only` = round 2's headline (`--workload leaves`: prove() only, synthetic
@@ -24,7 +25,9 @@ the gate terms, FRI). "verified": k counts those prove() calls; any mismatch mak
 the `cpu_baseline` sample at N=1 (plus 1-thread / all-thread medians of 5 on one fixed prove() call, CPU model printed).
 
 Rows shard across ranks as blocks with no data-path collective ("scaling": "weak"); log2(N) join levels above the block roots
-move one final proof each, device to device over RCCL.
+move one final proof each, device to device over RCCL. Before anything is timed every join pair moves a small libmp2gpu-allocated
+buffer the same way (sharding.probe_handoff); if that fails anywhere, all levels use the staged hand-off (download + torch tensor)
+and `config.sharding` says so.
 
 The NTT half of the metric is the `roofline` object: BASELINE configs[1]'s 2^22-point forward NTT, timed with HIP events on the
 context's stream in this same run, algorithmic 16 B/point.
@@ -659,7 +662,9 @@ def main(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle self-check of the sampled proofs")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work for the cpu_baseline sample")
     ap.add_argument("--trees", type=int, default=8, help="--workload recursion: independent trees per rank and step, one host thread + GPU stream each")
-    ap.add_argument("--rows", type=int, default=1024, help="--workload table: table rows per rank and step (5 framework proofs each)")
+    ap.add_argument("--rows", type=int, default=None, help="--workload table: table rows per rank and step (5 framework proofs each). Unset (the driver's command): the "
+                    "rank's block is 2^17 rows whatever --steps says -- a step is 1/steps of it -- so that 8 ranks build the metric's 2^20-row table (8 x 2^17 rows + 7 "
+                    "separator rows) and 1 / 2 / 4 ranks the same block per rank (weak scaling that ends on the named configuration); see block_plan()")
     ap.add_argument("--workers", type=int, default=4, help="--workload table: concurrent work-plan items per rank, one host thread + GPU stream + prover set each")
     ap.add_argument("--table-batch", type=int, default=48, help="--workload table: proofs per prove() launch sequence of a worker (round 5: 4 x 48 in flight = 238 GB of the "
                     "GPU's 288 does 912 proofs/s where 4 x 32 = 162 GB does 842: the per-batch latency kernels -- witness replay, transcript, tree tops -- are paid once per 48 proofs; "
@@ -1008,6 +1013,27 @@ def config2_leg(rig, n_leaves, seed=0xC0FFEE03):
             "setup_s": round(setup_s, 1), "root_verified": True, "root_public_inputs": [int(x) for x in pis]}
 
 
+DEFAULT_BLOCK_ROWS = 1 << 17   # rows of one rank's block when --rows is not given: 8 ranks x 2^17 = BASELINE configs[3]'s 2^20-row table
+WARMUP_ROWS_CAP = 5120         # the warm-up block creates the provers of every circuit; more rows than this add nothing to that
+
+
+def block_plan(rows, steps, warmup, default_rows=None):
+    """Rows of a rank's timed block and of its warm-up block. `rows` given: steps x rows (a step = `rows` rows). `rows` None: the block
+    is `default_rows` rows (2^17; MP2G_BENCH_BLOCK_ROWS scales the default down for tests) and a step is 1/steps of it -- steps - 1
+    steps of ceil(block / steps) rows and a shorter last one; the block is ONE work plan either way, steps are only the unit of
+    ms_per_step. The warm-up block is warmup steps, never more than WARMUP_ROWS_CAP rows. Returns (block rows, rows per step, warm-up rows)."""
+    steps = max(1, int(steps))
+    if rows is None:
+        n_rows = int(default_rows if default_rows is not None else os.environ.get("MP2G_BENCH_BLOCK_ROWS", DEFAULT_BLOCK_ROWS))
+        assert n_rows >= 1
+        per_step = -(-n_rows // steps)
+    else:
+        per_step = int(rows)
+        n_rows = steps * per_step
+    warm = min(max(0, int(warmup)) * per_step, WARMUP_ROWS_CAP)
+    return n_rows, per_step, warm
+
+
 def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     """--workload table (the default, the headline): BASELINE configs[3] as ONE contiguous block of `--steps` x `--rows` table rows per
     rank. Per row the reference proves C = 4 cells-tree nodes (ryhope sbbst over the value columns: two leaves, a full node, a partial
@@ -1021,9 +1047,9 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     -- value digests, their accumulation up both trees, row ids (mp2g_map_to_curve_batch, mp2g_row_digests, mp2g_curve_sum_ranges) --
     is inside the timed region too.
 
-    A STEP is `--rows` rows (5 x rows framework proofs). The W warm-up steps are one contiguous block of W x rows rows (other rows than
-    the timed ones; it creates the provers), the K timed steps one contiguous block of K x rows rows -- one work plan, a row tree
-    log2(K x rows) deep -- not K rebuilds of the same rows. With several ranks every rank builds its own block and log2(ranks) join
+    A STEP is `--rows` rows (5 x rows framework proofs); without `--rows` the block is 2^17 rows and a step 1/K of it (block_plan).
+    The W warm-up steps are one contiguous block of W steps' rows, 5120 at most (other rows than the timed ones; it creates the
+    provers), the K timed steps one contiguous block -- one work plan, a row tree log2(rows) deep -- not K rebuilds of the same rows. With several ranks every rank builds its own block and log2(ranks) join
     levels follow inside the timed region: the owner of a parent receives the other block's root proof (device to device over RCCL)
     and proves the separator row between the blocks. value = framework proofs per second.
 
@@ -1047,7 +1073,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     rig = TableRig(mods, local_rank, VARIANT, args.workers, args.table_batch, args.subtree, args.host_witness, ranks_here, pad_bits=args.pad_base_bits,
                    group_rows=args.group_rows, native=args.native_build)
     params, ctx = rig.params, rig.ctx
-    n_rows = max(1, args.steps) * args.rows           # the timed block of this rank
+    n_rows, rows_per_step, warm_rows = block_plan(args.rows, args.steps, args.warmup)  # the timed block of this rank, and its warm-up block
     lean = args.lean or n_rows > 16384                # a block this large keeps the frontier of the tree + the sampled nodes only
     nccl = dist is not None and dist.get_backend() == "nccl"
     dev = torch.device("cuda", local_rank) if nccl else None
@@ -1094,7 +1120,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
             head = head.cpu().numpy()
             other = sharding.recv_device_proof(dist, proof_sizes, rank + bit, dev)
             cur = T.join_blocks(rig.join_build(), ctx, cur, (other, names[int(head[0])], head[1:6].view(np.uint64)), 2 * (rank + bit) - 1, n_cols, seed_, VARIANT)
-            rig.n_proofs += 5
+            rig.n_proofs += n_cols + 1  # the separator row: its cells tree (one proof per value column) and its row node
         return st, cur
 
     def barrier():
@@ -1110,8 +1136,26 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
         dist.all_reduce(one)
         rccl_ranks = int(one.item())
         assert rccl_ranks == world, f"{rccl_ranks} of {world} ranks answered"
-    if args.warmup > 0:  # the warm-up block creates the provers of every circuit (with --warmup 0 that falls into the timed region)
-        block(args.warmup * args.rows, seed ^ 0x5A5A5A, args.lean or args.warmup * args.rows > 16384)
+        # every join pair moves one small buffer the way its root proof will move -- under RCCL a view of a buffer allocated by
+        # libmp2gpu, the one thing single-GPU tests cannot exercise; if any pair's direct send fails, ALL levels use the staged
+        # hand-off (download + torch tensor). Decided here, before t0; the line's config.sharding names the mode.
+        def direct(words):
+            buf = ctx.to_device(words)
+            ctx.sync()
+            if os.environ.get("MP2G_HANDOFF_PROBE_FAIL") == str(rank):  # test knob: this rank's direct send "fails"
+                raise RuntimeError("MP2G_HANDOFF_PROBE_FAIL")
+            if not nccl:  # (the knob under gloo: the other ranks' "direct" tensors are host tensors)
+                return staged(words)
+            return torch.as_tensor(sharding._RawView(buf.ptr.value, len(words), buf), device=dev)
+
+        def staged(words):
+            t = torch.from_numpy(np.ascontiguousarray(words, dtype=np.uint64).view(np.int64).copy())
+            return t.to(dev) if nccl else t
+        handoff = sharding.probe_handoff(dist, direct if nccl or os.environ.get("MP2G_HANDOFF_PROBE_FAIL") else None, staged, dev)
+    else:
+        handoff = {"mode": None, "reason": None}
+    if warm_rows > 0:  # the warm-up block creates the provers of every circuit (with --warmup 0 that falls into the timed region)
+        block(warm_rows, seed ^ 0x5A5A5A, args.lean or warm_rows > 16384)
     barrier()
     n0, perms0 = rig.n_proofs, mp2.leaf_permutations_queued()
     t0 = time.perf_counter()
@@ -1277,7 +1321,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     out = None
     full_rec = completed_table_record()
     if rank == 0:
-        rows_per_s = world * n_rows / dt
+        rows_per_s = (world * n_rows + world - 1) / dt
         depth = max(1, (n_rows - 1).bit_length())
         out = {"metric": "leaf proofs/sec (whole node) + NTT GB/s vs HBM peak, 2^20-row table build, 1/2/4/8 GPU",
                "value": n_total / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -1285,16 +1329,18 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                "dtype": "u64 (Goldilocks field)", "data": "synthetic", "verified": verified,
                "rows_per_s": rows_per_s,
                "table_2p20_rows_extrapolated_s": (1 << 20) / rows_per_s + (digest_ms or 0) / 1e3,  # = the measured time when this run is the whole table
-               "table_rows_total": world * n_rows,
+               "table_rows_total": world * n_rows + world - 1,  # the ranks' blocks and the separator rows between them
                "table_digest_2p20_rows_ms": digest_ms,
-               "config": {"workload": f"table: configs[3], ONE contiguous block of {n_rows} rows per rank (= {args.steps} steps x {args.rows} rows; row tree {depth} levels deep, one work plan) "
+               "config": {"workload": f"table: configs[3], ONE contiguous block of {n_rows} rows per rank (= {args.steps} steps of " + (f"{rows_per_step} rows" if args.rows is not None else
+                                      f"1/{args.steps} of the block, {rows_per_step} rows but for the last: --rows unset = the 2^17-row block of the metric's table") +
+                                      f"; row tree {depth} levels deep, one work plan" + (f"; {world} blocks + {world - 1} separator rows = {world * n_rows + world - 1} rows, joined in {n_levels} level(s)" if world > 1 else "") + ") "
                                       f"-- per row {n_cols} cells-tree proofs (2 leaves, 1 full, 1 partial) + 1 row-tree proof (leaf / partial / full + the cells root through the "
                                       "cells-set verifier gadget), all REAL framework proofs = witness program + base prove() + wrap chain to 2^12 rows, witness check on; row tree "
                                       "scheduled by the batched UpdateTree work plan; the rows' multiset digests (map-to-curve, row ids, accumulation up both trees) inside the timed "
                                       "region; value = framework proofs/s (5 per row). " + ("THIS IS the full 2^20-row build of configs[3]" if world * n_rows >= 1 << 20 else
                                       full_table_note(full_rec)) + "; configs[2] at "
                                       "full size = `config2`; base degrees 12..15 = `by_base_degree`; roofline leg = configs[1] 2^22-point NTT",
-                          "rows_per_rank": n_rows, "rows_per_step": args.rows, "row_tree_depth": depth, "warmup_rows_per_rank": args.warmup * args.rows,
+                          "rows_per_rank": n_rows, "rows_per_step": rows_per_step, "row_tree_depth": depth, "warmup_rows_per_rank": warm_rows,
                           "value_columns": n_cols, "workers": workers, "batch": args.table_batch, "subtree_size": args.subtree, "group_rows": args.group_rows or 32 * args.table_batch, "pad_base_bits": args.pad_base_bits,
                           "lean": bool(lean), "host_orchestration": glue,  # the workers' time in the timed block: total, inside the C ABI (mp2g_chain_run), the rest = Python glue
                           "work_plan_waves": waves,  # (the native scheduler drains the plan inside the library and reports the items per wave only)  # per wave of the work plan: [items, framework proofs, seconds]
@@ -1307,7 +1353,11 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                           "setup_s": round(setup_s, 1), "hasher": "Poseidon2", "backend": (dist.get_backend() if dist is not None else None), "rccl_ranks": rccl_ranks,
                           "join_levels": n_levels,
                           "sharding": f"{world} rank(s): one block of rows each, no collective below the block roots; {n_levels} join level(s) move a root proof point to point "
-                                      f"({sum(proof_sizes) * 8} B" + (")" if world == 1 else ", device to device over RCCL into the parent's device-side witness inputs)" if nccl else ", host tensors over gloo)"),
+                                      f"({sum(proof_sizes) * 8} B" + (")" if world == 1 else
+                                          ", device to device over RCCL straight from the prover's buffers into the parent's device-side witness inputs; path chosen by the pre-timing probe: every join pair moved a libmp2gpu-allocated buffer)" if nccl and handoff["mode"] == "device" else
+                                          f", STAGED: downloaded by the sender, sent as a torch tensor -- chosen before t0 because the pre-timing probe of the direct path failed: {handoff['reason']})" if handoff["mode"] == "staged" else
+                                          ", host tensors over gloo; every join pair probed before t0)"),
+                          "handoff": handoff,
                           "root_public_inputs": root_pis_out,
                           "verified": f"{verified} prove() calls: on every rank the block root passes the oracle's verifier and one framework proof of every circuit kind of the timed "
                                       "block equals the CPU oracle's proofs of the same witnesses bit for bit and passes its verifier; the block roots expose the off-circuit "
@@ -1392,7 +1442,7 @@ def run_table_resumable(args, local_rank, VARIANT, clocks):
     import oracle as O
     n_cols, seed, blocks = 4, 0xC0FFEE04, args.table_blocks
     assert blocks >= 1 and blocks & (blocks - 1) == 0, "--table-blocks: a power of two (binary join levels)"
-    n_rows = max(1, args.steps) * args.rows
+    n_rows, _, warm_rows = block_plan(args.rows, args.steps, args.warmup)
     table_id = f"synthetic_{seed:x}_{blocks}x{n_rows}"
     store = PS.ProofStore(args.resume_dir)
     rig = TableRig(mods, local_rank, VARIANT, args.workers, args.table_batch, args.subtree, False, 1, pad_bits=args.pad_base_bits,
@@ -1418,8 +1468,8 @@ def run_table_resumable(args, local_rank, VARIANT, clocks):
         elapsed = time.perf_counter() - t_call
         if est is not None and elapsed + 1.15 * est > args.max_seconds:
             break
-        if not warm and args.warmup > 0:  # creates the provers of every circuit, outside the block's clock
-            rig.build(args.warmup * args.rows, 2 * b, seed ^ 0x5A5A5A, n_cols, args.warmup * args.rows > 16384)
+        if not warm and warm_rows > 0:  # creates the provers of every circuit, outside the block's clock
+            rig.build(warm_rows, 2 * b, seed ^ 0x5A5A5A, n_cols, warm_rows > 16384)
             warm = True
         for c in rig.ctxs:
             c.sync()

@@ -15,6 +15,8 @@ updatetree.rs:154-163,362-470: a node becomes Ready when all its children are do
 Everything here is backend-agnostic torch.distributed ("nccl" = RCCL on the GPU box, "gloo" in the
 CPU tests); no arithmetic happens in this module.
 """
+import re
+
 import numpy as np
 
 
@@ -34,7 +36,12 @@ HBM_BYTES = 288 * 10**9
 
 def scratch_is_shared():
     import os
-    return os.environ.get("MP2G_SHARE_SCRATCH", "1") != "0"
+    # the same reading as the library's (csrc/prover.hip: atoi(value) != 0; unset = shared): "0", "off", "" all mean "not shared"
+    v = os.environ.get("MP2G_SHARE_SCRATCH")
+    if v is None:
+        return True
+    m = re.match(r"\s*[+-]?\d+", v)
+    return bool(m) and int(m.group(0)) != 0
 
 
 def plan_rank_resources(shapes, workers, batch, ranks_on_host, host_cpus, hbm_bytes=HBM_BYTES, shared=None):
@@ -182,18 +189,95 @@ class _RawView:
         self._keep = keep
 
 
+# How root proofs move between ranks above the shard boundary, decided ONCE per run by `probe_handoff` before anything is timed:
+#   "device": RCCL reads the prover's own output ranges (libmp2gpu allocations wrapped as tensor views) -- no copy on the sender;
+#   "staged": the sender downloads the proof (DeviceProof.to_host), and a torch-allocated tensor travels (RCCL: uploaded first);
+#   "host":   gloo -- host tensors (the CPU tests, and MP2G_BENCH_BACKEND=gloo on a box with fewer GPUs than ranks).
+HANDOFF = {"mode": None, "reason": None}
+PROBE_WORDS = 64
+
+
+def join_pairs(world):
+    """[(level, src, dst)] of the binary join above the shard boundary: at level l the ranks with the low l bits clear meet in pairs,
+    the upper one (bit l set) hands its tree's root proof to the lower one (log2(world) point-to-point hand-offs)."""
+    out = []
+    for lvl in range(max(0, int(world).bit_length() - 1)):
+        bit = 1 << lvl
+        for r in range(0, world, 2 * bit):
+            if r + bit < world:
+                out.append((lvl, r + bit, r))
+    return out
+
+
+def probe_pattern(src, marker):
+    w = (np.arange(PROBE_WORDS, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) ^ np.uint64((src + 1) << 40)
+    w[0] = marker
+    return w
+
+
+def probe_handoff(dist, direct_tensor, staged_tensor, device=None):
+    """Before anything is timed: every pair of `join_pairs` moves one small buffer exactly the way the root proofs will move.
+    `direct_tensor(words)` returns the tensor the direct path would send -- under RCCL a view of a buffer ALLOCATED BY libmp2gpu
+    holding `words` (the one thing no single-GPU test can exercise) -- or raises; `staged_tensor(words)` returns a torch-allocated
+    tensor of the same words (the other path). A sender whose direct send raises satisfies its peer's pending recv with the staged
+    tensor (marker word 2 instead of 1), a receiver that finds other words than the pattern reports a failure, and one all_reduce
+    (MAX) makes every rank choose the same mode for every level: "device" only if all pairs moved the pattern directly. With
+    direct_tensor = None (gloo) the pairs exchange host tensors and the mode is "host". Sets and returns HANDOFF."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    bad, reason = 0, None
+    for lvl, src, dst in join_pairs(world):
+        if rank == src:
+            if direct_tensor is None:
+                dist.send(staged_tensor(probe_pattern(src, 3)), dst)
+                continue
+            try:
+                t = direct_tensor(probe_pattern(src, 1))
+                dist.send(t, dst)
+                if device is not None:
+                    torch.cuda.synchronize()
+            except Exception as e:  # the peer is waiting in recv for PROBE_WORDS words: the staged tensor answers it, marked
+                bad, reason = 1, f"rank {src} -> {dst}: {type(e).__name__}: {e}"[:300]
+                dist.send(staged_tensor(probe_pattern(src, 2)), dst)
+                if device is not None:
+                    torch.cuda.synchronize()
+        elif rank == dst:
+            t = torch.empty(PROBE_WORDS, dtype=torch.int64, device=device)
+            dist.recv(t, src)
+            if device is not None:
+                torch.cuda.synchronize()
+            got = t.cpu().numpy().view(np.uint64)
+            marker = int(got[0])
+            if marker not in (1, 2, 3) or not np.array_equal(got[1:], probe_pattern(src, marker)[1:]):
+                bad, reason = 1, f"rank {src} -> {dst}: the probe arrived with other words than were sent"
+            elif marker == 2:
+                bad, reason = 1, f"rank {src} -> {dst}: the sender fell back to a staged tensor"
+    flag = torch.tensor([bad], dtype=torch.int64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if direct_tensor is None:
+        if int(flag.item()):
+            raise RuntimeError(f"hand-off probe failed over {dist.get_backend()}: {reason}")
+        HANDOFF.update(mode="host", reason=None)
+    elif int(flag.item()):
+        HANDOFF.update(mode="staged", reason=reason or "another pair's direct send failed")
+    else:
+        HANDOFF.update(mode="device", reason=None)
+    return dict(HANDOFF)
+
+
 def send_device_proof(dist, ctx, dp, dst, device=None):
-    """hand a final proof (recursion.DeviceProof) to the rank that proves its parent. RCCL (device given): the word ranges of the
-    prover's output buffers are sent as they are, device to device; gloo: through host tensors. The context's stream is drained
-    first: the collective runs on torch's stream."""
+    """hand a final proof (recursion.DeviceProof) to the rank that proves its parent. RCCL (device given) and HANDOFF mode "device"
+    (or no probe run): the word ranges of the prover's output buffers are sent as they are, device to device; mode "staged": the
+    proof is downloaded and a torch-allocated tensor travels; gloo: through host tensors. The context's stream is drained first:
+    the collective runs on torch's stream."""
     import torch
     from .recursion import DeviceProof
     ctx.sync()
-    if isinstance(dp, DeviceProof) and device is not None:
+    if isinstance(dp, DeviceProof) and device is not None and HANDOFF["mode"] != "staged":
         parts = [torch.as_tensor(_RawView(ptr, n, dp.keep), device=device) for ptr, n in dp.parts]
     else:
-        # a host proof tuple (the host-witness back end keeps no chain outputs on the device), or gloo: host tensors; with RCCL they
-        # go up first -- the receiver sees device tensors either way
+        # a host proof tuple (the host-witness back end keeps no chain outputs on the device), the staged mode, or gloo: host tensors;
+        # with RCCL they go up first -- the receiver sees device tensors either way
         caps, openings, fri, pis = dp.to_host(ctx) if isinstance(dp, DeviceProof) else dp
         parts = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64).ravel().copy()) for a in (pis, np.asarray(caps)[1:4], openings, fri)]
         if device is not None:

@@ -79,6 +79,30 @@ def main():
         acc += [int(x) for x in got[4] if int(x) >= 0]
     if rank == 0:
         assert sorted(acc) == list(range(world)), "every rank's subtree reaches the root exactly once"
+    # ---- the pre-timing hand-off probe of bench.py (sharding.probe_handoff): every join pair moves a small buffer the way its root
+    # proof will move; all pairs direct -> "device"; ONE sender whose direct tensor cannot be made -> its peer's pending recv is
+    # answered by the staged tensor and EVERY rank chooses "staged"; no direct path at all (gloo in bench.py) -> "host"
+    pairs = sh.join_pairs(world)
+    assert len(pairs) == world - 1 and sorted(src for _, src, _ in pairs) == list(range(1, world)), "every rank but 0 hands its tree over exactly once"
+    assert all(src - dst == 1 << lvl and dst % (2 << lvl) == 0 for lvl, src, dst in pairs)
+    host = lambda w: torch.from_numpy(np.ascontiguousarray(w, dtype=np.uint64).view(np.int64).copy())
+    assert sh.probe_handoff(dist, host, host)["mode"] == "device" and sh.HANDOFF["mode"] == "device"
+    failing = world - 1  # a sender at level 0
+    def direct(w):
+        if rank == failing:
+            raise RuntimeError("no tensor view of this allocation")
+        return host(w)
+    got = sh.probe_handoff(dist, direct, host)
+    assert got["mode"] == "staged" and got["reason"], got
+    if rank in (failing, failing - 1):
+        assert f"rank {failing} -> {failing - 1}" in got["reason"], got
+    def corrupt(w):  # a direct path that delivers other words than it was given
+        w = w.copy()
+        if rank == 1:
+            w[5] ^= np.uint64(1)
+        return host(w)
+    assert sh.probe_handoff(dist, corrupt, host)["mode"] == "staged"
+    assert sh.probe_handoff(dist, None, host)["mode"] == "host"
     # ---- work-plan driven proving: same UpdateTree on every rank, subtrees dealt per wave, root results
     # published by one all_gather per wave; the root must equal the sequential bottom-up result
     import hashlib

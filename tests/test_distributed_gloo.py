@@ -1,4 +1,4 @@
-"""N>1 path on CPU: world sizes 2 and 4 over gloo (no GPU)."""
+"""N>1 path on CPU: world sizes 2, 4 and 8 (the driver's scaling run: three join levels) over gloo (no GPU)."""
 import os
 import subprocess
 import sys
@@ -8,7 +8,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_digest_and_tree_handoff(world):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",

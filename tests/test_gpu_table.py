@@ -278,9 +278,12 @@ def test_bench_gpus_4_two_join_levels():
     the separator rows 1 and 5, then rank 2 hands the joined tree to rank 0, which proves separator 3 over two joined trees. The run asserts
     the root's digest = the digest of all 4 x 6 + 3 rows and its min = block 0's; every rank checks its block root and its sampled proofs."""
     line = _bench(["--gpus", "4", "--rows", "6", "--steps", "1", "--warmup", "1", "--workers", "1", "--table-batch", "8", "--subtree", "4", "--no-leaves-leg",
-                   "--no-cpu-baseline"], env={"MP2G_BENCH_BACKEND": "gloo"})
+                   "--no-cpu-baseline"], env={"MP2G_BENCH_BACKEND": "gloo", "MP2G_HANDOFF_PROBE_FAIL": "3"})
     assert line["n_gpus"] == 4 and "2 join level" in line["config"]["sharding"]
     assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * (4 * 6 + 3)) < 1e-6 and line["verified"] >= 4 * 13
+    # the pre-timing probe: rank 3's direct send "failed" (the test knob), its peer's recv was answered by the staged tensor, and every
+    # rank chose the staged hand-off for both levels before t0 -- the build still ends on the whole table's root
+    assert line["config"]["handoff"]["mode"] == "staged" and "STAGED" in line["config"]["sharding"] and line["table_rows_total"] == 27
 
 
 def test_bench_gpus_8_three_join_levels():
@@ -288,11 +291,15 @@ def test_bench_gpus_8_three_join_levels():
     three join levels (1 -> 0, 3 -> 2, 5 -> 4, 7 -> 6; 2 -> 0, 6 -> 4; 4 -> 0). The run asserts the root's digest = the digest of all
     8 x 2 + 7 rows and its min = block 0's; every rank checks its block root and its sampled proofs; all eight ranks answer the
     backend's all_reduce before anything is timed."""
-    line = _bench(["--gpus", "8", "--rows", "2", "--steps", "1", "--warmup", "1", "--workers", "1", "--table-batch", "4", "--subtree", "4", "--no-leaves-leg",
-                   "--no-cpu-baseline"], env={"MP2G_BENCH_BACKEND": "gloo"})
+    line = _bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--workers", "1", "--table-batch", "4", "--subtree", "4", "--no-leaves-leg",
+                   "--no-cpu-baseline"], env={"MP2G_BENCH_BACKEND": "gloo", "MP2G_BENCH_BLOCK_ROWS": "2"})
     assert line["n_gpus"] == 8 and line["config"]["join_levels"] == 3 and "3 join level" in line["config"]["sharding"]
     assert line["config"]["rccl_ranks"] == 8 and line["config"]["ranks_on_host"] == 8 and line["config"]["backend"] == "gloo"
-    assert abs(line["value"] * line["ms_per_step"] / 1e3 - 5 * (8 * 2 + 7)) < 1e-6 and line["verified"] >= 8 * 10
+    # the driver's command shape: no --rows, so the rank's block is the default block (2^17 rows; scaled to 2 rows here), a step is
+    # 1/steps of it, and 8 ranks build 8 blocks + 7 separator rows; every join pair was probed before t0
+    assert line["config"]["rows_per_rank"] == 2 and line["config"]["rows_per_step"] == 1 and line["steps"] == 2 and line["table_rows_total"] == 8 * 2 + 7
+    assert line["config"]["handoff"]["mode"] == "host" and "probed before t0" in line["config"]["sharding"]
+    assert abs(line["value"] * line["ms_per_step"] * 2 / 1e3 - 5 * (8 * 2 + 7)) < 1e-6 and line["verified"] >= 8 * 10
 
 
 def test_native_build_equals_the_python_build(ctx, mp2, params):
@@ -339,6 +346,11 @@ def test_native_build_equals_the_python_build(ctx, mp2, params):
     # ... and the failed build left the workers usable: the queued batches were rolled back, the good block proves again
     once_more, _ = nb.run(table, wit, root, nodes, keep=samples)
     assert all(np.array_equal(a, b) for a, b in zip(once_more, want))
+    nb.free()
+    for p in provers:
+        p.free()
+    for c in ctxs:
+        c.close()
 
 
 def test_pipelined_units_equal_the_synchronous_ones(ctx, mp2, params, monkeypatch):
@@ -369,11 +381,8 @@ def test_pipelined_units_equal_the_synchronous_ones(ctx, mp2, params, monkeypatc
         tight.free()
         for p_ in provers:
             p_.free()
-    nb.free()
-    for p in provers:
-        p.free()
-    for c in ctxs:
-        c.close()
+        for c in ctxs:
+            c.close()
 
 
 def test_bench_python_build():
