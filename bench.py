@@ -508,14 +508,32 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
     commit_ms, commit_all = median_ms(lambda: pb.recommit_from_values_dev(d_v), 5)
     intt_ms, _ = median_ms(lambda: ctx.ntt_dev(d_v, d_c, lg, w135, inverse=True), 5)
     lde_ms, lde_all = median_ms(lambda: ctx.lde_dev(d_c, lg, w135, 3, d_lde), 5)
+    # the two halves of the Merkle part by themselves, over the LDE values the batch holds (mp2g_batch_rehash_dev)
+    leafk_ms, _ = median_ms(lambda: pb.rehash_dev(1), 5)
+    levels_ms, _ = median_ms(lambda: pb.rehash_dev(2), 5)
     pb.free(); d_v.free(); d_c.free(); d_lde.free()
+    # the leaf sponge kernel ALONE at the size of the counter pass (profiles/r05/sponge_counters.json: 2^20 leaves x 135 limbs =
+    # 17 permutations per lane): what `roofline_alu.isolated` is about -- the same kernel its instruction count was taken from
+    lg17 = 17
+    d_v17 = ctx.alloc(w135 * (1 << lg17) * 8)
+    for k in range(w135 * (1 << lg17) * 8 // part.nbytes + 1):
+        nb = min(part.nbytes, w135 * (1 << lg17) * 8 - k * part.nbytes)
+        if nb > 0:
+            d_v17.upload_at(part.reshape(-1)[:nb // 8], k * part.nbytes)
+    pb17 = mp2.PolynomialBatch.from_values_dev(ctx, d_v17, lg17, w135, 3, 4, VARIANT)
+    leaf17_ms, leaf17_all = median_ms(lambda: pb17.rehash_dev(1), 7)
+    pb17.free(); d_v17.free()
+    leaf_kernel_rate = (1 << (lg17 + 3)) * ((w135 + 7) // 8) / (leaf17_ms / 1e3)
     perms = L * ((w135 + 7) // 8) + L - 16
     merkle_ms = max(commit_ms - intt_ms - lde_ms, 1e-6)
     commit = {"workload": "configs[1](ii): PolynomialBatch::from_values of 135 x 2^15 resident values -> iNTT, LDE to 2^18 leaves x 135, Poseidon2 leaf sponges and tree "
                           "levels to cap(4); medians of 5 launches between HIP events", "seconds": commit_ms / 1e3, "runs_ms": commit_all,
               "intt_ms": intt_ms, "lde_ms": lde_ms, "lde_GBps": 72.0 * n15 * w135 / (lde_ms / 1e3) / 1e9, "lde_frac_of_hbm_peak": 72.0 * n15 * w135 / (lde_ms / 1e3) / 1e9 / HBM_PEAK_GBPS,
               "merkle_ms": merkle_ms, "merkle_permutations": perms, "merkle_permutations_per_s": perms / (merkle_ms / 1e3),
-              "merkle_note": "merkle_ms = commit - iNTT - LDE (the same launches timed apart); 17 of 18 permutations are the leaf sponge's (leaf_hash_poly_major_kernel)"}
+              "merkle_note": "merkle_ms = commit - iNTT - LDE (the same launches timed apart); 17 of 18 permutations are the leaf sponge's (leaf_hash_poly_major_kernel)",
+              "leaf_sponge_ms": leafk_ms, "tree_levels_ms": levels_ms,
+              "leaf_sponge_permutations_per_s": L * ((w135 + 7) // 8) / (leafk_ms / 1e3), "tree_levels_permutations_per_s": (L - 16) / (levels_ms / 1e3),
+              "parts_note": "leaf_sponge_ms / tree_levels_ms: the two halves of MerkleTree::new by themselves over the resident LDE values (mp2g_batch_rehash_dev), medians of 5"}
 
     d_poly.free(); d_out.free()
     # HBM-side bytes of the same two launches from the TCC counters (collected in separate
@@ -541,18 +559,39 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
            "sponge": {"hasher": hasher, "permutations_per_s": sponge_rate, "bound": "VALU issue (integer ALU)", "median_of": len(hash_all), "runs_ms": hash_all,
                       "input": f"{n_hash} x {limbs} limbs of random field elements, hash_no_pad, resident"},
            "commit_135x2p15": commit}
-    alu = roofline_alu(sponge_rate, commit["merkle_permutations_per_s"])
+    # the 2^22 NTT against the OTHER roof as well: VALU instructions per point from the committed counter pass
+    # x this run's transforms per second, over the VALU issue peak
+    for rnd in ("r04", "r03"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "ntt_traffic.json")) as f:
+                kk = json.load(f)["kernels"]
+            insts = sum(v["SQ_INSTS_VALU"] for name, v in kk.items() if name.startswith("void mp2g::ntt_cols_v2_kernel") or name.startswith("void mp2g::ntt_rows_v2_kernel"))
+            with open(os.path.join(ROOT, "profiles", "r05", "sponge_counters.json")) as f:
+                peak = json.load(f)["peak_valu_wave_insts_per_s"]
+            out["roofline"]["valu"] = {"valu_insts_per_point": insts * 64.0 / n_ntt, "valu_wave_insts_per_launch": insts, "valu_wave_insts_per_s": insts / ntt_s,
+                                       "peak_valu_wave_insts_per_s": peak, "frac_of_valu_peak": insts / ntt_s / peak,
+                                       "reading": "the transform sits at `frac` of the HBM roof and at `frac_of_valu_peak` of the VALU issue roof: bound by neither (DESIGN.md section 4: one generation of tiles, "
+                                                  "load / butterfly / store phases that cannot overlap)",
+                                       "source": f"profiles/{rnd}/ntt_traffic.json (SQ_INSTS_VALU of the two launches, committed rocprofv3 --pmc pass; the kernels are unchanged since) x this run's launch time"}
+            break
+        except (OSError, KeyError, ValueError):
+            pass
+    alu = roofline_alu(leaf_kernel_rate, commit["merkle_permutations_per_s"], sponge_rate, leaf17_all)
     if alu is not None:
         out["roofline_alu"] = alu
     return out
 
 
-def roofline_alu(isolated_rate, commit_rate):
+def roofline_alu(isolated_rate, commit_rate, row_major_rate=None, isolated_runs_ms=None):
     """the ALU roofline of the kernel that dominates a step (the Poseidon2 leaf sponge: ~40 % of the kernel time of a table build):
     permutations/s x VALU wave-instructions per permutation (SQ_INSTS_VALU / permutations of the leaf kernel, a committed
-    rocprofv3 --pmc pass: profiles/rNN/sponge_counters.json) against the chip's VALU issue peak for that instruction mix
-    (1024 SIMDs x sclk / cycles per wave-instruction of the mix, from the same file). The in-step rate is the kernel's rate inside
-    a 4-worker table build (kernel-trace durations of the committed profile), not measured in this run."""
+    rocprofv3 --pmc pass: profiles/rNN/sponge_counters.json) against two peaks: the chip's VALU issue peak at 2 cycles per wave64
+    instruction (1024 SIMDs x sclk / 2) and the MIX peak -- the kernel's instruction histogram priced with the issue slots tools/ubench
+    measures per opcode (profiles/r06/leaf_sponge_mix.json, tools/dbg/isa_mix.py): v_mad_u64_u32 and v_lshl_add_u64 take ~1.7 slots
+    each, so a stream of this mix cannot issue at the 2-cycle rate however it is scheduled. `isolated` = the LEAF kernel alone
+    (mp2g_batch_rehash_dev over 2^20 resident leaves of 135 limbs: the launch the instruction count was taken from), timed in this
+    run. The in-step rate is the kernel's rate inside a table build (kernel-trace durations of the committed profile), not measured
+    in this run."""
     for rnd in ("r05",):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "sponge_counters.json")) as f:
@@ -564,20 +603,41 @@ def roofline_alu(isolated_rate, commit_rate):
             peak = k["peak_valu_wave_insts_per_s"]  # 1024 SIMDs x sclk / 2 cycles per wave64 instruction on a SIMD-32 (sclk = shader cycles of the profiled launch / its duration)
         except KeyError:
             continue
+        mix = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r06", "leaf_sponge_mix.json")) as f:
+                mix = json.load(f)
+        except (OSError, ValueError):
+            pass
         need = lambda rate: rate / 64.0 * per_perm
+        mix_peak = mix["mix_peak_valu_wave_insts_per_s"] if mix else None
+
+        def leg(rate, what):
+            d = {"perms_per_s": rate, "frac": need(rate) / peak, "leg": what}
+            if mix_peak:
+                d["frac_of_mix_peak"] = need(rate) / mix_peak
+            return d
         out = {"kernel": "leaf_hash_poly_major_kernel<0> (Poseidon2 sponge, one lane = one leaf)", "bound": "VALU issue", "unit": "VALU wave-instructions/s",
                "valu_insts_per_perm": per_perm, "peak_valu_wave_insts_per_s": peak, "sclk_hz": k["sclk_hz"],
                "cycles_per_valu_wave_inst_at_peak": k["cycles_per_valu_wave_inst_of_the_mix"], "cycles_per_valu_wave_inst_achieved_alone": k.get("cycles_per_valu_wave_inst_achieved"),
                "add32_stream_wave_insts_per_s_measured": k.get("add32_wave_insts_per_s_measured"),
-               "isolated": {"perms_per_s": isolated_rate, "frac": need(isolated_rate) / peak, "leg": "sponge (hash_no_pad_batch, 2^21 x 136 limbs)"},
-               "commit": {"perms_per_s": commit_rate, "frac": need(commit_rate) / peak, "leg": "commit_135x2p15 (leaf sponge + tree levels)"},
+               "isolated": leg(isolated_rate, "the leaf kernel alone: mp2g_batch_rehash_dev(parts = 1) over 2^20 resident leaves x 135 limbs (17 permutations per lane), median of 7 launches between HIP events, this run"),
+               "commit": leg(commit_rate, "commit_135x2p15 (leaf sponge + tree levels: the levels' launches are in the time, their permutations counted at the leaf kernel's instruction count)"),
                "source": f"profiles/{rnd}/sponge_counters.json (committed rocprofv3 --pmc passes; the rates are this run's)"}
+        if isolated_runs_ms is not None:
+            out["isolated"]["runs_ms"] = isolated_runs_ms
+        if row_major_rate is not None:
+            out["row_major_sponge_perms_per_s"] = row_major_rate  # hash_no_pad_batch_kernel (the `sponge` leg): another kernel, NOT priced with this kernel's instruction count
+        if mix:
+            out["mix_peak"] = {"valu_wave_insts_per_s": mix_peak, "slots_per_valu_inst": mix["slots_per_valu_inst_of_the_mix"],
+                               "top_of_the_mix": [[r["opcode"], r["share"], r["slots_each"]] for r in mix["histogram"][:6]],
+                               "source": "profiles/r06/leaf_sponge_mix.json: the kernel's instruction histogram (tools/dbg/isa_mix.py) x the issue slots tools/ubench measured per opcode "
+                                         "(profiles/r06/ubench.txt), over the measured add32 stream rate; frac_of_mix_peak = the same achieved rate against this peak"}
         if "step_valu_wave_insts_per_framework_proof" in k:
             out["step_valu_wave_insts_per_framework_proof"] = k["step_valu_wave_insts_per_framework_proof"]
             out["step_source"] = k.get("step_source")
         if "in_step_perms_per_s" in k:
-            out["in_step"] = {"perms_per_s": k["in_step_perms_per_s"], "frac": need(k["in_step_perms_per_s"]) / peak,
-                              "leg": k.get("in_step_source", "4-worker table build under rocprofv3 --kernel-trace (committed profile; not this run)")}
+            out["in_step"] = leg(k["in_step_perms_per_s"], k.get("in_step_source", "4-worker table build under rocprofv3 --kernel-trace (committed profile; not this run)"))
         return out
     return None
 
@@ -666,9 +726,9 @@ def main(argv=None):
                     "rank's block is 2^17 rows whatever --steps says -- a step is 1/steps of it -- so that 8 ranks build the metric's 2^20-row table (8 x 2^17 rows + 7 "
                     "separator rows) and 1 / 2 / 4 ranks the same block per rank (weak scaling that ends on the named configuration); see block_plan()")
     ap.add_argument("--workers", type=int, default=4, help="--workload table: concurrent work-plan items per rank, one host thread + GPU stream + prover set each")
-    ap.add_argument("--table-batch", type=int, default=48, help="--workload table: proofs per prove() launch sequence of a worker (round 5: 4 x 48 in flight = 238 GB of the "
-                    "GPU's 288 does 912 proofs/s where 4 x 32 = 162 GB does 842: the per-batch latency kernels -- witness replay, transcript, tree tops -- are paid once per 48 proofs; "
-                    "profiles/r05/variants_ab.txt)")
+    ap.add_argument("--table-batch", type=int, default=48, help="--workload table: proofs per prove() launch sequence of a worker (round 5: 4 x 48 in flight does 912 proofs/s "
+                    "where 4 x 32 does 842 -- the per-batch latency kernels, witness replay, transcript, tree tops, are paid once per 48 proofs; profiles/r05/variants_ab.txt -- and "
+                    "takes 78 GB of the GPU's 288 with the provers' shared scratch, 238 GB with MP2G_SHARE_SCRATCH=0)")
     ap.add_argument("--subtree", type=int, default=64, help="--workload table: into_batched_workplan(subtree_size), the rows of one work-plan item")
     ap.add_argument("--native-build", action="store_true", default=True, help="--workload table: the table build's scheduler in C++ (mp2g_forest_*: worker threads, "
                     "level batching, job assembly, child proofs in a device pool): the default")
@@ -686,7 +746,8 @@ def main(argv=None):
     ap.add_argument("--degree-sweep", default="12,13,14,15", help="--workload table at N = 1: after the headline, the table rate at these base degrees (one block of "
                     "--sweep-rows rows each) in the same line as `by_base_degree`; '' = skip")
     ap.add_argument("--sweep-rows", type=int, default=1024, help="rows of the block timed at every base degree of --degree-sweep (halved above k = 14)")
-    ap.add_argument("--sweep-runs", type=int, default=3, help="builds of that block per base degree; the median is reported")
+    ap.add_argument("--sweep-runs", type=int, default=2, help="builds of that block per base degree; the median is reported (of an even number: the lower middle one). "
+                    "Round 5 ran 3; 2 keeps the driver's N = 1 command inside its window now that the timed block is 2^17 rows")
     ap.add_argument("--config2-leaves", type=int, default=1024, help="--workload table at N = 1: leaves of the BASELINE configs[2] leg (2-to-1 aggregation of real leaf proofs, "
                     "2 x leaves - 1 framework proofs) reported as `config2`; 0 = skip")
     ap.add_argument("--resume-dir", default=None, help="--workload table at N = 1: build the table as --table-blocks blocks of --steps x --rows rows ACROSS CALLS -- every "
@@ -797,6 +858,107 @@ def cpu_medians(unit, runs=5):
             "all_threads": {"threads": cores, "median_s": float(np.median(allt)), "proofs_per_s": 1.0 / float(np.median(allt))},
             "one_thread": {"threads": 1, "median_s": float(np.median(single)), "proofs_per_s": 1.0 / float(np.median(single)),
                            "how": f"{runs} single-thread runs side by side on {cores} hardware threads, each timed by itself"}}
+
+
+def native_oracle():
+    """the CPU leg runs the oracle built for the machine at hand. `make -B liboracle_native.so` (-O3 -march=native
+    -fopenmp; ~7 s) and point tests/oracle.py at it through ORC_LIB -- before that module is first imported. The file never travels
+    (.gpurunignore). Returns what the line reports about the build; on any failure the portable build (-march=x86-64-v3) stays."""
+    if "oracle" in sys.modules or os.environ.get("ORC_LIB"):
+        return {"march": "as loaded", "lib": os.environ.get("ORC_LIB", "oracle/liboracle.so")}
+    import subprocess
+    try:
+        subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "liboracle_native.so"], timeout=300)
+        os.environ["ORC_LIB"] = os.path.join(ROOT, "oracle", "liboracle_native.so")
+        return {"march": "native", "lib": "oracle/liboracle_native.so (built by this run: -O3 -march=native -fopenmp)"}
+    except Exception as e:
+        return {"march": "x86-64-v3", "lib": f"oracle/liboracle.so (the native build failed: {type(e).__name__})"}
+
+
+def host_memory_available():
+    """bytes this process may still take: MemAvailable, narrowed by the cgroup's limit where there is one"""
+    avail = None
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            with open(lim) as f:
+                v = f.read().strip()
+            with open(cur) as f:
+                u = int(f.read().strip())
+            if v != "max" and int(v) < 1 << 60:
+                left = int(v) - u
+                avail = left if avail is None else min(avail, left)
+        except (OSError, ValueError):
+            pass
+    return avail
+
+
+def cpu_throughput(samples, seconds_per_mode=8.0, modes=None):
+    """The CPU's best configuration for THIS metric (framework proofs per second of a table build: embarrassingly parallel across
+    proofs): P oracle proofs side by side x T OpenMP threads inside each, P x T = the host's hardware threads, for
+    (P, T) = (cores, 1), (cores / 4, 4), (cores / 16, 16); the fourth point, one proof after the other with every thread inside
+    it, is the latency mode `check_against_oracle` has already timed. Work of a mode: the sampled framework proofs of the timed
+    block in the table's own proportion -- per two rows 2 x (4 cells-tree proofs) + a row leaf + a row full node --, each slot pulls
+    the next one until `seconds_per_mode` have passed and finishes the one it holds; value = proofs completed / wall time to the
+    last one. P is capped by the host's free memory (a proof's working set ~ 24 KB per row of its widest circuit).
+    `samples`: the captured prove() calls grouped by framework proof. Returns (best mode's dict, all modes)."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import circuits as OC
+    cores = os.cpu_count() or 1
+    omp = ctypes.CDLL("libgomp.so.1")
+    kind = lambda chain: chain[0][0].rsplit(" step", 1)[0]
+    cells = [c for c in samples if kind(c).startswith("cells")]
+    rows_leaf = [c for c in samples if kind(c) == "row_leaf"] or [c for c in samples if kind(c).startswith("row")][:1]
+    rows_full = [c for c in samples if kind(c) == "row_full"] or rows_leaf
+    cycle = (cells + rows_leaf[:1] + cells + rows_full[:1]) if cells else list(samples)
+    widest = max(1 << part[1].log_n for c in cycle for part in c)
+    per_proof_bytes = 24 * 1024 * widest
+    avail = host_memory_available()
+    p_cap = cores if avail is None else max(1, int(0.5 * avail) // per_proof_bytes)
+    if modes is None:
+        modes = []
+        for t in (1, 4, 16):
+            pt = (max(1, min(cores // t, p_cap)), t)
+            if cores >= t and pt not in modes:
+                modes.append(pt)
+    out = []
+    for P_, T_ in modes:
+        nxt, done, lock = [0], [0], threading.Lock()
+        t0 = time.perf_counter()
+
+        def slot():
+            omp.omp_set_num_threads(T_)  # per-thread ICV: the parallel regions this slot opens
+            while True:
+                with lock:
+                    if time.perf_counter() - t0 > seconds_per_mode and nxt[0] >= P_:
+                        return
+                    j = nxt[0]
+                    nxt[0] += 1
+                for label, ckt, ofp, cd, make_wires, ph, *_ in cycle[j % len(cycle)]:
+                    OC.prove_witness(ckt, ofp, cd, make_wires(), ph)
+                with lock:
+                    done[0] += 1
+
+        ths = [threading.Thread(target=slot) for _ in range(P_)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        wall = time.perf_counter() - t0
+        out.append({"mode": f"{P_} proofs side by side x {T_} thread(s) each", "concurrent_proofs": P_, "threads_per_proof": T_, "framework_proofs": done[0],
+                    "wall_s": round(wall, 2), "proofs_per_s": done[0] / wall})
+    omp.omp_set_num_threads(cores)
+    best = max(out, key=lambda m: m["proofs_per_s"])
+    return best, {"modes": out, "mix": "per two table rows: 2 x the 4 cells-tree proofs, 1 row leaf, 1 row full node (the sampled proofs of the timed block, their captured witnesses)",
+                  "memory_cap": {"available_bytes": avail, "assumed_bytes_per_proof": per_proof_bytes, "max_concurrent": p_cap}}
 
 
 class TableRig:
@@ -1070,6 +1232,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
     mods = (mp2, R, FW, C, T, IX)
     n_cols, seed = 4, 0xC0FFEE04
     ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    oracle_build = native_oracle() if world == 1 and not args.no_cpu_baseline and not args.no_verify else None  # before tests/oracle.py is first imported
     rig = TableRig(mods, local_rank, VARIANT, args.workers, args.table_batch, args.subtree, args.host_witness, ranks_here, pad_bits=args.pad_base_bits,
                    group_rows=args.group_rows, native=args.native_build)
     params, ctx = rig.params, rig.ctx
@@ -1200,9 +1363,22 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
             cpu_base["cpu_model"] = cpu_model()
             cpu_base["sample"] = (f"{len(samples)} framework proofs of the timed block ({', '.join(kinds)}: {sum(len(c) for c in samples)} prove() calls of 2^6..2^14 rows) re-proved "
                                   "from their captured witnesses by oracle/ (our C restatement, not the Rust prover), all hardware threads; every one compared bit for bit with "
-                                  "the GPU's and verified. `medians`: the same oracle on one fixed prove() call, 5 runs with all threads and 5 with one thread")
+                                  "the GPU's and verified (`latency_mode`). `value` = the best of `throughput_sweep` (the same proofs, P side by side x T threads each, in the table's proportion) "
+                                  "and the latency mode. `medians`: the same oracle on one fixed prove() call, 5 runs with all threads and 5 with one thread")
             # the fixed unit of the medians: the final wrap step of the first sampled proof (2^12 rows: the shape every framework proof ends with)
             cpu_base["medians"] = cpu_medians(samples[0][-1])
+            # the CPU's best configuration for this metric: proofs side by side. `value` = the maximum over the modes,
+            # the one-proof-after-the-other figure stays as `latency_mode`
+            lat = {"value": cpu_base["value"], "sample_wall_s": cpu_base["sample_wall_s"], "mode": "one framework proof after the other, every hardware thread inside each prove() "
+                   "(the self-check's own run: its proofs are the ones compared bit for bit)"}
+            best, sweep = cpu_throughput(samples, seconds_per_mode=max(2.0, args.cpu_budget * 0.4))
+            cpu_base["latency_mode"] = lat
+            cpu_base["throughput_sweep"] = sweep
+            if best["proofs_per_s"] > cpu_base["value"]:
+                cpu_base["value"], cpu_base["mode"], cpu_base["cores"] = best["proofs_per_s"], best["mode"], best["concurrent_proofs"] * best["threads_per_proof"]
+            else:
+                cpu_base["mode"] = lat["mode"]
+            cpu_base["oracle_build"] = oracle_build
     if dist is not None:
         v = torch.tensor([verified], device="cuda" if nccl else "cpu", dtype=torch.int64)
         dist.all_reduce(v)
@@ -1300,7 +1476,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
                         rk.check_root(stk, verify=not args.no_verify)
                     del stk
                 runs.sort()
-                val, dtk = runs[len(runs) // 2]
+                val, dtk = runs[(len(runs) - 1) // 2]
                 return {"value": val, "unit": "proofs/s", "rows": rows_k, "seconds": dtk, "median_of": len(runs), "runs": [round(v, 1) for v, _ in runs],
                         "trace_rows_per_s": val / (n_cols + 1) * sum(sum(1 << d for d in rk.params.shapes()[nm]) * cnt for nm, cnt in
                                                                       (("cells_leaf", 2.0), ("cells_full", 1.0), ("cells_partial", 1.0), ("row_leaf", 0.5), ("row_full", 0.5))),
@@ -1381,6 +1557,8 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
             # the whole table build against the same peak: (every kernel's VALU wave-instructions per framework proof, a committed counter pass) x this run's proofs/s
             rate = out["value"] / world * alu["step_valu_wave_insts_per_framework_proof"]
             alu["table_build"] = {"valu_wave_insts_per_s_per_gpu": rate, "frac": rate / alu["peak_valu_wave_insts_per_s"],
+                                  "how": "a committed counter pass (VALU wave-instructions per framework proof of a 512-row build, profiles/r05/step_counters_4workers.json) x THIS run's proofs/s: "
+                                         "not an in-run counter measurement",
                                   "leg": "the headline: every kernel of the build (sponges 71 % of the instructions), four workers' streams overlapped",
                                   "reading": "the build issues VALU instructions at least as fast as the leaf sponge does with the chip to itself: the headline is bound by the instruction count, not by scheduling"}
         if cpu_base is not None:
@@ -1402,9 +1580,12 @@ def completed_table_record():
     try:
         with open(os.path.join(ROOT, FULL_TABLE_RECORD)) as f:
             r = json.load(f)
-        return {"source": FULL_TABLE_RECORD + " (bench.py --resume-dir: 8 blocks of 2^17 rows + 7 separator rows built on one MI355X across calls; committed, not this run)",
+        blocks = r["blocks"]
+        rows_each = sorted({b.get("rows") for b in blocks if isinstance(b, dict)} - {None})
+        return {"source": FULL_TABLE_RECORD + f" (bench.py --resume-dir: {len(blocks)} blocks" + (f" of {rows_each[0]} rows" if len(rows_each) == 1 else "") +
+                          f" + {r['separator_rows']} separator rows built on one MI355X across calls; committed, not this run)",
                 "table_rows_total": r["table_rows_total"], "framework_proofs": r["framework_proofs"], "gpu_seconds": r["gpu_seconds"], "value": r["value"], "unit": r["unit"],
-                "join_levels": r["join_levels"], "root_verified_by_oracle": True, "root_digest_is_the_whole_tables": True,
+                "join_levels": r["join_levels"], "verified": r["verified"],  # the record's own statement of what the completing call checked
                 "root_proof_with_vk_fnv1a64": r["root_proof_with_vk_fnv1a64"]}
     except (OSError, ValueError, KeyError):
         return None
@@ -1772,13 +1953,8 @@ def run_leaves(args, rank, local_rank, world, dist, torch, VARIANT, clocks, brie
         }
         if legs is not None:
             out.update(legs)
-        alu = out.get("roofline_alu")
-        if alu is not None and alu.get("step_valu_wave_insts_per_framework_proof"):
-            # the whole table build against the same peak: (every kernel's VALU wave-instructions per framework proof, a committed counter pass) x this run's proofs/s
-            rate = out["value"] / world * alu["step_valu_wave_insts_per_framework_proof"]
-            alu["table_build"] = {"valu_wave_insts_per_s_per_gpu": rate, "frac": rate / alu["peak_valu_wave_insts_per_s"],
-                                  "leg": "the headline: every kernel of the build (sponges 71 % of the instructions), four workers' streams overlapped",
-                                  "reading": "the build issues VALU instructions at least as fast as the leaf sponge does with the chip to itself: the headline is bound by the instruction count, not by scheduling"}
+        # (no roofline_alu.table_build here: the instructions-per-framework-proof counter was taken on the TABLE build, and this workload
+        # proves synthetic circuits with resident witnesses -- only run_table multiplies it with a rate)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         if not brief:

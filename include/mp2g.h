@@ -120,6 +120,10 @@ int mp2g_commit_from_coeffs_dev(mp2g_ctx* ctx, int variant, const uint64_t* d_co
 /* re-run the commitment into an existing batch of the same shape (no allocation: the form the
  * batched prover and bench.py use) */
 int mp2g_recommit_from_values_dev(mp2g_ctx* ctx, mp2g_batch* batch, const uint64_t* d_values);
+/* MerkleTree::new(leaves, cap_height) again over the LDE values the batch already holds ([dep] plonky2 hash/merkle_tree.rs;
+ * called by PolynomialBatch::from_coeffs): parts = 1 the leaf sponges only (digests of the 2^(log_n + rate_bits) leaves),
+ * 2 the tree levels above them only, 3 both. Same cap as the commitment made; what bench.py times the leaf kernel with. */
+int mp2g_batch_rehash_dev(mp2g_ctx* ctx, mp2g_batch* batch, int parts);
 int mp2g_batch_cap(const mp2g_batch* batch, uint64_t* cap);
 int mp2g_batch_coeffs(const mp2g_batch* batch, uint64_t* coeffs /* [w][n] */);
 int mp2g_batch_open(const mp2g_batch* batch, const uint32_t* idx, uint32_t n_idx,

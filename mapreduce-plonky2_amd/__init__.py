@@ -294,6 +294,10 @@ class PolynomialBatch:
     def recommit_from_values_dev(self, d_values):
         _ck(load().mp2g_recommit_from_values_dev(self.ctx.h, self.h, d_values.ptr))
 
+    def rehash_dev(self, parts=3):
+        """MerkleTree::new over the LDE values the batch holds: parts 1 = leaf sponges, 2 = tree levels, 3 = both"""
+        _ck(load().mp2g_batch_rehash_dev(self.ctx.h, self.h, parts))
+
     @property
     def cap(self):
         out = np.empty((1 << self.cap_height, 4), dtype=np.uint64)

@@ -348,6 +348,15 @@ int mp2g_recommit_from_values_dev(mp2g_ctx* c, mp2g_batch* b, const uint64_t* d_
   CK(batch_commit(b));
   return 0;
 }
+int mp2g_batch_rehash_dev(mp2g_ctx* c, mp2g_batch* b, int parts) {
+  NEED(c && b, "ctx/batch");
+  NEED(b->ctx == c, "batch belongs to another context");
+  NEED(parts >= 1 && parts <= 3, "parts: 1 = leaf sponges, 2 = tree levels, 3 = both");
+  const u64 N = ((u64)1 << b->log_n) << b->rate_bits;
+  if (parts & 1) CK(leaf_hash_poly_major(c->stream, b->variant, b->values.p, b->w, N, N, b->levels.p));
+  if (parts & 2) CK(merkle_reduce(c->stream, b->variant, b->levels.p, b->log_n + b->rate_bits, b->cap_h));
+  return 0;
+}
 int mp2g_commit_from_values_dev(mp2g_ctx* c, int variant, const uint64_t* d_values, uint32_t log_n, uint32_t w,
                                 uint32_t rate_bits, uint32_t cap_height, mp2g_batch** out) {
   NEED(d_values, "values");

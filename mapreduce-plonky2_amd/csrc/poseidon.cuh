@@ -97,11 +97,28 @@ GLHD void p2_internal(u64 s[12]) {
   // the 68-bit sum from the 32-bit halves (each v_mad_u64_u32 adds a zero-extended word into a 64-bit accumulator: no carry
   // chains), reduced ONCE to a canonical element; every limb is then weak multiply + weak add
   u64 al = 0, ah = 0;
+#ifdef P2_INTERNAL_MADSUM
+  // A/B (round 6, variant builds only): every 32-bit word enters its 64-bit accumulator through the addend path of a multiply-add
+  // by 1 -- one v_mad_u64_u32 (1.7 slots) instead of the two register moves + v_lshl_add_u64 (2.4 slots) hipcc makes of a
+  // zero-extended 64-bit add; two accumulators per half keep the chains at six
+  {
+    u64 l0 = 0, l1 = 0, h0 = 0, h1 = 0, dmy;
+#pragma unroll
+    for (int i = 0; i < 12; i += 2) {
+      asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(l0), "=s"(dmy) : "v"((u32)s[i]), "v"(l0));
+      asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(h0), "=s"(dmy) : "v"((u32)(s[i] >> 32)), "v"(h0));
+      asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(l1), "=s"(dmy) : "v"((u32)s[i + 1]), "v"(l1));
+      asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(h1), "=s"(dmy) : "v"((u32)(s[i + 1] >> 32)), "v"(h1));
+    }
+    al = l0 + l1; ah = h0 + h1;
+  }
+#else
 #pragma unroll
   for (int i = 0; i < 12; i++) {
     al += (u64)(u32)s[i];
     ah += s[i] >> 32;
   }
+#endif
   ah += al >> 32;  // < 2^37
 #ifdef P2_INTERNAL_ADDW
   const u64 sum = gl_canon(gl_reduce96w(gl_mk((u32)al, (u32)ah), ah >> 32));

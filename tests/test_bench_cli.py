@@ -47,3 +47,26 @@ def test_block_plan_rows_per_rank():
         assert bench.block_plan(None, 5, 2) == (24, 5, 10)
     finally:
         del os.environ["MP2G_BENCH_BLOCK_ROWS"]
+
+
+def test_cpu_throughput_sweep_reports_the_best_mode():
+    """bench.py's cpu_baseline as THROUGHPUT: the sampled framework proofs proved P side by side x T OpenMP threads each by the oracle;
+    the value reported is the best mode's. Here on a small circuit (the GPU run hands it the timed block's captured witnesses)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import bench
+    import circuits as C
+    import oracle as O
+    ckt = C.build(5, C.ALL_KINDS, 1)
+    ofp = O.standard_params(5, (ckt.num_constants + C.NUM_ROUTED, C.NUM_WIRES, 20, 16), pow_bits=4, num_queries=2)
+    cd = O.rand_field(4, 2)
+    chain = lambda name: [(f"{name} step {i}", ckt, ofp, cd, (lambda: ckt.wires), ckt.pi_hash) for i in range(2)]
+    samples = [chain("cells_leaf"), chain("cells_full"), chain("row_leaf"), chain("row_full")]
+    best, sweep = bench.cpu_throughput(samples, seconds_per_mode=0.3, modes=[(2, 1), (1, 2)])
+    assert len(sweep["modes"]) == 2 and all(m["framework_proofs"] >= m["concurrent_proofs"] and m["proofs_per_s"] > 0 for m in sweep["modes"])
+    assert best["proofs_per_s"] == max(m["proofs_per_s"] for m in sweep["modes"]) and sweep["memory_cap"]["max_concurrent"] >= 1
+    # the default modes: P x T = the host's threads, capped by memory
+    _, sweep = bench.cpu_throughput(samples, seconds_per_mode=0.05)
+    cores = os.cpu_count()
+    assert [(m["concurrent_proofs"], m["threads_per_proof"]) for m in sweep["modes"]][0] == (cores, 1)

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""The instruction MIX of a kernel priced with measured per-instruction costs (round 6).
+
+    python3 tools/dbg/isa_mix.py --ubench profiles/r06/ubench.txt --out profiles/r06/leaf_sponge_mix.json
+
+Compiles csrc/merkle.hip to gfx950 assembly with the product's flags (hipcc cross-compiles: no GPU needed), takes the text of ONE
+kernel (default: leaf_hash_poly_major_kernel<0>, the Poseidon2 leaf sponge), counts its VALU instructions by opcode and prices every
+opcode class with the issue slots tools/ubench measured for it on the GPU (`inst ...` rows: 8 independent single-instruction
+streams per lane; a slot = the time of one full-rate 32-bit add). Result: slots per VALU instruction of the mix, and with the
+measured add32 rate the kernel's MIX PEAK in VALU wave-instructions per second -- the ceiling a perfectly scheduled stream of THIS
+mix could reach, against which bench.py reports `roofline_alu.frac_of_mix_peak` beside the 2-cycles-per-instruction figure.
+
+The histogram is the static one of the kernel text. The text is two unrolled copies of the permutation plus a short prologue, every
+part of it multiply-reduce code of the same composition, so the static shares stand in for the dynamic ones (the dynamic TOTAL is the
+SQ_INSTS_VALU counter's, profiles/r05/sponge_counters.json)."""
+import argparse
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "mapreduce-plonky2_amd", "csrc")
+
+# opcode -> ubench row that prices it
+CLASS = [
+    (r"^v_mov_b(32|64)", "v_mov_b32"),
+    (r"^v_lshl_add_u64", "v_lshl_add_u64"),
+    (r"^v_mad_u64_u32", "v_mad_u64_u32(asm)"),
+    (r"^v_cndmask_b32", "v_cndmask_b32(sgpr)"),
+    (r"^v_(sub|subb|subbrev|add|addc)_co_u32", "carry chain"),
+    (r"^v_bitop3_b32", "v_bitop3_b32"),
+    (r"^v_sub_u32", "v_sub_u32"),
+    (r"^v_add_u32", "v_add_u32"),
+    (r"^v_(xor|and|or)_b32", "v_xor_b32"),
+]
+
+
+def kernel_text(src, symbol, flags):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w", "-I" + os.path.join(ROOT, "include")] + flags +
+                              ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], stderr=subprocess.DEVNULL)
+        lines = open(out).read().splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith(symbol + ":"))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return lines[start:end]
+
+
+def ubench_slots(path):
+    """rows `inst <name> <ms> ms <slots> slots` of tools/ubench's output"""
+    slots = {}
+    for line in open(path):
+        m = re.match(r"inst (.+?)\s+([0-9.]+) ms\s+([0-9.]+) slots", line)
+        if m:
+            slots[m.group(1).strip()] = float(m.group(3))
+    if "sub_co+subbrev+subb(+xor)" in slots:  # three carry-chain instructions and one xor per operation
+        slots["carry chain"] = (slots["sub_co+subbrev+subb(+xor)"] - slots.get("v_xor_b32", 1.0)) / 3.0
+    return slots
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--src", default="merkle.hip")
+    ap.add_argument("--symbol", default="_ZN4mp2g27leaf_hash_poly_major_kernelILi0EEEvPKmjmmPmmm")
+    ap.add_argument("--flags", default="")
+    ap.add_argument("--ubench", required=True, help="output of tools/ubench/ubench on the GPU (its `inst` rows)")
+    ap.add_argument("--counters", default=os.path.join(ROOT, "profiles", "r05", "sponge_counters.json"))
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    text = kernel_text(a.src, a.symbol, a.flags.split())
+    hist = collections.Counter()
+    for l in text:
+        m = re.match(r"\s+(v_[a-z0-9_]+)", l)
+        if m:
+            hist[re.sub(r"_e(32|64)$", "", m.group(1))] += 1
+    slots = ubench_slots(a.ubench)
+    total = sum(hist.values())
+    priced, rows, unpriced = 0.0, [], 0
+    for op, n in hist.most_common():
+        cls = next((c for pat, c in CLASS if re.match(pat, op)), None)
+        s = slots.get(cls) if cls else None
+        if s is None:
+            s, cls = slots.get("v_add_u32", 1.0), "(priced as a 32-bit add)"
+            unpriced += n
+        priced += n * s
+        rows.append({"opcode": op, "count": n, "share": round(n / total, 4), "class": cls, "slots_each": round(s, 3)})
+    k = json.load(open(a.counters))
+    add32 = k["add32_wave_insts_per_s_measured"]
+    per_inst = priced / total
+    out = {"kernel": a.symbol, "source": f"hipcc -O3 -S --cuda-device-only csrc/{a.src} {a.flags}".strip(), "valu_instructions_static": total,
+           "histogram": rows, "instructions_priced_as_add32": unpriced, "slot_table": slots, "slot_unit": "time of one full-rate 32-bit add (tools/ubench, same run)",
+           "ubench": os.path.relpath(a.ubench, ROOT), "slots_per_valu_inst_of_the_mix": per_inst,
+           "add32_wave_insts_per_s_measured": add32, "mix_peak_valu_wave_insts_per_s": add32 / per_inst,
+           "valu_insts_per_perm_dynamic": k["valu_insts_per_perm"],
+           "note": "static histogram of the kernel text (two unrolled copies of the permutation + prologue); the dynamic total per permutation is the SQ_INSTS_VALU counter's"}
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    json.dump(out, open(a.out, "w"), indent=1)
+    print(f"{total} VALU instructions, {per_inst:.3f} slots each on average -> mix peak {add32 / per_inst / 1e12:.3f} x 10^12 wave-instructions/s "
+          f"(2-cycle peak {k['peak_valu_wave_insts_per_s'] / 1e12:.3f}); top: " + ", ".join(f"{r['opcode']} {r['share']:.0%}" for r in rows[:5]))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

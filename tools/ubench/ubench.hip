@@ -156,6 +156,37 @@ __global__ void kcheck(u64* bad, u64 seed) {
       atomicAdd((unsigned long long*)bad, 1ull);
   }
 }
+// ---- single-instruction streams (round 6): what ONE instruction of each class in the leaf sponge's listing costs, in issue slots of
+// the 32-bit add, measured as 8 independent streams per lane like the rows above. asm volatile: the instruction named is the
+// instruction issued. profiles/r06/leaf_sponge_mix.json prices the kernel's instruction histogram with these rows.
+template <int OP>
+__global__ void __launch_bounds__(256) kinst(u64* out, u64 seed) {
+  u64 a[8];
+  u32 x[8];
+  for (int i = 0; i < 8; i++) { a[i] = seed * (threadIdx.x + 1 + i * 977) + blockIdx.x; x[i] = (u32)(a[i] >> 7); }
+  u64 sc = seed | (blockIdx.x & 1);  // a wave-uniform 64-bit mask in SGPRs (v_cndmask's condition)
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int j = (i + 1) & 7;
+      if (OP == 0) asm volatile("v_mov_b32 %0, %1" : "=v"(x[i]) : "v"(x[j]));
+      if (OP == 1) asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(a[i]) : "v"(a[i]), "v"(a[j]));
+      if (OP == 2) { u64 c; asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(a[i]), "=s"(c) : "v"(x[i]), "v"(x[j]), "v"(a[i])); }
+      if (OP == 3) asm volatile("v_cndmask_b32 %0, %1, %2, %3" : "=v"(x[i]) : "v"(x[i]), "v"(x[j]), "s"(sc));
+      if (OP == 4) { u32 t; asm volatile("v_sub_co_u32 %0, vcc, %2, %3\n\tv_subbrev_co_u32 %1, vcc, 0, %4, vcc\n\tv_subb_co_u32 %0, vcc, %0, %0, vcc"
+                                         : "=&v"(x[i]), "=&v"(t) : "v"(x[i]), "v"(x[j]), "v"((u32)a[i]) : "vcc"); x[i] ^= t; }  // three carry-chain instructions (+ one xor)
+      if (OP == 5) asm volatile("v_sub_u32 %0, %1, %2" : "=v"(x[i]) : "v"(x[i]), "v"(x[j]));
+      if (OP == 6) asm volatile("v_bitop3_b32 %0, %1, %2, %1 bitop3:0x30" : "=v"(x[i]) : "v"(x[i]), "v"(x[j]));
+      if (OP == 7) asm volatile("v_add_u32 %0, %1, %2" : "=v"(x[i]) : "v"(x[i]), "v"(x[j]));
+      if (OP == 8) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x[i]) : "v"(x[i]), "v"(x[j]));
+      if (OP == 9) { u64 c; asm volatile("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(a[i]), "=s"(c) : "v"(x[j]), "v"(a[i])); }  // acc += zext(word)
+      if (OP == 10) { u64 t = gl_mk(x[j], 0u); asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(a[i]) : "v"(a[i]), "v"(t)); }  // acc += zext(word) as hipcc does it
+    }
+  }
+  u64 r = 0;
+  for (int i = 0; i < 8; i++) r ^= a[i] ^ x[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
 template <class F>
 float timeit(F f) {
   hipEvent_t a, b;
@@ -192,6 +223,14 @@ int main() {
     hipError_t e_ = hipGetLastError(); \
     printf("%-14s %8.3f ms  %8.2f Gop/s (lane-ops)  %5.1f slots%s\n", names[N], ms, ops / ms / 1e6, ms / add32_ms, e_ == hipSuccess ? "" : "  LAUNCH FAILED"); }
   RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(23) RUN(24) RUN(25) RUN(26)
+  {
+    const char* inames[] = {"v_mov_b32", "v_lshl_add_u64", "v_mad_u64_u32(asm)", "v_cndmask_b32(sgpr)", "sub_co+subbrev+subb(+xor)", "v_sub_u32", "v_bitop3_b32", "v_add_u32",
+                            "v_xor_b32", "mad acc+=zext(w)", "mov,mov,lshl_add acc+=zext(w)"};
+#define RUNI(N) { float ms = timeit([&] { hipLaunchKernelGGL(kinst<N>, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull); }); \
+    hipError_t e_ = hipGetLastError(); \
+    printf("inst %-30s %8.3f ms  %5.2f slots%s\n", inames[N], ms, ms / add32_ms, e_ == hipSuccess ? "" : "  LAUNCH FAILED"); }
+    RUNI(0) RUNI(1) RUNI(2) RUNI(3) RUNI(4) RUNI(5) RUNI(6) RUNI(7) RUNI(8) RUNI(9) RUNI(10)
+  }
   {
     int reps = 64;
     float ms = timeit([&] { hipLaunchKernelGGL(kperm, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull, reps); });
