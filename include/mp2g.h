@@ -428,21 +428,126 @@ int mp2g_eval_gate_constraints(mp2g_ctx* ctx, const mp2g_gate* gates, uint32_t n
                                const uint64_t* consts, uint32_t num_constants, const uint64_t* wires, uint32_t wires_w,
                                uint64_t npts, const uint64_t pi_hash[4], uint64_t* out);
 
-/* ---- witness generation for the recursion circuits (host side, no GPU) -----------------------------------
- * Replaces [dep] plonky2 iop/generator.rs generate_partial_witness for the circuits the recursion framework builds
- * (the wrap circuit, the universal-verifier circuits and their logic): the first line of prove() at
- * recursion-framework/src/circuit_builder.rs:308 and wrap_circuit.rs:143. The circuit builder of the host
- * (mapreduce-plonky2_amd/recursion.py) records its operations once as a straight-line program over value slots --
- * the structure of these circuits does not depend on the witness -- and this entry replays it per proof:
- *   tape        opcodes + operands (recursion.py OP_*: ArithmeticGate / ArithmeticExtensionGate operations,
- *               Poseidon2Gate rows, BaseSumGate splits, RandomAccessGate copies, ReducingGate / ReducingExtensionGate
- *               rows, CosetInterpolationGate rows, plain wire writes, division / split hints; parallel regions: runs of
- *               sections that do not read each other's values -- the query rounds of a FRI verifier -- which spare threads replay
- *               concurrently when the batch is smaller than `threads`)
- *   input_sids  the slots the caller provides, in order (the inner proof's public inputs, caps, openings, FRI proof
- *               words, verifier data, membership proof, the circuit's own inputs)
- *   const_slots (slot, value) pairs
- * Validated at create (opcodes, lengths, slot / row / wire bounds). */
+/* ---- witness generation: the witness tape ------------------------------------------------------------------
+ * Replaces [dep] plonky2 iop/generator.rs generate_partial_witness -- the first line of prove() at
+ * recursion-framework/src/circuit_builder.rs:308 and universal_verifier_gadget/wrap_circuit.rs:143 -- for circuits whose
+ * generator graph does not depend on the witness (every circuit of the recursion framework and of the table build: the
+ * set of generators and the wires they read and write are fixed when the circuit is built). plonky2 walks a dependency
+ * graph of the generators of mp2-common/src/serialization/circuit_data_serialization.rs:186-231 per proof; here the host
+ * records them ONCE, in an order in which every value is produced before it is used, as a flat array of u64 words -- the
+ * TAPE -- and the library replays it per proof, on host threads (mp2g_witness_program_run) or on the device for a whole batch
+ * (mp2g_witness_program_run_dev: one block per proof, the instructions grouped by dependency level). INTEGRATION.md
+ * section 6 maps every generator of the reference's registry to its opcode.
+ *
+ * VALUES live in SLOTS: n_slots u64 cells per proof, indexed by the tape. A slot plays the part of a plonky2 Target's
+ * value; copy constraints need no instruction (two wires that are copies of each other are written from the same slot).
+ * Before the tape runs, slot const_slots[2 i] holds the canonical field element const_slots[2 i + 1] and slot input_sids[j]
+ * holds the proof's j-th input word; every other slot holds 0 until an instruction writes it.
+ * WIRES: wire (col, row) of the 135 x 2^log_n matrix prove() commits to (standard_recursion_config: 135 wires, the first
+ * 80 routed). The matrix is zero-filled per proof; an instruction writes the wires of ITS generator's gate (listed below),
+ * MP2G_OP_WIRE writes a single one.
+ *
+ * INSTRUCTION = one opcode word followed by its operands. Operand kinds below: `row` a gate row (< 2^log_n); `i`, `col`,
+ * counts: small integers as stated; `k...` a canonical field element (< p); `s...` a slot that is READ; `d...` a slot
+ * that is WRITTEN; x[n] = n consecutive operand words; an extension element takes two slots (c0, c1).
+ *
+ * RULES. (1) Host replay executes the tape in order. (2) The device replay re-orders: an instruction's level is one more
+ * than the highest level of the slots it reads (inputs and constants are level 0), and a level's instructions run
+ * concurrently; it therefore needs single assignment -- no slot written twice, no slot written after an earlier
+ * instruction read it. mp2g_witness_program_run_dev refuses a tape that breaks this (the host replay still accepts it).
+ * (3) Two instructions must not write the same wire with different values (they may run in either order on the device).
+ * (4) MP2G_OP_PAR brackets sections that neither read each other's written slots nor write the same slots or wires.
+ *
+ * What mp2g_witness_program_create VALIDATES (a tape that fails is refused with a message, nothing is run): every opcode
+ * is known, no instruction is truncated, every row < 2^log_n, every column < 135, gate-operation indices and counts are in
+ * the ranges given below, constants are canonical, every slot operand, input slot and constant slot is < n_slots,
+ * parallel regions do not nest and their section lengths end on instruction boundaries. It does NOT check that the
+ * values satisfy the circuit: that is prove()'s witness check (mp2g_prover_enable_witness_check), which fails the proof
+ * the way plonky2's prove() panics on an unsatisfied witness. */
+enum mp2g_witness_op {
+  /* ArithmeticGate (20 operations a row) / ArithmeticBaseGenerator: out = k_c0 m0 m1 + k_c1 addend.
+   * operands: row, i (< 20), k_c0, k_c1, s_m0, s_m1, s_addend, d_out.   wires 4i .. 4i+3 = m0, m1, addend, out.
+   * k_c0, k_c1 must be the row's two gate constants (the caller's preprocessed constants hold them). */
+  MP2G_OP_ARITH = 1,
+  /* ArithmeticExtensionGate (10 operations a row) / ArithmeticExtensionGenerator, over the quadratic extension.
+   * operands: row, i (< 10), k_c0, k_c1, s_m0[2], s_m1[2], s_addend[2], d_out[2].   wires 8i .. 8i+7 in that order. */
+  MP2G_OP_ARITH_EXT = 2,
+  /* Poseidon2Gate / Poseidon2Generator: one permutation, with the swap of the first two 4-limb chunks.
+   * operands: row, s_in[12], s_swap (0 or 1), d_out[12].   wires 0..11 inputs, 12..23 outputs, 24 swap, 25..28 the swap
+   * deltas, 29..64 / 65..86 / 87..134 the S-box inputs of the first full rounds 1..3, the 22 partial rounds, the last 4 full rounds. */
+  MP2G_OP_P2 = 3,
+  /* BaseSumGate<2> with 63 limbs / BaseSplitGenerator<2>: the bits of a value below 2^63, little endian.
+   * operands: row, s_x, d_bit[63].   wire 0 = x, wires 1..63 = bits.  (other bases / limb counts: MP2G_OP_BASE_SPLIT) */
+  MP2G_OP_BASE_SUM = 4,
+  /* RandomAccessGate (bits = 4, 4 copies a row, 2 extra constants) / RandomAccessGenerator: out = value[index].
+   * operands: row, copy (< 4), s_index (< 16), s_value[16], d_out.   wires 18 copy + 0 = index, + 1 = out, + 2..17 = values;
+   * the 4 bits of the index at wires 74 + 4 copy .. (not routed).  (wires 72, 73: the row's extra constants, MP2G_OP_WIRE) */
+  MP2G_OP_RA = 5,
+  /* ReducingGate with 43 coefficients / ReducingGenerator: acc <- acc alpha + coeff_j for j = 0..42, base-field coefficients.
+   * operands: row, s_alpha[2], s_old_acc[2], s_coeff[43], d_out[2].   wires 0,1 out; 2,3 alpha; 4,5 old acc; 6..48 coefficients;
+   * 49.. the 42 intermediate accumulators. */
+  MP2G_OP_REDUCING = 6,
+  /* ReducingExtensionGate with 32 coefficients / ReducingExtensionGenerator: the same with extension coefficients.
+   * operands: row, s_alpha[2], s_old_acc[2], s_coeff[32][2], d_out[2].   wires 0,1 out; 2,3 alpha; 4,5 old acc; 6..69 coefficients; 70.. accumulators. */
+  MP2G_OP_REDUCING_EXT = 7,
+  /* CosetInterpolationGate::with_max_degree(bits, 8) / InterpolationGenerator: the polynomial through 2^bits values on the coset
+   * shift <w> evaluated at a point.   operands: row, bits (2..5), s_shift, s_value[2^bits][2], s_point[2], d_out[2].
+   * wires 0 shift, 1.. values, then point, out, intermediate (eval, prod) pairs, shifted point (the gate's own layout). */
+  MP2G_OP_COSET = 8,
+  /* one wire from a slot: ConstantGenerator (ConstantGate wire j = the row's constant j), the PublicInputGate's four
+   * public-inputs-hash wires, RandomAccessGate's extra constants, CopyGenerator targets that no other instruction writes.
+   * operands: row, col (< 135), s_value. */
+  MP2G_OP_WIRE = 9,
+  /* QuotientGeneratorExtension: q = num / den in the extension (0 when den = 0: also EqualityGenerator's / NonzeroTestGenerator's
+   * "inverse or zero" with num = (1, 0)).   operands: s_num[2], s_den[2], d_q[2].   no wires. */
+  MP2G_OP_HINT_DIV_EXT = 10,
+  /* the two halves of split_le of a full field element: d = s & (2^63 - 1) / d = s >> 63.   operands: s, d.   no wires. */
+  MP2G_OP_HINT_LO63 = 11,
+  MP2G_OP_HINT_HI = 12,
+  /* LowHighGenerator / SplitToU32Generator (bit = 32): low = s & (2^bit - 1), high = s >> bit.
+   * operands: s, bit (1..63), d_low, d_high.   no wires. */
+  MP2G_OP_HINT_SPLIT = 13,
+  /* a parallel region (rule 4): operands: n_sections (<= 4096), length[n_sections] in words; the sections follow back to back.
+   * Host replay with fewer proofs than threads runs the sections on spare threads; the device replay ignores the marker. */
+  MP2G_OP_PAR = 14,
+  /* PoseidonGate / PoseidonGenerator (the original permutation, WrapC): operands and wires as MP2G_OP_P2. */
+  MP2G_OP_POSEIDON = 15,
+  /* U32ArithmeticGate with `ops` operations a row / U32ArithmeticGenerator: m0 m1 + addend = low + 2^32 high, all u32.
+   * operands: row, i (< ops), ops (1..3), s_m0, s_m1, s_addend, d_low, d_high.   wires 6i .. 6i+5 = m0, m1, addend, low, high,
+   * (2^32 - 1 - high)^-1 or 0; the 32 two-bit limbs of the 64-bit result at wires 6 ops + 32 i .. */
+  MP2G_OP_U32_ARITH = 16,
+  /* U32SubtractionGate / U32SubtractionGenerator: x - y - borrow_in = result - 2^32 borrow_out.
+   * operands: row, i (< ops), ops (1..6), s_x, s_y, s_borrow_in, d_result, d_borrow_out.   wires 5i .. 5i+4 in that order; the 16
+   * two-bit limbs of result at wires 5 ops + 16 i .. */
+  MP2G_OP_U32_SUB = 17,
+  /* U32AddManyGate(num_addends, ops) / U32AddManyGenerator: sum of the addends + carry_in = result + 2^32 carry_out.
+   * operands: row, i (< ops), ops, n (addends, 1..16), s_addend[n], s_carry_in, d_result, d_carry_out.   wires (n + 3) i .. =
+   * addends, carry_in, result, carry_out; 18 two-bit limbs (16 of result, 2 of carry_out) at wires (n + 3) ops + 18 i .. */
+  MP2G_OP_U32_ADD_MANY = 18,
+  /* U32RangeCheckGate(k) / U32RangeCheckGenerator: x < 2^32.   operands: row, i (< k), k (1..7), s_x.
+   * wire i = x, its 16 two-bit limbs at wires k + 16 i .. ; no slot is written. */
+  MP2G_OP_U32_RANGE_CHECK = 19,
+  /* ComparisonGate(num_bits, num_chunks) / ComparisonGenerator: result = (first <= second), both below 2^num_bits.
+   * operands: row, num_bits (1..63), num_chunks (1..16, chunks of ceil(num_bits / num_chunks) bits), s_first, s_second, d_result.
+   * wires 0 first, 1 second, 2 result, 3 most significant difference, then per chunk: first chunks, second chunks, equality
+   * dummies, chunks-equal flags, intermediate values, then the chunk_bits + 1 bits of 2^chunk_bits + most significant difference. */
+  MP2G_OP_COMPARISON = 20,
+  /* BaseSumGate<B> with n limbs, B = 2^base_bits / BaseSplitGenerator<B>: the base-B digits of x, little endian.
+   * operands: row, base_bits (1 or 2), n (1..63, n base_bits <= 63), s_x, d_limb[n].   wire 0 = x, wires 1..n = limbs. */
+  MP2G_OP_BASE_SPLIT = 21,
+  /* MulExtensionGate (13 operations a row) / MulExtensionGenerator: out = k_c0 m0 m1 over the extension.
+   * operands: row, i (< 13), k_c0, s_m0[2], s_m1[2], d_out[2].   wires 6i .. 6i+5 in that order. */
+  MP2G_OP_MUL_EXT = 22,
+  /* ExponentiationGate(n) / ExponentiationGenerator: out = base^(sum bit_j 2^j).
+   * operands: row, n (1..66), s_base, s_bit[n] (little endian), d_out.   wire 0 base, wires 1..n bits, wire n + 1 out, wires n + 2 ..
+   * the n intermediate values (most significant bit first). */
+  MP2G_OP_EXP = 23,
+  MP2G_OP_END = 24 /* one past the last opcode */
+};
+/* create: the tape is copied. input_sids [n_inputs]: the slots the caller provides per proof, in the order of the proof's input
+ * words (a framework circuit: the circuit-set digest, then per verified child its verifier data, public inputs, caps, openings, FRI
+ * proof words and set-membership path, then the circuit's own inputs -- recursion.py universal_inputs); const_slots [n_consts][2]:
+ * (slot, value) pairs. */
 typedef struct mp2g_witness_program mp2g_witness_program;
 int mp2g_witness_program_create(const uint64_t* tape, size_t tape_len, uint32_t n_slots, uint32_t log_n, const uint32_t* input_sids,
                                 uint32_t n_inputs, const uint64_t* const_slots, uint32_t n_consts, mp2g_witness_program** out);

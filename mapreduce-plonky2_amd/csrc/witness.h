@@ -6,8 +6,13 @@
 #include "ctx.h"
 
 namespace mp2g {
-enum { OP_ARITH = 1, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
-       OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR, OP_POSEIDON, OP_END };
+// the opcodes are the PUBLIC ones (include/mp2g.h enum mp2g_witness_op: operand layouts and rules are documented there)
+enum { OP_ARITH = MP2G_OP_ARITH, OP_ARITH_EXT = MP2G_OP_ARITH_EXT, OP_P2 = MP2G_OP_P2, OP_BASE_SUM = MP2G_OP_BASE_SUM, OP_RA = MP2G_OP_RA,
+       OP_REDUCING = MP2G_OP_REDUCING, OP_REDUCING_EXT = MP2G_OP_REDUCING_EXT, OP_COSET = MP2G_OP_COSET, OP_WIRE = MP2G_OP_WIRE,
+       OP_HINT_DIV_EXT = MP2G_OP_HINT_DIV_EXT, OP_HINT_LO63 = MP2G_OP_HINT_LO63, OP_HINT_HI = MP2G_OP_HINT_HI, OP_HINT_SPLIT = MP2G_OP_HINT_SPLIT,
+       OP_PAR = MP2G_OP_PAR, OP_POSEIDON = MP2G_OP_POSEIDON, OP_U32_ARITH = MP2G_OP_U32_ARITH, OP_U32_SUB = MP2G_OP_U32_SUB,
+       OP_U32_ADD_MANY = MP2G_OP_U32_ADD_MANY, OP_U32_RANGE_CHECK = MP2G_OP_U32_RANGE_CHECK, OP_COMPARISON = MP2G_OP_COMPARISON,
+       OP_BASE_SPLIT = MP2G_OP_BASE_SPLIT, OP_MUL_EXT = MP2G_OP_MUL_EXT, OP_EXP = MP2G_OP_EXP, OP_END = MP2G_OP_END };
 const u32 BASE_SUM_LIMBS = 63, RA_BITS = 4, RA_COPIES = 4, RED_COEFFS = 43, RED_EXT_COEFFS = 32, NUM_WIRES = 135;
 
 // the program's read-only data on one device (uploaded at the first device run there)

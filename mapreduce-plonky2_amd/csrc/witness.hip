@@ -13,6 +13,7 @@
 #include "perm_constants.h"
 #include "ctx.h"
 #include "witness.h"
+#include "witness_ops.h"
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -24,8 +25,9 @@ using namespace mp2g;
 #define NEED(c, msg) do { if (!(c)) return fail("invalid argument: %s", msg); } while (0)
 
 namespace {
-// operand count after the opcode; 0 = variable (OP_COSET: 3 + 2 * 2^bits + 4)
-u32 op_len(u64 op, const u64* t) {
+// operand count after the opcode (t = the operands, left = how many words the tape still holds after the opcode); ~0u = malformed.
+// Variable-length instructions read their counts from their first operands: those are checked to be there before they are read.
+u32 op_len(u64 op, const u64* t, size_t left = ~(size_t)0) {
   switch (op) {
     case OP_ARITH: return 8;
     case OP_ARITH_EXT: return 12;
@@ -34,12 +36,19 @@ u32 op_len(u64 op, const u64* t) {
     case OP_RA: return 3 + 16 + 1;
     case OP_REDUCING: return 5 + RED_COEFFS + 2;
     case OP_REDUCING_EXT: return 5 + 2 * RED_EXT_COEFFS + 2;
-    case OP_COSET: return 3 + (2u << t[1]) + 4;
+    case OP_COSET: return left >= 2 && t[1] <= 5 ? 3 + (2u << t[1]) + 4 : ~0u;
     case OP_WIRE: return 3;
     case OP_HINT_DIV_EXT: return 6;
     case OP_HINT_LO63: case OP_HINT_HI: return 2;
     case OP_HINT_SPLIT: return 4;  // source slot, bit position, low slot, high slot (split_low_high's LowHighGenerator)
-    case OP_PAR: return t[0] <= 4096 ? 1 + (u32)t[0] : ~0u;  // section count, then the sections' lengths in words; the sections follow
+    case OP_PAR: return left >= 1 && t[0] <= 4096 ? 1 + (u32)t[0] : ~0u;  // section count, then the sections' lengths in words; the sections follow
+    case OP_U32_ARITH: case OP_U32_SUB: return 8;
+    case OP_U32_ADD_MANY: return left >= 4 && t[3] >= 1 && t[3] <= 16 ? 4 + (u32)t[3] + 3 : ~0u;
+    case OP_U32_RANGE_CHECK: return 4;
+    case OP_COMPARISON: return 6;
+    case OP_BASE_SPLIT: return left >= 3 && t[2] >= 1 && t[2] <= 63 ? 4 + (u32)t[2] : ~0u;
+    case OP_MUL_EXT: return 9;
+    case OP_EXP: return left >= 2 && t[1] >= 1 && t[1] <= 66 ? 3 + (u32)t[1] + 1 : ~0u;
     default: return ~0u;
   }
 }
@@ -307,7 +316,10 @@ void exec(const mp2g_witness_program& P, const u64* t, const u64* end, u64* vals
       case OP_HINT_LO63: vals[t[1]] = vals[t[0]] & (((u64)1 << 63) - 1); t += 2; break;
       case OP_HINT_HI: vals[t[1]] = vals[t[0]] >> 63; t += 2; break;
       case OP_HINT_SPLIT: vals[t[2]] = vals[t[0]] & (((u64)1 << t[1]) - 1); vals[t[3]] = vals[t[0]] >> t[1]; t += 4; break;
-      default: return;  // validated at create
+      default:  // the leaf-circuit gates (witness_ops.h: shared with the device executor)
+        if (!exec_gate_op(op, t, vals, [&](u64 col, u64 row, u64 v) { W(col, row) = v; })) return;  // validated at create
+        t += op_len(op, t);
+        break;
     }
   }
 #undef W
@@ -353,7 +365,7 @@ static int witness_program_create(const uint64_t* tape, size_t tape_len, uint32_
     if (op < OP_ARITH || op >= OP_END) return bad("unknown opcode");
     if (op == OP_COSET && (t + 2 > end || t[1] < 2 || t[1] > 5)) return bad("CosetInterpolation bits");
     if (op == OP_PAR && (t + 1 > end || par_end)) return bad("parallel region header / nesting");
-    const u32 len = op_len(op, t);
+    const u32 len = op_len(op, t, (size_t)(end - t));
     if (len == ~0u || t + len > end) return bad("truncated instruction");
     if (op == OP_PAR) {
       const u64* body = t + len;
@@ -377,6 +389,20 @@ static int witness_program_create(const uint64_t* tape, size_t tape_len, uint32_
       case OP_COSET: if (t[0] >= n) return bad("row"); first_slot = 2; break;
       case OP_WIRE: if (t[0] >= n || t[1] >= NUM_WIRES) return bad("wire"); first_slot = 2; break;
       case OP_HINT_SPLIT: if (t[0] >= n_slots || t[1] < 1 || t[1] > 63) return bad("split hint"); first_slot = 2; break;
+      case OP_U32_ARITH: if (t[0] >= n || t[2] < 1 || t[2] > 3 || t[1] >= t[2]) return bad("U32Arithmetic operands"); first_slot = 3; break;
+      case OP_U32_SUB: if (t[0] >= n || t[2] < 1 || t[2] > 6 || t[1] >= t[2]) return bad("U32Subtraction operands"); first_slot = 3; break;
+      case OP_U32_ADD_MANY: if (t[0] >= n || t[2] < 1 || t[1] >= t[2] || (t[3] + 3 + 18) * t[2] > NUM_WIRES) return bad("U32AddMany operands"); first_slot = 4; break;
+      case OP_U32_RANGE_CHECK: if (t[0] >= n || t[2] < 1 || t[2] > 7 || t[1] >= t[2]) return bad("U32RangeCheck operands"); first_slot = 3; break;
+      case OP_COMPARISON: {
+        if (t[0] >= n || t[1] < 1 || t[1] > 63 || t[2] < 1 || t[2] > 16) return bad("Comparison operands");
+        const u64 cb = (t[1] + t[2] - 1) / t[2];
+        if (4 + 5 * t[2] + cb + 1 > NUM_WIRES) return bad("Comparison operands");
+        first_slot = 3;
+        break;
+      }
+      case OP_BASE_SPLIT: if (t[0] >= n || t[1] < 1 || t[1] > 2 || t[1] * t[2] > 63) return bad("BaseSplit operands"); first_slot = 3; break;
+      case OP_MUL_EXT: if (t[0] >= n || t[1] >= 13 || t[2] >= GL_P) return bad("MulExtension operands"); first_slot = 3; break;
+      case OP_EXP: if (t[0] >= n) return bad("row"); first_slot = 2; break;
       default: first_slot = 0; break;
     }
     for (u32 i = first_slot; i < len; i++) if (t[i] >= n_slots) return bad("slot out of range");
@@ -424,6 +450,13 @@ static int witness_program_create(const uint64_t* tape, size_t tape_len, uint32_
         case OP_HINT_DIV_EXT: r0 = 0; nr = 4; w0 = 4; nw = 2; break;
         case OP_HINT_LO63: case OP_HINT_HI: r0 = 0; nr = 1; w0 = 1; nw = 1; break;
         case OP_HINT_SPLIT: r0 = 0; nr = 1; w0 = 2; nw = 2; break;
+        case OP_U32_ARITH: case OP_U32_SUB: r0 = 3; nr = 3; w0 = 6; nw = 2; break;
+        case OP_U32_ADD_MANY: r0 = 4; nr = (u32)a[3] + 1; w0 = 5 + (u32)a[3]; nw = 2; break;
+        case OP_U32_RANGE_CHECK: r0 = 3; nr = 1; break;
+        case OP_COMPARISON: r0 = 3; nr = 2; w0 = 5; nw = 1; break;
+        case OP_BASE_SPLIT: r0 = 3; nr = 1; w0 = 4; nw = (u32)a[2]; break;
+        case OP_MUL_EXT: r0 = 3; nr = 4; w0 = 7; nw = 2; break;
+        case OP_EXP: r0 = 2; nr = 1 + (u32)a[1]; w0 = 3 + (u32)a[1]; nw = 1; break;
         default: break;
       }
       u32 l = 0;

@@ -13,6 +13,7 @@
 #include "poseidon.cuh"
 #include "poseidon_wave.cuh"
 #include "witness.h"
+#include "witness_ops.h"
 
 namespace mp2g {
 namespace {
@@ -261,7 +262,9 @@ GLD void exec_one(const u64* t, u64* vals, u64* wires, u64 n, const u64* domtab)
     case OP_HINT_LO63: vals[t[1]] = vals[t[0]] & (((u64)1 << 63) - 1); break;
     case OP_HINT_HI: vals[t[1]] = vals[t[0]] >> 63; break;
     case OP_HINT_SPLIT: vals[t[2]] = vals[t[0]] & (((u64)1 << t[1]) - 1); vals[t[3]] = vals[t[0]] >> t[1]; break;
-    default: break;  // validated at create
+    default:  // the leaf-circuit gates (witness_ops.h: shared with the host executor); anything else was refused at create
+      exec_gate_op(op, t, vals, [wires](u64 col, u64 row, u64 v) { W(col, row) = v; });
+      break;
   }
 }
 #undef W

@@ -74,7 +74,9 @@ class T:
 # (plonky2's generate_partial_witness for this circuit): csrc/witness.hip replays it for a batch of input vectors.
 # Every instruction: opcode, then its operands (row / slot indices, u64 constants), fixed length per opcode.
 (OP_ARITH, OP_ARITH_EXT, OP_P2, OP_BASE_SUM, OP_RA, OP_REDUCING, OP_REDUCING_EXT, OP_COSET, OP_WIRE, OP_HINT_DIV_EXT,
- OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR, OP_POSEIDON) = range(1, 16)
+ OP_HINT_LO63, OP_HINT_HI, OP_HINT_SPLIT, OP_PAR, OP_POSEIDON,
+ # the leaf circuits' user-logic gates (round 6; include/mp2g.h enum mp2g_witness_op documents every operand layout)
+ OP_U32_ARITH, OP_U32_SUB, OP_U32_ADD_MANY, OP_U32_RANGE_CHECK, OP_COMPARISON, OP_BASE_SPLIT, OP_MUL_EXT, OP_EXP) = range(1, 24)
 
 
 class E:
@@ -101,7 +103,8 @@ class Row:
 def tape_instructions(tape):
     """(position, opcode) of every instruction of a recorded witness program (the lengths csrc/witness.hip's op_len gives)"""
     fixed = {OP_ARITH: 8, OP_ARITH_EXT: 12, OP_P2: 26, OP_POSEIDON: 26, OP_BASE_SUM: 2 + 63, OP_RA: 20, OP_REDUCING: 5 + 43 + 2, OP_REDUCING_EXT: 5 + 64 + 2,
-             OP_WIRE: 3, OP_HINT_DIV_EXT: 6, OP_HINT_LO63: 2, OP_HINT_HI: 2, OP_HINT_SPLIT: 4}
+             OP_WIRE: 3, OP_HINT_DIV_EXT: 6, OP_HINT_LO63: 2, OP_HINT_HI: 2, OP_HINT_SPLIT: 4, OP_U32_ARITH: 8, OP_U32_SUB: 8, OP_U32_RANGE_CHECK: 4,
+             OP_COMPARISON: 6, OP_MUL_EXT: 9}
     t, n = 0, len(tape)
     while t < n:
         op = int(tape[t])
@@ -110,6 +113,12 @@ def tape_instructions(tape):
             t += 1 + 3 + (2 << int(tape[t + 2])) + 4
         elif op == OP_PAR:
             t += 1 + 1 + int(tape[t + 1])
+        elif op == OP_U32_ADD_MANY:
+            t += 1 + 4 + int(tape[t + 4]) + 3
+        elif op == OP_BASE_SPLIT:
+            t += 1 + 4 + int(tape[t + 3])
+        elif op == OP_EXP:
+            t += 1 + 3 + int(tape[t + 2]) + 1
         else:
             t += 1 + fixed[op]
 
@@ -149,6 +158,27 @@ def instruction_slots(tape, pos):
         return [t[0]], [t[1]], [], pos + 3
     if op == OP_HINT_SPLIT:
         return [t[0]], t[2:4], [], pos + 5
+    t = tape[pos + 1:]
+    if op in (OP_U32_ARITH, OP_U32_SUB):
+        per, limbs = (6, 32) if op == OP_U32_ARITH else (5, 16)
+        row, i, ops = t[0], t[1], t[2]
+        return t[3:6], t[6:8], [(row, per * i + k) for k in range(per)] + [(row, per * ops + limbs * i + j) for j in range(limbs)], pos + 9
+    if op == OP_U32_ADD_MANY:
+        row, i, ops, na = t[0], t[1], t[2], t[3]
+        per = na + 3
+        return t[4:5 + na], t[5 + na:7 + na], [(row, per * i + k) for k in range(per)] + [(row, per * ops + 18 * i + j) for j in range(18)], pos + 1 + 4 + na + 3
+    if op == OP_U32_RANGE_CHECK:
+        row, i, k = t[0], t[1], t[2]
+        return [t[3]], [], [(row, i)] + [(row, k + 16 * i + j) for j in range(16)], pos + 5
+    if op == OP_COMPARISON:
+        return t[3:5], [t[5]], [(t[0], c) for c in range(135)], pos + 7
+    if op == OP_BASE_SPLIT:
+        return [t[3]], t[4:4 + t[2]], [(t[0], c) for c in range(1 + t[2])], pos + 1 + 4 + t[2]
+    if op == OP_MUL_EXT:
+        return t[3:7], t[7:9], [(t[0], 6 * t[1] + k) for k in range(6)], pos + 10
+    if op == OP_EXP:
+        nb = t[1]
+        return t[2:3 + nb], [t[3 + nb]], [(t[0], c) for c in range(2 * nb + 2)], pos + 1 + 3 + nb + 1
     raise ValueError(f"opcode {op}")
 
 
@@ -660,6 +690,128 @@ class Builder:
     def or_(self, a, b):
         """a + b - a b for booleans"""
         return self.sub(self.add(a, b), self.mul(a, b))
+
+    # ---- the leaf circuits' user-logic gates (plonky2-u32, BaseSumGate<4>, MulExtensionGate, ExponentiationGate) ------------------
+    # Each method places one operation in a row of its gate (gate parameters = the reference's leaf gate set, circuits.LEAF_KINDS),
+    # and records ONE tape instruction for it (MP2G_OP_U32_ARITH ..: the generator runs inside the witness replay, host or device).
+    def u32_arithmetic(self, m0, m1, addend, ops=3):
+        """U32ArithmeticGate / U32ArithmeticGenerator: m0 m1 + addend = low + 2^32 high over u32 operands. Returns (low, high)."""
+        row, i = self._slot(("u32arith", ops), ops, lambda: self._new_row(C.U32_ARITHMETIC, ops))
+        out = (m0.v * m1.v + addend.v) % P
+        lo, hi, b = out & 0xFFFFFFFF, out >> 32, 6 * i
+        self._put(row, b, m0), self._put(row, b + 1, m1), self._put(row, b + 2, addend)
+        tlo, thi = self._out(row, b + 3, lo), self._out(row, b + 4, hi)
+        w = self.rows[row].wires
+        w[b + 5] = pow((0xFFFFFFFF - hi) % P, P - 2, P)
+        for j in range(32):
+            w[6 * ops + 32 * i + j] = (out >> (2 * j)) & 3
+        self.tape += [OP_U32_ARITH, row, i, ops, m0.sid, m1.sid, addend.sid, tlo.sid, thi.sid]
+        return tlo, thi
+
+    def u32_sub(self, x, y, borrow_in, ops=6):
+        """U32SubtractionGate / U32SubtractionGenerator: x - y - borrow_in = result - 2^32 borrow_out. Returns (result, borrow_out)."""
+        row, i = self._slot(("u32sub", ops), ops, lambda: self._new_row(C.U32_SUBTRACTION, ops))
+        r0 = (x.v - y.v - borrow_in.v) % P
+        bo = 1 if r0 > 1 << 32 else 0
+        r, b = (r0 + (bo << 32)) % P, 5 * i
+        self._put(row, b, x), self._put(row, b + 1, y), self._put(row, b + 2, borrow_in)
+        tr, tb = self._out(row, b + 3, r), self._out(row, b + 4, bo)
+        w = self.rows[row].wires
+        for j in range(16):
+            w[5 * ops + 16 * i + j] = (r >> (2 * j)) & 3
+        self.tape += [OP_U32_SUB, row, i, ops, x.sid, y.sid, borrow_in.sid, tr.sid, tb.sid]
+        return tr, tb
+
+    def u32_add_many(self, addends, carry_in, ops=5):
+        """U32AddManyGate(len(addends), ops) / U32AddManyGenerator: sum + carry_in = result + 2^32 carry_out. Returns (result, carry_out)."""
+        na = len(addends)
+        per = na + 3
+        row, i = self._slot(("u32addmany", na, ops), ops, lambda: self._new_row(C.U32_ADD_MANY, na, ops))
+        tot = (sum(a.v for a in addends) + carry_in.v) % P
+        res, co, b = tot & 0xFFFFFFFF, tot >> 32, per * i
+        for k, a in enumerate(addends):
+            self._put(row, b + k, a)
+        self._put(row, b + na, carry_in)
+        tr, tc = self._out(row, b + na + 1, res), self._out(row, b + na + 2, co)
+        w = self.rows[row].wires
+        for j in range(16):
+            w[per * ops + 18 * i + j] = (res >> (2 * j)) & 3
+        for j in range(2):
+            w[per * ops + 18 * i + 16 + j] = (co >> (2 * j)) & 3
+        self.tape += [OP_U32_ADD_MANY, row, i, ops, na] + [a.sid for a in addends] + [carry_in.sid, tr.sid, tc.sid]
+        return tr, tc
+
+    def u32_range_check(self, x, k=7):
+        """U32RangeCheckGate(k) / U32RangeCheckGenerator: x < 2^32"""
+        row, i = self._slot(("u32rc", k), k, lambda: self._new_row(C.U32_RANGE_CHECK, k))
+        self._put(row, i, x)
+        w = self.rows[row].wires
+        for j in range(16):
+            w[k + 16 * i + j] = (x.v >> (2 * j)) & 3
+        self.tape += [OP_U32_RANGE_CHECK, row, i, k, x.sid]
+
+    def comparison_le(self, first, second, num_bits=32, num_chunks=16):
+        """ComparisonGate(num_bits, num_chunks) / ComparisonGenerator: the boolean first <= second for operands below 2^num_bits"""
+        row = self._new_row(C.COMPARISON, num_bits, num_chunks)
+        cb = (num_bits + num_chunks - 1) // num_chunks
+        a, b = first.v, second.v
+        self._put(row, 0, first), self._put(row, 1, second)
+        w = self.rows[row].wires
+        msd = 0
+        for i in range(num_chunks):
+            fc, sc = (a >> (cb * i)) & ((1 << cb) - 1), (b >> (cb * i)) & ((1 << cb) - 1)
+            diff = (sc - fc) % P
+            eq = 1 if diff == 0 else 0
+            w[4 + i], w[4 + num_chunks + i] = fc, sc
+            w[4 + 2 * num_chunks + i] = 1 if eq else pow(diff, P - 2, P)
+            w[4 + 3 * num_chunks + i] = eq
+            iv = msd if eq else 0
+            w[4 + 4 * num_chunks + i] = iv
+            msd = iv if eq else diff
+        w[3] = msd
+        val = ((1 << cb) + msd) % P
+        for i in range(cb + 1):
+            w[4 + 5 * num_chunks + i] = (val >> i) & 1
+        res = self._out(row, 2, (val >> cb) & 1)
+        self.tape += [OP_COMPARISON, row, num_bits, num_chunks, first.sid, second.sid, res.sid]
+        return res
+
+    def base_split(self, x, base_bits, n_limbs):
+        """BaseSumGate<2^base_bits> with n_limbs limbs / BaseSplitGenerator: the little-endian digits of x (the reference's leaf gate
+        set carries BaseSumGate<4> with 20 limbs beside the bit splits)"""
+        row = self._new_row(C.BASE_SUM, n_limbs, 1 << base_bits)
+        self._put(row, 0, x)
+        limbs = [self._out(row, 1 + j, (x.v >> (base_bits * j)) & ((1 << base_bits) - 1)) for j in range(n_limbs)]
+        self.tape += [OP_BASE_SPLIT, row, base_bits, n_limbs, x.sid] + [t.sid for t in limbs]
+        return limbs
+
+    def mul_ext_gate(self, c0, m0, m1):
+        """MulExtensionGate (13 operations a row) / MulExtensionGenerator: c0 m0 m1 over the extension"""
+        c0 %= P
+        row, i = self._slot(("mulext", c0), 13, lambda: self._new_row(C.MUL_EXT, 13, consts=(c0, 0)))
+        b = 6 * i
+        self._put(row, b, m0.a), self._put(row, b + 1, m0.b), self._put(row, b + 2, m1.a), self._put(row, b + 3, m1.b)
+        o = xscale(xmul(m0.v, m1.v), c0)
+        out = E(self._out(row, b + 4, o[0]), self._out(row, b + 5, o[1]))
+        self.tape += [OP_MUL_EXT, row, i, c0, m0.a.sid, m0.b.sid, m1.a.sid, m1.b.sid, out.a.sid, out.b.sid]
+        return out
+
+    def exponentiation(self, base, bits):
+        """ExponentiationGate(len(bits)) / ExponentiationGenerator: base^(sum bits_j 2^j)"""
+        nb = len(bits)
+        row = self._new_row(C.EXPONENTIATION, nb)
+        self._put(row, 0, base)
+        for j, bt in enumerate(bits):
+            self._put(row, 1 + j, bt)
+        w = self.rows[row].wires
+        cur = 1
+        for i in range(nb):
+            prev = 1 if i == 0 else cur * cur % P
+            cur = prev * (base.v if bits[nb - 1 - i].v else 1) % P
+            w[nb + 2 + i] = cur
+        out = self._out(row, nb + 1, cur)
+        self.tape += [OP_EXP, row, nb, base.sid] + [bt.sid for bt in bits] + [out.sid]
+        return out
 
     # ---- RandomAccessGate (bits 4, 4 copies, 2 extra constants) ---------------------------------------------------------------
     def random_access(self, index, values):

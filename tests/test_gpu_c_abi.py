@@ -51,6 +51,10 @@ def test_header_compiles_as_c():
     build_prove_circuit()
     build_generate_proof()
     build_forest()
+    # the hand-assembled witness tape (tests/test_gpu_witness_tape.py runs it): uses enum mp2g_witness_op from the header alone
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_witness_tape.c"), "-L" + os.path.join(ROOT, "mapreduce-plonky2_amd"),
+                           "-lmp2gpu", "-Wl,-rpath," + os.path.join(ROOT, "mapreduce-plonky2_amd"), "-o", os.path.join(ROOT, "examples", "c_witness_tape")])
 
 
 @pytest.mark.gpu
