@@ -1685,20 +1685,34 @@ def run_table_resumable(args, local_rank, VARIANT, clocks):
     names = list(params.rows.circuits)
     by_digest = {tuple(int(x) for x in params.rows.vds[n][1]): n for n in names}
     cur, notes, ws = {}, {}, {}
+
+    def stored_block_is_bad(b, why):
+        # a stored root that fails its checks would block the join for ever: it is dropped, and the next call rebuilds that block
+        store.remove(keys[b])
+        rig.close()
+        clocks.close()
+        raise SystemExit(f"bench.py: the stored root of block {b} failed its check ({why}); it was removed from {args.resume_dir}: run the same command again to rebuild the block")
+
     for b in range(blocks):
-        proof, vk_cap, vk_dig = mp2.deserialize_proof_with_vk(final_fp, final_ckt.num_constants, store.get_proof_exact(keys[b]), n_pis)
+        try:
+            proof, vk_cap, vk_dig = mp2.deserialize_proof_with_vk(final_fp, final_ckt.num_constants, store.get_proof_exact(keys[b]), n_pis)
+        except (mp2.Mp2gError, KeyError, ValueError) as e:
+            stored_block_is_bad(b, f"not a ProofWithVK of this shape: {e}")
         name = by_digest[tuple(int(x) for x in vk_dig)]  # the verifier key names the circuit (KeyError: not a circuit of this set)
         assert np.array_equal(vk_cap.ravel(), np.asarray(params.rows.vds[name][0], dtype=np.uint64).ravel()), "stored verifier key: cap"
         pis = proof[3]
         # the stored root against the table, not against its note: digest of the block's rows, min / max, circuit-set digest; the oracle verifies it
         w_b, wei_b = mp2.compute_table_row_digest(ctx, tables[b].col_ids, tables[b].values, tables[b].values[:, 0:1])
-        assert np.array_equal(wei_b, pis[4:15]), f"block {b}: stored root's digest != compute_table_row_digest of the block"
-        assert np.array_equal(pis[26:34], T.u256_to_limbs([ints(tables[b].values[0, 0])])[0]) and np.array_equal(pis[34:42], T.u256_to_limbs([ints(tables[b].values[-1, 0])])[0]), "min / max"
-        assert np.array_equal(pis[T.ROWS_IO:], np.asarray(params.rows.set_digest, dtype=np.uint64)), "circuit-set digest"
+        if not np.array_equal(wei_b, pis[4:15]):
+            stored_block_is_bad(b, "its digest != compute_table_row_digest of the block")
+        if not (np.array_equal(pis[26:34], T.u256_to_limbs([ints(tables[b].values[0, 0])])[0]) and np.array_equal(pis[34:42], T.u256_to_limbs([ints(tables[b].values[-1, 0])])[0])):
+            stored_block_is_bad(b, "min / max")
+        if not np.array_equal(pis[T.ROWS_IO:], np.asarray(params.rows.set_digest, dtype=np.uint64)):
+            stored_block_is_bad(b, "circuit-set digest")
         wckt, _, wdig = params.rows.chains[name][-1]
         rc = OC.verify(wckt, OC.oracle_params(wckt), np.asarray(wdig, dtype=np.uint64), O.hash_n_to_m_no_pad(pis, 4), *proof[:3])
         if rc:
-            raise SystemExit(f"bench.py: the oracle's verifier rejects the stored root of block {b} (code {rc})")
+            stored_block_is_bad(b, f"the oracle's verifier rejects it (code {rc})")
         cur[b], notes[b], ws[b] = (proof, name, w_b), store.note(keys[b]), w_b
     for c in rig.ctxs:
         c.sync()

@@ -636,7 +636,11 @@ int mp2g_forest_group_units(const uint32_t* item_sizes, uint32_t n_items, uint32
 /* (one mp2g_forest_prove / mp2g_forest_prove_plan call at a time per forest: the call starts the forest's worker threads itself.
  * Inside it a worker keeps up to two batches queued behind the running one; a node counts as proved, and its children's pool
  * slots return, when its batch has been CONFIRMED -- witness flags read, one batch late; a failure rolls the queued batches back.
- * A worker that finds the pool empty waits for slots and fails only when every worker of the call waits.) */
+ * A worker that finds the pool empty waits for slots and fails only when every worker of the call waits. A node is PUBLISHED --
+ * visible to mp2g_forest_proof and usable as a child by another unit -- only when its batch is confirmed; inside its own unit it
+ * is usable as soon as it is queued (same stream). The units of one call must therefore not name each other's nodes as children
+ * (the waves of an update plan never do). After a failed call the nodes of the confirmed batches stay proved: resubmit the unit
+ * without them -- a unit that names a proved node is refused.) */
 int mp2g_forest_prove(mp2g_forest* f, const uint64_t* unit_nodes, const uint32_t* unit_offsets /* [n_units + 1] */, uint32_t n_units);
 /* the harness loop over an update plan (declared below), inside the library: drain the Ready items of a wave, group them into units of
  * about group_nodes plan nodes (never fewer units than workers), prove, mark done, until the plan is finished. A plan node k stands for

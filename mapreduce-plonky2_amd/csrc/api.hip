@@ -47,6 +47,17 @@ int mp2g_ctx_create(int device, mp2g_ctx** out) {
   if (e == hipSuccess) {
     c->own_stream = true;
     c->ntt.stream = c->stream;
+#ifdef MP2G_EXPERIMENT_NTT_PRIORITY
+    if (const char* pe = getenv("MP2G_NTT_PRIORITY"); pe && atoi(pe) != 0) {
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (hipStreamCreateWithPriority(&c->ntt.hi_stream, hipStreamNonBlocking, greatest) != hipSuccess) c->ntt.hi_stream = nullptr;
+      if (c->ntt.hi_stream && (hipEventCreateWithFlags(&c->ntt.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                               hipEventCreateWithFlags(&c->ntt.ev_join, hipEventDisableTiming) != hipSuccess)) c->ntt.hi_stream = nullptr;
+      static bool said = false;
+      if (!said) { said = true; fprintf(stderr, "libmp2gpu (variant): NTT on a priority-%d stream (range %d..%d): %s\n", greatest, least, greatest, c->ntt.hi_stream ? "on" : "FAILED"); }
+    }
+#endif
     e = hipEventCreate(&c->ev0);
   }
   if (e == hipSuccess) e = hipEventCreate(&c->ev1);

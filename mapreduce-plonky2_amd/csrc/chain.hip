@@ -61,6 +61,8 @@ int mp2g_chain_create(mp2g_ctx* c, uint32_t n_steps, mp2g_prover* const* provers
 int mp2g_chain_run(mp2g_chain* ch, const uint64_t* inputs, uint32_t batch, const mp2g_chain_patch* patches, uint32_t n_patches,
                    uint64_t* caps, uint64_t* openings, uint64_t* proof, uint64_t* public_inputs) {
   NEED(ch && inputs && batch >= 1 && batch <= ch->cap && (patches || !n_patches), "chain / inputs / batch <= capacity");
+  // (a caller that mixes the two entry points: an upload of h_in queued by chain_enqueue must have left the buffer BEFORE it is overwritten)
+  if (ch->in_ev_set[0]) CK(hipEventSynchronize(ch->in_ev[0]));
   memcpy(ch->h_in, inputs, (size_t)batch * ch->steps[0].n_in * sizeof(u64));
   return chain_run_staged(ch, batch, patches, n_patches, nullptr, caps, openings, proof, public_inputs);
 }
@@ -144,7 +146,7 @@ int mp2g::chain_run_staged(mp2g_chain* ch, uint32_t batch, const mp2g_chain_patc
   mp2g_chain::Step& s0 = ch->steps[0];
   for (uint32_t i = 0; i < n_patches; i++)
     NEED(patches[i].job < batch && patches[i].d_src && (size_t)patches[i].offset + patches[i].n_words <= s0.n_in, "patch outside the inputs");
-  if (ch->in_ev_set[0]) CK(hipEventSynchronize(ch->in_ev[0]));  // (a caller that mixes the two entry points: h_in's queued upload first)
+  if (ch->in_ev_set[0]) CK(hipEventSynchronize(ch->in_ev[0]));  // (callers that fill h_in themselves, e.g. the forest's synchronous mode: the queued upload first)
   {
     int rc = chain_steps(ch, batch, ch->h_in, patches, n_patches, hooks, nullptr, nullptr);
     if (rc) return rc;

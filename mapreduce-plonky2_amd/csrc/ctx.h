@@ -26,6 +26,10 @@ struct DevBuf {
     bytes = b;
     return hipSuccess;
   }
+  void release() {
+    if (p && !borrowed) (void)hipFree(p);
+    p = nullptr; bytes = 0; borrowed = false;
+  }
   void borrow(u64* q, size_t b) {
     if (p && !borrowed) (void)hipFree(p);
     p = q; bytes = b; borrowed = true;
@@ -47,6 +51,7 @@ struct mp2g_ctx {
   // prover needs, not the sum over the circuits (a table build holds 17 provers per worker and runs one at a time: 238 GB -> 64 GB
   // at 4 x 48 proofs in flight). MP2G_SHARE_SCRATCH=0 gives every prover buffers of its own again (the A/B switch).
   mp2g::DevBuf prover_scratch;
+  uint32_t scratch_users = 0;  // provers that have bound buffers into it; freed when the last of them is (mp2g_prover_free)
   bool share_scratch = true;
 };
 struct mp2g_tree {

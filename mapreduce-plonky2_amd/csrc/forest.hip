@@ -45,7 +45,8 @@ struct Node {
   int32_t slot = -1;        // pool slot of the proof, -1 = not proved (or released)
   uint32_t proof_words = 0; // words of the proof in its slot
   bool keep = false;        // the slot survives the parent (a checker downloads the proof later)
-  bool proved = false;
+  bool proved = false;      // PUBLISHED: the device has written the slot and the witness check of its batch passed (set in confirm_oldest)
+  uint32_t queued_by = 0;   // worker + 1 of the unit whose stream holds the node's batch, queued and not yet confirmed; 0 = none
 };
 struct Circuit {
   mp2g_forest_circuit d{};
@@ -113,7 +114,27 @@ struct InFlight {
 };
 
 // one unit on one worker; errors are returned as the library's code with mp2g_last_error() set by the failing call
+int prove_unit_body(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count, std::deque<InFlight>& flight);
+// one unit; an allocation failure between a batch's enqueue and its confirmation must not leave its nodes queued and its slots
+// taken: whatever is still in flight is rolled back before the error is returned
 int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) {
+  std::deque<InFlight> flight;  // queued batches, oldest first
+  try {
+    return prove_unit_body(f, w, ids, count, flight);
+  } catch (...) {
+    (void)hipStreamSynchronize(f->ctxs[w]->stream);
+    {
+      std::lock_guard<std::mutex> g(f->mu);
+      for (InFlight& b : flight) {
+        for (uint32_t i : b.nodes) { Node& n = f->nodes[i]; n.proved = false; n.queued_by = 0; n.slot = -1; n.proof_words = 0; }
+        for (int32_t sl : b.slots) f->free_slots.push_back(sl);
+      }
+    }
+    f->slots_back.notify_all();
+    return fail("forest: out of memory (or another exception) inside a unit of worker %u: its queued batches were rolled back", w);
+  }
+}
+int prove_unit_body(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count, std::deque<InFlight>& flight) {
   if (!count) return 0;
   CK(hipSetDevice(f->ctxs[w]->device));
   std::vector<uint32_t> unit(count);
@@ -123,7 +144,10 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
     if (it == f->index.end()) return fail("forest: unknown node %llu in a unit", (unsigned long long)ids[i]);
     unit[i] = it->second;
     if (!level.emplace(it->second, ~0u).second) return fail("forest: node %llu is listed twice in a unit", (unsigned long long)ids[i]);
-    if (f->nodes[it->second].proved) return fail("forest: node %llu is already proved", (unsigned long long)ids[i]);
+    // a unit may be submitted again after a failure: its confirmed batches stay proved (their slots are valid), and a node that is
+    // proved already -- or queued by another worker's unit of this call -- must not be proved twice
+    if (f->nodes[it->second].proved || f->nodes[it->second].queued_by)
+      return fail("forest: node %llu is already proved (a unit that failed half way is resubmitted WITHOUT the nodes its confirmed batches proved: mp2g_forest_proof succeeds on exactly those)", (unsigned long long)ids[i]);
   }
   // levels by repeated relaxation over the unit (children may come after their parents in `ids`)
   uint32_t max_level = 0;
@@ -153,7 +177,6 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
   for (uint32_t i : unit) by[(size_t)level[i] * f->n_circuits + f->nodes[i].circuit].push_back(i);
   mp2g_forest::Worker& W = f->workers[w];
   hipStream_t stream = f->ctxs[w]->stream;
-  std::deque<InFlight> flight;  // queued batches, oldest first
   const uint32_t depth = f->pipelined ? mp2g_forest::RING - 1 : 0;  // batches that may stay queued behind the one being assembled
 
   // the oldest queued batch has run: its witness-check flags, then its children's slots go back (a slot returns when the parent is proved)
@@ -166,7 +189,9 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
     {
       std::lock_guard<std::mutex> g(f->mu);
       for (uint32_t i : b.nodes) {
-        const Node& n = f->nodes[i];
+        Node& n = f->nodes[i];
+        n.proved = true;  // published only now: the slot is written and checked (another worker's unit may name it as a child from here on)
+        n.queued_by = 0;
         for (uint32_t k = 0; k < n.n_children; k++) {
           Node& cn = f->nodes[f->index[n.child[k]]];
           if (!cn.keep && cn.slot >= 0) { f->free_slots.push_back(cn.slot); cn.slot = -1; }
@@ -183,7 +208,7 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
     (void)hipStreamSynchronize(stream);
     std::lock_guard<std::mutex> g(f->mu);
     for (InFlight& b : flight) {
-      for (uint32_t i : b.nodes) { Node& n = f->nodes[i]; n.proved = false; n.slot = -1; n.proof_words = 0; }
+      for (uint32_t i : b.nodes) { Node& n = f->nodes[i]; n.proved = false; n.queued_by = 0; n.slot = -1; n.proof_words = 0; }
       for (int32_t sl : b.slots) f->free_slots.push_back(sl);
     }
     flight.clear();
@@ -264,7 +289,9 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
               {
                 std::lock_guard<std::mutex> g(f->mu);
                 ch_node = &f->nodes[f->index[n.child[k]]];
-                if (!ch_node->proved || ch_node->slot < 0) return fail("forest: child %llu of node %llu is not proved (or was released)", (unsigned long long)n.child[k], (unsigned long long)n.id);
+                // a child is usable when it is published, or when THIS unit queued it on this worker's stream (stream order puts its
+                // batch before this one); a node queued by another worker's unit is not: its slot may not be written yet
+                if (!(ch_node->proved || ch_node->queued_by == w + 1) || ch_node->slot < 0) return fail("forest: child %llu of node %llu is not proved (or was released)", (unsigned long long)n.child[k], (unsigned long long)n.id);
               }
               if (at + ch_node->proof_words > C.d.n_inputs) return fail("forest: circuit %u: a child proof runs past the inputs", c);
               R.h_jobs[nb++] = Copy{f->pool.p + (size_t)ch_node->slot * f->slot_words, s0.in.p + (size_t)j * s0.n_in + at, ch_node->proof_words, 0};
@@ -297,8 +324,8 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
         int rc = chain_enqueue(ch, B, which, &hooks, R.h_flags);
         if (!rc) { hipError_t e = hipEventRecord(R.done, stream); if (e != hipSuccess) rc = fail("forest: event record: %s", hipGetErrorString(e)); }
         if (rc) { std::string msg = mp2g_last_error(); (void)hipStreamSynchronize(stream); give_back(); roll_back(); return fail("%s", msg.c_str()); }
-        // queued: later levels of this unit (the same stream) may name these nodes as children from now on; nobody else sees them
-        // before the unit returns
+        // queued: later levels of this unit (the same stream) may name these nodes as children from now on; other workers' units
+        // see them once their batch is confirmed (confirm_oldest publishes)
         InFlight fl;
         fl.ring = ring; fl.B = B; fl.out_words = out_words; fl.ch = ch; fl.slots = slots;
         fl.nodes.assign(todo.begin() + lo, todo.begin() + lo + B);
@@ -306,7 +333,7 @@ int prove_unit(mp2g_forest* f, uint32_t w, const uint64_t* ids, uint32_t count) 
           std::lock_guard<std::mutex> g(f->mu);
           for (uint32_t j = 0; j < B; j++) {
             Node& n = f->nodes[todo[lo + j]];
-            n.slot = slots[j]; n.proof_words = out_words; n.proved = true;
+            n.slot = slots[j]; n.proof_words = out_words; n.queued_by = w + 1;
           }
         }
         flight.push_back(std::move(fl));

@@ -180,6 +180,33 @@ __global__ void __launch_bounds__(256) merkle_level_wave_kernel(const u64* __res
   x = wp2_perm(x, l);
   if (active && l < 4) out[4 * i + l] = x;
 }
+// SEVERAL levels of a tree in one launch (round 6): a block owns 2^s consecutive nodes of the input level and the whole subtree above
+// them -- s levels, s <= 6. Every 16-lane group hashes one node at a time (wp2_perm); a level's digests go to global memory (the
+// levels array keeps every level: Merkle paths are read from it) and, through LDS, to the block's next level: one barrier per level
+// instead of one launch per level. The small levels of a tree are a chain of dependent permutations (~25 us each as a launch of
+// their own, of which the permutation's latency is half): a lone commitment of 2^18 leaves spent 11 launches on its last 6 % of
+// permutations. levels: `in` holds n_in nodes per tree, level j of the subtree (n_in >> j nodes) starts 4 (2 n_in - (n_in >> (j - 1)))
+// words after it (the levels are stored back to back).
+__global__ void __launch_bounds__(256) merkle_subtree_wave_kernel(const u64* __restrict__ in, u64 n_in, u32 s, u64 bstride) {
+  __shared__ u64 buf[2][32 * 4];
+  const int l = (int)(threadIdx.x & 15), g = (int)(threadIdx.x >> 4);
+  const u64* src_g = in + blockIdx.y * bstride + ((u64)blockIdx.x << s) * 4;   // this block's 2^s input nodes
+  u64* lvl = const_cast<u64*>(in) + blockIdx.y * bstride + 4 * n_in;          // level 1 of the tree (n_in / 2 nodes)
+  u64 n_lvl = n_in >> 1;
+  for (u32 j = 1; j <= s; j++) {
+    const u32 m = 1u << (s - j);                                               // nodes of this block at level j
+    u64* dst_g = lvl + (u64)blockIdx.x * m * 4;
+    for (u32 node = g; node < m; node += 16) {
+      u64 x = 0;
+      if (l < 8) x = j == 1 ? src_g[8 * node + l] : buf[j & 1][8 * node + l];
+      x = wp2_perm(x, l);
+      if (l < 4) { dst_g[4 * node + l] = x; buf[(j + 1) & 1][4 * node + l] = x; }
+    }
+    __syncthreads();
+    lvl += 4 * n_lvl;
+    n_lvl >>= 1;
+  }
+}
 template <int V>
 __global__ void __launch_bounds__(256) hash_no_pad_batch_kernel(const u64* __restrict__ in, u32 in_len, u64 count, u32 out_len, u64* __restrict__ out) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -287,10 +314,20 @@ hipError_t merkle_reduce(hipStream_t st, int variant, u64* levels, u32 log_leave
   for (u32 lv = log_leaves; lv > cap_h; lv--) {
     u64 n_in = (u64)1 << lv;
     u64* nxt = cur + 4 * n_in;
-    // below ~2^14 nodes in flight the level is latency-bound: spread each permutation over 16 lanes
-    if (variant == MP2G_POSEIDON2 && (n_in / 2) * (u64)batch <= 16384)
+    // below ~2^14 nodes in flight the level is latency-bound: spread each permutation over 16 lanes, and take the remaining
+    // levels -- a chain of dependent permutations -- in as few launches as 6 levels a block allow, balanced
+    if (variant == MP2G_POSEIDON2 && (n_in / 2) * (u64)batch <= 16384) {
+#ifndef MP2G_MERKLE_LEVEL_PER_LAUNCH
+      const u32 left = lv - cap_h, launches = (left + 5) / 6, sl = (left + launches - 1) / launches;
+      if (sl >= 2) {
+        hipLaunchKernelGGL(merkle_subtree_wave_kernel, dim3((u32)(n_in >> sl), batch), dim3(256), 0, st, cur, n_in, sl, bstride);
+        for (u32 j = 0; j < sl; j++) { cur += 4 * (n_in >> j); }
+        lv -= sl - 1;  // the loop's own step takes the last of the sl levels
+        continue;
+      }
+#endif
       hipLaunchKernelGGL(merkle_level_wave_kernel, grid1(n_in / 2 * 16, 256, batch), dim3(256), 0, st, cur, nxt, n_in / 2, bstride);
-    else
+    } else
       LAUNCH_V(merkle_level_kernel, grid1(n_in / 2, 256, batch), dim3(256), st, cur, nxt, n_in / 2, bstride);
     cur = nxt;
   }

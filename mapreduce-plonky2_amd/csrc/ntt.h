@@ -30,6 +30,15 @@ struct NttEngine {
   // bumped whenever a device buffer a launched kernel may reference (scratch, coset tables) is freed or
   // replaced: a hipGraph captured under an older generation must not be replayed
   u64 generation = 0;
+#ifdef MP2G_EXPERIMENT_NTT_PRIORITY
+  // A/B of round 6 (variant libraries only; tools/dbg/ntt_priority_ab.sh): the transforms of this engine run on a second, HIGH
+  // priority stream, forked from and joined to `stream` by events around every run(), so that a worker's 0.5 ms transform is not
+  // dispatched behind the other workers' sponge workgroups
+  hipStream_t hi_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipError_t run_impl(const u64* in, u64* out, u32 log_n, u32 polys, u32 logK, u64 in_poly_stride, u64 out_poly_stride, bool inverse,
+                      const CosetTables* pre, bool bitrev_out);
+#endif
   ~NttEngine();
 
   hipError_t plan(u32 log_n, bool inverse, NttPlan** out);

@@ -1001,8 +1001,26 @@ static hipError_t dispatch_cols(u32 lt, const NttArgs& a, u64* dense, hipStream_
   }
 }
 
+#ifdef MP2G_EXPERIMENT_NTT_PRIORITY
 hipError_t NttEngine::run(const u64* in, u64* out, u32 log_n, u32 polys, u32 logK, u64 in_poly_stride,
                           u64 out_poly_stride, bool inverse, const CosetTables* pre, bool bitrev_out) {
+  if (!hi_stream) return run_impl(in, out, log_n, polys, logK, in_poly_stride, out_poly_stride, inverse, pre, bitrev_out);
+  hipStream_t base = stream;
+  HIPCHK(hipEventRecord(ev_fork, base));
+  HIPCHK(hipStreamWaitEvent(hi_stream, ev_fork, 0));
+  stream = hi_stream;
+  hipError_t e = run_impl(in, out, log_n, polys, logK, in_poly_stride, out_poly_stride, inverse, pre, bitrev_out);
+  stream = base;
+  if (e != hipSuccess) return e;
+  HIPCHK(hipEventRecord(ev_join, hi_stream));
+  return hipStreamWaitEvent(base, ev_join, 0);
+}
+hipError_t NttEngine::run_impl(const u64* in, u64* out, u32 log_n, u32 polys, u32 logK, u64 in_poly_stride,
+                               u64 out_poly_stride, bool inverse, const CosetTables* pre, bool bitrev_out) {
+#else
+hipError_t NttEngine::run(const u64* in, u64* out, u32 log_n, u32 polys, u32 logK, u64 in_poly_stride,
+                          u64 out_poly_stride, bool inverse, const CosetTables* pre, bool bitrev_out) {
+#endif
   if (log_n == 0 || log_n > 24) return hipErrorInvalidValue;
   NttPlan* p;
   HIPCHK(plan(log_n, inverse, &p));

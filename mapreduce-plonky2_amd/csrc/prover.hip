@@ -66,6 +66,7 @@ struct mp2g_prover {
   std::vector<std::pair<DevBuf*, size_t>> shared;
   const u64* bound_base = nullptr;
   size_t bound_total = 0;
+  bool counted = false;  // this prover is one of ctx->scratch_users (it has bound buffers into the shared scratch)
   // a per-batch working buffer: in the shared scratch (recorded, bound later) or, with sharing off, memory of its own
   hipError_t want(DevBuf& d, size_t bytes) {
     if (!ctx->share_scratch) return d.alloc(bytes);
@@ -294,8 +295,13 @@ ProverGuard::~ProverGuard() { if (pr) mp2g_prover_free(pr); }
 extern "C" {
 void mp2g_prover_free(mp2g_prover* pr) {
   if (!pr) return;
-  (void)hipStreamSynchronize(pr->ctx->stream);
+  mp2g_ctx* c = pr->ctx;
+  (void)hipStreamSynchronize(c->stream);
+  const bool counted = pr->counted;
   delete pr;
+  // the shared scratch goes with the LAST prover that used it: a long-lived context that ran one large one-shot prove (mp2g_pcs_prove,
+  // mp2g_fri_prove, a bench leg) does not keep that working set until mp2g_ctx_destroy
+  if (counted && c->scratch_users && --c->scratch_users == 0) c->prover_scratch.release();
 }
 // coefficients in pr->coeffs[o] -> LDE values, Merkle levels (PolynomialBatch::from_coeffs)
 static hipError_t commit_oracle_coeffs(mp2g_prover* pr, uint32_t o, uint32_t nb) {
@@ -449,6 +455,7 @@ static int prove_impl(mp2g_prover* pr, const uint64_t* const* d_values, const ui
 static int bind_scratch(mp2g_prover* pr) {
   if (pr->shared.empty()) return 0;
   mp2g_ctx* c = pr->ctx;
+  if (!pr->counted) { pr->counted = true; c->scratch_users++; }
   size_t total = 0;
   for (auto& e : pr->shared) total += (e.second + 255) & ~(size_t)255;
   if (c->prover_scratch.bytes < total) {

@@ -5,8 +5,8 @@ block, another process) picks a child up as serialized `ProofWithVK` bytes (mp2-
 table too large for one GPU lease be built block by block across calls -- every block's root goes in as ProofWithVK bytes
 (mp2g_proof_with_vk_serialize), the join levels take them out (mp2g_proof_with_vk_deserialize).
 
-A directory of files, not a storage engine: one file per key, written to a temporary name and renamed, so a call that is cut off
-leaves either the whole proof or nothing."""
+A directory of files, not a storage engine: one file per key (header + proof), written to a temporary name and renamed, so a call
+that is cut off leaves either the whole proof with its header or nothing."""
 import json
 import os
 
@@ -55,16 +55,23 @@ class ProofKey:
         return f"ProofKey({self.canonical()})"
 
 
+MAGIC = b"MP2GPRF1"
+
+
 class ProofStore:
-    """ProofStorage (proof_storage.rs:139-140) over a directory. Files: <kind>_<hash:016x>.bin = the proof bytes,
-    <kind>_<hash:016x>.json = the key in clear and what the caller wants kept beside the proof (never read back for the proof
-    itself: a loaded proof is checked against its verifier key and public inputs, not against the note)."""
+    """ProofStorage (proof_storage.rs:139-140) over a directory. ONE file per key, <kind>_<hash:016x>.bin = MAGIC, u32 header length,
+    header (JSON: the key in clear, the proof's length, what the caller wants kept beside the proof), the proof bytes -- written to a
+    temporary name and renamed, so that a key holds a whole proof WITH its own header or nothing: a call that is cut off, or two ranks
+    storing under one key, cannot leave the note of one proof beside the bytes of another. The header's clear-text key is compared with
+    the key asked for on every read (two keys whose 64-bit hashes collide cannot alias). The note is never read back for the proof
+    itself: a loaded proof is checked against its verifier key and public inputs. Stores written before round 6 (the proof bytes alone
+    in the .bin, the header in a .json beside it: profiles/r05/table_2p20_store) are still read."""
 
     def __init__(self, path):
         self.path = path
         os.makedirs(path, exist_ok=True)
 
-    def _file(self, key, ext):
+    def _file(self, key, ext="bin"):
         return os.path.join(self.path, f"{key.kind}_{key.compute_hash():016x}.{ext}")
 
     def _write(self, name, data):
@@ -77,28 +84,62 @@ class ProofStore:
             os.fsync(f.fileno())
         os.replace(tmp, name)
 
+    def _read(self, path):
+        """(header dict or None, proof bytes) of a store file: the one-file form, or the proof alone of an older store"""
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:8] == MAGIC:
+            n = int.from_bytes(data[8:12], "little")
+            head = json.loads(data[12:12 + n].decode())
+            proof = data[12 + n:]
+            if len(proof) != head["bytes"]:
+                raise ValueError(f"{path}: the header announces {head['bytes']} proof bytes, the file holds {len(proof)}")
+            return head, proof
+        side = path[:-4] + ".json"
+        head = None
+        if os.path.exists(side):
+            with open(side) as f:
+                head = json.load(f)
+        return head, data
+
     def store_proof(self, key, proof, note=None):
         """store_proof(key, proof): overwrites an earlier proof under the same key (proof_storage.rs:30-33: the latest one counts)"""
-        self._write(self._file(key, "json"), json.dumps({"key": key.canonical(), "bytes": len(proof), "note": note or {}}).encode())
-        self._write(self._file(key, "bin"), bytes(proof))
+        head = json.dumps({"key": key.canonical(), "bytes": len(proof), "note": note or {}}).encode()
+        self._write(self._file(key), MAGIC + len(head).to_bytes(4, "little") + head + bytes(proof))
+        try:
+            os.remove(self._file(key, "json"))  # the side file of an older store's entry under this key
+        except FileNotFoundError:
+            pass
 
     def contains(self, key):
-        return os.path.exists(self._file(key, "bin"))
+        return os.path.exists(self._file(key))
+
+    def _entry(self, key):
+        try:
+            head, proof = self._read(self._file(key))
+        except FileNotFoundError:
+            raise KeyError(f"proof with key {key!r} not found in {self.path}") from None
+        if head is not None and head.get("key") != key.canonical():
+            raise KeyError(f"proof with key {key!r} not found in {self.path}: the file of its hash holds the key {head.get('key')!r} (a 64-bit hash collision)")
+        return head, proof
 
     def get_proof_exact(self, key):
         """get_proof_exact(key): the bytes, or KeyError naming the key (proof_storage.rs:262-272 `proof with key .. not found`)"""
-        try:
-            with open(self._file(key, "bin"), "rb") as f:
-                return f.read()
-        except FileNotFoundError:
-            raise KeyError(f"proof with key {key!r} not found in {self.path}") from None
+        return self._entry(key)[1]
 
     def note(self, key):
-        try:
-            with open(self._file(key, "json")) as f:
-                return json.load(f)["note"]
-        except FileNotFoundError:
-            raise KeyError(f"proof with key {key!r} not found in {self.path}") from None
+        head, _ = self._entry(key)
+        if head is None:
+            raise KeyError(f"proof with key {key!r} has no header in {self.path}")
+        return head["note"]
+
+    def remove(self, key):
+        """drop a key's proof (a stored proof that failed its checks: the caller rebuilds it); silent when there is none"""
+        for ext in ("bin", "json"):
+            try:
+                os.remove(self._file(key, ext))
+            except FileNotFoundError:
+                pass
 
     def move_proof(self, old_key, new_key):
         """move_proof(old, new): a silent no-op when the old key holds nothing (proof_storage.rs:236-260)"""
@@ -106,13 +147,15 @@ class ProofStore:
             return
         proof, note = self.get_proof_exact(old_key), self.note(old_key)
         self.store_proof(new_key, proof, note)
-        os.remove(self._file(old_key, "bin"))
-        os.remove(self._file(old_key, "json"))
+        self.remove(old_key)
 
     def keys(self):
+        """the clear-text keys of the proofs the store holds (a header without its proof does not exist in the one-file form; an
+        older store's side file without a .bin is not a proof)"""
         out = []
         for name in sorted(os.listdir(self.path)):
-            if name.endswith(".json"):
-                with open(os.path.join(self.path, name)) as f:
-                    out.append(json.load(f)["key"])
+            if name.endswith(".bin"):
+                head, _ = self._read(os.path.join(self.path, name))
+                if head is not None:
+                    out.append(head["key"])
         return out

@@ -937,14 +937,18 @@ class Builder:
         gate of a circuit at every point of the LDE domain, so a circuit's proving cost depends on its gate SET and its degree, not
         on how many rows each gate has: this is how a circuit whose own logic is light is given the gate set (and with
         build(min_log_n) the degree) of the reference's heavier circuit of the same role (base degrees k = 12..15).
-        The rows' wires are fixed values (circuits.fill_row: a satisfying assignment), written by OP_WIRE from constant slots, so the
-        witness program reproduces them on host and device; no copy constraint touches them."""
+        A gate whose generator is a tape instruction (the u32 gates, ComparisonGate, BaseSumGate<4>, MulExtensionGate,
+        ExponentiationGate) gets its row from that generator, replayed on host or device like the circuit's own logic
+        (_generated_gate_row); the other rows' wires are fixed values (circuits.fill_row: a satisfying assignment) written by OP_WIRE from
+        constant slots. No copy constraint touches either."""
         present = {(r.kind, r.p0, r.p1, r.p2) for r in self.rows}
         for kind, p0, p1, p2 in kinds:
             if kind in (C.NOOP, C.PUBLIC_INPUT, C.CONSTANT) or (kind, p0, p1, p2) in present:
                 continue
             present.add((kind, p0, p1, p2))
             rng = np.random.default_rng([seed, kind, p0, p1, p2])
+            if self._generated_gate_row(kind, p0, p1, p2, rng):
+                continue
             w = [None] * NUM_WIRES
             # gate constants (0, 0): a RandomAccessGate row's two extra-constant cells stay free for _place_constants
             C.fill_row(Gate(kind, p0, p1, p2, 0, 0, 0), w, (0, 0), lambda col: int(rng.integers(0, P, dtype=np.uint64)), rng, (0, 0, 0, 0))
@@ -959,6 +963,45 @@ class Builder:
                     sid = self._sid()
                     self.const_slots.append((sid, v))
                     self.tape += [OP_WIRE, row, col, sid]
+
+    def _free(self, v):
+        """a target whose value is preloaded into its slot and that no constraint ties to anything: the operand of a padding row's
+        generator (its home is the wire the generator's gate puts it in)"""
+        t = T(int(v) % P, None, self._sid())
+        self.const_slots.append((t.sid, t.v))
+        return t
+
+    def _generated_gate_row(self, kind, p0, p1, p2, rng):
+        """add_gate_rows for the gates whose generators are tape instructions (round 6): the row is filled by the gate's own
+        generator -- MP2G_OP_U32_ARITH .. MP2G_OP_EXP replayed on host or device -- from preloaded operands, every operation of the
+        row used, instead of 30-130 plain wire writes. False: no generator opcode for this gate (the caller writes the wires)."""
+        u32 = lambda: self._free(int(rng.integers(0, 1 << 32)))
+        if kind == C.U32_ARITHMETIC and 1 <= p0 <= 3:
+            for _ in range(p0):
+                self.u32_arithmetic(u32(), u32(), u32(), ops=p0)
+        elif kind == C.U32_SUBTRACTION and 1 <= p0 <= 6:
+            for _ in range(p0):
+                self.u32_sub(u32(), u32(), self._free(int(rng.integers(0, 2))), ops=p0)
+        elif kind == C.U32_ADD_MANY and 1 <= p0 <= 16 and (p0 + 3 + 18) * p1 <= NUM_WIRES:
+            for _ in range(p1):
+                self.u32_add_many([u32() for _ in range(p0)], self._free(int(rng.integers(0, 1 << 4))), ops=p1)
+        elif kind == C.U32_RANGE_CHECK and 1 <= p0 <= 7:
+            for _ in range(p0):
+                self.u32_range_check(u32(), k=p0)
+        elif kind == C.COMPARISON and 1 <= p0 <= 63 and 1 <= p1 <= 16:
+            self.comparison_le(self._free(int(rng.integers(0, 1 << p0, dtype=np.uint64))), self._free(int(rng.integers(0, 1 << p0, dtype=np.uint64))), p0, p1)
+        elif kind == C.BASE_SUM and p1 == 4 and 2 * p0 <= 63:
+            self.base_split(self._free(int(rng.integers(0, 1 << (2 * p0), dtype=np.uint64))), 2, p0)
+        elif kind == C.MUL_EXT and p0 == 13:
+            fe = lambda: self._free(int(rng.integers(0, P, dtype=np.uint64)))
+            for _ in range(13):
+                self.mul_ext_gate(1, E(fe(), fe()), E(fe(), fe()))
+            del self.open[("mulext", 1)]  # the row is full; user logic that multiplies later opens its own
+        elif kind == C.EXPONENTIATION and 1 <= p0 <= 66:
+            self.exponentiation(self._free(int(rng.integers(0, P, dtype=np.uint64))), [self._free(int(rng.integers(0, 2))) for _ in range(p0)])
+        else:
+            return False
+        return True
 
     # ---- public inputs -------------------------------------------------------------------------------------------------------------
     def register_public_inputs(self, targets):

@@ -131,6 +131,11 @@ def test_base_degree_padding_and_reference_gate_set():
     other[0] = 12345
     wires, pi_hash, pis = prog.run(np.array([[1, 2, 3, 4] + inputs, [1, 2, 3, 4] + other], dtype=np.uint64))  # inputs: the set digest, then the circuit's own
     assert np.array_equal(wires[0], padded.wires), "witness program != builder (the extra gate rows are part of the witness)"
+    # the leaf set's u32 / comparison / base-4 / exponentiation rows come from their GENERATORS' tape instructions (include/mp2g.h
+    # MP2G_OP_U32_ARITH ..), every operation of each row used -- not from plain wire writes
+    ops = [op for _, op in R.tape_instructions(padded.tape)]
+    assert ops.count(R.OP_U32_ARITH) == 3 and ops.count(R.OP_U32_SUB) == 6 and ops.count(R.OP_U32_ADD_MANY) == 5 and ops.count(R.OP_U32_RANGE_CHECK) == 7
+    assert ops.count(R.OP_COMPARISON) == 1 and ops.count(R.OP_BASE_SPLIT) == 1 and ops.count(R.OP_EXP) == 1 and ops.count(R.OP_MUL_EXT) == 13
     again = R.FrameworkCircuit("cells_leaf", 0, logic, T.CELLS_IO, min_log_n=8, extra_gates=PC.LEAF_KINDS).build_base(None, [], [], [], other, [1, 2, 3, 4])
     assert np.array_equal(again.pre, padded.pre) and np.array_equal(wires[1], again.wires)
     fp = C.oracle_params(padded, pow_bits=8, num_queries=4)

@@ -109,6 +109,24 @@ def test_proof_store(tmp_path):
     again.move_proof(PS.ProofKey.index("t", 9), k1)  # silent
     assert not again.contains(k1) and again.get_proof_exact(k3) == b"abcd" and len(again.keys()) == 2
     assert not [f for f in __import__("os").listdir(str(tmp_path / "s")) if f.endswith(".tmp")]
+    # one file per key: the header travels with its proof (no orphan note, no note of one writer beside the bytes of another)
+    import os
+    assert sorted(f.rsplit(".", 1)[1] for f in os.listdir(str(tmp_path / "s"))) == ["bin", "bin"]
+    # the header's clear-text key is compared on every read: a file under another key's hash does not alias it
+    os.replace(again._file(k3), again._file(k1))
+    with pytest.raises(KeyError, match="hash collision"):
+        again.get_proof_exact(k1)
+    again.remove(k1)
+    assert not again.contains(k1) and again.keys() == [k2.canonical()]
+    # a file cut short is refused, not returned as a shorter proof
+    with open(again._file(k2), "r+b") as f:
+        f.truncate(os.path.getsize(again._file(k2)) - 5)
+    with pytest.raises(ValueError, match="proof bytes"):
+        again.get_proof_exact(k2)
+    # the committed store of round 5 (proof bytes in the .bin, header in a .json beside it) is still read
+    old = PS.ProofStore(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05", "table_2p20_store"))
+    ks = old.keys()
+    assert len(ks) >= 8 and all(k.startswith("row_tree.") for k in ks)
 
 
 def fnv1a(data):
