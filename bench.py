@@ -107,6 +107,149 @@ class ClockReader:
             self.p = None
 
 
+class CpuFarm:
+    """The CPU baseline's THROUGHPUT modes run as separate PROCESSES (one address space per proof: threads of one process doing large
+    allocations serialise on the kernel's memory-map lock -- 256 oracle proofs as threads of this process took 166 s, profiles/r06).
+    A process that has initialised the GPU must not fork + exec, so the farm's parent is a helper started before this process
+    touches the GPU (like ClockReader); it gets its jobs over a pipe and starts the workers itself."""
+
+    def __init__(self):
+        import subprocess
+        if "rocprofiler" in os.environ.get("LD_PRELOAD", "").lower():
+            self.p = None
+            return
+        try:
+            self.p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-farm"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        except Exception:
+            self.p = None
+
+    def run(self, spool, modes, seconds):
+        """modes [(P processes, T threads each)] over the spooled samples; returns the farm's list of mode dicts (or raises)"""
+        self.p.stdin.write(json.dumps({"spool": spool, "modes": modes, "seconds": seconds, "orc_lib": os.environ.get("ORC_LIB", "")}) + "\n")
+        self.p.stdin.flush()
+        line = self.p.stdout.readline()
+        if not line:
+            raise RuntimeError("the CPU farm's helper process ended")
+        return json.loads(line)
+
+    def close(self):
+        if self.p is not None:
+            try:
+                self.p.stdin.close()
+                self.p.wait(timeout=10)
+            except Exception:
+                self.p.kill()
+            self.p = None
+
+
+def spool_samples(samples, path):
+    """the captured prove() calls of the sampled framework proofs as files a worker process maps: per prove() its preprocessed
+    polynomials and wires (.npy), in meta.json its shape, gate table, oracle parameters, digest, public-inputs hash; `cycle` = the
+    order in which framework proofs are pulled (the table's proportion: per two rows 2 x 4 cells proofs, a row leaf, a row full node)"""
+    os.makedirs(path, exist_ok=True)
+    kind = lambda chain: chain[0][0].rsplit(" step", 1)[0]
+    cells = [i for i, c in enumerate(samples) if kind(c).startswith("cells")]
+    leaf = [i for i, c in enumerate(samples) if kind(c) == "row_leaf"] or [i for i, c in enumerate(samples) if kind(c).startswith("row")][:1]
+    full = [i for i, c in enumerate(samples) if kind(c) == "row_full"] or leaf
+    cycle = (cells + leaf[:1] + cells + full[:1]) if cells else list(range(len(samples)))
+    meta, k = {"cycle": cycle, "proofs": []}, 0
+    for chain in samples:
+        steps = []
+        for label, ckt, ofp, cd, make_wires, ph, *_ in chain:
+            np.save(os.path.join(path, f"p{k}_pre.npy"), np.ascontiguousarray(ckt.pre, dtype=np.uint64))
+            np.save(os.path.join(path, f"p{k}_wires.npy"), np.ascontiguousarray(make_wires(), dtype=np.uint64))
+            steps.append({"k": k, "label": label, "log_n": int(ckt.log_n), "num_selectors": int(ckt.num_selectors), "num_constants": int(ckt.num_constants),
+                          "gates": [[int(g.kind), int(g.p0), int(g.p1), int(g.p2), int(g.selector_index), int(g.group_start), int(g.group_end)] for g in ckt.gates],
+                          "fp": bytes(ofp).hex(), "cd": [int(x) for x in cd], "ph": [int(x) for x in ph]})
+            k += 1
+        meta["proofs"].append(steps)
+    with open(os.path.join(path, "meta.json"), "w") as f:
+        json.dump(meta, f)
+    return path
+
+
+def cpu_farm_worker(argv):
+    """bench.py --cpu-farm-worker SPOOL IDX P SECONDS: one slot of a throughput mode (OMP_NUM_THREADS is set by the farm). Loads the
+    oracle and the spooled samples, says `ready`, waits for `go`, proves framework proofs IDX, IDX + P, ... of the cycle until SECONDS
+    have passed (at least one), prints how many and how long."""
+    spool, idx, P_, seconds = argv[0], int(argv[1]), int(argv[2]), float(argv[3])
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import circuits as OC
+    import oracle as O
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")  # the ctypes structure of a gate descriptor; the GPU library is never loaded here
+    with open(os.path.join(spool, "meta.json")) as f:
+        meta = json.load(f)
+
+    class Ckt:
+        pass
+    proofs = []
+    for steps in meta["proofs"]:
+        chain = []
+        for st in steps:
+            c = Ckt()
+            c.pre = np.load(os.path.join(spool, f"p{st['k']}_pre.npy"), mmap_mode="c")
+            c.log_n, c.num_selectors, c.num_constants, c.luts = st["log_n"], st["num_selectors"], st["num_constants"], None
+            c.gates = [mp2.Gate(*g) for g in st["gates"]]
+            c.gate_array = (mp2.Gate * len(c.gates))(*c.gates)
+            fp = O.FriParams.from_buffer_copy(bytes.fromhex(st["fp"]))
+            chain.append((c, fp, np.array(st["cd"], dtype=np.uint64), np.load(os.path.join(spool, f"p{st['k']}_wires.npy"), mmap_mode="c"), np.array(st["ph"], dtype=np.uint64)))
+        proofs.append(chain)
+    O.lib()
+    cycle = meta["cycle"]
+    print("ready", flush=True)
+    sys.stdin.readline()
+    t0, done, j = time.perf_counter(), 0, idx
+    while True:
+        for c, fp, cd, wires, ph in proofs[cycle[j % len(cycle)]]:
+            OC.prove_witness(c, fp, cd, wires, ph)
+        done += 1
+        j += P_
+        if time.perf_counter() - t0 > seconds:
+            break
+    print(json.dumps({"done": done, "seconds": time.perf_counter() - t0}), flush=True)
+    return 0
+
+
+def cpu_farm_main():
+    """bench.py --cpu-farm: the helper behind CpuFarm. One JSON job per input line; per mode (P, T): P worker processes with
+    OMP_NUM_THREADS = T, released together once all are ready; value = framework proofs completed / time from the release to the last
+    worker's end. Answers one JSON line per job."""
+    import subprocess
+    for line in sys.stdin:
+        try:
+            job = json.loads(line)
+            out = []
+            for P_, T_ in job["modes"]:
+                env = dict(os.environ, OMP_NUM_THREADS=str(T_), OMP_WAIT_POLICY="passive", GOMP_SPINCOUNT="0")
+                if job.get("orc_lib"):
+                    env["ORC_LIB"] = job["orc_lib"]
+                ws = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-farm-worker", job["spool"], str(i), str(P_), str(job["seconds"])],
+                                       stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env) for i in range(P_)]
+                ok = [w.stdout.readline().strip() == "ready" for w in ws]
+                t0 = time.perf_counter()
+                for w in ws:
+                    try:
+                        w.stdin.write("go\n")
+                        w.stdin.flush()
+                    except Exception:
+                        pass
+                done, failed = 0, ok.count(False)
+                for w in ws:
+                    res = w.stdout.readline()
+                    try:
+                        done += json.loads(res)["done"]
+                    except Exception:
+                        failed += 1
+                    w.wait()
+                wall = time.perf_counter() - t0
+                out.append({"mode": f"{P_} processes x {T_} thread(s) each", "concurrent_proofs": P_, "threads_per_proof": T_, "framework_proofs": done,
+                            "wall_s": round(wall, 2), "proofs_per_s": done / wall, "workers_failed": failed})
+            print(json.dumps(out), flush=True)
+        except Exception as e:
+            print(json.dumps({"error": f"{type(e).__name__}: {e}"[:300]}), flush=True)
+    return 0
+
+
 def check_against_oracle(samples, budget_s, timed, ranks_on_host=1):
     """The checker leg (and, at N=1, the `cpu_baseline` sample): the CPU oracle proves the witnesses of the sampled
     GPU proofs -- leaf proof = one base + one wrap prove() -- `groups` leaf proofs at a time with cores/groups
@@ -702,6 +845,11 @@ def launch_ranks(n, argv):
 
 
 def main(argv=None):
+    av = sys.argv[1:] if argv is None else list(argv)
+    if av[:1] == ["--cpu-farm"]:
+        return cpu_farm_main()
+    if av[:1] == ["--cpu-farm-worker"]:
+        return cpu_farm_worker(av[1:])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -740,7 +888,9 @@ def main(argv=None):
                     "instead of on the device (mp2g_witness_program_run_dev, the default): the A/B switch")
     ap.add_argument("--lean", action="store_true", help="--workload table: keep only the frontier of the row tree in host memory (automatic above 16384 rows); the "
                     "self-check is then the root's public inputs and the oracle's verifier on the root, not the re-proving of sampled nodes")
-    ap.add_argument("--no-leaves-leg", action="store_true", help="--workload table: skip the short prove()-only leg reported beside the headline")
+    ap.add_argument("--leaves-leg", action="store_true", help="--workload table at N = 1: also run the short prove()-only leg on synthetic circuits (round 2's headline, "
+                    "`leaves_prove_only`); off by default since round 6: the driver's window goes to the 2^17-row block")
+    ap.add_argument("--no-leaves-leg", action="store_true", help="(the default now; kept so that older command lines still parse)")
     ap.add_argument("--pad-base-bits", type=int, default=0, help="--workload table: pad every base circuit of both circuit sets to 2^k rows (no-op rows) and give it "
                     "the reference's leaf gate set (SURVEY 8(d): base degrees k = 12..15); 0 = the circuits' natural degrees (the headline)")
     ap.add_argument("--degree-sweep", default="12,13,14,15", help="--workload table at N = 1: after the headline, the table rate at these base degrees (one block of "
@@ -772,6 +922,9 @@ def main(argv=None):
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv))
     clocks = ClockReader()  # before anything initialises the GPU
+    # the CPU baseline's process farm (N = 1 only, like cpu_baseline itself): its helper too must exist before the GPU is touched
+    farm = CpuFarm() if (args.workload == "table" and not args.resume_dir and not args.no_cpu_baseline and not args.no_verify
+                         and int(os.environ.get("WORLD_SIZE", "1")) == 1) else None
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -807,7 +960,11 @@ def main(argv=None):
         assert world == 1, "--resume-dir builds the blocks one after another on one GPU (with N ranks, every rank builds its block in one call: --gpus N)"
         return run_table_resumable(args, local_rank, VARIANT, clocks)
     if args.workload == "table":
-        return run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks)
+        try:
+            return run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks, farm)
+        finally:
+            if farm is not None:
+                farm.close()
     return run_leaves(args, rank, local_rank, world, dist, torch, VARIANT, clocks)
 
 
@@ -958,6 +1115,41 @@ def cpu_throughput(samples, seconds_per_mode=8.0, modes=None):
     omp.omp_set_num_threads(cores)
     best = max(out, key=lambda m: m["proofs_per_s"])
     return best, {"modes": out, "mix": "per two table rows: 2 x the 4 cells-tree proofs, 1 row leaf, 1 row full node (the sampled proofs of the timed block, their captured witnesses)",
+                  "memory_cap": {"available_bytes": avail, "assumed_bytes_per_proof": per_proof_bytes, "max_concurrent": p_cap}}
+
+
+def cpu_throughput_modes(samples, farm, seconds_per_mode):
+    """cpu_baseline's throughput modes: P oracle proofs side by side x T OpenMP threads each with P x T = the host's hardware
+    threads, for T = 1 and 4 -- as separate PROCESSES through the farm (CpuFarm: one address space per proof), or, without a farm
+    (a profiler preloaded, the helper could not start), as threads of this process (cpu_throughput). Returns (best mode, sweep)."""
+    cores = os.cpu_count() or 1
+    if farm is None or farm.p is None:
+        best, sweep = cpu_throughput(samples, seconds_per_mode)
+        sweep["how"] = "threads of one process (no farm helper available)"
+        return best, sweep
+    import shutil
+    import tempfile
+    widest = max(1 << part[1].log_n for c in samples for part in c)
+    per_proof_bytes = 24 * 1024 * widest
+    avail = host_memory_available()
+    p_cap = cores if avail is None else max(1, int(0.5 * avail) // per_proof_bytes)
+    modes = []
+    for t in (1, 4):
+        pt = [max(1, min(cores // t, p_cap)), t]
+        if cores >= t and pt not in modes:
+            modes.append(pt)
+    spool = tempfile.mkdtemp(prefix="mp2g_cpu_spool_")
+    try:
+        spool_samples(samples, spool)
+        res = farm.run(spool, modes, seconds_per_mode)
+    finally:
+        shutil.rmtree(spool, ignore_errors=True)
+    if isinstance(res, dict):
+        raise RuntimeError(f"CPU farm: {res.get('error')}")
+    best = max(res, key=lambda m: m["proofs_per_s"])
+    return best, {"modes": res, "how": "separate processes (bench.py --cpu-farm: a helper started before the GPU was touched spawns P workers per mode; each maps the "
+                                       "spooled samples, all are released together; proofs completed / time to the last worker's end)",
+                  "mix": "per two table rows: 2 x the 4 cells-tree proofs, 1 row leaf, 1 row full node (the sampled proofs of the timed block, their captured witnesses)",
                   "memory_cap": {"available_bytes": avail, "assumed_bytes_per_proof": per_proof_bytes, "max_concurrent": p_cap}}
 
 
@@ -1196,7 +1388,7 @@ def block_plan(rows, steps, warmup, default_rows=None):
     return n_rows, per_step, warm
 
 
-def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
+def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks, farm=None):
     """--workload table (the default, the headline): BASELINE configs[3] as ONE contiguous block of `--steps` x `--rows` table rows per
     rank. Per row the reference proves C = 4 cells-tree nodes (ryhope sbbst over the value columns: two leaves, a full node, a partial
     node) and one row-tree node that verifies the cells root against the cells circuit set and its 0 / 1 / 2 row children
@@ -1371,7 +1563,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
             # the one-proof-after-the-other figure stays as `latency_mode`
             lat = {"value": cpu_base["value"], "sample_wall_s": cpu_base["sample_wall_s"], "mode": "one framework proof after the other, every hardware thread inside each prove() "
                    "(the self-check's own run: its proofs are the ones compared bit for bit)"}
-            best, sweep = cpu_throughput(samples, seconds_per_mode=max(2.0, args.cpu_budget * 0.4))
+            best, sweep = cpu_throughput_modes(samples, farm, max(2.0, args.cpu_budget * 0.4))
             cpu_base["latency_mode"] = lat
             cpu_base["throughput_sweep"] = sweep
             if best["proofs_per_s"] > cpu_base["value"]:
@@ -1460,7 +1652,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
             try:
                 # the full block up to k = 14 (1024 rows by default), half of it at k = 15 (a run there is 15 s as it is), never below 64 rows
                 rows_k = max(min(64, args.sweep_rows), args.sweep_rows >> max(0, k - 14))
-                rk.build(min(64, rows_k), 0, seed ^ 0x5A5A5A, n_cols, False)
+                rk.build(min(256, rows_k), 0, seed ^ 0x5A5A5A, n_cols, False)  # creates the provers and grows the scratch to the full batch: 4 x 48 proofs in flight need > 192 proofs
                 runs = []
                 for rep in range(max(1, args.sweep_runs)):  # the same block proved again: one work plan each, the median reported
                     for c in rk.ctxs:
@@ -1489,7 +1681,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks):
 
     # the prove()-only loop on synthetic circuits (round 2's headline) beside it, briefly
     leaves = None
-    if side and not args.no_leaves_leg:
+    if side and args.leaves_leg and not args.no_leaves_leg:
         import copy
         a2 = copy.copy(args)
         a2.steps, a2.warmup, a2.batch = 3, 1, 128

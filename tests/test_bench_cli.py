@@ -70,3 +70,32 @@ def test_cpu_throughput_sweep_reports_the_best_mode():
     _, sweep = bench.cpu_throughput(samples, seconds_per_mode=0.05)
     cores = os.cpu_count()
     assert [(m["concurrent_proofs"], m["threads_per_proof"]) for m in sweep["modes"]][0] == (cores, 1)
+
+
+def test_cpu_farm_runs_the_throughput_modes_as_processes():
+    """the farm behind cpu_baseline's throughput modes: a helper process (started before the GPU is touched in a real run) spawns P
+    worker processes per mode, each maps the spooled samples and proves framework proofs with T OpenMP threads; here two modes on a
+    small circuit, and the fallback to threads when no farm is there"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    import circuits as C
+    import oracle as O
+    ckt = C.build(5, C.ALL_KINDS, 1)
+    ofp = O.standard_params(5, (ckt.num_constants + C.NUM_ROUTED, C.NUM_WIRES, 20, 16), pow_bits=4, num_queries=2)
+    cd = O.rand_field(4, 2)
+    chain = lambda name: [(f"{name} step {i}", ckt, ofp, cd, (lambda: ckt.wires), ckt.pi_hash) for i in range(2)]
+    samples = [chain("cells_leaf"), chain("cells_full"), chain("row_leaf"), chain("row_full")]
+    farm = bench.CpuFarm()
+    try:
+        assert farm.p is not None
+        best, sweep = bench.cpu_throughput_modes(samples, farm, 0.3)
+        assert "separate processes" in sweep["how"] and len(sweep["modes"]) >= 1
+        cores = os.cpu_count()
+        assert sweep["modes"][0]["concurrent_proofs"] == cores and sweep["modes"][0]["threads_per_proof"] == 1
+        assert all(m["workers_failed"] == 0 and m["framework_proofs"] >= m["concurrent_proofs"] and m["proofs_per_s"] > 0 for m in sweep["modes"])
+        assert best["proofs_per_s"] == max(m["proofs_per_s"] for m in sweep["modes"])
+    finally:
+        farm.close()
+    best, sweep = bench.cpu_throughput_modes(samples, None, 0.1)
+    assert "threads of one process" in sweep["how"] and best["proofs_per_s"] > 0

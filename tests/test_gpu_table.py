@@ -164,7 +164,7 @@ def test_bench_default_workload_is_the_table_build():
     cpu_baseline objects (all-thread / one-thread medians, CPU model), and the side legs of the driver's line at small sizes: BASELINE
     configs[2] (a 64-leaf tree of real proofs here), the table rate at a padded base degree, the prove()-only loop"""
     line = _bench(["--rows", "8", "--steps", "2", "--warmup", "1", "--workers", "2", "--table-batch", "8", "--subtree", "8", "--cpu-budget", "1",
-                   "--config2-leaves", "64", "--degree-sweep", "12", "--sweep-rows", "8", "--sweep-runs", "2"])
+                   "--config2-leaves", "64", "--degree-sweep", "12", "--sweep-rows", "8", "--sweep-runs", "2", "--leaves-leg"])
     assert line["config"]["workload"].startswith("table:") and line["unit"] == "proofs/s" and line["n_gpus"] == 1
     assert line["config"]["rows_per_rank"] == 16 and line["config"]["row_tree_depth"] == 4 and line["steps"] == 2
     assert abs(line["value"] * line["ms_per_step"] * 2 / 1e3 - 5 * 16) < 1e-6  # one 16-row block, 5 framework proofs per row
@@ -179,6 +179,14 @@ def test_bench_default_workload_is_the_table_build():
     assert line["sponge"]["median_of"] == 7 and line["roofline"]["traffic_source"] and line["config2"]["device_memory_used_bytes"] > 0 and line["config"]["device_memory_used_bytes"] > 0
     assert k12["value"] > 0 and k12["root_verified"] and all(ch[0] >= 12 for ch in k12["shapes"].values()) and k12["shapes"]["cells_leaf"][0] == 12 and k12["shapes"]["cells_leaf"][-1] == 12
     assert line["config"]["device_memory_used_bytes"] > 0 and line["config"]["host_orchestration"]["scheduler"].startswith("native")
+    # round 6: the CPU baseline is a throughput (the best of the process-farm modes and the latency mode), the leaf kernel is timed alone
+    # and priced against the mix peak, the 2^22 NTT is stated against the VALU roof as well
+    cb = line["cpu_baseline"]
+    assert cb["value"] >= cb["latency_mode"]["value"] > 0 and cb["mode"] and cb["oracle_build"]["march"] in ("native", "x86-64-v3")
+    assert "separate processes" in cb["throughput_sweep"]["how"] and all(m["workers_failed"] == 0 for m in cb["throughput_sweep"]["modes"])
+    alu = line["roofline_alu"]
+    assert alu["isolated"]["perms_per_s"] > 0 and 0 < alu["isolated"]["frac_of_mix_peak"] < 1.2 and alu["mix_peak"]["slots_per_valu_inst"] > 1
+    assert 0 < line["roofline"]["valu"]["frac_of_valu_peak"] < 1 and line["commit_135x2p15"]["leaf_sponge_ms"] > 0 and line["commit_135x2p15"]["tree_levels_ms"] > 0
 
 
 def test_bench_gpus_2_starts_its_own_ranks():
