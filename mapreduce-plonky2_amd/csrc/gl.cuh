@@ -20,9 +20,11 @@ typedef uint32_t u32;
 #define GLD __device__ __forceinline__
 #define GLHD __host__ __device__ __forceinline__
 
-// What the operations cost on gfx950, in issue slots of a plain 32-bit add (tools/ubench, profiles/r02/ubench_alu.txt): register move
-// ~0.4, v_cndmask ~0.8, 64-bit add WITHOUT carry-out (v_lshl_add_u64) 1.6, v_mad_u64_u32 1.7, an add_co / addc pair with the hazard
-// nop hipcc puts between them 4.4, a compare ~2.5, a 64-bit compare + select + add 6.2. Hence the rules below: a carry (or borrow)
+// What the operations cost on gfx950, in issue slots of a plain 32-bit add (tools/ubench; single-instruction streams measured in
+// round 6, profiles/r06/ubench.txt): register move 0.79 (rounds 2-5 had inferred ~0.4 from A/B residuals), any 32-bit VALU operation
+// 0.85, v_cndmask with an SGPR condition 1.5, 64-bit add WITHOUT carry-out (v_lshl_add_u64) 1.5-1.6, v_mad_u64_u32 1.7, a carry-chain
+// instruction inside an asm chain 1.2, an add_co / addc pair with the hazard nop hipcc puts between them 4.4, a compare ~2.5, a 64-bit
+// compare + select + add 6.2. Hence the rules below: a carry (or borrow)
 // is taken from an add_co / addc pair or from the multiply-add's own carry-out only where the value really can wrap; every
 // correction that provably cannot wrap is a carry-less 64-bit add of a mask; sums of products go through carry-free columns
 // (gl_cols) or ride in the addend slots of the multiply-adds (gl_mul_add_wide); compares are avoided altogether.

@@ -180,13 +180,15 @@ __global__ void __launch_bounds__(256) merkle_level_wave_kernel(const u64* __res
   x = wp2_perm(x, l);
   if (active && l < 4) out[4 * i + l] = x;
 }
-// SEVERAL levels of a tree in one launch (round 6): a block owns 2^s consecutive nodes of the input level and the whole subtree above
-// them -- s levels, s <= 6. Every 16-lane group hashes one node at a time (wp2_perm); a level's digests go to global memory (the
-// levels array keeps every level: Merkle paths are read from it) and, through LDS, to the block's next level: one barrier per level
-// instead of one launch per level. The small levels of a tree are a chain of dependent permutations (~25 us each as a launch of
-// their own, of which the permutation's latency is half): a lone commitment of 2^18 leaves spent 11 launches on its last 6 % of
-// permutations. levels: `in` holds n_in nodes per tree, level j of the subtree (n_in >> j nodes) starts 4 (2 n_in - (n_in >> (j - 1)))
-// words after it (the levels are stored back to back).
+#ifdef MP2G_EXPERIMENT_MERKLE_FUSED
+// A/B of round 6 (variant libraries only; tools/dbg/merkle_fused_ab.sh, profiles/r06/merkle_fused_ab.txt): SEVERAL levels of a tree
+// in one launch -- a block owns 2^s consecutive nodes of the input level and the whole subtree above them, s <= 6; every 16-lane
+// group hashes one node at a time (wp2_perm), a level's digests go to global memory (Merkle paths are read from the levels array)
+// and, through LDS, to the block's next level: one barrier per level instead of one launch per level. MEASURED SLOWER than one launch
+// per level: the 14 levels of a 2^18-leaf tree 0.324 ms against 0.302 ms, the 11 levels of a 2^15-leaf tree 0.199 against 0.175 ms,
+// a lone 2^12-row proof 4.22 against 4.19-4.23 ms, the table block 919 against 920 proofs/s. A level as a launch of its own costs
+// ~16-21 us (the launches of a stream queue behind one another: their overhead overlaps the running kernel), a level inside the
+// fused kernel a full lane-cooperative permutation plus the barrier. The product keeps one launch per level.
 __global__ void __launch_bounds__(256) merkle_subtree_wave_kernel(const u64* __restrict__ in, u64 n_in, u32 s, u64 bstride) {
   __shared__ u64 buf[2][32 * 4];
   const int l = (int)(threadIdx.x & 15), g = (int)(threadIdx.x >> 4);
@@ -207,6 +209,7 @@ __global__ void __launch_bounds__(256) merkle_subtree_wave_kernel(const u64* __r
     n_lvl >>= 1;
   }
 }
+#endif
 template <int V>
 __global__ void __launch_bounds__(256) hash_no_pad_batch_kernel(const u64* __restrict__ in, u32 in_len, u64 count, u32 out_len, u64* __restrict__ out) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -314,10 +317,9 @@ hipError_t merkle_reduce(hipStream_t st, int variant, u64* levels, u32 log_leave
   for (u32 lv = log_leaves; lv > cap_h; lv--) {
     u64 n_in = (u64)1 << lv;
     u64* nxt = cur + 4 * n_in;
-    // below ~2^14 nodes in flight the level is latency-bound: spread each permutation over 16 lanes, and take the remaining
-    // levels -- a chain of dependent permutations -- in as few launches as 6 levels a block allow, balanced
+    // below ~2^14 nodes in flight the level is latency-bound: spread each permutation over 16 lanes
     if (variant == MP2G_POSEIDON2 && (n_in / 2) * (u64)batch <= 16384) {
-#ifndef MP2G_MERKLE_LEVEL_PER_LAUNCH
+#ifdef MP2G_EXPERIMENT_MERKLE_FUSED  // the remaining levels in as few launches as 6 levels a block allow (measured slower: see the kernel)
       const u32 left = lv - cap_h, launches = (left + 5) / 6, sl = (left + launches - 1) / launches;
       if (sl >= 2) {
         hipLaunchKernelGGL(merkle_subtree_wave_kernel, dim3((u32)(n_in >> sl), batch), dim3(256), 0, st, cur, n_in, sl, bstride);

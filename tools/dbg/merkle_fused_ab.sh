@@ -1,13 +1,15 @@
 #!/bin/bash
-# Round 6, VERDICT r05 item 7: the small levels of a tree in one launch per <= 6 levels (csrc/merkle.hip merkle_subtree_wave_kernel)
-# against one launch per level (-DMP2G_MERKLE_LEVEL_PER_LAUNCH variant): a lone commitment, a lone proof, the table block.
+# Round 6, VERDICT r05 item 7: the small levels of a tree in one launch per <= 6 levels (csrc/merkle.hip merkle_subtree_wave_kernel,
+# -DMP2G_EXPERIMENT_MERKLE_FUSED: bash tools/dbg/build_variant.sh merkle_fused "-DMP2G_EXPERIMENT_MERKLE_FUSED" merkle.hip) against
+# one launch per level (the product): a lone commitment, a lone proof, the table block. (The committed run, profiles/r06/
+# merkle_fused_ab.txt, was made while the fused form was the default and the per-level form the variant: same two libraries.)
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r06
 mkdir -p $O
 QUIET="--no-leaves-leg --no-verify --config2-leaves 0 --degree-sweep= --no-cpu-baseline"
 : > $O/merkle_fused_ab.txt
 for mode in fused per_level fused per_level; do
-  if [ $mode = per_level ]; then export MP2G_LIB=$R/build_dbg/merkle_perlevel/libmp2gpu.so; else unset MP2G_LIB; fi
+  if [ $mode = fused ]; then export MP2G_LIB=$R/build_dbg/merkle_fused/libmp2gpu.so; else unset MP2G_LIB; fi
   echo "== $mode" >> $O/merkle_fused_ab.txt
   python3 $R/tools/dbg/merkle_fused_ab.py >> $O/merkle_fused_ab.txt 2>> $O/merkle_fused_ab.err
   for b in 1 4; do
