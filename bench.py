@@ -1133,11 +1133,16 @@ def cpu_throughput_modes(samples, farm, seconds_per_mode):
     per_proof_bytes = 24 * 1024 * widest
     avail = host_memory_available()
     p_cap = cores if avail is None else max(1, int(0.5 * avail) // per_proof_bytes)
+    # cores / 4 x 4 and cores / 16 x 16 in every run; cores x 1 only on request (MP2G_CPU_MODES=1,4,16): every worker must finish a
+    # whole framework proof, 167 s on the 256-thread host of the GPU box for the same 1.5 proofs/s (profiles/r06/cpu_throughput_modes.json)
+    ts = [int(x) for x in os.environ.get("MP2G_CPU_MODES", "4,16").split(",") if x.strip()]
     modes = []
-    for t in (1, 4):
+    for t in ts:
         pt = [max(1, min(cores // t, p_cap)), t]
         if cores >= t and pt not in modes:
             modes.append(pt)
+    if not modes:
+        modes = [[max(1, min(cores, p_cap)), 1]]
     spool = tempfile.mkdtemp(prefix="mp2g_cpu_spool_")
     try:
         spool_samples(samples, spool)
@@ -1150,7 +1155,19 @@ def cpu_throughput_modes(samples, farm, seconds_per_mode):
     return best, {"modes": res, "how": "separate processes (bench.py --cpu-farm: a helper started before the GPU was touched spawns P workers per mode; each maps the "
                                        "spooled samples, all are released together; proofs completed / time to the last worker's end)",
                   "mix": "per two table rows: 2 x the 4 cells-tree proofs, 1 row leaf, 1 row full node (the sampled proofs of the timed block, their captured witnesses)",
-                  "memory_cap": {"available_bytes": avail, "assumed_bytes_per_proof": per_proof_bytes, "max_concurrent": p_cap}}
+                  "memory_cap": {"available_bytes": avail, "assumed_bytes_per_proof": per_proof_bytes, "max_concurrent": p_cap},
+                  "recorded": recorded_cpu_modes()}
+
+
+def recorded_cpu_modes():
+    """the committed record of ALL modes (cores x 1 included: 167 s a run), measured on the GPU box's host in round 6"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06", "cpu_throughput_modes.json")) as f:
+            r = json.load(f)
+        return {"source": "profiles/r06/cpu_throughput_modes.json (committed; not this run)", "cpu_model": r.get("cpu_model"),
+                "proofs_per_s": {m["mode"]: round(m["proofs_per_s"], 3) for part in ("separate_processes", "threads_of_one_process") for m in r[part]["modes"]}}
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 class TableRig:
@@ -1652,7 +1669,7 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks, farm=
             try:
                 # the full block up to k = 14 (1024 rows by default), half of it at k = 15 (a run there is 15 s as it is), never below 64 rows
                 rows_k = max(min(64, args.sweep_rows), args.sweep_rows >> max(0, k - 14))
-                rk.build(min(256, rows_k), 0, seed ^ 0x5A5A5A, n_cols, False)  # creates the provers and grows the scratch to the full batch: 4 x 48 proofs in flight need > 192 proofs
+                rk.build(min(128, rows_k), 0, seed ^ 0x5A5A5A, n_cols, False)  # creates the provers and grows the scratch (4 x 48 proofs in flight: 640 proofs are several full batches)
                 runs = []
                 for rep in range(max(1, args.sweep_runs)):  # the same block proved again: one work plan each, the median reported
                     for c in rk.ctxs:

@@ -17,8 +17,13 @@
 
 namespace mp2g {
 
+#ifdef MP2G_EXPERIMENT_LEAF_PREFETCH
+#define LEAF_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))  // the prefetched limbs must not cost the fourth wave (161 VGPRs unconstrained)
+#else
+#define LEAF_KERNEL_ATTR
+#endif
 template <int V>
-__global__ void __launch_bounds__(256) leaf_hash_poly_major_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ digests,
+__global__ void __launch_bounds__(256) LEAF_KERNEL_ATTR leaf_hash_poly_major_kernel(const u64* __restrict__ values, u32 w, u64 stride, u64 n, u64* __restrict__ digests,
                                                                    u64 in_bstride, u64 out_bstride) {
   u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -40,6 +45,28 @@ __global__ void __launch_bounds__(256) leaf_hash_poly_major_kernel(const u64* __
 #pragma unroll
       for (int k = 0; k < 8; k++)
         if (p + k < w) s[k] = v[(u64)(p + k) * stride];
+      perm<V>(s);
+    }
+#elif defined(MP2G_EXPERIMENT_LEAF_PREFETCH)
+    // A/B of round 6 (variant libraries only): the next chunk's 8 limbs are requested BEFORE the permutation of the current one, so
+    // that their latency passes under ~19 k instructions instead of in front of them (one generation of blocks starts in lockstep:
+    // every wave of the chip waits for its loads at the same moments)
+    u64 nx[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) nx[k] = k < (int)w ? v[(u64)k * stride] : 0;
+    u32 p = 0;
+    for (; p + 8 <= w; p += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = nx[k];
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (p + 8 + k < w) nx[k] = v[(u64)(p + 8 + k) * stride];
+      perm<V>(s);
+    }
+    if (p < w) {
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (p + k < w) s[k] = nx[k];
       perm<V>(s);
     }
 #else

@@ -92,7 +92,7 @@ def test_cpu_farm_runs_the_throughput_modes_as_processes():
         best, sweep = bench.cpu_throughput_modes(samples, farm, 0.3)
         assert "separate processes" in sweep["how"] and len(sweep["modes"]) >= 1
         cores = os.cpu_count()
-        assert sweep["modes"][0]["concurrent_proofs"] == cores and sweep["modes"][0]["threads_per_proof"] == 1
+        assert sweep["modes"][0]["threads_per_proof"] in (1, 4) and sweep["modes"][0]["concurrent_proofs"] * sweep["modes"][0]["threads_per_proof"] <= cores
         assert all(m["workers_failed"] == 0 and m["framework_proofs"] >= m["concurrent_proofs"] and m["proofs_per_s"] > 0 for m in sweep["modes"])
         assert best["proofs_per_s"] == max(m["proofs_per_s"] for m in sweep["modes"])
     finally:
