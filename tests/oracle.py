@@ -18,7 +18,15 @@ _lib = None
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+    """incremental `make` of oracle/liboracle.so, serialised across processes: the ranks of a multi-GPU run (and pytest-xdist workers)
+    all come through here, and two `make`s writing one .so at the same time leave a file neither of them meant"""
+    import fcntl
+    with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def lib():
