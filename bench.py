@@ -682,7 +682,7 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
     # HBM-side bytes of the same two launches from the TCC counters (collected in separate
     # --pmc passes and corrected as MI355X_MICROARCH.md prescribes; profiles/rNN/ntt_traffic.json)
     traffic, traffic_source = None, None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "ntt_traffic.json")) as f:
                 traffic = json.load(f)["ntt_2p22_forward_bitrev"]["traffic_bytes"]
@@ -709,8 +709,16 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
             with open(os.path.join(ROOT, "profiles", rnd, "ntt_traffic.json")) as f:
                 kk = json.load(f)["kernels"]
             insts = sum(v["SQ_INSTS_VALU"] for name, v in kk.items() if name.startswith("void mp2g::ntt_cols_v2_kernel") or name.startswith("void mp2g::ntt_rows_v2_kernel"))
-            with open(os.path.join(ROOT, "profiles", "r05", "sponge_counters.json")) as f:
-                peak = json.load(f)["peak_valu_wave_insts_per_s"]
+            peak = None
+            for rnd2 in ("r06", "r05"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", rnd2, "sponge_counters.json")) as f:
+                        peak = json.load(f)["peak_valu_wave_insts_per_s"]
+                    break
+                except (OSError, KeyError, ValueError):
+                    pass
+            if peak is None:
+                raise KeyError("no sponge_counters.json")
             out["roofline"]["valu"] = {"valu_insts_per_point": insts * 64.0 / n_ntt, "valu_wave_insts_per_launch": insts, "valu_wave_insts_per_s": insts / ntt_s,
                                        "peak_valu_wave_insts_per_s": peak, "frac_of_valu_peak": insts / ntt_s / peak,
                                        "reading": "the transform sits at `frac` of the HBM roof and at `frac_of_valu_peak` of the VALU issue roof: bound by neither (DESIGN.md section 4: one generation of tiles, "
@@ -726,16 +734,18 @@ def kernel_legs(ctx, mp2, C, VARIANT, hasher, rank=0):
 
 
 def roofline_alu(isolated_rate, commit_rate, row_major_rate=None, isolated_runs_ms=None):
-    """the ALU roofline of the kernel that dominates a step (the Poseidon2 leaf sponge: ~40 % of the kernel time of a table build):
-    permutations/s x VALU wave-instructions per permutation (SQ_INSTS_VALU / permutations of the leaf kernel, a committed
-    rocprofv3 --pmc pass: profiles/rNN/sponge_counters.json) against two peaks: the chip's VALU issue peak at 2 cycles per wave64
-    instruction (1024 SIMDs x sclk / 2) and the MIX peak -- the kernel's instruction histogram priced with the issue slots tools/ubench
-    measures per opcode (profiles/r06/leaf_sponge_mix.json, tools/dbg/isa_mix.py): v_mad_u64_u32 and v_lshl_add_u64 take ~1.7 slots
-    each, so a stream of this mix cannot issue at the 2-cycle rate however it is scheduled. `isolated` = the LEAF kernel alone
-    (mp2g_batch_rehash_dev over 2^20 resident leaves of 135 limbs: the launch the instruction count was taken from), timed in this
-    run. The in-step rate is the kernel's rate inside a table build (kernel-trace durations of the committed profile), not measured
-    in this run."""
-    for rnd in ("r05",):
+    """the ALU roofline of the kernel that dominates a step (the Poseidon2 leaf sponge: ~40 % of the kernel time of a table build).
+    Clock-free quantities come from committed rocprofv3 --pmc passes (profiles/rNN/sponge_counters.json): VALU instructions per
+    permutation (SQ_INSTS_VALU / permutations) and the shader cycles the kernel ALONE spends per VALU wave-instruction and SIMD
+    (GRBM_GUI_ACTIVE x 1024 / SQ_INSTS_VALU). The floor is 2 cycles per wave64 instruction on a SIMD-32, so the kernel alone sits at
+    2 / cycles_alone of the VALU issue peak whatever the clock. THIS run's legs are rates (permutations/s); they are compared with the
+    peak at the shader clock THIS run's isolated leaf-kernel leg implies (rate x instructions x cycles_alone / 1024 SIMDs -- it
+    reproduces rocm-smi's reading), not with a peak at another run's clock: the sponge runs power-limited and its clock moves by
+    10 % between boxes and loads. `isolated` = the LEAF kernel alone (mp2g_batch_rehash_dev over 2^20 resident leaves of 135 limbs:
+    the launch the instruction count was taken from). `mix_model`: the kernel's instruction histogram priced with the cycles each
+    opcode class costs as a single-instruction stream (tools/ubench under --pmc, profiles/r06/leaf_sponge_mix.json): the kernel issues
+    FASTER than that additive price -- nothing of its time is left to scheduling."""
+    for rnd in ("r06", "r05"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "sponge_counters.json")) as f:
                 k = json.load(f)
@@ -743,7 +753,7 @@ def roofline_alu(isolated_rate, commit_rate, row_major_rate=None, isolated_runs_
             continue
         try:
             per_perm = k["valu_insts_per_perm"]  # VALU instructions of ONE permutation (one lane); a wave instruction serves 64 of them
-            peak = k["peak_valu_wave_insts_per_s"]  # 1024 SIMDs x sclk / 2 cycles per wave64 instruction on a SIMD-32 (sclk = shader cycles of the profiled launch / its duration)
+            cyc_alone = k["cycles_per_valu_wave_inst_achieved"]  # shader cycles per VALU wave-instruction and SIMD of the kernel alone (counter pass: clock-free)
         except KeyError:
             continue
         mix = None
@@ -753,34 +763,45 @@ def roofline_alu(isolated_rate, commit_rate, row_major_rate=None, isolated_runs_
         except (OSError, ValueError):
             pass
         need = lambda rate: rate / 64.0 * per_perm
-        mix_peak = mix["mix_peak_valu_wave_insts_per_s"] if mix else None
+        sclk = need(isolated_rate) * cyc_alone / 1024.0  # the clock at which 3.0 cycles per instruction give this run's isolated rate
+        peak = 1024.0 * sclk / 2.0
+        additive = mix["cycles"]["cycles_per_valu_inst_additive"] if mix and "cycles" in mix else None
 
         def leg(rate, what):
-            d = {"perms_per_s": rate, "frac": need(rate) / peak, "leg": what}
-            if mix_peak:
-                d["frac_of_mix_peak"] = need(rate) / mix_peak
+            d = {"perms_per_s": rate, "frac": need(rate) / peak, "cycles_per_valu_wave_inst": 1024.0 * sclk / need(rate), "leg": what}
+            if additive:
+                d["additive_mix_price_over_achieved"] = additive / d["cycles_per_valu_wave_inst"]
             return d
         out = {"kernel": "leaf_hash_poly_major_kernel<0> (Poseidon2 sponge, one lane = one leaf)", "bound": "VALU issue", "unit": "VALU wave-instructions/s",
-               "valu_insts_per_perm": per_perm, "peak_valu_wave_insts_per_s": peak, "sclk_hz": k["sclk_hz"],
-               "cycles_per_valu_wave_inst_at_peak": k["cycles_per_valu_wave_inst_of_the_mix"], "cycles_per_valu_wave_inst_achieved_alone": k.get("cycles_per_valu_wave_inst_achieved"),
-               "add32_stream_wave_insts_per_s_measured": k.get("add32_wave_insts_per_s_measured"),
-               "isolated": leg(isolated_rate, "the leaf kernel alone: mp2g_batch_rehash_dev(parts = 1) over 2^20 resident leaves x 135 limbs (17 permutations per lane), median of 7 launches between HIP events, this run"),
+               "valu_insts_per_perm": per_perm, "cycles_per_valu_wave_inst_alone": cyc_alone, "floor_cycles_per_valu_wave_inst": 2.0,
+               "frac_alone_clock_free": 2.0 / cyc_alone,
+               "sclk_hz_this_run_inferred": sclk, "peak_valu_wave_insts_per_s": peak,
+               "peak_note": "1024 SIMDs x sclk / 2 cycles per wave64 instruction, sclk = the clock this run's isolated leg implies at the counter pass's cycles per instruction "
+                            "(rounds 4-5 divided this run's rates by a peak at the COUNTER pass's clock, 10 % lower: their 0.73 was 0.665)",
+               "isolated": leg(isolated_rate, "the leaf kernel alone: mp2g_batch_rehash_dev(parts = 1) over 2^20 resident leaves x 135 limbs (17 permutations per lane), median of 7 launches between HIP events, this run; "
+                                              "its frac is 2 / cycles_alone by construction (the run's clock is inferred from this leg)"),
                "commit": leg(commit_rate, "commit_135x2p15 (leaf sponge + tree levels: the levels' launches are in the time, their permutations counted at the leaf kernel's instruction count)"),
-               "source": f"profiles/{rnd}/sponge_counters.json (committed rocprofv3 --pmc passes; the rates are this run's)"}
+               "source": f"profiles/{rnd}/sponge_counters.json (committed rocprofv3 --pmc passes: instructions per permutation, cycles per instruction; the rates are this run's)"}
         if isolated_runs_ms is not None:
             out["isolated"]["runs_ms"] = isolated_runs_ms
         if row_major_rate is not None:
             out["row_major_sponge_perms_per_s"] = row_major_rate  # hash_no_pad_batch_kernel (the `sponge` leg): another kernel, NOT priced with this kernel's instruction count
-        if mix:
-            out["mix_peak"] = {"valu_wave_insts_per_s": mix_peak, "slots_per_valu_inst": mix["slots_per_valu_inst_of_the_mix"],
-                               "top_of_the_mix": [[r["opcode"], r["share"], r["slots_each"]] for r in mix["histogram"][:6]],
-                               "source": "profiles/r06/leaf_sponge_mix.json: the kernel's instruction histogram (tools/dbg/isa_mix.py) x the issue slots tools/ubench measured per opcode "
-                                         "(profiles/r06/ubench.txt), over the measured add32 stream rate; frac_of_mix_peak = the same achieved rate against this peak"}
+        if mix and "cycles" in mix:
+            c = mix["cycles"]
+            out["mix_model"] = {"cycles_per_valu_inst_additive": additive, "cycles_per_valu_inst_achieved_alone": cyc_alone, "additive_over_achieved": additive / cyc_alone,
+                                "cycles_per_instruction_class": c["per_instruction_class"],
+                                "top_of_the_mix": [[r["opcode"], r["share"], r.get("cycles_each")] for r in mix["histogram"][:6]],
+                                "reading": c["reading"], "source": "profiles/r06/leaf_sponge_mix.json (tools/dbg/isa_mix.py: the kernel's histogram x " + c["source"] + ")"}
         if "step_valu_wave_insts_per_framework_proof" in k:
             out["step_valu_wave_insts_per_framework_proof"] = k["step_valu_wave_insts_per_framework_proof"]
             out["step_source"] = k.get("step_source")
         if "in_step_perms_per_s" in k:
-            out["in_step"] = leg(k["in_step_perms_per_s"], k.get("in_step_source", "4-worker table build under rocprofv3 --kernel-trace (committed profile; not this run)"))
+            # the committed one-worker trace ran at ITS clock: its fraction is clock-free only as a ratio of rates measured in the same session
+            alone_then = k.get("isolated_perms_per_s_kernel_trace")
+            out["in_step"] = {"perms_per_s": k["in_step_perms_per_s"], "leg": k.get("in_step_source", "table build under rocprofv3 --kernel-trace (committed profile; not this run)")}
+            if alone_then:
+                out["in_step"]["over_alone_in_the_same_session"] = k["in_step_perms_per_s"] / alone_then
+                out["in_step"]["frac"] = k["in_step_perms_per_s"] / alone_then * 2.0 / cyc_alone
         return out
     return None
 
@@ -1769,7 +1790,9 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks, farm=
                                   "how": "a committed counter pass (VALU wave-instructions per framework proof of a 512-row build, profiles/r05/step_counters_4workers.json) x THIS run's proofs/s: "
                                          "not an in-run counter measurement",
                                   "leg": "the headline: every kernel of the build (sponges 71 % of the instructions), four workers' streams overlapped",
-                                  "reading": "the build issues VALU instructions at least as fast as the leaf sponge does with the chip to itself: the headline is bound by the instruction count, not by scheduling"}
+                                  "over_the_sponge_alone": rate / alu["peak_valu_wave_insts_per_s"] / alu["frac_alone_clock_free"],
+                                  "reading": "`over_the_sponge_alone`: the whole build's VALU issue rate over the leaf sponge's with the chip to itself, both at this run's clock: the build issues "
+                                             "almost as fast as its dominant kernel alone -- the headline is bound by the instruction count, not by scheduling"}
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         print(json.dumps(out))

@@ -185,7 +185,8 @@ def test_bench_default_workload_is_the_table_build():
     assert cb["value"] >= cb["latency_mode"]["value"] > 0 and cb["mode"] and cb["oracle_build"]["march"] in ("native", "x86-64-v3")
     assert "separate processes" in cb["throughput_sweep"]["how"] and all(m["workers_failed"] == 0 for m in cb["throughput_sweep"]["modes"])
     alu = line["roofline_alu"]
-    assert alu["isolated"]["perms_per_s"] > 0 and 0 < alu["isolated"]["frac_of_mix_peak"] < 1.2 and alu["mix_peak"]["slots_per_valu_inst"] > 1
+    assert alu["isolated"]["perms_per_s"] > 0 and abs(alu["isolated"]["frac"] - alu["frac_alone_clock_free"]) < 1e-9 and 0.5 < alu["frac_alone_clock_free"] < 1
+    assert 1.5e9 < alu["sclk_hz_this_run_inferred"] < 3e9 and alu["mix_model"]["cycles_per_valu_inst_additive"] > 2 and 0 < alu["table_build"]["frac"] < 1
     assert 0 < line["roofline"]["valu"]["frac_of_valu_peak"] < 1 and line["commit_135x2p15"]["leaf_sponge_ms"] > 0 and line["commit_135x2p15"]["tree_levels_ms"] > 0
 
 

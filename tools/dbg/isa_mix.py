@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The instruction MIX of a kernel priced with measured per-instruction costs (round 6).
 
-    python3 tools/dbg/isa_mix.py --ubench profiles/r06/ubench.txt --out profiles/r06/leaf_sponge_mix.json
+    python3 tools/dbg/isa_mix.py --ubench profiles/r06/ubench.txt --counters profiles/r06/sponge_counters.json \
+        --pmc profiles/r06/ubench_pmc_summary.json --out profiles/r06/leaf_sponge_mix.json
 
 Compiles csrc/merkle.hip to gfx950 assembly with the product's flags (hipcc cross-compiles: no GPU needed), takes the text of ONE
 kernel (default: leaf_hash_poly_major_kernel<0>, the Poseidon2 leaf sponge), counts its VALU instructions by opcode and prices every
@@ -62,6 +63,23 @@ def ubench_slots(path):
     return slots
 
 
+def ubench_cycles(path):
+    """tools/ubench under rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE (tools/dbg/profile_r06.sh ubench_pmc): SHADER CYCLES per VALU
+    wave-instruction and SIMD of every single-instruction stream -- GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 x 1024 SIMDs /
+    SQ_INSTS_VALU: a clock-free price, unlike the time-based slots (a sub-millisecond stream runs at the boost clock, the sponge
+    power-limited)"""
+    k = json.load(open(path))["kernels"]
+    cyc = lambda name: k[name]["GRBM_GUI_ACTIVE"] / 8 * 1024 / k[name]["SQ_INSTS_VALU"]
+    names = {"v_mov_b32": "void kinst<0>", "v_lshl_add_u64": "void kinst<1>", "v_mad_u64_u32(asm)": "void kinst<2>", "v_cndmask_b32(sgpr)": "void kinst<3>",
+             "v_sub_u32": "void kinst<5>", "v_bitop3_b32": "void kinst<6>", "v_add_u32": "void kinst<7>", "v_xor_b32": "void kinst<8>"}
+    out = {c: cyc(n) for c, n in names.items() if n in k}
+    if "void kinst<4>" in k:  # three carry-chain instructions and one xor per operation
+        out["carry chain"] = (4 * cyc("void kinst<4>") - out.get("v_xor_b32", 2.34)) / 3.0
+    out["_add32_compiler_loop"] = cyc("void k<7>") if "void k<7>" in k else None
+    out["_poseidon2_perm_kernel"] = cyc("kperm") if "kperm" in k else None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--src", default="merkle.hip")
@@ -69,6 +87,7 @@ def main():
     ap.add_argument("--flags", default="")
     ap.add_argument("--ubench", required=True, help="output of tools/ubench/ubench on the GPU (its `inst` rows)")
     ap.add_argument("--counters", default=os.path.join(ROOT, "profiles", "r05", "sponge_counters.json"))
+    ap.add_argument("--pmc", default=None, help="pmc_summary.py output of tools/ubench under --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE: prices the mix in cycles as well")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     text = kernel_text(a.src, a.symbol, a.flags.split())
@@ -97,6 +116,26 @@ def main():
            "add32_wave_insts_per_s_measured": add32, "mix_peak_valu_wave_insts_per_s": add32 / per_inst,
            "valu_insts_per_perm_dynamic": k["valu_insts_per_perm"],
            "note": "static histogram of the kernel text (two unrolled copies of the permutation + prologue); the dynamic total per permutation is the SQ_INSTS_VALU counter's"}
+    if a.pmc:
+        cyc = ubench_cycles(a.pmc)
+        tot_c = 0.0
+        for r in rows:
+            c = cyc.get(r["class"])
+            if c is None:
+                c = cyc.get("v_add_u32", 2.35)
+            r["cycles_each"] = round(c, 3)
+            tot_c += r["count"] * c
+        achieved = k.get("cycles_per_valu_wave_inst_achieved")
+        out["cycles"] = {"per_instruction_class": {c: round(v, 3) for c, v in cyc.items() if v is not None},
+                         "cycles_per_valu_inst_additive": tot_c / total,
+                         "cycles_per_valu_inst_achieved_by_the_kernel_alone": achieved,
+                         "additive_over_achieved": tot_c / total / achieved if achieved else None,
+                         "floor_cycles_per_valu_inst": 2.0,
+                         "source": os.path.relpath(a.pmc, ROOT) + " (rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES -- tools/ubench/ubench; cycles = GRBM_GUI_ACTIVE / 8 x 1024 / SQ_INSTS_VALU)",
+                         "reading": "priced one kind at a time the kernel's instructions would take `additive` cycles each on average; the kernel issues them FASTER than that "
+                                    "(`achieved`): instructions of different kinds overlap in part (a v_mad_u64_u32 or v_lshl_add_u64 holds its pipe for ~4.3 cycles, a move or a 32-bit "
+                                    "operation ~2.3, and they are not the same pipe all the way). Nothing of the kernel's time is left to scheduling; what is left between it and the "
+                                    "2-cycle floor is the multi-cycle cost the hardware charges for 64-bit integer work"}
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
     print(f"{total} VALU instructions, {per_inst:.3f} slots each on average -> mix peak {add32 / per_inst / 1e12:.3f} x 10^12 wave-instructions/s "
