@@ -83,6 +83,23 @@ GLHD u64 gl_addw(u64 a, u64 b) {
 GLHD u64 gl_reduce128w(u64 lo, u64 hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
   u32 hl = (u32)hi, hh = (u32)(hi >> 32);
+#ifdef GL_REDUCE_VCC
+  // A/B of round 6 (variant builds only): the multiply-add leaves its carry in VCC and the mask is selected by VCC in the VOP2
+  // encoding (a v_cndmask_b32 that selects by an SGPR pair costs 4.2 cycles as a stream, a VOP2 one 2.3: profiles/r06)
+  {
+    u64 tv;
+    u32 mcv, q0, q1, mbv;
+    const u32 ones = 0xFFFFFFFFu;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\t"
+        "v_cndmask_b32_e32 %1, 0, %4, vcc"
+        : "=&v"(tv), "=&v"(mcv) : "v"(hl), "v"(lo), "v"(ones) : "vcc");
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\t"
+        "v_subbrev_co_u32 %1, vcc, 0, %4, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %0, %0, vcc"
+        : "=&v"(q0), "=&v"(q1), "=&v"(mbv) : "v"((u32)tv), "v"((u32)(tv >> 32)), "v"(hh) : "vcc");
+    return gl_mk(q0, q1) + gl_mk(mcv - mbv, mbv & ~mcv);
+  }
+#endif
   u64 t, c;
   asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(hl), "v"(lo));
   u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mb, mc;
@@ -128,6 +145,17 @@ GLHD u64 gl_reduce128w(u64 lo, u64 hi) {
 // hi*2^64 + lo with hi < 2^32
 GLHD u64 gl_reduce96w(u64 lo, u64 hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
+#ifdef GL_REDUCE_VCC
+  {
+    u64 tv;
+    u32 mv;
+    const u32 ones = 0xFFFFFFFFu;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\t"
+        "v_cndmask_b32_e32 %1, 0, %4, vcc"
+        : "=&v"(tv), "=&v"(mv) : "v"((u32)hi), "v"(lo), "v"(ones) : "vcc");
+    return tv + (u64)mv;
+  }
+#endif
   u64 t, c;
   asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"((u32)hi), "v"(lo));
 #ifndef GL_REDUCE_CARRYCHAIN

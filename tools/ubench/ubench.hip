@@ -165,6 +165,9 @@ __global__ void __launch_bounds__(256) kinst(u64* out, u64 seed) {
   u32 x[8];
   for (int i = 0; i < 8; i++) { a[i] = seed * (threadIdx.x + 1 + i * 977) + blockIdx.x; x[i] = (u32)(a[i] >> 7); }
   u64 sc = seed | (blockIdx.x & 1);  // a wave-uniform 64-bit mask in SGPRs (v_cndmask's condition)
+  u32 ones = ~0u;
+  asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(x[0]), "v"(x[1]) : "vcc");  // some mask in VCC for the rows that select by it
+  asm volatile("" : "+v"(ones));
   for (int it = 0; it < ITERS; it++) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -181,6 +184,11 @@ __global__ void __launch_bounds__(256) kinst(u64* out, u64 seed) {
       if (OP == 8) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x[i]) : "v"(x[i]), "v"(x[j]));
       if (OP == 9) { u64 c; asm volatile("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(a[i]), "=s"(c) : "v"(x[j]), "v"(a[i])); }  // acc += zext(word)
       if (OP == 10) { u64 t = gl_mk(x[j], 0u); asm volatile("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(a[i]) : "v"(a[i]), "v"(t)); }  // acc += zext(word) as hipcc does it
+      if (OP == 11) asm volatile("v_cndmask_b32_e64 %0, %1, %2, vcc" : "=v"(x[i]) : "v"(x[i]), "v"(x[j]) : );       // the mask in VCC, VOP3 encoding
+      if (OP == 12) asm volatile("v_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(x[i]) : "v"(x[i]), "v"(x[j]) : );       // the mask in VCC, VOP2 encoding
+      if (OP == 13) asm volatile("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(x[i]) : "s"(sc));                            // constants selected by an SGPR mask (gl_reduce128w's form)
+      if (OP == 14) { u64 c; asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %4\n\tv_cndmask_b32_e32 %1, 0, %5, vcc" : "=&v"(a[i]), "=&v"(x[i]) : "v"(x[i]), "v"(x[j]), "v"(a[i]), "v"(ones) : "vcc"); (void)c; }  // mad with its carry in VCC + the mask from it (2 instructions)
+      if (OP == 15) { u64 c; asm volatile("v_mad_u64_u32 %0, %1, %3, %4, %5\n\ts_nop 1\n\tv_cndmask_b32_e64 %2, 0, -1, %1" : "=&v"(a[i]), "=&s"(c), "=&v"(x[i]) : "v"(x[i]), "v"(x[j]), "v"(a[i])); }  // the same through an SGPR pair (today's form; 2 VALU instructions)
     }
   }
   u64 r = 0;
@@ -225,11 +233,12 @@ int main() {
   RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17) RUN(18) RUN(19) RUN(23) RUN(24) RUN(25) RUN(26)
   {
     const char* inames[] = {"v_mov_b32", "v_lshl_add_u64", "v_mad_u64_u32(asm)", "v_cndmask_b32(sgpr)", "sub_co+subbrev+subb(+xor)", "v_sub_u32", "v_bitop3_b32", "v_add_u32",
-                            "v_xor_b32", "mad acc+=zext(w)", "mov,mov,lshl_add acc+=zext(w)"};
+                            "v_xor_b32", "mad acc+=zext(w)", "mov,mov,lshl_add acc+=zext(w)", "v_cndmask_b32_e64 vcc", "v_cndmask_b32_e32 vcc", "v_cndmask 0,-1,sgpr",
+                            "mad(vcc)+cndmask_e32(vcc)", "mad(sgpr)+cndmask_e64(sgpr)"};
 #define RUNI(N) { float ms = timeit([&] { hipLaunchKernelGGL(kinst<N>, dim3(blocks), dim3(threads), 0, 0, d, 0x9E3779B97F4A7C15ull); }); \
     hipError_t e_ = hipGetLastError(); \
     printf("inst %-30s %8.3f ms  %5.2f slots%s\n", inames[N], ms, ms / add32_ms, e_ == hipSuccess ? "" : "  LAUNCH FAILED"); }
-    RUNI(0) RUNI(1) RUNI(2) RUNI(3) RUNI(4) RUNI(5) RUNI(6) RUNI(7) RUNI(8) RUNI(9) RUNI(10)
+    RUNI(0) RUNI(1) RUNI(2) RUNI(3) RUNI(4) RUNI(5) RUNI(6) RUNI(7) RUNI(8) RUNI(9) RUNI(10) RUNI(11) RUNI(12) RUNI(13) RUNI(14) RUNI(15)
   }
   {
     int reps = 64;
