@@ -789,6 +789,8 @@ def roofline_alu(isolated_rate, commit_rate, row_major_rate=None, isolated_runs_
         if mix and "cycles" in mix:
             c = mix["cycles"]
             out["mix_model"] = {"cycles_per_valu_inst_additive": additive, "cycles_per_valu_inst_achieved_alone": cyc_alone, "additive_over_achieved": additive / cyc_alone,
+                                "cycles_per_valu_inst_additive_without_stream_overhead": c.get("cycles_per_valu_inst_additive_without_stream_overhead"),
+                                "simd_busy_fraction_alone": c.get("busy_fraction_of_the_kernel_alone"),
                                 "cycles_per_instruction_class": c["per_instruction_class"],
                                 "top_of_the_mix": [[r["opcode"], r["share"], r.get("cycles_each")] for r in mix["histogram"][:6]],
                                 "reading": c["reading"], "source": "profiles/r06/leaf_sponge_mix.json (tools/dbg/isa_mix.py: the kernel's histogram x " + c["source"] + ")"}
