@@ -275,17 +275,82 @@ GLHD u32 bitrev32(u32 x, unsigned bits) {
 #endif
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_MUL_FUSED_TAIL)
+// A/B of round 6 (variant builds only; MEASURED SLOWER, profiles/r06/ubench_fused_tail.txt: 2.55-2.67 against 2.83 G permutations/s --
+// fewer instructions, 37.2 against 38.9 G wave-instructions per run, but 3.42 cycles each instead of 2.97: a carry that travels through an
+// SGPR pair costs more than the move and the 64-bit add it replaces).
+// lo + (g + w) 2^64 -> some u64 congruent to it, for g any u64 and w < 2^32 with g + w < 2^64 + 2^32 (round 6). What gl_mul_wide adds
+// last to the high half of a product -- the high word w of the second middle term -- is not added at all: with s = g0 + w (carry k)
+// and 2^32 EPS = -1 (mod p) the value is lo + s EPS - g1 - k, so w enters through ONE 32-bit add whose carry-out k is the carry-IN of
+// the subtraction that takes g1 off anyway (v_subb_co_u32 with an SGPR-pair carry operand). That replaces a register move and a
+// 64-bit add (2 + 4 SIMD cycles) by one carry-chain instruction (~3.2), and the mask of the multiply-add's carry comes from a
+// subtract-with-borrow of a register from itself (~3.2) instead of a v_cndmask_b32 selecting by a scalar mask (4). Corrections as in
+// gl_reduce128w: c = 1, b = 0: t <= 2^64 - 2^33, + EPS cannot wrap; c = 0, b = 1: g1 + k <= 2^32, so t - g1 - k + 2^64 >= p - 1 and
+// - EPS cannot wrap. Hazards: k and c are VALU-written SGPR pairs read by later VALU instructions: two wait states (s_nop 1) stand
+// in front of k's reader, three instructions in front of c's.
+GLD u64 gl_reduce128w_split(u64 lo, u64 g, u32 w) {
+  u32 g0 = (u32)g, g1 = (u32)(g >> 32), s;
+  u64 k, t, c;
+#ifdef GL_SPLIT_TAIL_SGPR
+  asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s), "=s"(k) : "v"(g0), "v"(w));
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(s), "v"(lo));
+  u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mb, mc;
+  asm("s_nop 1\n\t"
+      "v_subb_co_u32_e64 %0, vcc, %4, %6, %8\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %0, %0, vcc\n\t"
+      "v_subb_co_u32_e64 %3, vcc, %0, %0, %7"
+      : "=&v"(r0), "=&v"(r1), "=&v"(mb), "=&v"(mc)
+      : "v"(t0), "v"(t1), "v"(g1), "s"(c), "s"(k)
+      : "vcc");
+#else
+  // variant B: k through an SGPR pair, the multiply-add's carry mask by v_cndmask_b32 as in gl_reduce128w, no explicit wait states in
+  // front of k's reader (the multiply-add stands between its writer and its reader)
+  asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s), "=s"(k) : "v"(g0), "v"(w));
+  asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(t), "=s"(c) : "v"(s), "v"(lo));
+  u32 t0 = (u32)t, t1 = (u32)(t >> 32), r0, r1, mb, mc;
+  asm(
+#ifdef GL_SPLIT_TAIL_NOP
+      "s_nop 0\n\t"
+#endif
+      "v_subb_co_u32_e64 %0, vcc, %4, %6, %8\n\t"
+      "v_subbrev_co_u32 %1, vcc, 0, %5, vcc\n\t"
+      "v_subb_co_u32 %2, vcc, %0, %0, vcc\n\t"
+      "v_cndmask_b32 %3, 0, -1, %7"
+      : "=&v"(r0), "=&v"(r1), "=&v"(mb), "=&v"(mc)
+      : "v"(t0), "v"(t1), "v"(g1), "s"(c), "s"(k)
+      : "vcc");
+#endif
+  return gl_mk(r0, r1) + gl_mk(mc - mb, mb & ~mc);
+}
+#endif
 // a * b + c as some u64 representative (any u64 a, b, c)
 GLHD u64 gl_mul_addw(u64 a, u64 b, u64 c) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_MUL_FUSED_TAIL)
+  u64 a0 = (u32)a, a1 = a >> 32, b0 = (u32)b, b1 = b >> 32;
+  u64 p00 = a0 * b0 + (u64)(u32)c;
+  u64 m1 = a0 * b1 + ((p00 >> 32) + (c >> 32));
+  u64 m2 = a1 * b0 + (m1 & GL_EPS);
+  return gl_reduce128w_split((m2 << 32) | (p00 & GL_EPS), a1 * b1 + (m1 >> 32), (u32)(m2 >> 32));
+#else
   u64 lo, hi;
   gl_mul_add_wide(a, b, c, lo, hi);
   return gl_reduce128w(lo, hi);
+#endif
 }
 GLHD u64 gl_mul_add(u64 a, u64 b, u64 c) { return gl_canon(gl_mul_addw(a, b, c)); }  // canonical a b + c, any u64 inputs
 GLHD u64 gl_mulw(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(GL_MUL_FUSED_TAIL)
+  u64 a0 = (u32)a, a1 = a >> 32, b0 = (u32)b, b1 = b >> 32;
+  u64 p00 = a0 * b0;
+  u64 m1 = a0 * b1 + (p00 >> 32);
+  u64 m2 = a1 * b0 + (m1 & GL_EPS);
+  return gl_reduce128w_split((m2 << 32) | (p00 & GL_EPS), a1 * b1 + (m1 >> 32), (u32)(m2 >> 32));
+#else
   u64 lo, hi;
   gl_mul_wide(a, b, lo, hi);
   return gl_reduce128w(lo, hi);
+#endif
 }
 
 // ---- sums of products without carry chains ------------------------------------------------------------------------------

@@ -151,6 +151,17 @@ __global__ void kcheck(u64* bad, u64 seed) {
     if (hi > hmax) hi = hmax;
     u64 want = gl_canon(red64(lo, hi));  // portable formulation
     u64 h32 = hi & 0xFFFFFFFFull;
+    {  // the multiply-reduce forms against 128-bit integer arithmetic reduced the portable way (operands: the same stream, with the extremes)
+      u64 a = x, b = y, cadd = lo ^ (hi << 7);
+      if (it % 8 == 4) { a = ~0ull; b = ~0ull; cadd = ~0ull; }
+      if (it % 8 == 5) { a = 0xFFFFFFFF00000000ull; b = 0xFFFFFFFFull; }
+      if (it % 8 == 6) { a = 0xFFFFFFFFull; b = 0xFFFFFFFF00000001ull; cadd = 0xFFFFFFFF00000000ull; }
+      unsigned __int128 pr = (unsigned __int128)a * b;
+      u64 want_m = gl_canon(red64((u64)pr, (u64)(pr >> 64)));
+      unsigned __int128 pa = pr + cadd;
+      u64 want_a = gl_canon(red64((u64)pa, (u64)(pa >> 64)));
+      if (gl_canon(gl_mulw(a, b)) != want_m || gl_canon(gl_mul_addw(a, b, cadd)) != want_a || gl_mul(a, b) != want_m) atomicAdd((unsigned long long*)bad, 1ull);
+    }
     if (gl_canon(gl_reduce128w(lo, hi)) != want || gl_canon(gl_reduce96w(lo, h32)) != gl_canon(red64(lo, h32)) ||
         gl_canon(red_asm(lo, hi)) != want || gl_canon(red_asm2(lo, hi)) != want || gl_canon(red_asm3(lo, hi)) != want)
       atomicAdd((unsigned long long*)bad, 1ull);
