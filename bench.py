@@ -919,7 +919,7 @@ def main(argv=None):
     ap.add_argument("--degree-sweep", default="12,13,14,15", help="--workload table at N = 1: after the headline, the table rate at these base degrees (one block of "
                     "--sweep-rows rows each) in the same line as `by_base_degree`; '' = skip")
     ap.add_argument("--sweep-rows", type=int, default=1024, help="rows of the block timed at every base degree of --degree-sweep (halved above k = 14)")
-    ap.add_argument("--sweep-runs", type=int, default=2, help="builds of that block per base degree; the median is reported (of an even number: the lower middle one). "
+    ap.add_argument("--sweep-runs", type=int, default=2, help="builds of that block per base degree; the median is reported (of two builds: the later one, the first still grows buffers). "
                     "Round 5 ran 3; 2 keeps the driver's N = 1 command inside its window now that the timed block is 2^17 rows")
     ap.add_argument("--config2-leaves", type=int, default=1024, help="--workload table at N = 1: leaves of the BASELINE configs[2] leg (2-to-1 aggregation of real leaf proofs, "
                     "2 x leaves - 1 framework proofs) reported as `config2`; 0 = skip")
@@ -1707,9 +1707,12 @@ def run_table(args, rank, local_rank, world, dist, torch, VARIANT, clocks, farm=
                     if rep == 0:
                         rk.check_root(stk, verify=not args.no_verify)
                     del stk
-                runs.sort()
-                val, dtk = runs[(len(runs) - 1) // 2]
-                return {"value": val, "unit": "proofs/s", "rows": rows_k, "seconds": dtk, "median_of": len(runs), "runs": [round(v, 1) for v, _ in runs],
+                # the first build after the provers were created still grows buffers to the block's size (round 5's three builds: 413 / 442 / 444
+                # at k = 12): with three or more builds the median is reported, with two the LATER one (the steady state), both listed in order
+                in_order = [round(v, 1) for v, _ in runs]
+                val, dtk = sorted(runs)[len(runs) // 2] if len(runs) >= 3 else runs[-1]
+                return {"value": val, "unit": "proofs/s", "rows": rows_k, "seconds": dtk, "median_of": len(runs), "runs": in_order,
+                        "value_is": "the median of the builds" if len(runs) >= 3 else "the later of the two builds (the first still grows buffers): `runs` lists them in order",
                         "trace_rows_per_s": val / (n_cols + 1) * sum(sum(1 << d for d in rk.params.shapes()[nm]) * cnt for nm, cnt in
                                                                       (("cells_leaf", 2.0), ("cells_full", 1.0), ("cells_partial", 1.0), ("row_leaf", 0.5), ("row_full", 0.5))),
                         "batch": bk, "shapes": rk.params.shapes(), "setup_s": round(rk.setup_s, 1), "root_verified": not args.no_verify}
