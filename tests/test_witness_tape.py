@@ -135,3 +135,79 @@ def test_public_header_and_python_agree_on_the_opcodes():
     internal = open(os.path.join(ROOT, "mapreduce-plonky2_amd", "csrc", "witness.h")).read()
     for name in public:
         assert f"{name} = MP2G_{name}" in internal
+
+
+def test_random_tapes_are_refused_or_replayed_without_harm():
+    """the tape indexes host memory (slot table, wire matrix): whatever words a caller hands to mp2g_witness_program_create, the library
+    either refuses the tape or replays it inside its buffers. 400 random tapes -- well-formed instructions with operands drawn around
+    their limits (rows, columns, counts, slots one past the end), some truncated -- each created and, if accepted, replayed on the
+    host for two random input vectors into a guarded wire buffer"""
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    lib = mp2.load()
+    rng = np.random.default_rng(0xC0FFEE07)
+    log_n, n_slots, n = 3, 40, 8
+    P = O.P
+
+    def slot():
+        return int(rng.integers(0, n_slots + (1 if rng.random() < 0.05 else 0)))
+
+    def row():
+        return int(rng.integers(0, n + (1 if rng.random() < 0.05 else 0)))
+
+    def instr():
+        op = int(rng.integers(1, 25))
+        sl = lambda k: [slot() for _ in range(k)]
+        if op == R.OP_ARITH: return [op, row(), int(rng.integers(0, 21)), int(rng.integers(0, P, dtype=np.uint64)), int(rng.integers(0, P, dtype=np.uint64))] + sl(4)
+        if op == R.OP_ARITH_EXT: return [op, row(), int(rng.integers(0, 11)), 1, 2] + sl(8)
+        if op in (R.OP_P2, R.OP_POSEIDON): return [op, row()] + sl(25)
+        if op == R.OP_BASE_SUM: return [op, row()] + sl(64)
+        if op == R.OP_RA: return [op, row(), int(rng.integers(0, 5))] + sl(18)
+        if op == R.OP_REDUCING: return [op, row()] + sl(4 + 43 + 2)
+        if op == R.OP_REDUCING_EXT: return [op, row()] + sl(4 + 64 + 2)
+        if op == R.OP_COSET:
+            bits = int(rng.integers(1, 7))
+            return [op, row(), bits] + sl(1 + (2 << min(bits, 5)) + 4)
+        if op == R.OP_WIRE: return [op, row(), int(rng.integers(0, 137))] + sl(1)
+        if op == R.OP_HINT_DIV_EXT: return [op] + sl(6)
+        if op in (R.OP_HINT_LO63, R.OP_HINT_HI): return [op] + sl(2)
+        if op == R.OP_HINT_SPLIT: return [op, slot(), int(rng.integers(0, 66))] + sl(2)
+        if op == R.OP_PAR: return [op, 1, 4, R.OP_HINT_HI, slot(), slot()][:int(rng.integers(3, 7))]
+        if op == R.OP_U32_ARITH: return [op, row(), int(rng.integers(0, 4)), int(rng.integers(0, 5))] + sl(5)
+        if op == R.OP_U32_SUB: return [op, row(), int(rng.integers(0, 7)), int(rng.integers(0, 8))] + sl(5)
+        if op == R.OP_U32_ADD_MANY:
+            na = int(rng.integers(0, 19))
+            return [op, row(), int(rng.integers(0, 6)), int(rng.integers(0, 7)), na] + sl(min(na, 17) + 3)
+        if op == R.OP_U32_RANGE_CHECK: return [op, row(), int(rng.integers(0, 8)), int(rng.integers(0, 9))] + sl(1)
+        if op == R.OP_COMPARISON: return [op, row(), int(rng.integers(0, 66)), int(rng.integers(0, 19))] + sl(3)
+        if op == R.OP_BASE_SPLIT:
+            nl = int(rng.integers(0, 66))
+            return [op, row(), int(rng.integers(0, 4)), nl] + sl(1 + min(nl, 64))
+        if op == R.OP_MUL_EXT: return [op, row(), int(rng.integers(0, 15)), int(rng.integers(0, P, dtype=np.uint64))] + sl(6)
+        if op == R.OP_EXP:
+            nb = int(rng.integers(0, 69))
+            return [op, row(), nb] + sl(1 + min(nb, 67) + 1)
+        return [op, 0, 0]  # MP2G_OP_END and beyond: no such opcode
+
+    accepted = 0
+    ins = np.arange(4, dtype=np.uint32)
+    for _ in range(400):
+        tape = []
+        for _ in range(int(rng.integers(1, 6))):
+            tape += instr()
+        if rng.random() < 0.1:
+            tape = tape[:-1]
+        t = np.ascontiguousarray(tape, dtype=np.uint64)
+        h = ctypes.c_void_p()
+        rc = lib.mp2g_witness_program_create(t.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(t.size), n_slots, log_n,
+                                             ins.ctypes.data_as(ctypes.c_void_p), 4, None, 0, ctypes.byref(h))
+        if rc:
+            continue
+        accepted += 1
+        guard = 64
+        wires = np.full(2 * 135 * n + 2 * guard, 0xDEADBEEFDEADBEEF, dtype=np.uint64)
+        inputs = np.ascontiguousarray(O.rand_field(8, int(rng.integers(1, 1 << 30))).reshape(2, 4))
+        rc = lib.mp2g_witness_program_run(h, inputs.ctypes.data_as(ctypes.c_void_p), 2, 2, ctypes.c_void_p(wires.ctypes.data + 8 * guard), None, 0, None)
+        assert rc == 0
+        assert (wires[:guard] == 0xDEADBEEFDEADBEEF).all() and (wires[-guard:] == 0xDEADBEEFDEADBEEF).all(), "a replay wrote outside the wire matrix"
+        lib.mp2g_witness_program_free(h)
+    assert 20 <= accepted <= 380, accepted  # both outcomes occur

@@ -13,4 +13,4 @@ done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fsanitize=address,undefined -fno-gpu-sanitize -o build_dbg/asan/libmp2gpu_asan.so build_dbg/asan/*.o
 RT=$($CLANG -print-file-name=libclang_rt.asan-x86_64.so)
 export LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 MP2G_LIB=$PWD/build_dbg/asan/libmp2gpu_asan.so
-python -m pytest tests/test_workplan.py tests/test_wire_host.py tests/test_recursion.py -q -x -k "not map_reduce_with" "$@"
+python -m pytest tests/test_workplan.py tests/test_wire_host.py tests/test_recursion.py tests/test_witness_tape.py -q -x -k "not map_reduce_with" "$@"
