@@ -9,7 +9,8 @@ import pytest
 
 import oracle as O
 
-G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "oracle_vectors.json")))
 
 
 def fnv(a):
@@ -136,3 +137,56 @@ def test_hip_reproduces_golden_commitment(ctx):
     for name, v in (("poseidon2", 0), ("poseidon", 1)):
         assert dg.update_off_chain_data_commitment(ctx, pid, primary, col_ids, values, ucols, None, v).hex() == GC[name]["fresh"]
         assert dg.update_off_chain_data_commitment(ctx, pid, primary, col_ids, values, ucols, old, v).hex() == GC[name]["update"]
+
+
+def _tape_program(mp2, spec):
+    import ctypes
+    t = np.ascontiguousarray(spec["tape"], dtype=np.uint64)
+    ins = np.ascontiguousarray(spec["input_sids"], dtype=np.uint32)
+    cs = np.ascontiguousarray(spec["const_slots"], dtype=np.uint64).reshape(-1, 2)
+    h = ctypes.c_void_p()
+    rc = mp2.load().mp2g_witness_program_create(t.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(t.size), spec["n_slots"], spec["log_n"],
+                                                ins.ctypes.data_as(ctypes.c_void_p), int(ins.size), cs.ctypes.data_as(ctypes.c_void_p), int(cs.shape[0]), ctypes.byref(h))
+    assert rc == 0, mp2.load().mp2g_last_error()
+    return h
+
+
+@pytest.mark.parametrize("name", ["c_witness_tape_demo", "leaf_gate_opcodes"])
+def test_host_replay_reproduces_the_golden_tapes(name):
+    """tests/golden/witness_tape_vectors.json (tools/gen_golden_tape.py): the public tape format as data -- the hand-written tape of
+    examples/c_witness_tape.c and a tape using every round-6 opcode, opcodes by number; the library's HOST replay must give the wire
+    matrices and probe values the file holds (they were computed by the Python builder, not by the library)"""
+    import ctypes
+    import importlib
+    mp2 = importlib.import_module("mapreduce-plonky2_amd")
+    spec = json.load(open(os.path.join(HERE, "golden", "witness_tape_vectors.json")))[name]
+    h = _tape_program(mp2, spec)
+    n = 1 << spec["log_n"]
+    probe = np.ascontiguousarray(spec["probe"], dtype=np.uint32)
+    for case in spec["cases"]:
+        inputs = np.ascontiguousarray([case["inputs"]], dtype=np.uint64)
+        wires = np.zeros((135, n), dtype=np.uint64)
+        got = np.zeros(probe.size, dtype=np.uint64)
+        rc = mp2.load().mp2g_witness_program_run(h, inputs.ctypes.data_as(ctypes.c_void_p), 1, 1, wires.ctypes.data_as(ctypes.c_void_p),
+                                                 probe.ctypes.data_as(ctypes.c_void_p), int(probe.size), got.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0 and fnv(wires) == case["wires_fnv1a"] and [int(x) for x in got] == case["probe"]
+    mp2.load().mp2g_witness_program_free(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c_witness_tape_demo", "leaf_gate_opcodes"])
+def test_device_replay_reproduces_the_golden_tapes(ctx, mp2, name):
+    """the same tapes through mp2g_witness_program_run_dev: all cases as one batch"""
+    import ctypes
+    spec = json.load(open(os.path.join(HERE, "golden", "witness_tape_vectors.json")))[name]
+    h = _tape_program(mp2, spec)
+    n, B = 1 << spec["log_n"], len(spec["cases"])
+    probe = np.ascontiguousarray(spec["probe"], dtype=np.uint32)
+    assert mp2.load().mp2g_witness_program_set_probe(h, probe.ctypes.data_as(ctypes.c_void_p), int(probe.size)) == 0
+    d_in = ctx.to_device(np.ascontiguousarray([c["inputs"] for c in spec["cases"]], dtype=np.uint64))
+    d_w, d_pr = ctx.alloc(B * 135 * n * 8), ctx.alloc(B * probe.size * 8)
+    assert mp2.load().mp2g_witness_program_run_dev(h, ctx.h, d_in.ptr, B, d_w.ptr, d_pr.ptr) == 0, mp2.load().mp2g_last_error()
+    wires, got = d_w.download((B, 135, n)), d_pr.download((B, probe.size))
+    for k, case in enumerate(spec["cases"]):
+        assert fnv(wires[k]) == case["wires_fnv1a"] and [int(x) for x in got[k]] == case["probe"]
+    mp2.load().mp2g_witness_program_free(h)
