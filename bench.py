@@ -108,8 +108,9 @@ class ClockReader:
 
 
 class CpuFarm:
-    """The CPU baseline's THROUGHPUT modes run as separate PROCESSES (one address space per proof: threads of one process doing large
-    allocations serialise on the kernel's memory-map lock -- 256 oracle proofs as threads of this process took 166 s, profiles/r06).
+    """The CPU baseline's THROUGHPUT modes run as separate PROCESSES: one address space per proof, so that nothing the proofs share
+    inside one process (the memory map, the allocator, the OpenMP runtime) can be what limits them. (It is not: 256 oracle proofs
+    side by side do 1.5 proofs/s as threads and as processes -- profiles/r06/cpu_throughput_modes.json: the host's memory system.)
     A process that has initialised the GPU must not fork + exec, so the farm's parent is a helper started before this process
     touches the GPU (like ClockReader); it gets its jobs over a pipe and starts the workers itself."""
 
