@@ -61,16 +61,31 @@ GLHD bool exec_gate_op(u64 op, const u64* t, u64* vals, Put put) {
       const u32 nb = (u32)t[1], nch = (u32)t[2], cb = (nb + nch - 1) / nch;
       const u64 a = vals[t[3]], b = vals[t[4]], cmask = ((u64)1 << cb) - 1;
       put(0, row, a); put(1, row, b);
-      u64 msd = 0;
+      // the chunks' differences first, then ALL their inverses from one field inversion (Montgomery's trick: prefix products over the
+      // non-zero differences, one gl_inv, back-substitution): a lane replays the whole row, and 16 inversions of 64 squarings each
+      // one after the other would make this row the longest instruction of its level
+      u64 diff[16], pre[16], msd = 0, acc = 1;
       for (u32 i = 0; i < nch; i++) {
         const u64 fc = cb * i < 64 ? (a >> (cb * i)) & cmask : 0, sc = cb * i < 64 ? (b >> (cb * i)) & cmask : 0;
-        const u64 diff = gl_sub(sc, fc), eq = diff == 0 ? 1 : 0;
         put(4 + i, row, fc); put(4 + nch + i, row, sc);
-        put(4 + 2 * nch + i, row, eq ? 1 : gl_inv(diff));  // equality dummy: 1 / (second - first), 1 for equal chunks
+        diff[i] = gl_sub(sc, fc);
+        pre[i] = acc;                                   // product of the non-zero differences before chunk i
+        if (diff[i]) acc = gl_mul(acc, diff[i]);
+      }
+      u64 inv_all = gl_inv(acc);                        // acc != 0: a product of non-zero field elements (1 when every chunk is equal)
+      for (u32 i = nch; i-- > 0;) {
+        if (!diff[i]) { pre[i] = 1; continue; }         // equality dummy of equal chunks: 1
+        const u64 inv_i = gl_mul(inv_all, pre[i]);      // 1 / diff[i]
+        inv_all = gl_mul(inv_all, diff[i]);
+        pre[i] = inv_i;
+      }
+      for (u32 i = 0; i < nch; i++) {
+        const u64 eq = diff[i] == 0 ? 1 : 0;
+        put(4 + 2 * nch + i, row, pre[i]);              // equality dummy: 1 / (second - first), 1 for equal chunks
         put(4 + 3 * nch + i, row, eq);
         const u64 iv = eq ? msd : 0;
         put(4 + 4 * nch + i, row, iv);
-        msd = eq ? iv : diff;  // intermediate + (1 - equal) diff
+        msd = eq ? iv : diff[i];                        // intermediate + (1 - equal) diff
       }
       put(3, row, msd);
       const u64 val = gl_add((u64)1 << cb, msd);  // 2^chunk_bits + most significant difference, in [1, 2^(chunk_bits + 1))
